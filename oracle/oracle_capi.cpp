@@ -1,0 +1,296 @@
+// TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  C entry points (ctypes) onto the CPU restatement in
+// cstone_oracle.hpp.  All pointers are HOST pointers.  key_bits in {32,64}, real_bits in {32,64},
+// curve 0 = Morton, 1 = Hilbert.  box = {xmin,xmax,ymin,ymax,zmin,zmax}, bc = boundary type per axis.
+#include "cstone_oracle.hpp"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace orc;
+
+namespace
+{
+template<class T>
+Box<T> mkBox(const double* lim, const int* bc)
+{
+    return Box<T>(T(lim[0]), T(lim[1]), T(lim[2]), T(lim[3]), T(lim[4]), T(lim[5]), bc[0], bc[1], bc[2]);
+}
+
+template<class F>
+int withKey(int keyBits, F&& f)
+{
+    if (keyBits == 32) { f(uint32_t{}); }
+    else if (keyBits == 64) { f(uint64_t{}); }
+    else { return -1; }
+    return 0;
+}
+template<class F>
+int withReal(int realBits, F&& f)
+{
+    if (realBits == 32) { f(float{}); }
+    else if (realBits == 64) { f(double{}); }
+    else { return -1; }
+    return 0;
+}
+} // namespace
+
+extern "C"
+{
+
+int cstone_oracle_compute_sfc_keys(int curve, int key_bits, int real_bits, const void* x, const void* y, const void* z,
+                                   void* keys, size_t n, const double* lim, const int* bc)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    computeKeys<K, T>(Curve(curve), (const T*)x, (const T*)y, (const T*)z, (K*)keys, n,
+                                                      mkBox<T>(lim, bc));
+                                });
+                   });
+}
+
+//! scalar helpers for known-answer tests
+uint64_t cstone_oracle_encode(int curve, int key_bits, unsigned ix, unsigned iy, unsigned iz)
+{
+    return key_bits == 32 ? uint64_t(sfcEncode<uint32_t>(Curve(curve), ix, iy, iz))
+                          : sfcEncode<uint64_t>(Curve(curve), ix, iy, iz);
+}
+
+void cstone_oracle_decode(int curve, int key_bits, uint64_t key, unsigned* out3)
+{
+    if (key_bits == 32) { sfcDecode<uint32_t>(Curve(curve), uint32_t(key), out3[0], out3[1], out3[2]); }
+    else { sfcDecode<uint64_t>(Curve(curve), key, out3[0], out3[1], out3[2]); }
+}
+
+void cstone_oracle_node_ibox(int curve, int key_bits, uint64_t key, unsigned level, int* out6)
+{
+    IBox b = key_bits == 32 ? nodeIBox<uint32_t>(Curve(curve), uint32_t(key), level)
+                            : nodeIBox<uint64_t>(Curve(curve), key, level);
+    for (int d = 0; d < 3; ++d)
+        out6[2 * d] = b.lo[d], out6[2 * d + 1] = b.hi[d];
+}
+
+int cstone_oracle_sort_pairs(int key_bits, void* keys, unsigned* vals, size_t n)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       sortByKey<K, unsigned>((K*)keys, vals, n);
+                   });
+}
+
+int cstone_oracle_gather(int elem_bytes, const unsigned* map, size_t n, const void* src, void* dst)
+{
+    const char* s = (const char*)src;
+    char* d       = (char*)dst;
+    for (size_t i = 0; i < n; ++i)
+        std::memcpy(d + i * elem_bytes, s + size_t(map[i]) * elem_bytes, elem_bytes);
+    return 0;
+}
+
+int cstone_oracle_node_counts(int key_bits, const void* tree, unsigned* counts, int num_nodes, const void* keys,
+                              size_t n, unsigned max_count)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       nodeCounts<K>((const K*)tree, counts, num_nodes, (const K*)keys, n, max_count);
+                   });
+}
+
+//! node_ops[num_nodes+1]; returns converged flag through *converged; node_ops left UNSCANNED
+int cstone_oracle_node_ops(int key_bits, const void* tree, int num_nodes, const unsigned* counts, unsigned bucket,
+                           int* node_ops, int* converged)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K    = decltype(k);
+                       *converged = rebalanceDecision<K>((const K*)tree, counts, num_nodes, bucket, node_ops);
+                   });
+}
+
+/*! one updateOctree step. tree_io holds *num_leaves+1 keys on entry and must have room for cap_leaves+1;
+ *  counts_io likewise (cap_leaves). Returns -2 if capacity is too small. */
+int cstone_oracle_update_octree(int key_bits, const void* keys, size_t n, unsigned bucket, void* tree_io,
+                                unsigned* counts_io, int* num_leaves, int cap_leaves, unsigned max_count,
+                                int* converged)
+{
+    int rc = 0;
+    int st = withKey(key_bits,
+                     [&](auto k)
+                     {
+                         using K = decltype(k);
+                         std::vector<K> tree((K*)tree_io, (K*)tree_io + *num_leaves + 1);
+                         std::vector<unsigned> counts(counts_io, counts_io + *num_leaves);
+                         *converged = updateOctree<K>((const K*)keys, n, bucket, tree, counts, max_count);
+                         if (int(counts.size()) > cap_leaves)
+                         {
+                             rc = -2;
+                             return;
+                         }
+                         std::copy(tree.begin(), tree.end(), (K*)tree_io);
+                         std::copy(counts.begin(), counts.end(), counts_io);
+                         *num_leaves = int(counts.size());
+                     });
+    return st ? st : rc;
+}
+
+//! build from the root until converged; returns number of update iterations via *iterations
+int cstone_oracle_compute_octree(int key_bits, const void* keys, size_t n, unsigned bucket, void* tree_out,
+                                 unsigned* counts_out, int* num_leaves, int cap_leaves, unsigned max_count,
+                                 int* iterations)
+{
+    int rc = 0;
+    int st = withKey(key_bits,
+                     [&](auto k)
+                     {
+                         using K = decltype(k);
+                         std::vector<K> tree;
+                         std::vector<unsigned> counts;
+                         *iterations = computeOctree<K>((const K*)keys, n, bucket, tree, counts, max_count);
+                         *num_leaves = int(counts.size());
+                         if (int(counts.size()) > cap_leaves)
+                         {
+                             rc = -2;
+                             return;
+                         }
+                         std::copy(tree.begin(), tree.end(), (K*)tree_out);
+                         std::copy(counts.begin(), counts.end(), counts_out);
+                     });
+    return st ? st : rc;
+}
+
+int cstone_oracle_spanning_tree(int key_bits, const void* span_keys, int num_keys, void* tree_out, int cap,
+                                int* num_leaves)
+{
+    int rc = 0;
+    int st = withKey(key_bits,
+                     [&](auto k)
+                     {
+                         using K = decltype(k);
+                         auto t  = spanningTree<K>((const K*)span_keys, num_keys);
+                         *num_leaves = int(t.size()) - 1;
+                         if (int(t.size()) > cap + 1)
+                         {
+                             rc = -2;
+                             return;
+                         }
+                         std::copy(t.begin(), t.end(), (K*)tree_out);
+                     });
+    return st ? st : rc;
+}
+
+/*! linked octree. Array sizes (M = L + (L-1)/7): prefixes[M], child_offsets[M+1], parents[max(1,(M-1)/8)],
+ *  level_range[maxLevel+2], internal_to_leaf[M], leaf_to_internal[M] */
+int cstone_oracle_build_octree(int key_bits, const void* leaves, int num_leaves, void* prefixes, int* child_offsets,
+                               int* parents, int* level_range, int* internal_to_leaf, int* leaf_to_internal)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       LinkedOctree<K> o;
+                       buildLinkedOctree<K>((const K*)leaves, num_leaves, o);
+                       std::copy(o.prefixes.begin(), o.prefixes.end(), (K*)prefixes);
+                       std::copy(o.childOffsets.begin(), o.childOffsets.end(), child_offsets);
+                       std::copy(o.parents.begin(), o.parents.end(), parents);
+                       std::copy(o.levelRange.begin(), o.levelRange.end(), level_range);
+                       std::copy(o.internalToLeaf.begin(), o.internalToLeaf.end(), internal_to_leaf);
+                       std::copy(o.leafToInternal.begin(), o.leafToInternal.end(), leaf_to_internal);
+                   });
+}
+
+int cstone_oracle_upsweep_counts(const int* level_range, int num_level_entries, const int* child_offsets,
+                                 unsigned* counts)
+{
+    upsweepCounts(level_range, num_level_entries, child_offsets, counts);
+    return 0;
+}
+
+//! layout = (last-first+1) offsets starting at 0 for leaf `first`; radii[num_leaves]
+int cstone_oracle_halo_radii(int h_bits, const void* h, const unsigned* layout, int first, int last, int num_leaves,
+                             float ext, float* radii)
+{
+    return withReal(h_bits,
+                    [&](auto t)
+                    {
+                        using Th = decltype(t);
+                        haloRadii<Th>((const Th*)h, layout, first, last, num_leaves, ext, radii);
+                    });
+}
+
+int cstone_oracle_find_halos(int curve, int key_bits, int real_bits, const void* prefixes, const int* child_offsets,
+                             const int* internal_to_leaf, const void* leaves, const float* radii, const double* lim,
+                             const int* bc, int first, int last, int* flags)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    findHalos<K, T, float>(Curve(curve), (const K*)prefixes, child_offsets,
+                                                           internal_to_leaf, (const K*)leaves, radii,
+                                                           mkBox<T>(lim, bc), first, last, flags);
+                                });
+                   });
+}
+
+//! centers/sizes: [num_nodes][3] of real_bits reals
+int cstone_oracle_node_centers(int curve, int key_bits, int real_bits, const void* prefixes, int num_nodes,
+                               const double* lim, const int* bc, void* centers, void* sizes)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    nodeCenters<K, T>(Curve(curve), (const K*)prefixes, num_nodes, mkBox<T>(lim, bc),
+                                                      (T*)centers, (T*)sizes);
+                                });
+                   });
+}
+
+/*! neighbor search for particles [first,last): coordinates and h share real_bits.
+ *  neighbors[(last-first)*ngmax] row-major, counts[last-first] (true count, may exceed ngmax) */
+int cstone_oracle_find_neighbors(int real_bits, const void* x, const void* y, const void* z, const void* h,
+                                 unsigned first, unsigned last, const double* lim, const int* bc,
+                                 const int* child_offsets, const int* internal_to_leaf, const unsigned* layout,
+                                 const void* centers, const void* sizes, float ext, unsigned ngmax,
+                                 unsigned* neighbors, unsigned* counts)
+{
+    return withReal(real_bits,
+                    [&](auto t)
+                    {
+                        using T = decltype(t);
+                        NsTree<T> tree{child_offsets, internal_to_leaf, layout, (const T*)centers, (const T*)sizes,
+                                       ext};
+                        findNeighbors<T, T>((const T*)x, (const T*)y, (const T*)z, (const T*)h, first, last,
+                                            mkBox<T>(lim, bc), tree, ngmax, neighbors, counts);
+                    });
+}
+
+int cstone_oracle_num_threads()
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+} // extern "C"

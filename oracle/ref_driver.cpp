@@ -1,0 +1,298 @@
+// TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+//
+// Thin C entry points onto the REFERENCE's own CPU implementation, compiled from the headers where
+// they lie under /root/reference/include (never copied into this repository).  Built by
+// oracle/Makefile into oracle/_ref/libcstone_ref.so (git-ignored).  Used to pin the restatement in
+// cstone_oracle.hpp and, optionally, as bench.py's cpu_baseline (kind = "reference").
+//
+// Signatures mirror oracle_capi.cpp (prefix cstone_ref_).  The reference hard-wires
+// SfcKind = HilbertKey (sfc/sfc.hpp:53-55), so everything that goes through sfcIBox/sfcKey
+// (halos, node centers) exists for curve = 1 (Hilbert) only and returns -3 for Morton.
+#include <cstring>
+#include <vector>
+
+#include "cstone/findneighbors.hpp"
+#include "cstone/focus/source_center.hpp"
+#include "cstone/primitives/gather.hpp"
+#include "cstone/sfc/sfc.hpp"
+#include "cstone/traversal/collisions.hpp"
+#include "cstone/tree/csarray.hpp"
+#include "cstone/tree/octree.hpp"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace cstone;
+
+namespace
+{
+template<class T>
+Box<T> mkBox(const double* lim, const int* bc)
+{
+    return Box<T>(T(lim[0]), T(lim[1]), T(lim[2]), T(lim[3]), T(lim[4]), T(lim[5]), BoundaryType(bc[0]),
+                  BoundaryType(bc[1]), BoundaryType(bc[2]));
+}
+
+template<class F>
+int withKey(int keyBits, F&& f)
+{
+    if (keyBits == 32) { f(unsigned{}); }
+    else if (keyBits == 64) { f(uint64_t{}); }
+    else { return -1; }
+    return 0;
+}
+template<class F>
+int withReal(int realBits, F&& f)
+{
+    if (realBits == 32) { f(float{}); }
+    else if (realBits == 64) { f(double{}); }
+    else { return -1; }
+    return 0;
+}
+} // namespace
+
+extern "C"
+{
+
+int cstone_ref_compute_sfc_keys(int curve, int key_bits, int real_bits, const void* x, const void* y, const void* z,
+                                void* keys, size_t n, const double* lim, const int* bc)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    auto box = mkBox<T>(lim, bc);
+                                    if (curve == 0)
+                                        computeSfcKeys((const T*)x, (const T*)y, (const T*)z, (MortonKey<K>*)keys, n,
+                                                       box);
+                                    else
+                                        computeSfcKeys((const T*)x, (const T*)y, (const T*)z, (HilbertKey<K>*)keys, n,
+                                                       box);
+                                });
+                   });
+}
+
+uint64_t cstone_ref_encode(int curve, int key_bits, unsigned ix, unsigned iy, unsigned iz)
+{
+    if (key_bits == 32) return curve == 0 ? iMorton<unsigned>(ix, iy, iz) : iHilbert<unsigned>(ix, iy, iz);
+    return curve == 0 ? iMorton<uint64_t>(ix, iy, iz) : iHilbert<uint64_t>(ix, iy, iz);
+}
+
+void cstone_ref_decode(int curve, int key_bits, uint64_t key, unsigned* out3)
+{
+    util::tuple<unsigned, unsigned, unsigned> t;
+    if (key_bits == 32) t = curve == 0 ? decodeMorton<unsigned>(unsigned(key)) : decodeHilbert<unsigned>(unsigned(key));
+    else t = curve == 0 ? decodeMorton<uint64_t>(key) : decodeHilbert<uint64_t>(key);
+    out3[0] = util::get<0>(t), out3[1] = util::get<1>(t), out3[2] = util::get<2>(t);
+}
+
+void cstone_ref_node_ibox(int curve, int key_bits, uint64_t key, unsigned level, int* out6)
+{
+    IBox b;
+    if (key_bits == 32) b = curve == 0 ? mortonIBox<unsigned>(unsigned(key), level) : hilbertIBox<unsigned>(unsigned(key), level);
+    else b = curve == 0 ? mortonIBox<uint64_t>(key, level) : hilbertIBox<uint64_t>(key, level);
+    out6[0] = b.xmin(), out6[1] = b.xmax(), out6[2] = b.ymin(), out6[3] = b.ymax(), out6[4] = b.zmin(), out6[5] = b.zmax();
+}
+
+int cstone_ref_sort_pairs(int key_bits, void* keys, unsigned* vals, size_t n)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       sort_by_key((K*)keys, (K*)keys + n, vals);
+                   });
+}
+
+int cstone_ref_node_counts(int key_bits, const void* tree, unsigned* counts, int num_nodes, const void* keys, size_t n,
+                           unsigned max_count)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       computeNodeCounts((const K*)tree, counts, num_nodes, (const K*)keys, (const K*)keys + n,
+                                         max_count, false);
+                   });
+}
+
+int cstone_ref_node_ops(int key_bits, const void* tree, int num_nodes, const unsigned* counts, unsigned bucket,
+                        int* node_ops, int* converged)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K    = decltype(k);
+                       *converged = rebalanceDecision((const K*)tree, counts, num_nodes, bucket, node_ops);
+                   });
+}
+
+int cstone_ref_update_octree(int key_bits, const void* keys, size_t n, unsigned bucket, void* tree_io,
+                             unsigned* counts_io, int* num_leaves, int cap_leaves, unsigned max_count, int* converged)
+{
+    int rc = 0;
+    int st = withKey(key_bits,
+                     [&](auto k)
+                     {
+                         using K = decltype(k);
+                         std::vector<K> tree((K*)tree_io, (K*)tree_io + *num_leaves + 1);
+                         std::vector<unsigned> counts(counts_io, counts_io + *num_leaves);
+                         *converged =
+                             updateOctree((const K*)keys, (const K*)keys + n, bucket, tree, counts, max_count);
+                         if (int(counts.size()) > cap_leaves)
+                         {
+                             rc = -2;
+                             return;
+                         }
+                         std::copy(tree.begin(), tree.end(), (K*)tree_io);
+                         std::copy(counts.begin(), counts.end(), counts_io);
+                         *num_leaves = int(counts.size());
+                     });
+    return st ? st : rc;
+}
+
+int cstone_ref_compute_octree(int key_bits, const void* keys, size_t n, unsigned bucket, void* tree_out,
+                              unsigned* counts_out, int* num_leaves, int cap_leaves, unsigned max_count,
+                              int* iterations)
+{
+    int rc = 0;
+    int st = withKey(key_bits,
+                     [&](auto k)
+                     {
+                         using K = decltype(k);
+                         auto [tree, counts] = computeOctree((const K*)keys, (const K*)keys + n, bucket, max_count);
+                         *iterations = -1;
+                         *num_leaves = int(counts.size());
+                         if (int(counts.size()) > cap_leaves)
+                         {
+                             rc = -2;
+                             return;
+                         }
+                         std::copy(tree.begin(), tree.end(), (K*)tree_out);
+                         std::copy(counts.begin(), counts.end(), counts_out);
+                     });
+    return st ? st : rc;
+}
+
+int cstone_ref_spanning_tree(int key_bits, const void* span_keys, int num_keys, void* tree_out, int cap,
+                             int* num_leaves)
+{
+    int rc = 0;
+    int st = withKey(key_bits,
+                     [&](auto k)
+                     {
+                         using K = decltype(k);
+                         auto t  = computeSpanningTree<K>({(const K*)span_keys, size_t(num_keys)});
+                         *num_leaves = int(t.size()) - 1;
+                         if (int(t.size()) > cap + 1)
+                         {
+                             rc = -2;
+                             return;
+                         }
+                         std::copy(t.begin(), t.end(), (K*)tree_out);
+                     });
+    return st ? st : rc;
+}
+
+int cstone_ref_build_octree(int key_bits, const void* leaves, int num_leaves, void* prefixes, int* child_offsets,
+                            int* parents, int* level_range, int* internal_to_leaf, int* leaf_to_internal)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       int numInternal = (num_leaves - 1) / 7;
+                       int numNodes    = num_leaves + numInternal;
+                       // the reference does not write childOffsets[numNodes]; keep the caller's buffer defined
+                       child_offsets[numNodes] = 0;
+                       buildOctreeCpu((const K*)leaves, num_leaves, numInternal, (K*)prefixes, child_offsets, parents,
+                                      level_range, internal_to_leaf, leaf_to_internal);
+                   });
+}
+
+int cstone_ref_upsweep_counts(const int* level_range, int num_level_entries, const int* child_offsets,
+                              unsigned* counts)
+{
+    upsweep({level_range, size_t(num_level_entries)}, {child_offsets, size_t(level_range[num_level_entries - 1])},
+            counts, NodeCount<unsigned>{});
+    return 0;
+}
+
+int cstone_ref_find_halos(int curve, int key_bits, int real_bits, const void* prefixes, const int* child_offsets,
+                          const int* internal_to_leaf, const void* leaves, const float* radii, const double* lim,
+                          const int* bc, int first, int last, int* flags)
+{
+    if (curve != 1) return -3;
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    findHalos((const K*)prefixes, child_offsets, internal_to_leaf, (const K*)leaves,
+                                              radii, mkBox<T>(lim, bc), first, last, flags);
+                                });
+                   });
+}
+
+int cstone_ref_node_centers(int curve, int key_bits, int real_bits, const void* prefixes, int num_nodes,
+                            const double* lim, const int* bc, void* centers, void* sizes)
+{
+    if (curve != 1) return -3;
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    static_assert(sizeof(Vec3<T>) == 3 * sizeof(T));
+                                    nodeFpCenters<K>({(const K*)prefixes, size_t(num_nodes)}, (Vec3<T>*)centers,
+                                                     (Vec3<T>*)sizes, mkBox<T>(lim, bc));
+                                });
+                   });
+}
+
+int cstone_ref_find_neighbors(int real_bits, const void* x, const void* y, const void* z, const void* h,
+                              unsigned first, unsigned last, const double* lim, const int* bc,
+                              const int* child_offsets, const int* internal_to_leaf, const unsigned* layout,
+                              const void* centers, const void* sizes, float ext, unsigned ngmax, unsigned* neighbors,
+                              unsigned* counts)
+{
+    return withReal(real_bits,
+                    [&](auto t)
+                    {
+                        using T = decltype(t);
+                        OctreeNsView<T, uint64_t> view{0,
+                                                       nullptr,
+                                                       child_offsets,
+                                                       internal_to_leaf,
+                                                       nullptr,
+                                                       nullptr,
+                                                       layout,
+                                                       (const Vec3<T>*)centers,
+                                                       (const Vec3<T>*)sizes,
+                                                       ext};
+                        findNeighbors((const T*)x, (const T*)y, (const T*)z, (const T*)h, first, last,
+                                      mkBox<T>(lim, bc), view, ngmax, neighbors, counts);
+                    });
+}
+
+int cstone_ref_num_threads()
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+} // extern "C"
