@@ -1,0 +1,256 @@
+// runtime part of the C ABI: context, memory, copies, stage timers
+// replaces R/cuda/device_vector.{h,cu}, cuda_stubs.h:48-57, errorcheck.cuh (R = reference include/cstone)
+#include "ctx.hpp"
+#include "hilbert_tables.hpp"
+
+namespace cship
+{
+
+int arenaReserve(cstone_hip_ctx* ctx, size_t totalBytes)
+{
+    totalBytes = alignUp(totalBytes) + 4096;
+    if (totalBytes <= ctx->arenaBytes) return CSTONE_OK;
+    if (ctx->arenaUsed != 0) return fail(ctx, CSTONE_E_INTERNAL, "arena grow while slices are live");
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->arena) CS_HIP(ctx, hipFree(ctx->arena));
+    ctx->arena      = nullptr;
+    ctx->arenaBytes = 0;
+    size_t want     = totalBytes + totalBytes / 16;
+    CS_HIP(ctx, hipMalloc((void**)&ctx->arena, want));
+    ctx->arenaBytes = want;
+    return CSTONE_OK;
+}
+
+void* arenaTake(cstone_hip_ctx* ctx, size_t bytes)
+{
+    size_t off = alignUp(ctx->arenaUsed);
+    if (off + bytes > ctx->arenaBytes) return nullptr;
+    ctx->arenaUsed = off + bytes;
+    return ctx->arena + off;
+}
+
+static hipEvent_t takeEvent(cstone_hip_ctx* ctx)
+{
+    if (!ctx->eventPool.empty())
+    {
+        hipEvent_t e = ctx->eventPool.back();
+        ctx->eventPool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+StageTimer::StageTimer(cstone_hip_ctx* c, int stage)
+    : ctx(c)
+{
+    if (!ctx->profiling) return;
+    if (ctx->timerDepth++ > 0) return;
+    cstone_hip_ctx::Bracket b{stage, takeEvent(ctx), takeEvent(ctx)};
+    (void)hipEventRecord(b.a, ctx->stream);
+    idx = int(ctx->brackets.size());
+    ctx->brackets.push_back(b);
+}
+
+StageTimer::~StageTimer()
+{
+    if (!ctx->profiling) return;
+    --ctx->timerDepth;
+    if (idx >= 0) (void)hipEventRecord(ctx->brackets[idx].b, ctx->stream);
+}
+
+static int drainBrackets(cstone_hip_ctx* ctx)
+{
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& b : ctx->brackets)
+    {
+        float ms = 0;
+        CS_HIP(ctx, hipEventElapsedTime(&ms, b.a, b.b));
+        ctx->stageMs[b.stage] += ms;
+        ctx->stageLaunches[b.stage] += 1;
+        ctx->eventPool.push_back(b.a);
+        ctx->eventPool.push_back(b.b);
+    }
+    ctx->brackets.clear();
+    return CSTONE_OK;
+}
+
+} // namespace cship
+
+using namespace cship;
+
+extern "C"
+{
+
+int cstone_hip_ctx_create(cstone_hip_ctx** out, int device, void* stream)
+{
+    if (!out) return CSTONE_E_ARG;
+    *out      = nullptr;
+    auto* ctx = new cstone_hip_ctx;
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess)
+    {
+        delete ctx;
+        return CSTONE_E_HIP;
+    }
+    if (stream) { ctx->stream = (hipStream_t)stream; }
+    else
+    {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess)
+        {
+            delete ctx;
+            return CSTONE_E_HIP;
+        }
+        ctx->ownStream = true;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->numCu = prop.multiProcessorCount;
+    if (hipHostMalloc((void**)&ctx->hostScalars, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&ctx->devScalars, 64 * sizeof(int)) != hipSuccess)
+    {
+        delete ctx;
+        return CSTONE_E_HIP;
+    }
+    if (hipMemset(ctx->devScalars, 0, 64 * sizeof(int)) != hipSuccess)
+    {
+        delete ctx;
+        return CSTONE_E_HIP;
+    }
+    {
+        HilbertTables t = makeHilbertTables();
+        if (hipMalloc(&ctx->hilbertTables, sizeof t) != hipSuccess ||
+            hipMemcpy(ctx->hilbertTables, &t, sizeof t, hipMemcpyHostToDevice) != hipSuccess)
+        {
+            delete ctx;
+            return CSTONE_E_HIP;
+        }
+    }
+    *out = ctx;
+    return CSTONE_OK;
+}
+
+int cstone_hip_ctx_destroy(cstone_hip_ctx* ctx)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : ctx->brackets)
+    {
+        (void)hipEventDestroy(b.a);
+        (void)hipEventDestroy(b.b);
+    }
+    for (auto e : ctx->eventPool)
+        (void)hipEventDestroy(e);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->devScalars) (void)hipFree(ctx->devScalars);
+    if (ctx->hilbertTables) (void)hipFree(ctx->hilbertTables);
+    if (ctx->hostScalars) (void)hipHostFree(ctx->hostScalars);
+    if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CSTONE_OK;
+}
+
+int cstone_hip_ctx_sync(cstone_hip_ctx* ctx)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    // sticky device-side error word (bounded spins, traversal stack overflow ...)
+    CS_HIP(ctx, hipMemcpyAsync(ctx->hostScalars + 63, ctx->devScalars + 63, sizeof(int), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->hostScalars[63] != 0)
+        return fail(ctx, CSTONE_E_INTERNAL, "device-side check failed, code 0x%x", unsigned(ctx->hostScalars[63]));
+    return CSTONE_OK;
+}
+
+const char* cstone_hip_last_error(cstone_hip_ctx* ctx) { return ctx ? ctx->lastError.c_str() : "null context"; }
+
+int cstone_hip_device_info(cstone_hip_ctx* ctx, int* num_cu, int* wave_size)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    if (num_cu) *num_cu = ctx->numCu;
+    if (wave_size) *wave_size = 64;
+    return CSTONE_OK;
+}
+
+int cstone_hip_malloc(cstone_hip_ctx* ctx, void** ptr, size_t bytes)
+{
+    if (!ctx || !ptr) return CSTONE_E_ARG;
+    *ptr = nullptr;
+    if (bytes == 0) return CSTONE_OK;
+    CS_HIP(ctx, hipMalloc(ptr, bytes));
+    return CSTONE_OK;
+}
+
+int cstone_hip_free(cstone_hip_ctx* ctx, void* ptr)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    if (!ptr) return CSTONE_OK;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CS_HIP(ctx, hipFree(ptr));
+    return CSTONE_OK;
+}
+
+int cstone_hip_memcpy_h2d(cstone_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    if (bytes == 0) return CSTONE_OK;
+    CS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // pageable source must stay valid: complete before returning
+    return CSTONE_OK;
+}
+
+int cstone_hip_memcpy_d2h(cstone_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    if (bytes == 0) return CSTONE_OK;
+    CS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CSTONE_OK;
+}
+
+int cstone_hip_memcpy_d2d(cstone_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    if (bytes == 0) return CSTONE_OK;
+    CS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return CSTONE_OK;
+}
+
+int cstone_hip_memset(cstone_hip_ctx* ctx, void* dst, int value, size_t bytes)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    if (bytes == 0) return CSTONE_OK;
+    CS_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return CSTONE_OK;
+}
+
+int cstone_hip_profile_enable(cstone_hip_ctx* ctx, int on)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    CS_TRY(drainBrackets(ctx));
+    ctx->profiling = on != 0;
+    return CSTONE_OK;
+}
+
+int cstone_hip_profile_reset(cstone_hip_ctx* ctx)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    CS_TRY(drainBrackets(ctx));
+    for (int s = 0; s < CSTONE_NUM_STAGES; ++s)
+        ctx->stageMs[s] = 0, ctx->stageLaunches[s] = 0;
+    return CSTONE_OK;
+}
+
+int cstone_hip_profile_get(cstone_hip_ctx* ctx, int stage, double* total_ms, int* launches)
+{
+    if (!ctx || stage < 0 || stage >= CSTONE_NUM_STAGES) return CSTONE_E_ARG;
+    CS_TRY(drainBrackets(ctx));
+    if (total_ms) *total_ms = ctx->stageMs[stage];
+    if (launches) *launches = ctx->stageLaunches[stage];
+    return CSTONE_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,99 @@
+// Internal runtime of libcstone_hip: context, workspace arena, stage timers, launch helpers.
+// gfx950 only (wave64, 256 CUs); no CUDA/HIP dual paths.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "cstone_hip.h"
+
+struct cstone_hip_ctx
+{
+    int device         = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream     = false;
+    int numCu          = 256;
+    std::string lastError;
+
+    // grow-only device workspace handed out in 256-byte aligned slices for the duration of one API call
+    char* arena       = nullptr;
+    size_t arenaBytes = 0;
+    size_t arenaUsed  = 0;
+
+    // pinned host block for scalar results (one sync per read-back instead of symbol copies)
+    int* hostScalars = nullptr; // [64]
+    int* devScalars  = nullptr; // [64]
+
+    // Hilbert transducer tables (device_keys.hpp), device copy
+    void* hilbertTables = nullptr;
+
+    // stage timers
+    bool profiling = false;
+    int timerDepth = 0; // only the outermost StageTimer of a call records (nested helper launches are part of it)
+    struct Bracket
+    {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<Bracket> brackets;
+    std::vector<hipEvent_t> eventPool;
+    double stageMs[CSTONE_NUM_STAGES]   = {0};
+    int stageLaunches[CSTONE_NUM_STAGES] = {0};
+};
+
+namespace cship
+{
+
+inline int fail(cstone_hip_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->lastError = buf;
+    return code;
+}
+
+#define CS_HIP(ctx, call)                                                                                              \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e_ = (call);                                                                                        \
+        if (e_ != hipSuccess)                                                                                          \
+            return cship::fail(ctx, CSTONE_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,     \
+                               __LINE__);                                                                              \
+    } while (0)
+
+#define CS_TRY(expr)                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        int rc_ = (expr);                                                                                              \
+        if (rc_ != CSTONE_OK) return rc_;                                                                              \
+    } while (0)
+
+//! reserve bytes from the arena; grows (with a stream sync) when too small. Pointers stay valid until arenaReset.
+int arenaReserve(cstone_hip_ctx* ctx, size_t totalBytes);
+void* arenaTake(cstone_hip_ctx* ctx, size_t bytes);
+inline void arenaReset(cstone_hip_ctx* ctx) { ctx->arenaUsed = 0; }
+inline size_t alignUp(size_t b, size_t a = 256) { return (b + a - 1) / a * a; }
+
+//! RAII stage timer: records an event pair around the enclosed launches when profiling is enabled
+struct StageTimer
+{
+    cstone_hip_ctx* ctx;
+    int idx = -1;
+    StageTimer(cstone_hip_ctx* c, int stage);
+    ~StageTimer();
+};
+
+inline unsigned gridFor(size_t n, unsigned block, unsigned perThread = 1)
+{
+    size_t per = size_t(block) * perThread;
+    return unsigned((n + per - 1) / per);
+}
+
+} // namespace cship

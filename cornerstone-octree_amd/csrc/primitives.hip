@@ -1,0 +1,233 @@
+// Streaming primitives for gfx950: gather / scatter, min-max reduction, prefix sums.
+// Replace the Thrust/CUB one-liners and small kernels of R/primitives/primitives_gpu.cu
+// (gatherGpu :110-148, scatterGpu :151-175, MinMaxGpu :178-187, exclusive/inclusiveScanGpu :395-437).
+#include <algorithm>
+
+#include "ctx.hpp"
+#include "device_keys.hpp"
+#include "scan.hpp"
+
+namespace cship
+{
+
+namespace
+{
+
+template<int B>
+struct alignas(B >= 16 ? 16 : (B >= 8 ? 8 : B)) Elem
+{
+    unsigned char b[B];
+};
+template<>
+struct alignas(4) Elem<12>
+{
+    unsigned char b[12];
+};
+template<>
+struct alignas(8) Elem<24>
+{
+    unsigned char b[24];
+};
+
+// dst[i] = src[map[i]]: map and dst are streamed, src is a random read (4 + 2E bytes per element)
+template<class E, int PER>
+__global__ __launch_bounds__(256) void gatherKernel(const uint32_t* __restrict__ map, size_t n,
+                                                    const E* __restrict__ src, E* __restrict__ dst)
+{
+    size_t base = size_t(blockIdx.x) * (256 * PER) + threadIdx.x;
+    uint32_t idx[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+    {
+        size_t i = base + size_t(k) * 256;
+        idx[k]   = i < n ? map[i] : 0u;
+    }
+    E v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+    {
+        size_t i = base + size_t(k) * 256;
+        if (i < n) v[k] = src[idx[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+    {
+        size_t i = base + size_t(k) * 256;
+        if (i < n) dst[i] = v[k];
+    }
+}
+
+template<class E, int PER>
+__global__ __launch_bounds__(256) void scatterKernel(const uint32_t* __restrict__ map, size_t n,
+                                                     const E* __restrict__ src, E* __restrict__ dst)
+{
+    size_t base = size_t(blockIdx.x) * (256 * PER) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+    {
+        size_t i = base + size_t(k) * 256;
+        if (i < n) dst[map[i]] = src[i];
+    }
+}
+
+template<bool GATHER, int B>
+void launchPermute(cstone_hip_ctx* ctx, const uint32_t* map, size_t n, const void* src, void* dst)
+{
+    constexpr int PER = 4;
+    unsigned grid     = gridFor(n, 256, PER);
+    if (GATHER)
+        hipLaunchKernelGGL((gatherKernel<Elem<B>, PER>), grid, 256, 0, ctx->stream, map, n, (const Elem<B>*)src,
+                           (Elem<B>*)dst);
+    else
+        hipLaunchKernelGGL((scatterKernel<Elem<B>, PER>), grid, 256, 0, ctx->stream, map, n, (const Elem<B>*)src,
+                           (Elem<B>*)dst);
+}
+
+template<bool GATHER>
+int permute(cstone_hip_ctx* ctx, int elemBytes, const uint32_t* map, size_t n, const void* src, void* dst)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    if (n == 0) return CSTONE_OK;
+    if (!map || !src || !dst) return fail(ctx, CSTONE_E_ARG, "gather/scatter: null array");
+    StageTimer timer(ctx, CSTONE_STAGE_GATHER);
+    int natural = elemBytes >= 16 ? 16 : (elemBytes == 12 ? 4 : (elemBytes == 24 ? 8 : elemBytes));
+    if (elemBytes == 32) natural = 16;
+    if ((uintptr_t(src) % natural) || (uintptr_t(dst) % natural))
+        return fail(ctx, CSTONE_E_ARG, "gather/scatter: arrays must be aligned to %d bytes", natural);
+    switch (elemBytes)
+    {
+        case 1: launchPermute<GATHER, 1>(ctx, map, n, src, dst); break;
+        case 2: launchPermute<GATHER, 2>(ctx, map, n, src, dst); break;
+        case 4: launchPermute<GATHER, 4>(ctx, map, n, src, dst); break;
+        case 8: launchPermute<GATHER, 8>(ctx, map, n, src, dst); break;
+        case 12: launchPermute<GATHER, 12>(ctx, map, n, src, dst); break;
+        case 16: launchPermute<GATHER, 16>(ctx, map, n, src, dst); break;
+        case 24: launchPermute<GATHER, 24>(ctx, map, n, src, dst); break;
+        case 32: launchPermute<GATHER, 32>(ctx, map, n, src, dst); break;
+        default: return fail(ctx, CSTONE_E_ARG, "gather/scatter: element size %d unsupported", elemBytes);
+    }
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+// ---- min/max: per-block partials, then one workgroup folds them (two launches: the launch boundary
+//      provides the cross-XCD visibility, no in-kernel hand-off needed)
+template<class T>
+__device__ __forceinline__ void blockMinMax(T& lo, T& hi, T* smin, T* smax)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        T a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
+        lo  = a < lo ? a : lo;
+        hi  = b > hi ? b : hi;
+    }
+    unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (lane == 0) smin[w] = lo, smax[w] = hi;
+    __syncthreads();
+    for (int i = 0; i < 4; ++i)
+    {
+        lo = smin[i] < lo ? smin[i] : lo;
+        hi = smax[i] > hi ? smax[i] : hi;
+    }
+}
+
+template<class T>
+__global__ __launch_bounds__(256) void minMaxPartialKernel(const T* __restrict__ x, size_t n, T* __restrict__ partial)
+{
+    __shared__ T smin[4], smax[4];
+    T lo = x[0], hi = x[0];
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256)
+    {
+        T v = x[i];
+        lo  = v < lo ? v : lo;
+        hi  = v > hi ? v : hi;
+    }
+    blockMinMax(lo, hi, smin, smax);
+    if (threadIdx.x == 0) partial[2 * blockIdx.x] = lo, partial[2 * blockIdx.x + 1] = hi;
+}
+
+template<class T>
+__global__ __launch_bounds__(256) void minMaxFinalKernel(const T* __restrict__ partial, unsigned m, T* __restrict__ out)
+{
+    __shared__ T smin[4], smax[4];
+    T lo = partial[0], hi = partial[1];
+    for (unsigned b = threadIdx.x; b < m; b += 256)
+    {
+        T a = partial[2 * b], c = partial[2 * b + 1];
+        lo  = a < lo ? a : lo;
+        hi  = c > hi ? c : hi;
+    }
+    blockMinMax(lo, hi, smin, smax);
+    if (threadIdx.x == 0) out[0] = lo, out[1] = hi;
+}
+
+template<class T>
+int minMax(cstone_hip_ctx* ctx, const T* x, size_t n, double* out2)
+{
+    if (n == 0) return fail(ctx, CSTONE_E_ARG, "minmax: empty range");
+    unsigned grid = unsigned(std::min<size_t>(size_t(ctx->numCu) * 4, (n + 255) / 256));
+    CS_TRY(arenaReserve(ctx, alignUp(size_t(grid) * 2 * sizeof(T)) + 1024));
+    T* partial = (T*)arenaTake(ctx, size_t(grid) * 2 * sizeof(T));
+    T* out     = (T*)arenaTake(ctx, 2 * sizeof(T));
+    {
+        StageTimer timer(ctx, CSTONE_STAGE_MINMAX);
+        hipLaunchKernelGGL(minMaxPartialKernel<T>, grid, 256, 0, ctx->stream, x, n, partial);
+        hipLaunchKernelGGL(minMaxFinalKernel<T>, 1, 256, 0, ctx->stream, partial, grid, out);
+    }
+    T host[2];
+    hipError_t e = hipMemcpyAsync(host, out, sizeof host, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    arenaReset(ctx);
+    if (e != hipSuccess) return fail(ctx, CSTONE_E_HIP, "minmax: %s", hipGetErrorString(e));
+    out2[0] = host[0];
+    out2[1] = host[1];
+    return CSTONE_OK;
+}
+
+} // namespace
+
+} // namespace cship
+
+using namespace cship;
+
+extern "C"
+{
+
+int cstone_hip_gather(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map, size_t n, const void* src, void* dst)
+{
+    return permute<true>(ctx, elem_bytes, map, n, src, dst);
+}
+
+int cstone_hip_scatter(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map, size_t n, const void* src, void* dst)
+{
+    return permute<false>(ctx, elem_bytes, map, n, src, dst);
+}
+
+int cstone_hip_minmax(cstone_hip_ctx* ctx, int real_bits, const void* x, size_t n, double* out2_host)
+{
+    if (!ctx || !x || !out2_host) return fail(ctx, CSTONE_E_ARG, "minmax: bad argument");
+    if (real_bits == 32) return minMax<float>(ctx, (const float*)x, n, out2_host);
+    if (real_bits == 64) return minMax<double>(ctx, (const double*)x, n, out2_host);
+    return fail(ctx, CSTONE_E_ARG, "minmax: real_bits %d unsupported", real_bits);
+}
+
+int cstone_hip_exclusive_scan_u32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t init)
+{
+    if (!ctx || (n && (!in || !out))) return fail(ctx, CSTONE_E_ARG, "exclusive_scan: bad argument");
+    CS_TRY(arenaReserve(ctx, scanArenaBytes(n)));
+    int rc = scanU32(ctx, in, out, n, init, false);
+    arenaReset(ctx);
+    return rc;
+}
+
+int cstone_hip_inclusive_scan_u32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n)
+{
+    if (!ctx || (n && (!in || !out))) return fail(ctx, CSTONE_E_ARG, "inclusive_scan: bad argument");
+    CS_TRY(arenaReserve(ctx, scanArenaBytes(n)));
+    int rc = scanU32(ctx, in, out, n, 0u, true);
+    arenaReset(ctx);
+    return rc;
+}
+
+} // extern "C"

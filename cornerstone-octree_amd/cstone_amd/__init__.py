@@ -1,0 +1,347 @@
+"""Python plumbing for libcstone_hip.so (ctypes over the C ABI of include/cstone_hip.h).
+
+This is NOT the product: the product is the shared library and the C++20 headers in
+cornerstone-octree_amd/include/.  The module exists so that tests/, bench.py and smoke() can drive
+the C ABI with torch tensors as device buffers (torch = device memory + streams + torch.distributed).
+There is NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+LIBPATH = os.path.join(PKG, "lib", "libcstone_hip.so")
+
+MORTON, HILBERT = 0, 1
+
+STAGES = {
+    "encode": 0, "sort_hist": 1, "sort_pass": 2, "gather": 3, "node_counts": 4, "rebalance": 5, "link_octree": 6,
+    "halos": 7, "neighbors": 8, "minmax": 9,
+}
+
+EXPORTS = [
+    "cstone_hip_ctx_create", "cstone_hip_ctx_destroy", "cstone_hip_ctx_sync", "cstone_hip_last_error",
+    "cstone_hip_device_info", "cstone_hip_malloc", "cstone_hip_free", "cstone_hip_memcpy_h2d",
+    "cstone_hip_memcpy_d2h", "cstone_hip_memcpy_d2d", "cstone_hip_memset", "cstone_hip_profile_enable",
+    "cstone_hip_profile_reset", "cstone_hip_profile_get", "cstone_hip_compute_sfc_keys",
+    "cstone_hip_sort_pairs_temp_bytes", "cstone_hip_sort_pairs", "cstone_hip_sequence_u32", "cstone_hip_gather",
+    "cstone_hip_scatter", "cstone_hip_minmax", "cstone_hip_exclusive_scan_u32", "cstone_hip_inclusive_scan_u32",
+    "cstone_hip_compute_node_counts", "cstone_hip_compute_node_ops", "cstone_hip_rebalance_tree",
+    "cstone_hip_update_octree", "cstone_hip_compute_octree", "cstone_hip_build_octree", "cstone_hip_upsweep_sum",
+    "cstone_hip_node_centers", "cstone_hip_halo_radii", "cstone_hip_find_halos", "cstone_hip_find_neighbors",
+]
+
+
+class CBox(C.Structure):
+    _fields_ = [("lim", C.c_double * 6), ("bc", C.c_int32 * 3), ("pad_", C.c_int32)]
+
+
+def make_cbox(lim, bc=(0, 0, 0)):
+    b = CBox()
+    for i in range(6):
+        b.lim[i] = float(lim[i])
+    for i in range(3):
+        b.bc[i] = int(bc[i])
+    return b
+
+
+class CstoneError(RuntimeError):
+    pass
+
+
+def max_level(key_bits):
+    return {32: 10, 64: 21}[key_bits]
+
+
+def load_library():
+    """dlopen the product library; raises if it has not been built (no fallback of any kind)"""
+    if not os.path.exists(LIBPATH):
+        raise CstoneError(f"{LIBPATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          f"or `make -C cornerstone-octree_amd`")
+    lib = C.CDLL(LIBPATH)
+    lib.cstone_hip_last_error.restype = C.c_char_p
+    lib.cstone_hip_sort_pairs_temp_bytes.restype = C.c_size_t
+    return lib
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _ptr(t):
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def key_torch_dtype(key_bits):
+    torch = _torch()
+    # torch has no unsigned 32/64 arithmetic types we need; keys live in int32/int64 storage (bit patterns)
+    return {32: torch.int32, 64: torch.int64}[key_bits]
+
+
+def keys_to_numpy(t, key_bits):
+    a = t.cpu().numpy()
+    return a.view(np.uint32 if key_bits == 32 else np.uint64)
+
+
+def keys_from_numpy(a, device):
+    torch = _torch()
+    a = np.ascontiguousarray(a)
+    signed = a.view(np.int32 if a.dtype.itemsize == 4 else np.int64)
+    return torch.from_numpy(signed.copy()).to(device)
+
+
+class Context:
+    """One cstone_hip context bound to a torch device and (by default) torch's current stream."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        torch = _torch()
+        self.lib = load_library()
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        if not torch.cuda.is_available():
+            raise CstoneError("no GPU visible: libcstone_hip needs an MI355X (there is no CPU path)")
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else 0
+        self.h = C.c_void_p()
+        rc = self.lib.cstone_hip_ctx_create(C.byref(self.h), C.c_int(self.device.index), C.c_void_p(stream))
+        if rc != 0:
+            raise CstoneError(f"cstone_hip_ctx_create failed: {rc}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cstone_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.lib.cstone_hip_last_error(self.h)
+            raise CstoneError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def sync(self):
+        self._chk(self.lib.cstone_hip_ctx_sync(self.h), "ctx_sync")
+
+    # ---- profiling
+    def profile_enable(self, on=True):
+        self._chk(self.lib.cstone_hip_profile_enable(self.h, C.c_int(1 if on else 0)), "profile_enable")
+
+    def profile_reset(self):
+        self._chk(self.lib.cstone_hip_profile_reset(self.h), "profile_reset")
+
+    def profile_get(self, stage):
+        ms, cnt = C.c_double(0), C.c_int(0)
+        self._chk(self.lib.cstone_hip_profile_get(self.h, C.c_int(STAGES[stage]), C.byref(ms), C.byref(cnt)),
+                  "profile_get")
+        return ms.value, cnt.value
+
+    # ---- keys
+    def compute_sfc_keys(self, curve, key_bits, x, y, z, box, keys=None):
+        torch = _torch()
+        n = x.numel()
+        if keys is None:
+            keys = torch.zeros(n, dtype=key_torch_dtype(key_bits), device=x.device)
+        rb = x.element_size() * 8
+        self._chk(self.lib.cstone_hip_compute_sfc_keys(self.h, C.c_int(curve), C.c_int(key_bits), C.c_int(rb),
+                                                       _ptr(x), _ptr(y), _ptr(z), _ptr(keys), C.c_size_t(n),
+                                                       C.byref(box)), "compute_sfc_keys")
+        return keys
+
+    # ---- sort
+    def sort_temp_bytes(self, key_bits, n):
+        return int(self.lib.cstone_hip_sort_pairs_temp_bytes(C.c_int(key_bits), C.c_size_t(n)))
+
+    def sort_pairs(self, keys, vals, keys_alt=None, vals_alt=None, temp=None):
+        """in place; vals int32 storage holding uint32"""
+        kb = keys.element_size() * 8
+        n = keys.numel()
+        tb = temp.numel() * temp.element_size() if temp is not None else 0
+        self._chk(self.lib.cstone_hip_sort_pairs(self.h, C.c_int(kb), _ptr(keys), _ptr(vals), C.c_size_t(n),
+                                                 _ptr(keys_alt), _ptr(vals_alt), _ptr(temp), C.c_size_t(tb)),
+                  "sort_pairs")
+
+    def sequence(self, out, init=0):
+        self._chk(self.lib.cstone_hip_sequence_u32(self.h, _ptr(out), C.c_size_t(out.numel()), C.c_uint32(init)),
+                  "sequence_u32")
+
+    def gather(self, map_, src, dst, elem_bytes=None, n=None):
+        eb = elem_bytes or src.element_size()
+        n = map_.numel() if n is None else n
+        self._chk(self.lib.cstone_hip_gather(self.h, C.c_int(eb), _ptr(map_), C.c_size_t(n), _ptr(src), _ptr(dst)),
+                  "gather")
+
+    def scatter(self, map_, src, dst, elem_bytes=None):
+        eb = elem_bytes or src.element_size()
+        self._chk(self.lib.cstone_hip_scatter(self.h, C.c_int(eb), _ptr(map_), C.c_size_t(map_.numel()), _ptr(src),
+                                              _ptr(dst)), "scatter")
+
+    def minmax(self, x):
+        out = (C.c_double * 2)()
+        self._chk(self.lib.cstone_hip_minmax(self.h, C.c_int(x.element_size() * 8), _ptr(x), C.c_size_t(x.numel()),
+                                             out), "minmax")
+        return out[0], out[1]
+
+    def exclusive_scan(self, inp, out, init=0):
+        self._chk(self.lib.cstone_hip_exclusive_scan_u32(self.h, _ptr(inp), _ptr(out), C.c_size_t(inp.numel()),
+                                                         C.c_uint32(init)), "exclusive_scan")
+
+    def inclusive_scan(self, inp, out):
+        self._chk(self.lib.cstone_hip_inclusive_scan_u32(self.h, _ptr(inp), _ptr(out), C.c_size_t(inp.numel())),
+                  "inclusive_scan")
+
+    # ---- tree
+    def compute_node_counts(self, tree, keys, counts=None, max_count=0xFFFFFFFF, num_nodes=None):
+        torch = _torch()
+        kb = keys.element_size() * 8
+        nn = tree.numel() - 1 if num_nodes is None else num_nodes
+        if counts is None:
+            counts = torch.zeros(nn, dtype=torch.int32, device=tree.device)
+        self._chk(self.lib.cstone_hip_compute_node_counts(self.h, C.c_int(kb), _ptr(tree), _ptr(counts), C.c_int(nn),
+                                                          _ptr(keys), C.c_size_t(keys.numel()),
+                                                          C.c_uint32(max_count)), "compute_node_counts")
+        return counts
+
+    def compute_node_ops(self, tree, counts, bucket, num_nodes=None):
+        torch = _torch()
+        kb = tree.element_size() * 8
+        nn = tree.numel() - 1 if num_nodes is None else num_nodes
+        ops = torch.zeros(nn + 1, dtype=torch.int32, device=tree.device)
+        new_n, conv = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.cstone_hip_compute_node_ops(self.h, C.c_int(kb), _ptr(tree), C.c_int(nn), _ptr(counts),
+                                                       C.c_uint32(bucket), _ptr(ops), C.byref(new_n), C.byref(conv)),
+                  "compute_node_ops")
+        return ops, new_n.value, bool(conv.value)
+
+    def rebalance_tree(self, tree, ops, new_num_nodes, num_nodes=None):
+        torch = _torch()
+        kb = tree.element_size() * 8
+        nn = tree.numel() - 1 if num_nodes is None else num_nodes
+        new_tree = torch.zeros(new_num_nodes + 1, dtype=tree.dtype, device=tree.device)
+        self._chk(self.lib.cstone_hip_rebalance_tree(self.h, C.c_int(kb), _ptr(tree), C.c_int(nn),
+                                                     C.c_int(new_num_nodes), _ptr(ops), _ptr(new_tree)),
+                  "rebalance_tree")
+        return new_tree
+
+    def update_octree(self, keys, bucket, tree_buf, counts_buf, num_leaves, max_count=0xFFFFFFFF):
+        """tree_buf / counts_buf are capacity buffers; returns (num_leaves, converged)"""
+        kb = keys.element_size() * 8
+        cap = counts_buf.numel()
+        assert tree_buf.numel() >= cap + 1
+        nl, conv = C.c_int(num_leaves), C.c_int(0)
+        rc = self.lib.cstone_hip_update_octree(self.h, C.c_int(kb), _ptr(keys), C.c_size_t(keys.numel()),
+                                               C.c_uint32(bucket), _ptr(tree_buf), _ptr(counts_buf), C.byref(nl),
+                                               C.c_int(cap), C.c_uint32(max_count), C.byref(conv))
+        if rc == -2:
+            return -nl.value, False
+        self._chk(rc, "update_octree")
+        return nl.value, bool(conv.value)
+
+    def compute_octree(self, keys, bucket, cap_leaves=None, max_count=0xFFFFFFFF):
+        torch = _torch()
+        kb = keys.element_size() * 8
+        n = keys.numel()
+        cap = cap_leaves or max(4096, 4 * n // max(1, bucket) + 4096)
+        while True:
+            tree = torch.zeros(cap + 1, dtype=keys.dtype, device=keys.device)
+            counts = torch.zeros(cap, dtype=torch.int32, device=keys.device)
+            nl, iters = C.c_int(0), C.c_int(0)
+            rc = self.lib.cstone_hip_compute_octree(self.h, C.c_int(kb), _ptr(keys), C.c_size_t(n), C.c_uint32(bucket),
+                                                    _ptr(tree), _ptr(counts), C.byref(nl), C.c_int(cap),
+                                                    C.c_uint32(max_count), C.byref(iters))
+            if rc == -2:
+                cap = nl.value + 1
+                continue
+            self._chk(rc, "compute_octree")
+            return tree[:nl.value + 1], counts[:nl.value], iters.value
+
+    def build_octree(self, leaves, num_leaves=None):
+        torch = _torch()
+        kb = leaves.element_size() * 8
+        nl = leaves.numel() - 1 if num_leaves is None else num_leaves
+        ni = (nl - 1) // 7
+        nn = nl + ni
+        dev = leaves.device
+        o = dict(
+            num_leaves=nl, num_internal=ni, num_nodes=nn,
+            prefixes=torch.zeros(nn, dtype=leaves.dtype, device=dev),
+            child_offsets=torch.zeros(nn + 1, dtype=torch.int32, device=dev),
+            parents=torch.zeros(max(1, (nn - 1) // 8), dtype=torch.int32, device=dev),
+            level_range=torch.zeros(max_level(kb) + 2, dtype=torch.int32, device=dev),
+            internal_to_leaf=torch.zeros(nn, dtype=torch.int32, device=dev),
+            leaf_to_internal=torch.zeros(nn, dtype=torch.int32, device=dev),
+        )
+        self._chk(self.lib.cstone_hip_build_octree(self.h, C.c_int(kb), _ptr(leaves), C.c_int(nl), _ptr(o["prefixes"]),
+                                                   _ptr(o["child_offsets"]), _ptr(o["parents"]),
+                                                   _ptr(o["level_range"]), _ptr(o["internal_to_leaf"]),
+                                                   _ptr(o["leaf_to_internal"])), "build_octree")
+        return o
+
+    def upsweep_sum(self, octree, counts):
+        self._chk(self.lib.cstone_hip_upsweep_sum(self.h, C.c_int(octree["level_range"].numel()),
+                                                  _ptr(octree["level_range"]), _ptr(octree["child_offsets"]),
+                                                  _ptr(counts)), "upsweep_sum")
+
+    def node_centers(self, curve, prefixes, box, real_bits=64):
+        torch = _torch()
+        kb = prefixes.element_size() * 8
+        nn = prefixes.numel()
+        dt = torch.float32 if real_bits == 32 else torch.float64
+        centers = torch.zeros((nn, 3), dtype=dt, device=prefixes.device)
+        sizes = torch.zeros((nn, 3), dtype=dt, device=prefixes.device)
+        self._chk(self.lib.cstone_hip_node_centers(self.h, C.c_int(curve), C.c_int(kb), C.c_int(real_bits),
+                                                   _ptr(prefixes), C.c_int(nn), C.byref(box), _ptr(centers),
+                                                   _ptr(sizes)), "node_centers")
+        return centers, sizes
+
+    # ---- halos
+    def halo_radii(self, h, layout, first, last, num_leaves, ext=1.0):
+        torch = _torch()
+        radii = torch.empty(num_leaves, dtype=torch.float32, device=h.device)
+        self._chk(self.lib.cstone_hip_halo_radii(self.h, C.c_int(h.element_size() * 8), _ptr(h), _ptr(layout),
+                                                 C.c_int(first), C.c_int(last), C.c_int(num_leaves), C.c_float(ext),
+                                                 _ptr(radii)), "halo_radii")
+        return radii
+
+    def find_halos(self, curve, octree, leaves, radii, box, first, last, real_bits=64, flags=None):
+        torch = _torch()
+        kb = leaves.element_size() * 8
+        if flags is None:
+            flags = torch.zeros(octree["num_leaves"], dtype=torch.int32, device=leaves.device)
+        self._chk(self.lib.cstone_hip_find_halos(self.h, C.c_int(curve), C.c_int(kb), C.c_int(real_bits),
+                                                 _ptr(octree["prefixes"]), _ptr(octree["child_offsets"]),
+                                                 _ptr(octree["internal_to_leaf"]), _ptr(leaves), _ptr(radii),
+                                                 C.byref(box), C.c_int(first), C.c_int(last), _ptr(flags)),
+                  "find_halos")
+        return flags
+
+    def find_neighbors(self, x, y, z, h, first, last, box, octree, layout, centers, sizes, ngmax, ext=1.0):
+        torch = _torch()
+        nw = last - first
+        nidx = torch.zeros((nw, ngmax), dtype=torch.int32, device=x.device)
+        nc = torch.zeros(nw, dtype=torch.int32, device=x.device)
+        self._chk(self.lib.cstone_hip_find_neighbors(self.h, C.c_int(x.element_size() * 8), _ptr(x), _ptr(y), _ptr(z),
+                                                     _ptr(h), C.c_uint32(first), C.c_uint32(last), C.byref(box),
+                                                     _ptr(octree["child_offsets"]), _ptr(octree["internal_to_leaf"]),
+                                                     _ptr(layout), _ptr(centers), _ptr(sizes), C.c_float(ext),
+                                                     C.c_uint32(ngmax), _ptr(nidx), _ptr(nc)), "find_neighbors")
+        return nidx, nc
+
+
+_DEFAULT = None
+
+
+def load(device=0):
+    """shared default context (tests)"""
+    global _DEFAULT
+    if _DEFAULT is None:
+        _DEFAULT = Context(device)
+    return _DEFAULT

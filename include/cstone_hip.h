@@ -1,0 +1,205 @@
+/* cstone_hip.h -- C ABI of the MI355X-native cornerstone-octree hot path (libcstone_hip.so)
+ *
+ * This is the drop-in boundary.  The reference (cornerstone-octree) has no FFI: its GPU flavour is
+ * reached through a LINK SEAM of `template<...> extern void fooGpu(...)` declarations whose
+ * definitions live in the .cu files of its cstone_gpu library.  Every entry point below replaces
+ * one of those seam functions (cited as R/<file>:<line>, R = /root/reference/include/cstone) with
+ * a plain-C signature: device pointers + sizes, no C++/torch types.  The C++20 header layer in
+ * cornerstone-octree_amd/include/cstone_amd/ turns these back into the reference's templates
+ * (same names and argument meaning), see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = error (CSTONE_E_*), message via cstone_hip_last_error
+ *   - all array pointers are DEVICE pointers unless the parameter name ends in _host
+ *   - work is enqueued on the context's HIP stream and is asynchronous unless a host result is
+ *     returned (those calls synchronise the stream)
+ *   - key_bits in {32,64} selects KeyType = uint32_t | uint64_t (R/tree/definitions.h:46-83)
+ *   - real_bits in {32,64} selects float | double coordinates
+ *   - curve: CSTONE_MORTON | CSTONE_HILBERT (the reference fixes this at build time through the
+ *     SfcKind alias, R/sfc/sfc.hpp:53-55; here it is a run-time argument)
+ *   - TreeNodeIndex = int32, LocalIndex = uint32 (R/tree/definitions.h:41-43)
+ *   - one context per (host thread, device); calls on one context must be serialised by the caller
+ */
+#ifndef CSTONE_HIP_H
+#define CSTONE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+#define CSTONE_MORTON 0
+#define CSTONE_HILBERT 1
+
+#define CSTONE_OK 0
+#define CSTONE_E_ARG (-1)      /* invalid argument (bad key_bits, null pointer, size too large ...) */
+#define CSTONE_E_CAPACITY (-2) /* caller-provided buffer too small; required size reported through out-params */
+#define CSTONE_E_HIP (-3)      /* a HIP runtime call failed */
+#define CSTONE_E_INTERNAL (-4) /* device-side consistency check failed (bounded spin expired, stack overflow ...) */
+
+    /* Global coordinate bounding box, POD image of cstone::Box<T> (R/sfc/box.hpp:112-191).
+     * lim = {xmin,xmax,ymin,ymax,zmin,zmax}; the library derives lengths and inverse lengths in the
+     * precision selected by real_bits exactly as the Box<T> constructor does (1/(max-min), :135).
+     * bc[d]: 0 open, 1 periodic, 2 fixed (BoundaryType, R/sfc/box.hpp:97-102). */
+    typedef struct cstone_box
+    {
+        double lim[6];
+        int32_t bc[3];
+        int32_t pad_;
+    } cstone_box;
+
+    typedef struct cstone_hip_ctx cstone_hip_ctx;
+
+    /* ---------------------------------------------------------------------------------------------
+     * runtime: replaces R/cuda/device_vector.h, cuda_stubs.h:48-57 (memcpyH2D/D2H/D2D, syncGpu),
+     * errorcheck.cuh:30-42 (we return codes instead of exit()).
+     * ------------------------------------------------------------------------------------------- */
+    /* stream: an existing hipStream_t (e.g. torch's current stream) or NULL to create a private one */
+    int cstone_hip_ctx_create(cstone_hip_ctx** out, int device, void* stream);
+    int cstone_hip_ctx_destroy(cstone_hip_ctx* ctx);
+    int cstone_hip_ctx_sync(cstone_hip_ctx* ctx);
+    const char* cstone_hip_last_error(cstone_hip_ctx* ctx);
+    /* number of compute units / wavefront size of the context's device (R/cuda/gpu_config.cuh:41-59) */
+    int cstone_hip_device_info(cstone_hip_ctx* ctx, int* num_cu, int* wave_size);
+
+    int cstone_hip_malloc(cstone_hip_ctx* ctx, void** ptr, size_t bytes);
+    int cstone_hip_free(cstone_hip_ctx* ctx, void* ptr);
+    int cstone_hip_memcpy_h2d(cstone_hip_ctx* ctx, void* dst, const void* src_host, size_t bytes);
+    int cstone_hip_memcpy_d2h(cstone_hip_ctx* ctx, void* dst_host, const void* src, size_t bytes);
+    int cstone_hip_memcpy_d2d(cstone_hip_ctx* ctx, void* dst, const void* src, size_t bytes);
+    int cstone_hip_memset(cstone_hip_ctx* ctx, void* dst, int value, size_t bytes);
+
+    /* Stage timers (HIP events on the context's stream).  When enabled, the library brackets each
+     * launch of the named stages with events; totals are read back with cstone_hip_profile_get.
+     * Stage ids: CSTONE_STAGE_*.  Adds two event records per bracket; off by default. */
+#define CSTONE_STAGE_ENCODE 0
+#define CSTONE_STAGE_SORT_HIST 1
+#define CSTONE_STAGE_SORT_PASS 2 /* one onesweep digit pass = one launch */
+#define CSTONE_STAGE_GATHER 3
+#define CSTONE_STAGE_NODE_COUNTS 4
+#define CSTONE_STAGE_REBALANCE 5
+#define CSTONE_STAGE_LINK_OCTREE 6
+#define CSTONE_STAGE_HALOS 7
+#define CSTONE_STAGE_NEIGHBORS 8
+#define CSTONE_STAGE_MINMAX 9
+#define CSTONE_NUM_STAGES 16
+    int cstone_hip_profile_enable(cstone_hip_ctx* ctx, int on);
+    int cstone_hip_profile_reset(cstone_hip_ctx* ctx);
+    /* synchronises the stream; total_ms and launches accumulated since the last reset */
+    int cstone_hip_profile_get(cstone_hip_ctx* ctx, int stage, double* total_ms, int* launches);
+
+    /* ---------------------------------------------------------------------------------------------
+     * SFC keys: replaces computeSfcKeysGpu (R/sfc/sfc_gpu.h:37-38, kernel R/sfc/sfc_gpu.cu:39-57).
+     * keys[i] = sfc3D(x[i],y[i],z[i],box) unless keys[i] already holds the remove marker
+     * 2^(3*maxLevel) (R/sfc/sfc.hpp:284-291).  Bit-exact with the reference's CPU path.
+     * ------------------------------------------------------------------------------------------- */
+    int cstone_hip_compute_sfc_keys(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x,
+                                    const void* y, const void* z, void* keys, size_t n, const cstone_box* box_host);
+
+    /* ---------------------------------------------------------------------------------------------
+     * sort: replaces sortByKeyGpu / sortByKeyTempStorage (R/primitives/primitives_gpu.h:93-100,
+     * R/primitives/primitives_gpu.cu:328-369,383-386) and sequenceGpu (:286).
+     * Stable ascending LSD radix sort of (key, uint32 value) pairs over ALL key bits; the sorted
+     * sequence ends up in keys/values (like the reference, which copies back from the alt buffer).
+     * n < 2^30.  keys_alt[n], values_alt[n] and temp (>= cstone_hip_sort_pairs_temp_bytes) are
+     * caller-provided scratch; pass NULL for all three to let the context's arena provide them.
+     * ------------------------------------------------------------------------------------------- */
+    size_t cstone_hip_sort_pairs_temp_bytes(int key_bits, size_t n);
+    int cstone_hip_sort_pairs(cstone_hip_ctx* ctx, int key_bits, void* keys, uint32_t* values, size_t n, void* keys_alt,
+                              uint32_t* values_alt, void* temp, size_t temp_bytes);
+    int cstone_hip_sequence_u32(cstone_hip_ctx* ctx, uint32_t* out, size_t n, uint32_t init);
+
+    /* gatherGpu / scatterGpu (R/primitives/primitives_gpu.h:48-56): dst[i] = src[map[i]] resp.
+     * dst[map[i]] = src[i] for elements of elem_bytes in {1,2,4,8,12,16,24,32} */
+    int cstone_hip_gather(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map, size_t n, const void* src,
+                          void* dst);
+    int cstone_hip_scatter(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map, size_t n, const void* src,
+                           void* dst);
+
+    /* MinMaxGpu (R/primitives/primitives_gpu.h:58-62): out_host = {min, max} as doubles (exact for float) */
+    int cstone_hip_minmax(cstone_hip_ctx* ctx, int real_bits, const void* x, size_t n, double* out2_host);
+
+    /* exclusiveScanGpu / inclusiveScanGpu on uint32/int32 (R/primitives/primitives_gpu.h:103-115).
+     * exclusive: out[i] = init + sum(in[0..i)), n outputs.  in == out allowed. */
+    int cstone_hip_exclusive_scan_u32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t init);
+    int cstone_hip_inclusive_scan_u32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n);
+
+    /* ---------------------------------------------------------------------------------------------
+     * cornerstone leaf array (R/tree/csarray_gpu.h:56-88, R/tree/update_gpu.cuh:59-82)
+     * ------------------------------------------------------------------------------------------- */
+    /* computeNodeCountsGpu: counts[i] = min(#keys in [tree[i],tree[i+1]), max_count); keys sorted */
+    int cstone_hip_compute_node_counts(cstone_hip_ctx* ctx, int key_bits, const void* tree, uint32_t* counts,
+                                       int num_nodes, const void* keys, size_t n, uint32_t max_count);
+    /* computeNodeOpsGpu: node_ops[num_nodes+1] <- exclusive scan of the rebalance decisions
+     * (R/tree/csarray.hpp:288-310); *new_num_nodes_host = node_ops[num_nodes];
+     * *converged_host = 1 iff every decision was "keep" */
+    int cstone_hip_compute_node_ops(cstone_hip_ctx* ctx, int key_bits, const void* tree, int num_nodes,
+                                    const uint32_t* counts, uint32_t bucket_size, int32_t* node_ops,
+                                    int* new_num_nodes_host, int* converged_host);
+    /* rebalanceTreeGpu: new_tree[new_num_nodes+1] from tree and scanned node_ops */
+    int cstone_hip_rebalance_tree(cstone_hip_ctx* ctx, int key_bits, const void* tree, int num_nodes,
+                                  int new_num_nodes, const int32_t* node_ops, void* new_tree);
+    /* updateOctreeGpu: one rebalance step + recount on device-resident buffers with capacity
+     * cap_leaves (tree: cap_leaves+1 keys).  *num_leaves_host is updated.  CSTONE_E_CAPACITY if the
+     * new tree does not fit (then *num_leaves_host holds the required leaf count, buffers unchanged). */
+    int cstone_hip_update_octree(cstone_hip_ctx* ctx, int key_bits, const void* keys, size_t n, uint32_t bucket_size,
+                                 void* tree, uint32_t* counts, int* num_leaves_host, int cap_leaves,
+                                 uint32_t max_count, int* converged_host);
+    /* computeOctree (R/tree/csarray.hpp:453-466): start at the root, update until converged */
+    int cstone_hip_compute_octree(cstone_hip_ctx* ctx, int key_bits, const void* keys, size_t n, uint32_t bucket_size,
+                                  void* tree, uint32_t* counts, int* num_leaves_host, int cap_leaves,
+                                  uint32_t max_count, int* iterations_host);
+
+    /* ---------------------------------------------------------------------------------------------
+     * linked octree: replaces buildOctreeGpu (R/tree/octree_gpu.h:47, R/tree/octree_gpu.cu:152-174).
+     * Sizes with L = num_leaves, I = (L-1)/7, M = L+I:
+     *   prefixes[M] child_offsets[M+1] parents[max(1,(M-1)/8)] level_range[maxLevel+2]
+     *   internal_to_leaf[M] leaf_to_internal[M]          (OctreeView, R/tree/octree.hpp:280-293)
+     * upsweepSumGpu (R/tree/octree_gpu.h:50): saturating u32 sum of 8 children, bottom-up.
+     * ------------------------------------------------------------------------------------------- */
+    int cstone_hip_build_octree(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int num_leaves, void* prefixes,
+                                int32_t* child_offsets, int32_t* parents, int32_t* level_range,
+                                int32_t* internal_to_leaf, int32_t* leaf_to_internal);
+    int cstone_hip_upsweep_sum(cstone_hip_ctx* ctx, int num_levels_plus2, const int32_t* level_range,
+                               const int32_t* child_offsets, uint32_t* counts);
+    /* computeGeoCentersGpu (R/focus/source_center_gpu.h): centers/sizes [M][3] reals */
+    int cstone_hip_node_centers(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* prefixes,
+                                int num_nodes, const cstone_box* box_host, void* centers, void* sizes);
+
+    /* ---------------------------------------------------------------------------------------------
+     * halo discovery: replaces segmentMax + scaleGpu (R/primitives/primitives_gpu.h:79-80,38-39) as
+     * used by Halos::discover (R/halos/halos.hpp:128-189) and findHalosGpu
+     * (R/traversal/collisions_gpu.h:57-66, kernel R/traversal/collisions_gpu.cu:40-104).
+     * halo_radii: radii[i] = float(max(h[layout[i-first]..layout[i-first+1])) * 2 * ext) for
+     *             i in [first,last) (0 if the leaf is empty), 0 elsewhere; layout = last-first+1 offsets
+     *             (this is the CPU branch's rounding, halos.hpp:176 -- parity is defined vs the CPU path)
+     * find_halos: flags[num_leaves] must be pre-zeroed by the caller (fillGpu in the reference);
+     *             flags[l] = 1 for every leaf l outside [leaves[first],leaves[last]) whose box
+     *             overlaps the radius-dilated box of a leaf in [first,last)
+     * ------------------------------------------------------------------------------------------- */
+    int cstone_hip_halo_radii(cstone_hip_ctx* ctx, int h_bits, const void* h, const uint32_t* layout, int first,
+                              int last, int num_leaves, float ext, float* radii);
+    int cstone_hip_find_halos(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* prefixes,
+                              const int32_t* child_offsets, const int32_t* internal_to_leaf, const void* leaves,
+                              const float* radii, const cstone_box* box_host, int first, int last, int32_t* flags);
+
+    /* ---------------------------------------------------------------------------------------------
+     * neighbor search: replaces findNeighbors (R/findneighbors.hpp:160-188) / the traverseNeighbors
+     * device function (R/traversal/find_neighbors.cuh:436-506) on an OctreeNsView
+     * (R/tree/octree.hpp:297-317).  For i in [first,last): counts[i-first] = number of j != i with
+     * |r_i - r_j|^2 < (2 h_i)^2 (minimum image if periodic); the first ngmax are stored row-major in
+     * neighbors[(i-first)*ngmax + k] in the reference's CPU traversal order.
+     * ------------------------------------------------------------------------------------------- */
+    int cstone_hip_find_neighbors(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y, const void* z,
+                                  const void* h, uint32_t first, uint32_t last, const cstone_box* box_host,
+                                  const int32_t* child_offsets, const int32_t* internal_to_leaf,
+                                  const uint32_t* layout, const void* centers, const void* sizes, float ext,
+                                  uint32_t ngmax, uint32_t* neighbors, uint32_t* counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSTONE_HIP_H */

@@ -1,0 +1,52 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol include/cstone_hip.h declares.
+No compute calls are made here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cstone_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cstone_hip_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    for must in ("cstone_hip_compute_sfc_keys", "cstone_hip_sort_pairs", "cstone_hip_update_octree",
+                 "cstone_hip_build_octree", "cstone_hip_find_halos", "cstone_hip_find_neighbors"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    import cstone_amd
+
+    lib = cstone_amd.load_library()  # raises if the library was not built: there is no fallback
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(cstone_amd.EXPORTS) == [s for s in declared_symbols() if s in cstone_amd.EXPORTS]
+    assert set(declared_symbols()) == set(cstone_amd.EXPORTS), set(declared_symbols()) ^ set(cstone_amd.EXPORTS)
+
+
+def test_box_pod_layout_matches_header():
+    import cstone_amd
+
+    assert ctypes.sizeof(cstone_amd.CBox) == 6 * 8 + 4 * 4
+    assert cstone_amd.CBox.bc.offset == 48
+
+
+def test_product_does_not_reference_the_oracle():
+    """the shipped sources must never include, link or call anything under oracle/"""
+    src = os.path.join(ROOT, "cornerstone-octree_amd")
+    for dirpath, _, files in os.walk(src):
+        if "build" in dirpath or "__pycache__" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".hip", ".hpp", ".h", ".py", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for needle in ("oracle/", "cstone_oracle", "libcstone_ref", "import oracle", "from oracle",
+                               "cstone_ref_"):
+                    assert needle not in text, (dirpath, f, needle)

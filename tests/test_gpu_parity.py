@@ -1,0 +1,349 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every entry point of the C ABI against the CPU oracle on the
+same seeded inputs.  Integer / byte / index results must be bit-exact; neighbor lists are compared exactly too
+(the HIP path evaluates the same IEEE operations in the same order as the reference's CPU path, no FMA)."""
+import numpy as np
+import pytest
+
+from helpers import Box, OctreeMaker, end_key, key_dtype, max_level, random_cloud, real_dtype
+from oracle.oracle import HILBERT, MORTON
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def dev(a):
+    """numpy -> device tensor (unsigned arrays travel as the signed type of the same width)"""
+    torch = _torch()
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint32:
+        a = a.view(np.int32)
+    elif a.dtype == np.uint64:
+        a = a.view(np.int64)
+    return torch.from_numpy(a.copy()).cuda()
+
+
+def host(t, unsigned=True):
+    a = t.cpu().numpy()
+    if unsigned and a.dtype == np.int32:
+        return a.view(np.uint32)
+    if unsigned and a.dtype == np.int64:
+        return a.view(np.uint64)
+    return a
+
+
+def cbox(box):
+    import cstone_amd
+
+    return cstone_amd.make_cbox(box.lim, box.bc)
+
+
+BOXES = [Box([0, 1]), Box([-1.3, 2.1, 0.2, 0.9, -5, 7])]
+
+
+@pytest.mark.parametrize("kb", [32, 64])
+@pytest.mark.parametrize("rb", [32, 64])
+@pytest.mark.parametrize("curve", [MORTON, HILBERT])
+def test_sfc_keys(hip, oracle, kb, rb, curve):
+    for box in BOXES:
+        for n in (1, 7, 1000, 100003):
+            x, y, z = random_cloud(n, box, rb, seed=n + kb + rb)
+            # box corners and faces are the clamping edge cases (sfc.hpp:166-168)
+            lim = box.lim.astype(real_dtype(rb))
+            x[0], y[0], z[0] = lim[1], lim[3], lim[5]
+            if n > 2:
+                x[1], y[1], z[1] = lim[0], lim[2], lim[4]
+            ref = oracle.compute_sfc_keys(curve, kb, x, y, z, box)
+            got = hip.compute_sfc_keys(curve, kb, dev(x), dev(y), dev(z), cbox(box))
+            assert np.array_equal(host(got), ref), (kb, rb, curve, n)
+
+
+@pytest.mark.parametrize("kb", [32, 64])
+def test_sfc_keys_keep_remove_marker_and_unaligned(hip, oracle, kb):
+    box = Box([0, 1])
+    n = 5000
+    x, y, z = random_cloud(n, box, 64, seed=3)
+    keys = np.zeros(n, dtype=key_dtype(kb))
+    keys[::7] = end_key(kb)  # particles flagged for removal keep their marker (sfc.hpp:289)
+    ref = oracle.compute_sfc_keys(HILBERT, kb, x, y, z, box, keys.copy())
+    got = hip.compute_sfc_keys(HILBERT, kb, dev(x), dev(y), dev(z), cbox(box), dev(keys))
+    assert np.array_equal(host(got), ref)
+    assert (ref[::7] == end_key(kb)).all()
+    # sub-range views that are only 8-byte aligned take the scalar path (Domain::setupHalos encodes tails)
+    xd, yd, zd, kd = dev(x), dev(y), dev(z), dev(np.zeros(n, dtype=key_dtype(kb)))
+    hip.compute_sfc_keys(HILBERT, kb, xd[1:], yd[1:], zd[1:], cbox(box), kd[1:])
+    ref2 = oracle.compute_sfc_keys(HILBERT, kb, x[1:], y[1:], z[1:], box)
+    assert np.array_equal(host(kd)[1:], ref2)
+
+
+@pytest.mark.parametrize("kb", [32, 64])
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 4095, 4096, 4097, 50000, 300001])
+def test_sort_pairs_stable(hip, oracle, kb, n):
+    torch = _torch()
+    rng = np.random.default_rng(n + kb)
+    top = end_key(kb)
+    keys = rng.integers(0, top, n, dtype=np.uint64).astype(key_dtype(kb))
+    if n > 10:
+        keys[rng.integers(0, n, n // 3)] = keys[0]  # plenty of duplicates: stability is observable
+        keys[-1] = key_dtype(kb)(np.iinfo(key_dtype(kb)).max)  # all bits set must sort last
+    vals = np.arange(n, dtype=np.uint32)
+    rk, rv = oracle.sort_pairs(keys, vals)
+    kd, vd = dev(keys), dev(vals)
+    hip.sort_pairs(kd, vd)
+    hip.sync()
+    assert np.array_equal(host(kd), rk)
+    assert np.array_equal(host(vd), rv)
+    # caller-provided scratch (the GpuSfcSorter calling convention, gather.cuh:81-98)
+    if n:
+        kd, vd = dev(keys), dev(vals)
+        ka, va = torch.empty_like(kd), torch.empty_like(vd)
+        tmp = torch.empty(hip.sort_temp_bytes(kb, n), dtype=torch.uint8, device="cuda")
+        hip.sort_pairs(kd, vd, ka, va, tmp)
+        hip.sync()
+        assert np.array_equal(host(kd), rk) and np.array_equal(host(vd), rv)
+
+
+@pytest.mark.parametrize("kb", [32, 64])
+def test_sort_sorted_and_constant_inputs(hip, oracle, kb):
+    n = 200000
+    keys = np.sort(np.random.default_rng(1).integers(0, end_key(kb), n, dtype=np.uint64)).astype(key_dtype(kb))
+    for k in (keys, keys[::-1].copy(), np.full(n, 12345, dtype=key_dtype(kb))):
+        rk, rv = oracle.sort_pairs(k, np.arange(n))
+        kd, vd = dev(k), dev(np.arange(n, dtype=np.uint32))
+        hip.sort_pairs(kd, vd)
+        assert np.array_equal(host(kd), rk) and np.array_equal(host(vd), rv)
+
+
+def test_sort_large_properties(hip):
+    """BASELINE config 2 size (10^7): sortedness + permutation checksum (size-independent properties)"""
+    torch = _torch()
+    n = 10_000_000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    keys = torch.randint(0, 2**62, (n,), dtype=torch.int64, device="cuda", generator=g)
+    orig = keys.clone()
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    hip.sort_pairs(keys, vals)
+    hip.sync()
+    assert bool((keys[1:] >= keys[:-1]).all())
+    assert bool((orig[vals.long()] == keys).all())           # values carry the keys' origin
+    assert int(vals.long().sum()) == n * (n - 1) // 2          # a permutation
+    same = keys[1:] == keys[:-1]
+    assert bool((vals[1:][same] > vals[:-1][same]).all())     # stability on ties
+
+
+@pytest.mark.parametrize("eb", [1, 2, 4, 8, 12, 16, 24, 32])
+def test_gather_scatter(hip, eb):
+    n = 70001
+    rng = np.random.default_rng(eb)
+    src = rng.integers(0, 255, (n, eb), dtype=np.uint8)
+    perm = rng.permutation(n).astype(np.uint32)
+    sd, pd = dev(src), dev(perm)
+    dd = _torch().zeros_like(sd)
+    hip.gather(pd, sd, dd, elem_bytes=eb)
+    assert np.array_equal(host(dd, False), src[perm])
+    dd2 = _torch().zeros_like(sd)
+    hip.scatter(pd, sd, dd2, elem_bytes=eb)
+    ref = np.zeros_like(src)
+    ref[perm] = src
+    assert np.array_equal(host(dd2, False), ref)
+
+
+@pytest.mark.parametrize("rb", [32, 64])
+def test_minmax_and_scans(hip, rb):
+    rng = np.random.default_rng(rb)
+    for n in (1, 100, 100000, 1234567):
+        x = rng.normal(0, 10, n).astype(real_dtype(rb))
+        lo, hi = hip.minmax(dev(x))
+        assert lo == x.min() and hi == x.max()
+    for n in (1, 255, 2048, 2049, 100000, 3000001):
+        v = rng.integers(0, 100, n, dtype=np.uint32)
+        vd = dev(v)
+        out = _torch().zeros_like(vd)
+        hip.exclusive_scan(vd, out, init=5)
+        ref = np.concatenate([[0], np.cumsum(v, dtype=np.uint64)[:-1]]).astype(np.uint32) + 5
+        assert np.array_equal(host(out), ref)
+        hip.inclusive_scan(vd, vd)  # in place
+        assert np.array_equal(host(vd), np.cumsum(v, dtype=np.uint64).astype(np.uint32))
+
+
+def _sorted_keys(oracle, curve, kb, n, box, rb, seed, kind):
+    x, y, z = random_cloud(n, box, rb, seed, kind)
+    keys = oracle.compute_sfc_keys(curve, kb, x, y, z, box)
+    ks, order = oracle.sort_pairs(keys, np.arange(n))
+    return x[order], y[order], z[order], ks
+
+
+@pytest.mark.parametrize("kb", [32, 64])
+@pytest.mark.parametrize("kind", ["uniform", "gaussian", "clustered"])
+@pytest.mark.parametrize("bucket", [1, 16, 64])
+def test_octree_build_stepwise_and_converged(hip, oracle, kb, kind, bucket):
+    n = 30000 if bucket > 1 else 3000
+    _, _, _, keys = _sorted_keys(oracle, HILBERT, kb, n, Box([0, 1]), 64, seed=11, kind=kind)
+    kd = dev(keys)
+    # converged tree
+    rt, rc = oracle.compute_octree(keys, bucket)
+    gt, gc, iters = hip.compute_octree(kd, bucket)
+    assert np.array_equal(host(gt), rt) and np.array_equal(host(gc), rc)
+    # iteration-for-iteration parity from the root (Domain performs exactly one update per sync)
+    tree = np.array([0, end_key(kb)], dtype=key_dtype(kb))
+    counts = np.array([n], dtype=np.uint32)
+    cap = rt.size + 4096 * 8
+    tb = _torch().zeros(cap + 1, dtype=kd.dtype, device="cuda")
+    cb = _torch().zeros(cap, dtype=_torch().int32, device="cuda")
+    tb[:2] = dev(tree)
+    cb[:1] = dev(counts)
+    nl = 1
+    for _ in range(iters + 1):
+        # individual seam functions
+        ops_ref, conv_ref = oracle.node_ops(tree, counts, bucket)
+        ops_scan, new_n, conv = hip.compute_node_ops(tb, cb, bucket, num_nodes=nl)
+        ex = np.concatenate([[0], np.cumsum(ops_ref)]).astype(np.int32)
+        assert np.array_equal(host(ops_scan, False), ex) and new_n == ex[-1] and conv == conv_ref
+        nt = hip.rebalance_tree(tb, ops_scan, new_n, num_nodes=nl)
+        tree, counts, conv_o = oracle.update_octree(keys, bucket, tree, counts)
+        assert np.array_equal(host(nt), tree)
+        assert np.array_equal(host(hip.compute_node_counts(nt, kd)), counts)
+        # composite update on capacity buffers
+        nl, conv_h = hip.update_octree(kd, bucket, tb, cb, nl)
+        assert conv_h == conv_o and nl == tree.size - 1
+        assert np.array_equal(host(tb[:nl + 1]), tree) and np.array_equal(host(cb[:nl]), counts)
+    assert conv_o
+
+
+@pytest.mark.parametrize("kb", [32, 64])
+def test_node_counts_max_count_and_empty(hip, oracle, kb):
+    tree = OctreeMaker(kb).divide().divide(0).make()
+    keys = np.sort(np.random.default_rng(2).integers(0, end_key(kb), 5000, dtype=np.uint64)).astype(key_dtype(kb))
+    for mc in (0xFFFFFFFF, 100, 1):
+        assert np.array_equal(host(hip.compute_node_counts(dev(tree), dev(keys), max_count=mc)),
+                              oracle.node_counts(tree, keys, mc))
+    # keys only in the last node / no keys at all
+    last = np.full(10, end_key(kb) - 1, dtype=key_dtype(kb))
+    assert np.array_equal(host(hip.compute_node_counts(dev(tree), dev(last))), oracle.node_counts(tree, last))
+    empty = _torch().zeros(0, dtype=dev(tree).dtype, device="cuda")
+    assert host(hip.compute_node_counts(dev(tree), empty)).sum() == 0
+
+
+def test_update_octree_capacity_error(hip, oracle):
+    keys = np.sort(np.random.default_rng(4).integers(0, end_key(64), 100000, dtype=np.uint64))
+    tb = _torch().zeros(65, dtype=_torch().int64, device="cuda")
+    cb = _torch().zeros(64, dtype=_torch().int32, device="cuda")
+    tb[:2] = dev(np.array([0, end_key(64)], dtype=np.uint64))
+    cb[:1] = 100000
+    nl, _ = hip.update_octree(dev(keys), 16, tb, cb, 1)
+    assert nl == -4096  # needs 4096 leaves, buffers untouched
+    assert host(tb[:2]).tolist() == [0, end_key(64)]
+
+
+def _octree_equal(got, ref):
+    for k in ("prefixes", "child_offsets", "parents", "level_range", "internal_to_leaf", "leaf_to_internal"):
+        g = host(got[k], unsigned=(k == "prefixes"))
+        r = ref[k]
+        if k == "parents":
+            g = g[:r.size]
+        if k == "child_offsets":
+            g, r = g[:ref["num_nodes"]], r[:ref["num_nodes"]]
+        assert np.array_equal(g, r), k
+
+
+@pytest.mark.parametrize("kb", [32, 64])
+def test_linked_octree(hip, oracle, kb):
+    trees = [OctreeMaker(kb).make(), OctreeMaker(kb).divide().make(), OctreeMaker(kb).divide().divide(0).make(),
+             OctreeMaker(kb).divide().divide(0).divide(0, 2).divide(3).make()]
+    m = OctreeMaker(kb).divide()
+    for i in range(8):
+        m.divide(i)
+    trees.append(m.make())
+    cs = np.array([0, 1, 0o30173, 0o3333333333, end_key(kb) - 1, end_key(kb)], dtype=key_dtype(kb))
+    trees.append(oracle.spanning_tree(cs))  # max-depth tree (octree.cpp:202-216)
+    for kind in ("uniform", "clustered"):
+        _, _, _, keys = _sorted_keys(oracle, HILBERT, kb, 40000, Box([0, 1]), 64, seed=21, kind=kind)
+        trees.append(oracle.compute_octree(keys, 8)[0])
+    for t in trees:
+        ref = oracle.build_octree(t)
+        got = hip.build_octree(dev(t))
+        _octree_equal(got, ref)
+        # saturating upsweep of leaf counts
+        rng = np.random.default_rng(t.size)
+        lc = rng.integers(0, 2**31, t.size - 1, dtype=np.uint32)
+        q_ref = oracle.upsweep_counts(ref, lc)
+        q = np.zeros(ref["num_nodes"], dtype=np.uint32)
+        q[ref["leaf_to_internal"][ref["num_internal"]:]] = lc
+        qd = dev(q)
+        hip.upsweep_sum(got, qd)
+        assert np.array_equal(host(qd), q_ref)
+
+
+@pytest.mark.parametrize("kb", [32, 64])
+@pytest.mark.parametrize("rb", [32, 64])
+@pytest.mark.parametrize("curve", [MORTON, HILBERT])
+def test_node_centers(hip, oracle, kb, rb, curve):
+    box = BOXES[1]
+    _, _, _, keys = _sorted_keys(oracle, curve, kb, 20000, box, rb, seed=5, kind="gaussian")
+    tree, _ = oracle.compute_octree(keys, 16)
+    o = oracle.build_octree(tree)
+    rc, rs = oracle.node_centers(curve, o["prefixes"], box, rb)
+    gc, gs = hip.node_centers(curve, dev(o["prefixes"]), cbox(box), rb)
+    assert np.array_equal(host(gc, False), rc) and np.array_equal(host(gs, False), rs)
+
+
+@pytest.mark.parametrize("kb", [32, 64])
+@pytest.mark.parametrize("curve", [MORTON, HILBERT])
+@pytest.mark.parametrize("bc", [(0, 0, 0), (1, 1, 1), (1, 0, 1)])
+def test_find_halos(hip, oracle, kb, curve, bc):
+    box = Box([-1.3, 2.1, 0.2, 0.9, -5, 7], bc)
+    for kind, n, bucket in (("uniform", 60000, 16), ("clustered", 40000, 8)):
+        x, y, z, keys = _sorted_keys(oracle, curve, kb, n, box, 64, seed=31, kind=kind)
+        tree, counts = oracle.compute_octree(keys, bucket)
+        o = oracle.build_octree(tree)
+        od = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in o.items()}
+        nl = tree.size - 1
+        rng = np.random.default_rng(nl)
+        for first, last in ((0, nl // 4), (nl // 4, 3 * nl // 4), (nl - 17, nl), (0, nl), (5, 5)):
+            # per-leaf radii from smoothing lengths, like Halos::discover
+            h = (rng.uniform(0.2, 1.5, n) * 0.02).astype(np.float64)
+            layout = np.concatenate([[0], np.cumsum(counts[first:last])]).astype(np.uint32)
+            hl = h[int(counts[:first].sum()):]
+            r_ref = oracle.halo_radii(hl, layout, first, last, nl, 1.0)
+            r_got = hip.halo_radii(dev(hl), dev(layout), first, last, nl, 1.0)
+            assert np.array_equal(host(r_got, False), r_ref)
+            f_ref = oracle.find_halos(curve, o, tree, r_ref, box, first, last)
+            f_got = hip.find_halos(curve, od, dev(tree), r_got, cbox(box), first, last)
+            hip.sync()
+            assert np.array_equal(host(f_got, False), f_ref), (kind, first, last, f_ref.sum())
+        # a large radius reaches across the whole box (deep stacks, PBC wrap on both sides)
+        big = np.full(nl, 0.4 * (box.lim[3] - box.lim[2]), dtype=np.float32)
+        f_ref = oracle.find_halos(curve, o, tree, big, box, nl // 3, nl // 2)
+        f_got = hip.find_halos(curve, od, dev(tree), dev(big), cbox(box), nl // 3, nl // 2)
+        hip.sync()
+        assert np.array_equal(host(f_got, False), f_ref)
+
+
+@pytest.mark.parametrize("rb", [32, 64])
+@pytest.mark.parametrize("bc", [(0, 0, 0), (1, 1, 1), (0, 1, 0)])
+def test_find_neighbors(hip, oracle, rb, bc):
+    box = Box([0, 1, 0, 1, 0, 1], bc)
+    n, ngmax = 20000, 64
+    for kind in ("uniform", "clustered"):
+        x, y, z, keys = _sorted_keys(oracle, HILBERT, 64, n, box, rb, seed=41, kind=kind)
+        rng = np.random.default_rng(9)
+        h = (0.03 * rng.uniform(0.6, 1.4, n)).astype(real_dtype(rb))
+        tree, counts = oracle.compute_octree(keys, 32)
+        o = oracle.build_octree(tree)
+        layout = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+        cen, siz = oracle.node_centers(HILBERT, o["prefixes"], box, rb)
+        n_ref, c_ref = oracle.find_neighbors(x, y, z, h, 100, n - 50, box, o, layout, cen, siz, ngmax)
+        od = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in o.items()}
+        n_got, c_got = hip.find_neighbors(dev(x), dev(y), dev(z), dev(h), 100, n - 50, cbox(box), od, dev(layout),
+                                          dev(cen), dev(siz), ngmax)
+        hip.sync()
+        c_got, n_got = host(c_got), host(n_got)
+        assert np.array_equal(c_got, c_ref)
+        assert c_ref.max() > ngmax // 2  # the case exercises both stored and overflowing lists
+        stored = np.minimum(c_ref, ngmax)
+        mask = np.arange(ngmax)[None, :] < stored[:, None]
+        assert np.array_equal(n_got[mask], n_ref[mask])
