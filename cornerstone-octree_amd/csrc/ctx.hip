@@ -83,7 +83,7 @@ using namespace cship;
 extern "C"
 {
 
-int cstone_hip_ctx_create(cstone_hip_ctx** out, int device, void* stream)
+int cstone_hip_ctx_create(cstone_hip_ctx** out, int device, void* stream, int private_stream)
 {
     if (!out) return CSTONE_E_ARG;
     *out      = nullptr;
@@ -95,7 +95,7 @@ int cstone_hip_ctx_create(cstone_hip_ctx** out, int device, void* stream)
         delete ctx;
         return CSTONE_E_HIP;
     }
-    if (stream) { ctx->stream = (hipStream_t)stream; }
+    if (!private_stream) { ctx->stream = (hipStream_t)stream; }
     else
     {
         e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);

@@ -108,7 +108,8 @@ class Context:
         torch.cuda.set_device(self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else 0
         self.h = C.c_void_p()
-        rc = self.lib.cstone_hip_ctx_create(C.byref(self.h), C.c_int(self.device.index), C.c_void_p(stream))
+        rc = self.lib.cstone_hip_ctx_create(C.byref(self.h), C.c_int(self.device.index), C.c_void_p(stream),
+                                            C.c_int(0 if use_torch_stream else 1))
         if rc != 0:
             raise CstoneError(f"cstone_hip_ctx_create failed: {rc}")
 

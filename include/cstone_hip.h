@@ -57,8 +57,10 @@ extern "C"
      * runtime: replaces R/cuda/device_vector.h, cuda_stubs.h:48-57 (memcpyH2D/D2H/D2D, syncGpu),
      * errorcheck.cuh:30-42 (we return codes instead of exit()).
      * ------------------------------------------------------------------------------------------- */
-    /* stream: an existing hipStream_t (e.g. torch's current stream) or NULL to create a private one */
-    int cstone_hip_ctx_create(cstone_hip_ctx** out, int device, void* stream);
+    /* private_stream != 0: the context creates (and owns) a non-blocking stream of its own;
+     * private_stream == 0: work goes to `stream`, an existing hipStream_t such as torch's current
+     *                      stream (NULL = the device's default stream) */
+    int cstone_hip_ctx_create(cstone_hip_ctx** out, int device, void* stream, int private_stream);
     int cstone_hip_ctx_destroy(cstone_hip_ctx* ctx);
     int cstone_hip_ctx_sync(cstone_hip_ctx* ctx);
     const char* cstone_hip_last_error(cstone_hip_ctx* ctx);
