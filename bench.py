@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- particles/sec through domain.sync (encode + sort + tree + halo) on MI355X.
+
+One "step" = one steady-state `sync` of the hot path over the resident particle set (SURVEY.md section 3.1,
+reference include/cstone/domain/domain.hpp:196-243 with the stages a rank executes):
+    bounding box (min/max of x,y,z) -> SFC key encode -> stable radix sort of (key, index) ->
+    global-tree rebalance step + node counts -> gather h -> focus-tree rebalance step + counts ->
+    linked octree + geometric centers -> halo radii (segment max of h) + halo discovery traversal ->
+    layout scan -> gather x,y,z into SFC order.
+Inputs are synthetic uniform-random particles, resident in HBM before the timed region starts.
+
+Usage: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank per GPU)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "cornerstone-octree_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--particles", type=float, default=1e8, help="GLOBAL particle count (strong scaling over --gpus)")
+    p.add_argument("--key-bits", type=int, default=64)
+    p.add_argument("--real-bits", type=int, default=64)
+    p.add_argument("--curve", default="hilbert", choices=["hilbert", "morton"])
+    p.add_argument("--bucket-focus", type=int, default=64)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample", type=float, default=4e6, help="particles in the CPU baseline sample")
+    return p.parse_args()
+
+
+class SyncPipeline:
+    """Steady-state single-rank domain.sync assembled from the C ABI (device-resident, one context)."""
+
+    def __init__(self, ctx, n, key_bits, real_bits, curve, bucket, bucket_focus, seed):
+        import torch
+
+        import cstone_amd
+
+        self.t, self.cs, self.ctx = torch, cstone_amd, ctx
+        self.n, self.kb, self.rb = n, key_bits, real_bits
+        self.curve = cstone_amd.HILBERT if curve == "hilbert" else cstone_amd.MORTON
+        self.bucket, self.bucket_focus = bucket, bucket_focus
+        dev = ctx.device
+        rdt = torch.float64 if real_bits == 64 else torch.float32
+        g = torch.Generator(device=dev).manual_seed(seed)
+        self.x = torch.rand(n, dtype=rdt, device=dev, generator=g)
+        self.y = torch.rand(n, dtype=rdt, device=dev, generator=g)
+        self.z = torch.rand(n, dtype=rdt, device=dev, generator=g)
+        # h ~ 1.2 * (3*100/(4 pi N))^(1/3) / 2  (about 100 neighbours inside 2h), SURVEY 8(d)
+        h0 = 0.6 * (3.0 * 100 / (4 * 3.141592653589793 * n)) ** (1.0 / 3.0)
+        self.h = torch.full((n,), h0, dtype=rdt, device=dev)
+        kdt = cstone_amd.key_torch_dtype(key_bits)
+        self.keys = torch.zeros(n, dtype=kdt, device=dev)
+        self.order = torch.empty(n, dtype=torch.int32, device=dev)
+        # scratch: alt buffers for the sort + one real-typed buffer the gathers swap through
+        self.keys_alt = torch.empty(n, dtype=kdt, device=dev)
+        self.order_alt = torch.empty(n, dtype=torch.int32, device=dev)
+        self.sort_tmp = torch.empty(ctx.sort_temp_bytes(key_bits, n), dtype=torch.uint8, device=dev)
+        self.swap = torch.empty(n, dtype=rdt, device=dev)
+        # trees: global (coarse bucket) and focus (bucket_focus); capacity for the worst case of this cloud
+        self.cap_g = max(4096, 8 * n // max(1, bucket) + 4096)
+        self.cap_f = max(4096, 4 * n // max(1, bucket_focus) + 4096)
+        self.gtree = torch.zeros(self.cap_g + 1, dtype=kdt, device=dev)
+        self.gcounts = torch.zeros(self.cap_g, dtype=torch.int32, device=dev)
+        self.ftree = torch.zeros(self.cap_f + 1, dtype=kdt, device=dev)
+        self.fcounts = torch.zeros(self.cap_f, dtype=torch.int32, device=dev)
+        self.layout = torch.zeros(self.cap_f + 1, dtype=torch.int32, device=dev)
+        self.flags = torch.zeros(self.cap_f, dtype=torch.int32, device=dev)
+        self.g_leaves = self.f_leaves = 0
+        self.box = None
+
+    def _box(self):
+        lim = []
+        for a in (self.x, self.y, self.z):
+            lim += list(self.ctx.minmax(a))
+        return self.cs.make_cbox(lim)
+
+    def first_sync(self):
+        """first call: both trees are built from the root until converged (domain.hpp:220-224)"""
+        ctx = self.ctx
+        self.box = self._box()
+        ctx.compute_sfc_keys(self.curve, self.kb, self.x, self.y, self.z, self.box, self.keys)
+        ctx.sequence(self.order)
+        ctx.sort_pairs(self.keys, self.order, self.keys_alt, self.order_alt, self.sort_tmp)
+        for tree, counts, bucket, attr in ((self.gtree, self.gcounts, self.bucket, "g_leaves"),
+                                           (self.ftree, self.fcounts, self.bucket_focus, "f_leaves")):
+            t, c, _ = ctx.compute_octree(self.keys, bucket, cap_leaves=counts.numel())
+            nl = c.numel()
+            tree[:nl + 1] = t
+            counts[:nl] = c
+            setattr(self, attr, nl)
+        self._finish()
+
+    def step(self):
+        ctx = self.ctx
+        self.box = self._box()
+        ctx.compute_sfc_keys(self.curve, self.kb, self.x, self.y, self.z, self.box, self.keys)
+        ctx.sequence(self.order)
+        ctx.sort_pairs(self.keys, self.order, self.keys_alt, self.order_alt, self.sort_tmp)
+        self.g_leaves, _ = ctx.update_octree(self.keys, self.bucket, self.gtree, self.gcounts, self.g_leaves)
+        self.f_leaves, _ = ctx.update_octree(self.keys, self.bucket_focus, self.ftree, self.fcounts, self.f_leaves)
+        assert self.g_leaves > 0 and self.f_leaves > 0
+        self._finish()
+
+    def _finish(self):
+        ctx, nl = self.ctx, self.f_leaves
+        # h into SFC order first: halo radii need it (domain.hpp:213-215)
+        ctx.gather(self.order, self.h, self.swap)
+        self.h, self.swap = self.swap, self.h
+        self.octree = ctx.build_octree(self.ftree, num_leaves=nl)
+        self.centers, self.sizes = ctx.node_centers(self.curve, self.octree["prefixes"], self.box, self.rb)
+        # halo discovery over the whole (single-rank) assignment, halos.hpp:128-189
+        self.layout[0] = 0
+        ctx.inclusive_scan(self.fcounts[:nl], self.layout[1:nl + 1])
+        radii = ctx.halo_radii(self.h, self.layout, 0, nl, nl, 1.0)
+        self.flags[:nl].zero_()
+        ctx.find_halos(self.curve, self.octree, self.ftree, radii, self.box, 0, nl, self.rb, self.flags)
+        for name in ("x", "y", "z"):
+            a = getattr(self, name)
+            ctx.gather(self.order, a, self.swap)
+            setattr(self, name, self.swap)
+            self.swap = a
+
+
+def cpu_baseline(n_sample, key_bits, real_bits, curve, bucket_focus, min_seconds=8.0):
+    """the same stages on the host cores, timed on a bounded sample (reference build if it travelled, else our port)"""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    if orc.reference_available():
+        impl, kind = orc.Reference(), "reference"
+    else:
+        if not os.path.exists(orc.Oracle.libpath):
+            orc.build("liboracle")
+        impl, kind = orc.Oracle(), "port"
+    cv = orc.HILBERT if curve == "hilbert" else orc.MORTON
+    rng = np.random.default_rng(7)
+    rdt = np.float64 if real_bits == 64 else np.float32
+    x, y, z = [rng.uniform(0, 1, n_sample).astype(rdt) for _ in range(3)]
+    h = np.full(n_sample, 0.01, dtype=rdt)
+    tree = counts = None
+    done, t_total = 0, 0.0
+    while t_total < min_seconds and done < 5:
+        t0 = time.perf_counter()
+        box = orc.Box([x.min(), x.max(), y.min(), y.max(), z.min(), z.max()])
+        keys = impl.compute_sfc_keys(cv, key_bits, x, y, z, box)
+        ks, order = impl.sort_pairs(keys, np.arange(n_sample, dtype=np.uint32))
+        if tree is None:
+            tree, counts = impl.compute_octree(ks, bucket_focus)
+        else:
+            tree, counts, _ = impl.update_octree(ks, bucket_focus, tree, counts)
+        octree = impl.build_octree(tree)
+        hs = h[order]
+        nl = tree.size - 1
+        layout = np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)]).astype(np.uint32)
+        if impl.has("halo_radii"):
+            radii = impl.halo_radii(hs, layout, 0, nl, nl, 1.0)
+        else:
+            radii = (np.maximum.reduceat(hs, np.minimum(layout[:-1], n_sample - 1)) * 2).astype(np.float32)
+        impl.find_halos(orc.HILBERT, octree, tree, radii, box, 0, nl, real_bits) if cv == orc.HILBERT else None
+        x, y, z, h = x[order], y[order], z[order], hs
+        t_total += time.perf_counter() - t0
+        done += 1
+    return {"value": n_sample * done / t_total, "unit": "particles/s", "cores": impl.num_threads(), "kind": kind,
+            "sample": f"{done} sync(s) of {n_sample} uniform particles, same stages, bucket {bucket_focus}"}
+
+
+def main():
+    args = parse()
+    import torch
+
+    import cstone_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    ctx = cstone_amd.Context(local_rank)
+
+    n_global = int(args.particles)
+    n_local = n_global // world
+    bucket_global = max(64, n_global // (100 * world))
+    pipe = SyncPipeline(ctx, n_local, args.key_bits, args.real_bits, args.curve, bucket_global, args.bucket_focus,
+                        seed=42 + rank)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    pipe.first_sync()
+    for _ in range(args.warmup):
+        pipe.step()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    pass_ms, pass_launches = ctx.profile_get("sort_pass")
+    stage_ms = {s: ctx.profile_get(s)[0] / args.steps for s in cstone_amd.STAGES}
+    ctx.profile_enable(False)
+    ctx.sync()  # raises if a device-side check tripped
+
+    if rank == 0:
+        kbytes = args.key_bits // 8
+        per_launch_bytes = 2.0 * (kbytes + 4) * n_local  # read + write of (key, u32 value), SURVEY 8(d)
+        avg_s = pass_ms * 1e-3 / max(1, pass_launches)
+        achieved = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        out = {
+            "metric": "particles/sec domain.sync (encode+sort+tree+halo), 10^8 uniform, 1/2/4/8 GPU",
+            "value": n_local * world * args.steps / elapsed,
+            "unit": "particles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": f"u{args.key_bits}/f{args.real_bits}",
+            "data": "synthetic",
+            "config": {"workload": f"{n_global:.0e} uniform particles, {args.key_bits}-bit {args.curve} keys, "
+                                   f"f{args.real_bits} coordinates, bucketFocus {args.bucket_focus}, "
+                                   f"bucket {bucket_global}, steady-state sync, single-rank stages per GPU",
+                       "particles_per_gpu": n_local, "focus_leaves": pipe.f_leaves, "global_leaves": pipe.g_leaves},
+            "roofline": {"bound": "hbm", "kernel": "onesweepKernel (one 8-bit radix pass over key+index pairs)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3,
+                         "launches": pass_launches},
+            "stage_ms_per_step": stage_ms,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample), args.key_bits, args.real_bits, args.curve,
+                                               args.bucket_focus)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
