@@ -5,23 +5,30 @@
 // pass one read and one write of key+value: K + P*2*(K+4) bytes, P = K passes (200 B for 64-bit
 // keys, 68 B for 32-bit keys).  HBM-bound; no MFMA.
 //
-// Pass kernel, one workgroup per tile of TILE = BLOCK*ITEMS pairs:
+// Pass kernel, one workgroup per tile of TILE = BLOCK*16 pairs (BLOCK = 1024 for large inputs: 16 Ki
+// pairs per tile, the whole 160 KB LDS of a CU; BLOCK = 256 for small inputs):
 //   1. tile index from an atomic ticket (earlier tiles are therefore running or done: the
 //      look-back below cannot deadlock whatever the dispatch order or residency)
 //   2. keys loaded wave-striped (64 consecutive keys per wave instruction)
 //   3. stable rank of every key among equal digits of its wave: 8 ballots build the mask of
-//      lanes holding the same digit (wave64 "match-any"), popcount below the lane gives the
-//      rank, the first lane of each group bumps the wave's private LDS digit counter
-//   4. per-digit thread: exclusive prefix over the waves, tile total -> published as AGGREGATE
-//      in the tile's 256-entry status row; tile-local exclusive scan over digits
+//      lanes holding the same digit (wave64 "match-any"), v_mbcnt below the lane gives the rank;
+//      every lane reads the wave's private LDS digit counter, the first lane of a group adds to it
+//   4. digit threads: prefix over the waves, tile-local exclusive scan over digits; wave 0 publishes
+//      the tile's AGGREGATE row
 //   5. keys are permuted into tile-sorted order through LDS
-//   6. decoupled look-back: thread d sums the status words of preceding tiles for digit d until
-//      it meets an INCLUSIVE entry, then publishes its own inclusive prefix.  Status words are
-//      32-bit {2-bit state, 30-bit count} granules moved with relaxed agent-scope atomics
-//      (value and flag in one word: no fence needed, coherent across the 8 XCD L2s).  Spins are bounded.
+//   6. decoupled look-back by wave 0: lane l owns digits 4l..4l+3 and reads the status rows of the
+//      preceding tiles FOUR ROWS AT A TIME as 16-byte agent-scope (sc1) loads until every digit has
+//      met an INCLUSIVE word, then publishes its own inclusive row.  Status words are 32-bit
+//      {2-bit state, 30-bit count} granules: value and flag travel in one word, so no fence is
+//      needed and tearing between words is harmless; sc1 accesses are coherent across the 8 XCD L2s.
+//      Why rows in bulk and big tiles: with hop latency L and P tiles in flight the look-back depth
+//      settles near L*sqrt(P); fewer, larger tiles and several rows per hop keep it off the critical path.
+//      Spins are bounded.
 //   7. keys, then values, are streamed from LDS to their global slots: consecutive lanes write
 //      consecutive addresses within each digit run
+// The last, partial tile is handled by a separate one-workgroup kernel without look-back.
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 
 #include "ctx.hpp"
@@ -36,28 +43,31 @@ namespace
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX      = 1 << RADIX_BITS;
 
-constexpr uint32_t STATE_AGG = 1u << 30;
-constexpr uint32_t STATE_INC = 2u << 30;
+constexpr uint32_t STATE_AGG  = 1u << 30;
+constexpr uint32_t STATE_INC  = 2u << 30;
 constexpr uint32_t COUNT_MASK = (1u << 30) - 1;
 
-constexpr int HIST_BLOCK = 256;
+constexpr int HIST_BLOCK   = 256;
+constexpr int SMALL_BLOCK  = 256;  // 4 Ki pairs per tile
+constexpr int LARGE_BLOCK  = 1024; // 16 Ki pairs per tile
+constexpr int LOOKBACK_ROWS = 4;
 
-template<class K>
+template<class K, int BLOCK_>
 struct SortCfg
 {
-    static constexpr int BLOCK = 256;
-    static constexpr int ITEMS = 16;
-    static constexpr int TILE  = BLOCK * ITEMS;
-    static constexpr int WAVES = BLOCK / 64;
+    static constexpr int BLOCK  = BLOCK_;
+    static constexpr int ITEMS  = 16;
+    static constexpr int TILE   = BLOCK * ITEMS;
+    static constexpr int WAVES  = BLOCK / 64;
     static constexpr int PASSES = sizeof(K);
 };
 
 struct SortTemp
 {
-    uint32_t* hist;     // [PASSES][RADIX] counts, then exclusive bases
-    uint32_t* tickets;  // [PASSES]
-    uint32_t* errors;   // [1]
-    uint32_t* status;   // [PASSES][numTiles][RADIX]
+    uint32_t* hist;    // [PASSES][RADIX] counts, then exclusive bases
+    uint32_t* tickets; // [PASSES]
+    uint32_t* errors;  // [1]
+    uint32_t* status;  // [PASSES][numTiles][RADIX]
 };
 
 __host__ __device__ inline size_t headerWords(int passes) { return size_t(passes) * RADIX + 64; }
@@ -69,7 +79,7 @@ template<class K>
 __global__ __launch_bounds__(HIST_BLOCK) void histogramKernel(const K* __restrict__ keys, size_t n,
                                                               uint32_t* __restrict__ hist)
 {
-    constexpr int P = SortCfg<K>::PASSES;
+    constexpr int P = int(sizeof(K));
     __shared__ uint32_t lh[P * RADIX];
     for (int i = threadIdx.x; i < P * RADIX; i += HIST_BLOCK)
         lh[i] = 0;
@@ -160,196 +170,346 @@ __global__ __launch_bounds__(RADIX) void scanHistogramKernel(uint32_t* __restric
 // -------------------------------------------------------------------------------------------------
 // one digit pass
 // -------------------------------------------------------------------------------------------------
-template<class K>
-__global__ __launch_bounds__(SortCfg<K>::BLOCK) void onesweepKernel(const K* __restrict__ keysIn,
-                                                                    const uint32_t* __restrict__ valsIn,
-                                                                    K* __restrict__ keysOut,
-                                                                    uint32_t* __restrict__ valsOut, size_t n,
-                                                                    int pass, uint32_t numTiles,
-                                                                    const uint32_t* __restrict__ bases,
-                                                                    uint32_t* __restrict__ ticket,
-                                                                    uint32_t* __restrict__ status,
-                                                                    uint32_t* __restrict__ errors)
+
+//! mask (two 32-bit halves) of the lanes of this wave whose digit equals mine: wave64 match-any by 8 ballots
+__device__ __forceinline__ void matchDigit(unsigned d, uint32_t& mlo, uint32_t& mhi)
 {
-    using Cfg           = SortCfg<K>;
-    constexpr int BLOCK = Cfg::BLOCK, ITEMS = Cfg::ITEMS, TILE = Cfg::TILE, WAVES = Cfg::WAVES;
+#pragma unroll
+    for (int b = 0; b < RADIX_BITS; ++b)
+    {
+        int32_t sb = int32_t(d << (31 - b)) >> 31; // 0 or -1
+        uint64_t v = __ballot(sb != 0);
+        mlo &= ~(uint32_t(v) ^ uint32_t(sb));
+        mhi &= ~(uint32_t(v >> 32) ^ uint32_t(sb));
+    }
+}
 
-    __shared__ uint32_t waveHist[WAVES * RADIX]; // per-wave digit counts -> exclusive prefix over waves
-    __shared__ uint32_t digitStart[RADIX];       // tile-local exclusive scan over digits
-    __shared__ uint32_t binOffset[RADIX];        // global slot of the digit's first tile element minus digitStart
-    __shared__ uint32_t scanTmp[WAVES];
-    __shared__ uint32_t tileShared;
-    __shared__ K stage[TILE];
+//! workgroup barrier that orders LDS traffic only: __syncthreads() would also wait for every outstanding global
+//! load and store (vmcnt(0)) and thereby serialise the value loads and the draining stores
+__device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+//! 16-byte agent-scope (sc1) row accesses for the look-back: one wave moves a whole 256-digit status row with a
+//! single instruction (dword-sized sc1 accesses cost one fabric transaction each)
+__device__ __forceinline__ void storeRowSc1(uint32_t* p, u32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+//! four status rows in flight at once; the wait is part of the statement because the compiler does not track
+//! loads issued from inline asm
+__device__ __forceinline__ void loadRows4Sc1(const uint32_t* p0, const uint32_t* p1, const uint32_t* p2,
+                                             const uint32_t* p3, u32x4 (&w)[LOOKBACK_ROWS])
+{
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                 "global_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                 : "memory");
+}
+
+template<class K, int BLOCK>
+struct alignas(16) SortSmem
+{
+    using Cfg = SortCfg<K, BLOCK>;
+    uint32_t waveHist[Cfg::WAVES * RADIX]; // per-wave digit counts, later: tile-local slot of (wave, digit)
+    uint32_t digitStart[RADIX];            // tile-local exclusive scan over digits
+    uint32_t binOffset[RADIX];             // global slot of a digit's first tile element minus digitStart
+    uint32_t total[RADIX];                 // digit counts of the tile
+    uint32_t scanTmp[RADIX / 64];
+    uint32_t tileShared[4];
+    K stage[Cfg::TILE];
+};
+
+/*! @brief rank, permute and scatter one tile whose keys are already in registers
+ *
+ *  TAIL = false: a full tile of TILE pairs inside the look-back chain (the hot path, no validity predicates)
+ *  TAIL = true : the last, partial tile. It sits at the END of every digit bin (it is the last tile in input
+ *                order), so its slots follow from the global digit bases alone and it needs no look-back:
+ *                first slot of digit d = end(d) - (tail count of d), end(d) = bases[d+1] (n for the last digit)
+ *  nextKeys    : if not null, the keys of the workgroup's NEXT tile; they are fetched into key[] as soon as the
+ *                current keys sit in LDS, i.e. the loads fly while this tile is looked back and stored */
+template<class K, int BLOCK, bool TAIL>
+__device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCfg<K, BLOCK>::ITEMS],
+                                         const K* __restrict__ nextKeys, uint32_t tile, unsigned tileCount,
+                                         const uint32_t* __restrict__ valsIn,
+                                         K* __restrict__ keysOut, uint32_t* __restrict__ valsOut, int shift,
+                                         const uint32_t* __restrict__ bases, uint32_t* __restrict__ status,
+                                         uint32_t* __restrict__ errors, uint32_t n)
+{
+    using Cfg           = SortCfg<K, BLOCK>;
+    constexpr int ITEMS = Cfg::ITEMS, TILE = Cfg::TILE, WAVES = Cfg::WAVES;
+    constexpr bool FULL = !TAIL;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const int shift = pass * RADIX_BITS;
+    const uint32_t tileBase = tile * uint32_t(TILE); // n < 2^30: 32-bit index arithmetic throughout
+    const unsigned segBase  = wave * (64 * ITEMS);
 
-    if (tid == 0) tileShared = atomicAdd(ticket, 1u);
-    for (int i = tid; i < WAVES * RADIX; i += BLOCK)
-        waveHist[i] = 0;
-    __syncthreads();
-    const uint32_t tile = tileShared;
-    if (tile >= numTiles) return; // cannot happen (grid == numTiles); keeps a stray launch harmless
-
-    const size_t tileBase = size_t(tile) * TILE;
-    const unsigned tileCount = unsigned(min(size_t(TILE), n - tileBase));
-    const unsigned segBase   = wave * (64 * ITEMS);
-
-    // ---- 2. load (wave-striped)
-    K key[ITEMS];
-    uint32_t val[ITEMS]; // fetched now so their latency hides behind the ranking
+    // values are fetched now so that their latency hides behind the ranking
+    uint32_t val[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r)
     {
         unsigned idx = segBase + r * 64 + lane;
-        key[r]       = idx < tileCount ? keysIn[tileBase + idx] : K(~K(0));
-    }
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r)
-    {
-        unsigned idx = segBase + r * 64 + lane;
-        val[r]       = idx < tileCount ? valsIn[tileBase + idx] : 0u;
+        val[r]       = (FULL || idx < tileCount) ? valsIn[tileBase + idx] : 0u;
     }
 
-    // ---- 3. stable in-wave ranking
+    // ---- stable in-wave ranking: every lane reads the wave's running count of its digit, the first lane of
+    //      each group of equal digits then adds the group size (LDS executes a wave's accesses in order)
     unsigned rank[ITEMS];
-    uint32_t* myHist = waveHist + wave * RADIX;
-    const uint64_t ltMask = (1ull << lane) - 1ull;
+    uint32_t* myHist = sm.waveHist + wave * RADIX;
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r)
     {
-        unsigned idx = segBase + r * 64 + lane;
-        bool valid   = idx < tileCount;
         unsigned d   = unsigned(key[r] >> shift) & (RADIX - 1);
-        uint64_t m   = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < RADIX_BITS; ++b)
+        uint32_t mlo = ~0u, mhi = ~0u;
+        bool valid   = true;
+        if (!FULL)
         {
-            bool bit    = (d >> b) & 1u;
-            uint64_t v  = __ballot(bit);
-            m &= bit ? v : ~v;
+            valid       = segBase + r * 64 + lane < tileCount;
+            uint64_t vm = __ballot(valid);
+            mlo = uint32_t(vm), mhi = uint32_t(vm >> 32);
         }
-        unsigned below  = __popcll(m & ltMask);
-        unsigned leader = __ffsll((unsigned long long)m) - 1; // lowest lane of my group (m has my own bit if valid)
-        unsigned base   = 0;
-        if (valid && below == 0)
-        {
-            base      = myHist[d];
-            myHist[d] = base + unsigned(__popcll(m));
-        }
-        base    = __shfl(base, valid ? int(leader) : int(lane));
+        matchDigit(d, mlo, mhi);
+        unsigned below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        unsigned base  = myHist[d];
+        if (below == 0 && valid) atomicAdd(&myHist[d], unsigned(__popc(mlo) + __popc(mhi)));
         rank[r] = base + below;
     }
-    __syncthreads();
+    ldsBarrier();
 
-    // ---- 4. per-digit: prefix over waves, publish aggregate, scan over digits
-    uint32_t total = 0;
+    // ---- digit threads (the first RADIX threads): tile totals and their scan over the digits
+    uint32_t total = 0, inc = 0;
     if (tid < RADIX)
     {
 #pragma unroll
         for (int w = 0; w < WAVES; ++w)
-        {
-            uint32_t c            = waveHist[w * RADIX + tid];
-            waveHist[w * RADIX + tid] = total;
-            total += c;
-        }
-        uint32_t word = (tile == 0 ? STATE_INC : STATE_AGG) | total;
-        __hip_atomic_store(status + size_t(tile) * RADIX + tid, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-        uint32_t inc = total;
+            total += sm.waveHist[w * RADIX + tid];
+        sm.total[tid] = total;
+        inc           = total;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1)
         {
             uint32_t t = __shfl_up(inc, o);
             if (lane >= unsigned(o)) inc += t;
         }
-        if (lane == 63) scanTmp[wave] = inc;
-        digitStart[tid] = inc - total; // wave-local for now
+        if (lane == 63) sm.scanTmp[wave] = inc;
     }
-    __syncthreads();
+    ldsBarrier();
     if (tid < RADIX)
     {
+        if (!TAIL && wave == 0)
+        {
+            // publish the tile aggregate (tile 0: already the inclusive prefix) as one 1 KiB row
+            u32x4 t4 = *reinterpret_cast<const u32x4*>(&sm.total[4 * lane]);
+            storeRowSc1(status + size_t(tile) * RADIX + 4 * lane, t4 | (tile == 0 ? STATE_INC : STATE_AGG));
+        }
         uint32_t off = 0;
         for (unsigned w = 0; w < wave; ++w)
-            off += scanTmp[w];
-        digitStart[tid] += off;
+            off += sm.scanTmp[w];
+        uint32_t run       = off + inc - total;
+        sm.digitStart[tid] = run;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w)
+        {
+            uint32_t c                   = sm.waveHist[w * RADIX + tid];
+            sm.waveHist[w * RADIX + tid] = run; // tile-local slot of the first element of (wave w, digit tid)
+            run += c;
+        }
     }
-    __syncthreads();
+    ldsBarrier();
 
-    // ---- 5. permute keys into tile-sorted order through LDS
+    // ---- permute keys into tile-sorted order through LDS
     unsigned pos[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r)
     {
-        unsigned idx = segBase + r * 64 + lane;
-        unsigned d   = unsigned(key[r] >> shift) & (RADIX - 1);
-        pos[r]       = digitStart[d] + waveHist[wave * RADIX + d] + rank[r];
-        if (idx < tileCount) stage[pos[r]] = key[r];
+        unsigned d = unsigned(key[r] >> shift) & (RADIX - 1);
+        pos[r]     = myHist[d] + rank[r];
+        if (FULL || segBase + r * 64 + lane < tileCount) sm.stage[pos[r]] = key[r];
+    }
+    // the key registers are free now: start fetching the next tile (wave 0 does so after its look-back, whose
+    // row loads wait on vmcnt(0))
+    if (nextKeys != nullptr && (TAIL || wave != 0))
+    {
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r)
+            key[r] = nextKeys[segBase + r * 64 + lane];
     }
 
-    // ---- 6. decoupled look-back, one thread per digit
-    if (tid < RADIX)
+    // ---- global slot of every digit run of this tile
+    if (TAIL)
     {
-        uint32_t exclusive = 0;
+        if (tid < RADIX)
+        {
+            uint32_t end      = (tid == RADIX - 1) ? n : bases[tid + 1];
+            sm.binOffset[tid] = end - total - sm.digitStart[tid];
+        }
+    }
+    else if (wave == 0)
+    {
+        // decoupled look-back by one wave: lane l owns digits 4l..4l+3
+        u32x4 tot  = *reinterpret_cast<const u32x4*>(&sm.total[4 * lane]);
+        u32x4 excl = {0, 0, 0, 0};
         if (tile > 0)
         {
-            int64_t t = int64_t(tile) - 1;
+            bool done[4]   = {false, false, false, false};
+            int32_t t      = int32_t(tile) - 1;
             unsigned spins = 0;
-            while (t >= 0)
+            bool finished  = false;
+            while (!finished)
             {
-                uint32_t w = __hip_atomic_load(status + size_t(t) * RADIX + tid, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t st = w & ~COUNT_MASK;
-                if (st == 0)
+                u32x4 w[LOOKBACK_ROWS];
+                const uint32_t* row = status + 4 * lane;
+                loadRows4Sc1(row + size_t(t) * RADIX, row + size_t(max(t - 1, 0)) * RADIX,
+                             row + size_t(max(t - 2, 0)) * RADIX, row + size_t(max(t - 3, 0)) * RADIX, w);
+                int consumed = 0;
+#pragma unroll
+                for (int r = 0; r < LOOKBACK_ROWS; ++r)
                 {
-                    if (++spins > (1u << 24)) // ~ seconds: something is badly wrong, do not hang the GPU
+                    if (finished || t - r < 0 || consumed != r) continue; // rows are consumed strictly in order
+                    bool ready = true;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        ready = ready && (done[c] || (w[r][c] & ~COUNT_MASK) != 0);
+                    if (!__all(ready)) continue; // this row is not there yet: poll again from here
+                    bool allDone = true;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
                     {
-                        atomicOr(errors, 1u);
-                        break;
+                        if (!done[c])
+                        {
+                            excl[c] += w[r][c] & COUNT_MASK;
+                            done[c] = (w[r][c] & ~COUNT_MASK) == STATE_INC;
+                        }
+                        allDone = allDone && done[c];
                     }
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;
+                    consumed = r + 1;
+                    if (__all(allDone)) finished = true;
                 }
-                exclusive += w & COUNT_MASK;
-                if (st == STATE_INC) break;
-                --t;
+                t -= consumed;
+                if (t < 0) finished = true; // row 0 is always inclusive: cannot be reached with open digits
+                if (consumed == 0)
+                {
+                    if (++spins > (1u << 22)) // seconds: something is badly wrong, do not hang the GPU
+                    {
+                        if (lane == 0) atomicOr(errors, 1u);
+                        finished = true;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
             }
-            __hip_atomic_store(status + size_t(tile) * RADIX + tid, STATE_INC | ((exclusive + total) & COUNT_MASK),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            storeRowSc1(status + size_t(tile) * RADIX + 4 * lane, ((excl + tot) & COUNT_MASK) | STATE_INC);
         }
-        binOffset[tid] = bases[tid] + exclusive - digitStart[tid];
+        const u32x4 base4  = *reinterpret_cast<const u32x4*>(bases + 4 * lane);
+        const u32x4 start4 = *reinterpret_cast<const u32x4*>(&sm.digitStart[4 * lane]);
+        *reinterpret_cast<u32x4*>(&sm.binOffset[4 * lane]) = base4 + excl - start4;
+        if (nextKeys != nullptr)
+        {
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r)
+                key[r] = nextKeys[segBase + r * 64 + lane];
+        }
     }
-    __syncthreads();
+    ldsBarrier();
 
-    // ---- 7. stream out keys (remember each slot for the values)
+    // ---- stream out keys (remember each slot for the values), then values through the same LDS block
     uint32_t dst[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k)
     {
         unsigned i = k * BLOCK + tid;
-        if (i < tileCount)
+        dst[k]     = n; // marks "nothing to store"
+        if (FULL || i < tileCount)
         {
-            K kk       = stage[i];
+            K kk       = sm.stage[i];
             unsigned d = unsigned(kk >> shift) & (RADIX - 1);
-            dst[k]     = binOffset[d] + i;
-            keysOut[dst[k]] = kk;
+            dst[k]     = sm.binOffset[d] + i;
+            if (dst[k] < n) { keysOut[dst[k]] = kk; }
+            else { atomicOr(errors, 8u); } // cannot happen; turns a would-be wild store into a reported error
         }
     }
-    __syncthreads();
-    uint32_t* vstage = reinterpret_cast<uint32_t*>(stage);
+    ldsBarrier();
+    uint32_t* vstage = reinterpret_cast<uint32_t*>(sm.stage);
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r)
     {
-        unsigned idx = segBase + r * 64 + lane;
-        if (idx < tileCount) vstage[pos[r]] = val[r];
+        if (FULL || segBase + r * 64 + lane < tileCount) vstage[pos[r]] = val[r];
     }
-    __syncthreads();
+    ldsBarrier();
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k)
     {
         unsigned i = k * BLOCK + tid;
-        if (i < tileCount) valsOut[dst[k]] = vstage[i];
+        if (dst[k] < n) valsOut[dst[k]] = vstage[i];
     }
+}
+
+/*! Full tiles, one per workgroup, tile index by ticket: every lower tile is owned by a workgroup that has started,
+ *  so the look-back cannot deadlock whatever the dispatch order or residency.  Workgroups retire and start
+ *  continuously, which keeps their phases (load / rank / look-back / store) staggered across the chip; persistent
+ *  variants (ticket per tile with key prefetch, or round-robin tiles) measured 8-40 % slower on MI355X because they
+ *  synchronise the look-back rounds. */
+template<class K, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void onesweepKernel(const K* __restrict__ keysIn,
+                                                        const uint32_t* __restrict__ valsIn, K* __restrict__ keysOut,
+                                                        uint32_t* __restrict__ valsOut, uint32_t n, int pass,
+                                                        uint32_t numFullTiles, const uint32_t* __restrict__ bases,
+                                                        uint32_t* __restrict__ ticket, uint32_t* __restrict__ status,
+                                                        uint32_t* __restrict__ errors)
+{
+    using Cfg           = SortCfg<K, BLOCK>;
+    constexpr int ITEMS = Cfg::ITEMS, TILE = Cfg::TILE, WAVES = Cfg::WAVES;
+    __shared__ SortSmem<K, BLOCK> sm;
+
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned segBase = wave * (64 * ITEMS);
+
+    if (tid == 0) sm.tileShared[0] = atomicAdd(ticket, 1u);
+    for (int i = tid; i < WAVES * RADIX; i += BLOCK)
+        sm.waveHist[i] = 0;
+    __syncthreads();
+    const uint32_t tile = sm.tileShared[0];
+    if (tile >= numFullTiles) return;
+    K key[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r)
+        key[r] = keysIn[tile * uint32_t(TILE) + segBase + r * 64 + lane];
+    sortTile<K, BLOCK, false>(sm, key, nullptr, tile, unsigned(TILE), valsIn, keysOut, valsOut, pass * RADIX_BITS,
+                              bases, status, errors, n);
+}
+
+//! the last, partial tile (n % TILE pairs): one workgroup, no look-back (see sortTile<TAIL = true>)
+template<class K, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void onesweepTailKernel(const K* __restrict__ keysIn,
+                                                            const uint32_t* __restrict__ valsIn,
+                                                            K* __restrict__ keysOut, uint32_t* __restrict__ valsOut,
+                                                            uint32_t n, int pass, uint32_t numFullTiles,
+                                                            const uint32_t* __restrict__ bases,
+                                                            uint32_t* __restrict__ errors)
+{
+    using Cfg           = SortCfg<K, BLOCK>;
+    constexpr int ITEMS = Cfg::ITEMS, TILE = Cfg::TILE, WAVES = Cfg::WAVES;
+    __shared__ SortSmem<K, BLOCK> sm;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned segBase   = wave * (64 * ITEMS);
+    const uint32_t tileBase  = numFullTiles * uint32_t(TILE);
+    const unsigned tileCount = n - tileBase;
+    for (int i = tid; i < WAVES * RADIX; i += BLOCK)
+        sm.waveHist[i] = 0;
+    K key[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r)
+    {
+        unsigned idx = segBase + r * 64 + lane;
+        key[r]       = idx < tileCount ? keysIn[tileBase + idx] : K(~K(0));
+    }
+    ldsBarrier();
+    sortTile<K, BLOCK, true>(sm, key, nullptr, numFullTiles, tileCount, valsIn, keysOut, valsOut, pass * RADIX_BITS, bases,
+                             nullptr, errors, n);
 }
 
 __global__ void sequenceKernel(uint32_t* out, size_t n, uint32_t init)
@@ -367,34 +527,77 @@ __global__ void sequenceKernel(uint32_t* out, size_t n, uint32_t init)
     }
 }
 
+//! inputs of at least this many pairs use the 16 Ki-pair tiles (CSTONE_SORT_LARGE_MIN overrides, for tuning runs)
+size_t largeTileThreshold()
+{
+    static const size_t value = []
+    {
+        const char* e = std::getenv("CSTONE_SORT_LARGE_MIN");
+        return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(1) << 18;
+    }();
+    return value;
+}
+
 template<class K>
 size_t sortTempBytes(size_t n)
 {
-    using Cfg       = SortCfg<K>;
-    size_t numTiles = (n + Cfg::TILE - 1) / Cfg::TILE;
-    return alignUp((headerWords(Cfg::PASSES) + size_t(Cfg::PASSES) * numTiles * RADIX) * sizeof(uint32_t));
+    // sized for the small tiles: an upper bound on the number of status rows of either configuration
+    constexpr int TILE = SortCfg<K, SMALL_BLOCK>::TILE;
+    constexpr int P    = SortCfg<K, SMALL_BLOCK>::PASSES;
+    size_t numTiles    = (n + TILE - 1) / TILE;
+    return alignUp((headerWords(P) + size_t(P) * numTiles * RADIX) * sizeof(uint32_t));
+}
+
+template<class K, int BLOCK>
+void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* vals, size_t n, K* keysAlt,
+                  uint32_t* valsAlt)
+{
+    using Cfg             = SortCfg<K, BLOCK>;
+    constexpr int P       = Cfg::PASSES;
+    uint32_t numFullTiles = uint32_t(n / Cfg::TILE);
+    bool haveTail         = (n % Cfg::TILE) != 0;
+    K* kIn         = keys;
+    uint32_t* vIn  = vals;
+    K* kOut        = keysAlt;
+    uint32_t* vOut = valsAlt;
+    for (int p = 0; p < P; ++p)
+    {
+        StageTimer timer(ctx, CSTONE_STAGE_SORT_PASS);
+        const uint32_t* bases = t.hist + size_t(p) * RADIX;
+        if (numFullTiles)
+            hipLaunchKernelGGL((onesweepKernel<K, BLOCK>), numFullTiles, BLOCK, 0, ctx->stream, kIn, vIn, kOut, vOut,
+                               uint32_t(n), p, numFullTiles, bases, t.tickets + p,
+                               t.status + size_t(p) * numFullTiles * RADIX, t.errors);
+        if (haveTail)
+            hipLaunchKernelGGL((onesweepTailKernel<K, BLOCK>), 1, BLOCK, 0, ctx->stream, kIn, vIn, kOut, vOut,
+                               uint32_t(n), p, numFullTiles, bases, t.errors);
+        std::swap(kIn, kOut);
+        std::swap(vIn, vOut);
+    }
+    static_assert(P % 2 == 0, "an even number of passes leaves the result in the caller's buffers");
 }
 
 template<class K>
 int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt, uint32_t* valsAlt, void* temp,
               size_t tempBytes)
 {
-    using Cfg = SortCfg<K>;
     if (n == 0) return CSTONE_OK;
     if (n >= (size_t(1) << 30)) return fail(ctx, CSTONE_E_ARG, "sort_pairs: n = %zu exceeds 2^30 - 1", n);
     size_t need = sortTempBytes<K>(n);
     if (tempBytes < need) return fail(ctx, CSTONE_E_CAPACITY, "sort_pairs: temp %zu < %zu bytes", tempBytes, need);
 
-    constexpr int P   = Cfg::PASSES;
-    uint32_t numTiles = uint32_t((n + Cfg::TILE - 1) / Cfg::TILE);
-    auto* words       = (uint32_t*)temp;
+    constexpr int P = sizeof(K);
+    auto* words     = (uint32_t*)temp;
     SortTemp t;
     t.hist    = words;
     t.tickets = words + size_t(P) * RADIX;
     t.errors  = (uint32_t*)ctx->devScalars + 63; // sticky; reported by cstone_hip_ctx_sync
     t.status  = words + headerWords(P);
 
-    CS_HIP(ctx, hipMemsetAsync(temp, 0, need, ctx->stream));
+    bool large       = n >= largeTileThreshold();
+    size_t tile      = large ? SortCfg<K, LARGE_BLOCK>::TILE : SortCfg<K, SMALL_BLOCK>::TILE;
+    size_t usedBytes = (headerWords(P) + size_t(P) * (n / tile) * RADIX) * sizeof(uint32_t);
+    CS_HIP(ctx, hipMemsetAsync(temp, 0, usedBytes, ctx->stream));
     {
         StageTimer timer(ctx, CSTONE_STAGE_SORT_HIST);
         size_t nVec   = n / (16 / sizeof(K));
@@ -403,20 +606,8 @@ int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt
         hipLaunchKernelGGL(histogramKernel<K>, grid, HIST_BLOCK, 0, ctx->stream, keys, n, t.hist);
         hipLaunchKernelGGL(scanHistogramKernel, P, RADIX, 0, ctx->stream, t.hist);
     }
-    K* kIn         = keys;
-    uint32_t* vIn  = vals;
-    K* kOut        = keysAlt;
-    uint32_t* vOut = valsAlt;
-    for (int p = 0; p < P; ++p)
-    {
-        StageTimer timer(ctx, CSTONE_STAGE_SORT_PASS);
-        hipLaunchKernelGGL(onesweepKernel<K>, numTiles, Cfg::BLOCK, 0, ctx->stream, kIn, vIn, kOut, vOut, n, p,
-                           numTiles, t.hist + size_t(p) * RADIX, t.tickets + p,
-                           t.status + size_t(p) * numTiles * RADIX, t.errors);
-        std::swap(kIn, kOut);
-        std::swap(vIn, vOut);
-    }
-    static_assert(P % 2 == 0, "an even number of passes leaves the result in the caller's buffers");
+    if (large) launchPasses<K, LARGE_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt);
+    else launchPasses<K, SMALL_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

@@ -57,10 +57,11 @@ def max_level(key_bits):
 
 def load_library():
     """dlopen the product library; raises if it has not been built (no fallback of any kind)"""
-    if not os.path.exists(LIBPATH):
+    path = os.environ.get("CSTONE_HIP_LIB", LIBPATH)  # tuning builds; the default is the in-tree product library
+    if not os.path.exists(path):
         raise CstoneError(f"{LIBPATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           f"or `make -C cornerstone-octree_amd`")
-    lib = C.CDLL(LIBPATH)
+    lib = C.CDLL(path)
     lib.cstone_hip_last_error.restype = C.c_char_p
     lib.cstone_hip_sort_pairs_temp_bytes.restype = C.c_size_t
     return lib
