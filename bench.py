@@ -227,6 +227,13 @@ def main():
     ctx.sync()  # raises if a device-side check tripped
 
     if rank == 0:
+        # HBM bytes of the dominant kernel from the PMC counters (FETCH_SIZE doubled per the gfx950 correction,
+        # + WRITE_SIZE), collected in their own rocprofv3 --pmc passes (tools/profile_r1.sh) and scaled per pair
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_onesweep_traffic.json")
+        if os.path.exists(tpath) and args.key_bits == 64:
+            tj = json.load(open(tpath))
+            traffic = tj["traffic_bytes_per_launch"] / tj["n_pairs"] * n_local
         kbytes = args.key_bits // 8
         per_launch_bytes = 2.0 * (kbytes + 4) * n_local  # read + write of (key, u32 value), SURVEY 8(d)
         avg_s = pass_ms * 1e-3 / max(1, pass_launches)
@@ -250,7 +257,7 @@ def main():
                        "particles_per_gpu": n_local, "focus_leaves": pipe.f_leaves, "global_leaves": pipe.g_leaves},
             "roofline": {"bound": "hbm", "kernel": "onesweepKernel (one 8-bit radix pass over key+index pairs)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3,
+                         "traffic": traffic, "bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3,
                          "launches": pass_launches},
             "stage_ms_per_step": stage_ms,
         }

@@ -533,7 +533,7 @@ size_t largeTileThreshold()
     static const size_t value = []
     {
         const char* e = std::getenv("CSTONE_SORT_LARGE_MIN");
-        return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(1) << 18;
+        return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(1) << 20;
     }();
     return value;
 }
