@@ -1,0 +1,518 @@
+// Device-resident orchestration of cstone::Domain::sync for ONE rank (R/domain/domain.hpp:196-243 and the pieces
+// it drives: GlobalAssignment R/domain/assignment.hpp:39-205, FocusedOctree R/focus/octree_focus_mpi.hpp,
+// CombinedUpdate::updateFocus R/focus/octree_focus.hpp:83-137, Halos R/halos/halos.hpp:128-222, layout
+// R/domain/layout.hpp:150-165).  Everything stays in HBM; per sync the host reads back the bounding box (6 scalars),
+// the number of valid particles and, per tree rebalance step, {changed flag, new leaf count}.
+//
+// Multi-rank operation (peers, MAC-driven focus resolution, treelet / particle / halo exchange over RCCL) is the next
+// row to build; the object refuses num_ranks > 1 instead of silently running something else.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <vector>
+
+#include "ctx.hpp"
+#include "device_keys.hpp"
+#include "scan.hpp"
+
+namespace cship
+{
+
+namespace
+{
+
+//! grow-only device buffer, growth factor like the reference's reallocate() (R/util/reallocate.hpp:37-47)
+struct DevBuf
+{
+    void* p      = nullptr;
+    size_t bytes = 0;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int ensure(cstone_hip_ctx* ctx, size_t need, bool keep = false)
+    {
+        if (need <= bytes) return CSTONE_OK;
+        size_t want = size_t(double(need) * 1.05) + 256;
+        void* q     = nullptr;
+        CS_HIP(ctx, hipMalloc(&q, want));
+        if (p)
+        {
+            if (keep) CS_HIP(ctx, hipMemcpyAsync(q, p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            CS_HIP(ctx, hipFree(p));
+        }
+        p     = q;
+        bytes = want;
+        return CSTONE_OK;
+    }
+    template<class V>
+    V* as() const
+    {
+        return static_cast<V*>(p);
+    }
+};
+
+// ---- focus-tree rebalance decisions for all nodes (leaves and internal), R/focus/rebalance.hpp:50-88.
+//      Single rank: the focus is the whole key range, so MAC flags never decide anything (inFringe / inFocus are
+//      always true) and the decision reduces to counts.
+template<class K>
+__global__ __launch_bounds__(256) void focusOpsKernel(const K* __restrict__ prefixes,
+                                                      const NodeIdx* __restrict__ childOffsets,
+                                                      const NodeIdx* __restrict__ parents,
+                                                      const uint32_t* __restrict__ counts, NodeIdx numNodes,
+                                                      uint32_t bucket, NodeIdx* __restrict__ ops)
+{
+    NodeIdx i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= numNodes) return;
+    int op = 1;
+    if (i > 0 && counts[parents[(i - 1) / 8]] <= bucket) { op = 0; }
+    else
+    {
+        unsigned level = prefixBits(prefixes[i]) / 3;
+        if (childOffsets[i] == 0 && level < maxLevel<K>() && counts[i] > bucket) op = 8;
+    }
+    ops[i] = op;
+}
+
+// ---- R/focus/rebalance.hpp:113-184: a merged node inherits the op of its closest kept ancestor iff both start at
+//      the same key; reads the ORIGINAL ops and writes a second array (the reference rewrites in place, race-free in
+//      outcome).  changed |= 1 if any op != 1.
+template<class K>
+__global__ __launch_bounds__(256) void protectAncestorsKernel(const K* __restrict__ prefixes,
+                                                              const NodeIdx* __restrict__ parents,
+                                                              const NodeIdx* __restrict__ opsIn, NodeIdx numNodes,
+                                                              NodeIdx* __restrict__ opsOut, int* __restrict__ changed)
+{
+    NodeIdx i = blockIdx.x * 256 + threadIdx.x;
+    int op    = 1;
+    if (i < numNodes)
+    {
+        if (i == 0) { op = opsIn[0]; }
+        else
+        {
+            NodeIdx a = i;
+            while (opsIn[a] == 0)
+                a = parents[(a - 1) / 8];
+            op = (fromPrefix(prefixes[i]) == fromPrefix(prefixes[a])) ? opsIn[a] : 0;
+        }
+        opsOut[i] = op;
+    }
+    if (__any(op != 1) && (threadIdx.x & 63) == 0) atomicOr(changed, 1);
+}
+
+//! leafOps[i] = ops[leafToInternal[numInternal + i]] for i < numLeaves, leafOps[numLeaves] = 0
+__global__ __launch_bounds__(256) void leafOpsKernel(const NodeIdx* __restrict__ ops,
+                                                     const NodeIdx* __restrict__ leafToInternal, NodeIdx numInternal,
+                                                     NodeIdx numLeaves, uint32_t* __restrict__ leafOps)
+{
+    NodeIdx i = blockIdx.x * 256 + threadIdx.x;
+    if (i < numLeaves) leafOps[i] = uint32_t(ops[leafToInternal[numInternal + i]]);
+    else if (i == numLeaves) leafOps[i] = 0;
+}
+
+//! counts[leafToInternal[numInternal + i]] = leafCounts[i]
+__global__ __launch_bounds__(256) void scatterLeafCountsKernel(const uint32_t* __restrict__ leafCounts,
+                                                               const NodeIdx* __restrict__ leafToInternal,
+                                                               NodeIdx numInternal, NodeIdx numLeaves,
+                                                               uint32_t* __restrict__ counts)
+{
+    NodeIdx i = blockIdx.x * 256 + threadIdx.x;
+    if (i < numLeaves) counts[leafToInternal[numInternal + i]] = leafCounts[i];
+}
+
+template<class K>
+__global__ void countValidKernel(const K* __restrict__ keys, size_t n, int* __restrict__ out)
+{
+    // number of keys below the end of the curve = index of the first remove marker (keys are sorted)
+    size_t lo = 0, len = n;
+    while (len > 0)
+    {
+        size_t half = len >> 1;
+        bool right  = keys[lo + half] < endKey<K>();
+        lo          = right ? lo + half + 1 : lo;
+        len         = right ? len - half - 1 : half;
+    }
+    out[0] = int(lo);
+}
+
+template<class K>
+__global__ void initTreeKernel(K* tree, uint32_t* counts, uint32_t c0)
+{
+    tree[0]   = 0;
+    tree[1]   = endKey<K>();
+    counts[0] = c0;
+}
+
+} // namespace
+
+struct DomainBase
+{
+    virtual ~DomainBase() = default;
+    virtual int sync(void** keys, void** x, void** y, void** z, void** h, size_t n, void** scratch, void** props,
+                     const int* propBytes, int numProps) = 0;
+    virtual int view(cstone_hip_domain_view* out)        = 0;
+};
+
+template<class K, class T>
+class DomainImpl final : public DomainBase
+{
+public:
+    DomainImpl(cstone_hip_ctx* ctx, int curve, uint32_t bucket, uint32_t bucketFocus, float theta, const cstone_box& box)
+        : ctx_(ctx)
+        , curve_(curve)
+        , bucket_(bucket)
+        , bucketFocus_(bucketFocus)
+        , theta_(theta)
+        , box_(box)
+    {
+    }
+
+    int sync(void** keysPP, void** xPP, void** yPP, void** zPP, void** hPP, size_t n, void** scratchPP, void** props,
+             const int* propBytes, int numProps) override
+    {
+        if (n == 0) return fail(ctx_, CSTONE_E_ARG, "domain_sync: no particles");
+        if (!firstCall_ && n != bufSize_)
+            return fail(ctx_, CSTONE_E_ARG, "Domain sync: input array sizes are inconsistent (%zu != %u)", n, bufSize_);
+        K* keys = static_cast<K*>(*keysPP);
+        const int kb = 8 * sizeof(K), rb = 8 * sizeof(T);
+
+        // ---- GlobalAssignment::assign (assignment.hpp:57-103): box, keys, sort, one global-tree step
+        double lim[6];
+        void* coords[3] = {*xPP, *yPP, *zPP};
+        for (int d = 0; d < 3; ++d)
+        {
+            if (box_.bc[d] == 1) { lim[2 * d] = box_.lim[2 * d], lim[2 * d + 1] = box_.lim[2 * d + 1]; }
+            else { CS_TRY(cstone_hip_minmax(ctx_, rb, coords[d], n, lim + 2 * d)); }
+        }
+        if (firstCall_) { std::copy(lim, lim + 6, box_.lim); }
+        else
+        {
+            // limitBoxShrinking (sfc/box.hpp:415-431), evaluated in T like the reference
+            const T shrink = T(0.05);
+            for (int d = 0; d < 3; ++d)
+            {
+                T lo = T(box_.lim[2 * d]), hi = T(box_.lim[2 * d + 1]);
+                T len = hi - lo;
+                T a = lo + shrink * len, b = hi - shrink * len;
+                box_.lim[2 * d]     = std::min(T(lim[2 * d]), a);
+                box_.lim[2 * d + 1] = std::max(T(lim[2 * d + 1]), b);
+            }
+        }
+        CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, *xPP, *yPP, *zPP, keys, n, &box_));
+
+        CS_TRY(order_.ensure(ctx_, n * sizeof(uint32_t)));
+        CS_TRY(orderAlt_.ensure(ctx_, n * sizeof(uint32_t)));
+        CS_TRY(keysAlt_.ensure(ctx_, n * sizeof(K)));
+        size_t tb = cstone_hip_sort_pairs_temp_bytes(kb, n);
+        CS_TRY(sortTmp_.ensure(ctx_, tb));
+        CS_TRY(cstone_hip_sequence_u32(ctx_, order_.as<uint32_t>(), n, 0));
+        CS_TRY(cstone_hip_sort_pairs(ctx_, kb, keys, order_.as<uint32_t>(), n, keysAlt_.p, orderAlt_.as<uint32_t>(),
+                                     sortTmp_.p, tb));
+
+        if (firstCall_)
+        {
+            // spanning tree of one rank = the root; counts = bucket - 1 (assignment.hpp:48-53)
+            CS_TRY(ensureTree(gTree_, gCounts_, gCap_, 4096));
+            hipLaunchKernelGGL(initTreeKernel<K>, 1, 1, 0, ctx_->stream, gTree_.as<K>(), gCounts_.as<uint32_t>(),
+                               bucket_ - 1);
+            gLeaves_ = 1;
+        }
+        int converged = 0;
+        CS_TRY(updateGlobal(keys, n, &converged));
+        if (firstCall_)
+        {
+            // `while (!updateOctreeGlobal(...));` (assignment.hpp:95-98): at least one more step, whatever the first said
+            int guard = 0;
+            do
+            {
+                CS_TRY(updateGlobal(keys, n, &converged));
+                if (++guard > 64) return fail(ctx_, CSTONE_E_INTERNAL, "global tree does not converge");
+            } while (!converged);
+        }
+
+        // particles flagged with the remove marker sort behind the end of the curve and leave the domain
+        hipLaunchKernelGGL(countValidKernel<K>, 1, 1, 0, ctx_->stream, keys, n, ctx_->devScalars + 2);
+        CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars + 2, ctx_->devScalars + 2, sizeof(int), hipMemcpyDeviceToHost,
+                                    ctx_->stream));
+        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
+        const uint32_t numAssigned = uint32_t(ctx_->hostScalars[2]);
+        if (numAssigned == 0) return fail(ctx_, CSTONE_E_ARG, "domain_sync: all particles removed");
+
+        // ---- GlobalAssignment::distribute on one rank: nothing to exchange; the second sort (assignment.hpp:156) of an
+        //      already sorted range is the identity and is skipped.
+        // ---- h into SFC order first, it feeds the halo radii (domain.hpp:213-215)
+        CS_TRY(cstone_hip_gather(ctx_, sizeof(T), order_.as<uint32_t>(), numAssigned, *hPP, *scratchPP));
+        std::swap(*hPP, *scratchPP);
+
+        // ---- focus tree (octree_focus_mpi.hpp:535-553 on first call, then :225-227)
+        if (firstCall_)
+        {
+            CS_TRY(ensureTree(fTree_, fLeafCounts_, fCap_, 4096));
+            hipLaunchKernelGGL(initTreeKernel<K>, 1, 1, 0, ctx_->stream, fTree_.as<K>(), fLeafCounts_.as<uint32_t>(),
+                               bucketFocus_ + 1);
+            fLeaves_ = 1;
+            CS_TRY(buildFocusOctree());
+            // counts_ of the single root node = bucketFocus + 1 (octree_focus_mpi.hpp:75)
+            CS_TRY(fCounts_.ensure(ctx_, sizeof(uint32_t)));
+            CS_HIP(ctx_, hipMemcpyAsync(fCounts_.p, fLeafCounts_.p, sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                                        ctx_->stream));
+            int conv = 0, guard = 0;
+            while (!conv)
+            {
+                CS_TRY(updateFocus(keys, numAssigned, &conv));
+                if (++guard > 64) return fail(ctx_, CSTONE_E_INTERNAL, "focus tree does not converge");
+            }
+        }
+        int conv = 0;
+        CS_TRY(updateFocus(keys, numAssigned, &conv));
+
+        // ---- Halos::discover + computeLayout (halos.hpp:128-222) for the assignment [0, L)
+        const NodeIdx L = fLeaves_;
+        CS_TRY(layout_.ensure(ctx_, size_t(L + 1) * sizeof(uint32_t)));
+        CS_TRY(radii_.ensure(ctx_, size_t(L) * sizeof(float)));
+        CS_TRY(flags_.ensure(ctx_, size_t(L) * sizeof(int)));
+        CS_HIP(ctx_, hipMemsetAsync(layout_.p, 0, sizeof(uint32_t), ctx_->stream));
+        CS_TRY(cstone_hip_inclusive_scan_u32(ctx_, fLeafCounts_.as<uint32_t>(), layout_.as<uint32_t>() + 1, size_t(L)));
+        CS_TRY(cstone_hip_halo_radii(ctx_, rb, *hPP, layout_.as<uint32_t>(), 0, L, L, haloSearchExt_,
+                                     radii_.as<float>()));
+        CS_HIP(ctx_, hipMemsetAsync(flags_.p, 0, size_t(L) * sizeof(int), ctx_->stream));
+        CS_TRY(cstone_hip_find_halos(ctx_, curve_, kb, rb, fPrefixes_.p, fChild_.as<int32_t>(), fItl_.as<int32_t>(),
+                                     fTree_.p, radii_.as<float>(), &box_, 0, L, flags_.as<int32_t>()));
+        // one rank: every leaf is assigned, no halo leaves: layout = exclusive scan of the leaf counts (layout.hpp:150-165),
+        // which is the inclusive scan written above shifted by one.
+
+        // ---- updateLayout (domain.hpp:542-604): keys already sit at offset 0; gather the unordered arrays
+        void** arrays[3] = {xPP, yPP, zPP};
+        for (auto a : arrays)
+        {
+            CS_TRY(cstone_hip_gather(ctx_, sizeof(T), order_.as<uint32_t>(), numAssigned, *a, *scratchPP));
+            std::swap(*a, *scratchPP);
+        }
+        for (int p = 0; p < numProps; ++p)
+        {
+            if (propBytes[p] > int(sizeof(T)))
+                return fail(ctx_, CSTONE_E_ARG, "domain_sync: property %d is wider than the scratch element", p);
+            CS_TRY(cstone_hip_gather(ctx_, propBytes[p], order_.as<uint32_t>(), numAssigned, props[p], *scratchPP));
+            std::swap(props[p], *scratchPP);
+        }
+
+        startIndex_ = 0;
+        endIndex_   = numAssigned;
+        bufSize_    = numAssigned;
+        firstCall_  = false;
+        return CSTONE_OK;
+    }
+
+    int view(cstone_hip_domain_view* v) override
+    {
+        v->start_index           = startIndex_;
+        v->end_index             = endIndex_;
+        v->num_particles_with_halos = bufSize_;
+        v->box                   = box_;
+        v->num_global_leaves     = gLeaves_;
+        v->global_leaves         = gTree_.p;
+        v->global_counts         = gCounts_.as<uint32_t>();
+        v->num_focus_leaves      = fLeaves_;
+        v->num_focus_nodes       = fLeaves_ + (fLeaves_ - 1) / 7;
+        v->focus_leaves          = fTree_.p;
+        v->focus_leaf_counts     = fLeafCounts_.as<uint32_t>();
+        v->prefixes              = fPrefixes_.p;
+        v->child_offsets         = fChild_.as<int32_t>();
+        v->parents               = fParents_.as<int32_t>();
+        v->level_range           = fLevelRange_.as<int32_t>();
+        v->internal_to_leaf      = fItl_.as<int32_t>();
+        v->leaf_to_internal      = fLti_.as<int32_t>();
+        v->layout                = layout_.as<uint32_t>();
+        v->centers               = fCenters_.p;
+        v->sizes                 = fSizes_.p;
+        v->halo_flags            = flags_.as<int32_t>();
+        v->sfc_order             = order_.as<uint32_t>();
+        return CSTONE_OK;
+    }
+
+    float haloSearchExt_ = 1.0f;
+
+private:
+    int ensureTree(DevBuf& tree, DevBuf& counts, int& cap, int need)
+    {
+        if (need <= cap) return CSTONE_OK;
+        int newCap = std::max(need, int(cap * 1.5));
+        CS_TRY(tree.ensure(ctx_, size_t(newCap + 1) * sizeof(K), true));
+        CS_TRY(counts.ensure(ctx_, size_t(newCap) * sizeof(uint32_t), true));
+        cap = newCap;
+        return CSTONE_OK;
+    }
+
+    //! updateOctreeGlobal on one rank (tree/update_mpi.hpp:71-94): rebalance with the previous counts, then recount
+    int updateGlobal(const K* keys, size_t n, int* converged)
+    {
+        while (true)
+        {
+            int leaves = gLeaves_;
+            int rc = cstone_hip_update_octree(ctx_, 8 * sizeof(K), keys, n, bucket_, gTree_.p, gCounts_.as<uint32_t>(),
+                                              &leaves, gCap_, 0xFFFFFFFFu, converged);
+            if (rc == CSTONE_E_CAPACITY)
+            {
+                CS_TRY(ensureTree(gTree_, gCounts_, gCap_, leaves + 1));
+                continue;
+            }
+            CS_TRY(rc);
+            gLeaves_ = leaves;
+            return CSTONE_OK;
+        }
+    }
+
+    int buildFocusOctree()
+    {
+        const NodeIdx L = fLeaves_, M = L + (L - 1) / 7;
+        CS_TRY(fPrefixes_.ensure(ctx_, size_t(M) * sizeof(K)));
+        CS_TRY(fChild_.ensure(ctx_, size_t(M + 1) * sizeof(NodeIdx)));
+        CS_TRY(fParents_.ensure(ctx_, size_t(std::max(1, (M - 1) / 8)) * sizeof(NodeIdx)));
+        CS_TRY(fLevelRange_.ensure(ctx_, (maxLevel<K>() + 2) * sizeof(NodeIdx)));
+        CS_TRY(fItl_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
+        CS_TRY(fLti_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
+        return cstone_hip_build_octree(ctx_, 8 * sizeof(K), fTree_.p, L, fPrefixes_.p, fChild_.as<int32_t>(),
+                                       fParents_.as<int32_t>(), fLevelRange_.as<int32_t>(), fItl_.as<int32_t>(),
+                                       fLti_.as<int32_t>());
+    }
+
+    /*! one FocusedOctree::updateTree + updateCounts + updateGeoCenters step on one rank
+     *  (octree_focus_mpi.hpp:108-187,205-273; octree_focus.hpp:83-137; rebalance.hpp:50-184) */
+    int updateFocus(const K* keys, size_t n, int* converged)
+    {
+        const NodeIdx L = fLeaves_, I = (L - 1) / 7, M = L + I;
+        CS_TRY(ops_.ensure(ctx_, size_t(M + 1) * sizeof(NodeIdx)));
+        CS_TRY(ops2_.ensure(ctx_, size_t(M + 1) * sizeof(NodeIdx)));
+        CS_TRY(leafOps_.ensure(ctx_, size_t(L + 1) * sizeof(uint32_t)));
+        int* scalars = ctx_->devScalars;
+        CS_HIP(ctx_, hipMemsetAsync(scalars, 0, 2 * sizeof(int), ctx_->stream));
+        hipLaunchKernelGGL(focusOpsKernel<K>, gridFor(M, 256), 256, 0, ctx_->stream, fPrefixes_.as<K>(),
+                           fChild_.as<NodeIdx>(), fParents_.as<NodeIdx>(), fCounts_.as<uint32_t>(), M, bucketFocus_,
+                           ops_.as<NodeIdx>());
+        // enforceKeys({focusStart, focusEnd}) is a no-op for the keys 0 and 2^(3 maxLevel) (rebalance.hpp:205)
+        hipLaunchKernelGGL(protectAncestorsKernel<K>, gridFor(M, 256), 256, 0, ctx_->stream, fPrefixes_.as<K>(),
+                           fParents_.as<NodeIdx>(), ops_.as<NodeIdx>(), M, ops2_.as<NodeIdx>(), scalars);
+        hipLaunchKernelGGL(leafOpsKernel, gridFor(L + 1, 256), 256, 0, ctx_->stream, ops2_.as<NodeIdx>(),
+                           fLti_.as<NodeIdx>(), I, L, leafOps_.as<uint32_t>());
+        CS_TRY(arenaReserve(ctx_, scanArenaBytes(size_t(L) + 1)));
+        int rc = scanU32(ctx_, leafOps_.as<uint32_t>(), leafOps_.as<uint32_t>(), size_t(L) + 1, 0u, false,
+                         (uint32_t*)scalars + 1);
+        arenaReset(ctx_);
+        CS_TRY(rc);
+        CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars, scalars, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx_->stream));
+        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
+        *converged           = ctx_->hostScalars[0] == 0;
+        const NodeIdx newL   = ctx_->hostScalars[1];
+        if (newL < 1) return fail(ctx_, CSTONE_E_INTERNAL, "focus rebalance produced %d leaves", newL);
+
+        CS_TRY(newTree_.ensure(ctx_, size_t(newL + 1) * sizeof(K)));
+        CS_TRY(cstone_hip_rebalance_tree(ctx_, 8 * sizeof(K), fTree_.p, L, newL, leafOps_.as<int32_t>(), newTree_.p));
+        CS_TRY(ensureTree(fTree_, fLeafCounts_, fCap_, newL));
+        CS_HIP(ctx_, hipMemcpyAsync(fTree_.p, newTree_.p, size_t(newL + 1) * sizeof(K), hipMemcpyDeviceToDevice,
+                                    ctx_->stream));
+        fLeaves_ = newL;
+        CS_TRY(buildFocusOctree());
+
+        // updateCounts: leaf counts from the particle keys, scattered to the linked layout, summed bottom-up
+        const NodeIdx newI = (newL - 1) / 7, newM = newL + newI;
+        CS_TRY(cstone_hip_compute_node_counts(ctx_, 8 * sizeof(K), fTree_.p, fLeafCounts_.as<uint32_t>(), newL, keys, n,
+                                              0xFFFFFFFFu));
+        CS_TRY(fCounts_.ensure(ctx_, size_t(newM) * sizeof(uint32_t)));
+        hipLaunchKernelGGL(scatterLeafCountsKernel, gridFor(newL, 256), 256, 0, ctx_->stream,
+                           fLeafCounts_.as<uint32_t>(), fLti_.as<NodeIdx>(), newI, newL, fCounts_.as<uint32_t>());
+        CS_TRY(cstone_hip_upsweep_sum(ctx_, int(maxLevel<K>()) + 2, fLevelRange_.as<int32_t>(), fChild_.as<int32_t>(),
+                                      fCounts_.as<uint32_t>()));
+        // updateGeoCenters
+        CS_TRY(fCenters_.ensure(ctx_, size_t(newM) * 3 * sizeof(T)));
+        CS_TRY(fSizes_.ensure(ctx_, size_t(newM) * 3 * sizeof(T)));
+        CS_TRY(cstone_hip_node_centers(ctx_, curve_, 8 * sizeof(K), 8 * sizeof(T), fPrefixes_.p, newM, &box_,
+                                       fCenters_.p, fSizes_.p));
+        CS_HIP(ctx_, hipGetLastError());
+        return CSTONE_OK;
+    }
+
+    cstone_hip_ctx* ctx_;
+    int curve_;
+    uint32_t bucket_, bucketFocus_;
+    float theta_;
+    cstone_box box_;
+    bool firstCall_ = true;
+    uint32_t startIndex_ = 0, endIndex_ = 0, bufSize_ = 0;
+
+    DevBuf order_, orderAlt_, keysAlt_, sortTmp_;
+    DevBuf gTree_, gCounts_;
+    int gCap_ = 0, gLeaves_ = 0;
+    DevBuf fTree_, fLeafCounts_, fCounts_, newTree_;
+    int fCap_ = 0, fLeaves_ = 0;
+    DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_, fCenters_, fSizes_;
+    DevBuf ops_, ops2_, leafOps_, layout_, radii_, flags_;
+};
+
+} // namespace cship
+
+using namespace cship;
+
+struct cstone_hip_domain
+{
+    cstone_hip_ctx* ctx;
+    std::unique_ptr<DomainBase> impl;
+};
+
+extern "C"
+{
+
+int cstone_hip_domain_create(cstone_hip_ctx* ctx, cstone_hip_domain** out, int curve, int key_bits, int real_bits,
+                             int rank, int num_ranks, uint32_t bucket_size, uint32_t bucket_size_focus, float theta,
+                             const cstone_box* box_host)
+{
+    if (!ctx || !out || !box_host) return fail(ctx, CSTONE_E_ARG, "domain_create: bad argument");
+    *out = nullptr;
+    if (bucket_size < bucket_size_focus)
+        return fail(ctx, CSTONE_E_ARG,
+                    "The bucket size of the global tree must not be smaller than the bucket size of the focused tree");
+    if (num_ranks != 1 || rank != 0)
+        return fail(ctx, CSTONE_E_ARG, "domain_create: only single-rank domains are implemented in this round");
+    if (curve != CSTONE_MORTON && curve != CSTONE_HILBERT) return fail(ctx, CSTONE_E_ARG, "domain_create: bad curve");
+    auto* d = new cstone_hip_domain{ctx, nullptr};
+    if (key_bits == 32 && real_bits == 32)
+        d->impl.reset(new DomainImpl<uint32_t, float>(ctx, curve, bucket_size, bucket_size_focus, theta, *box_host));
+    else if (key_bits == 32 && real_bits == 64)
+        d->impl.reset(new DomainImpl<uint32_t, double>(ctx, curve, bucket_size, bucket_size_focus, theta, *box_host));
+    else if (key_bits == 64 && real_bits == 32)
+        d->impl.reset(new DomainImpl<uint64_t, float>(ctx, curve, bucket_size, bucket_size_focus, theta, *box_host));
+    else if (key_bits == 64 && real_bits == 64)
+        d->impl.reset(new DomainImpl<uint64_t, double>(ctx, curve, bucket_size, bucket_size_focus, theta, *box_host));
+    else
+    {
+        delete d;
+        return fail(ctx, CSTONE_E_ARG, "domain_create: unsupported key/real width");
+    }
+    *out = d;
+    return CSTONE_OK;
+}
+
+int cstone_hip_domain_destroy(cstone_hip_domain* dom)
+{
+    if (!dom) return CSTONE_E_ARG;
+    (void)hipStreamSynchronize(dom->ctx->stream);
+    delete dom;
+    return CSTONE_OK;
+}
+
+int cstone_hip_domain_sync(cstone_hip_domain* dom, void** keys, void** x, void** y, void** z, void** h, size_t n,
+                           void** scratch, void** props, const int* prop_bytes, int num_props)
+{
+    if (!dom || !keys || !x || !y || !z || !h || !scratch || !*keys || !*x || !*y || !*z || !*h || !*scratch ||
+        num_props < 0 || (num_props && (!props || !prop_bytes)))
+        return fail(dom ? dom->ctx : nullptr, CSTONE_E_ARG, "domain_sync: bad argument");
+    return dom->impl->sync(keys, x, y, z, h, n, scratch, props, prop_bytes, num_props);
+}
+
+int cstone_hip_domain_view_get(cstone_hip_domain* dom, cstone_hip_domain_view* out)
+{
+    if (!dom || !out) return CSTONE_E_ARG;
+    return dom->impl->view(out);
+}
+
+} // extern "C"

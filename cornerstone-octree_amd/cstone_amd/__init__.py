@@ -31,6 +31,7 @@ EXPORTS = [
     "cstone_hip_compute_node_counts", "cstone_hip_compute_node_ops", "cstone_hip_rebalance_tree",
     "cstone_hip_update_octree", "cstone_hip_compute_octree", "cstone_hip_build_octree", "cstone_hip_upsweep_sum",
     "cstone_hip_node_centers", "cstone_hip_halo_radii", "cstone_hip_find_halos", "cstone_hip_find_neighbors",
+    "cstone_hip_domain_create", "cstone_hip_domain_destroy", "cstone_hip_domain_sync", "cstone_hip_domain_view_get",
 ]
 
 

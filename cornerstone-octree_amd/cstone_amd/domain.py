@@ -1,0 +1,76 @@
+"""ctypes plumbing for the cstone_hip_domain_* entry points (tests / bench only)."""
+import ctypes as C
+
+import numpy as np
+
+from . import CBox, Context, CstoneError, key_torch_dtype, make_cbox  # noqa: F401
+
+
+class DomainView(C.Structure):
+    _fields_ = [
+        ("start_index", C.c_uint32), ("end_index", C.c_uint32), ("num_particles_with_halos", C.c_uint32),
+        ("box", CBox),
+        ("num_global_leaves", C.c_int32), ("global_leaves", C.c_void_p), ("global_counts", C.c_void_p),
+        ("num_focus_leaves", C.c_int32), ("num_focus_nodes", C.c_int32),
+        ("focus_leaves", C.c_void_p), ("focus_leaf_counts", C.c_void_p), ("prefixes", C.c_void_p),
+        ("child_offsets", C.c_void_p), ("parents", C.c_void_p), ("level_range", C.c_void_p),
+        ("internal_to_leaf", C.c_void_p), ("leaf_to_internal", C.c_void_p), ("layout", C.c_void_p),
+        ("centers", C.c_void_p), ("sizes", C.c_void_p), ("halo_flags", C.c_void_p), ("sfc_order", C.c_void_p),
+    ]
+
+
+class Domain:
+    """cstone::Domain<KeyType, T, GpuTag> on one rank; arrays are torch tensors that the call may exchange"""
+
+    def __init__(self, ctx, curve, key_bits, real_bits, bucket, bucket_focus, theta=0.5, box=None, rank=0, nranks=1):
+        self.ctx, self.kb, self.rb = ctx, key_bits, real_bits
+        self.h = C.c_void_p()
+        box = box if box is not None else make_cbox([0, 1] * 3)
+        rc = ctx.lib.cstone_hip_domain_create(ctx.h, C.byref(self.h), C.c_int(curve), C.c_int(key_bits),
+                                              C.c_int(real_bits), C.c_int(rank), C.c_int(nranks), C.c_uint32(bucket),
+                                              C.c_uint32(bucket_focus), C.c_float(theta), C.byref(box))
+        ctx._chk(rc, "domain_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.cstone_hip_domain_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self, keys, x, y, z, h, scratch, props=()):
+        """returns (keys, x, y, z, h, scratch, props) as tensors after the buffer exchange, truncated to the new size"""
+        tensors = [x, y, z, h, scratch] + list(props)
+        by_ptr = {t.data_ptr(): t for t in tensors}
+        n = x.numel()
+        pk = C.c_void_p(keys.data_ptr())
+        ptrs = [C.c_void_p(t.data_ptr()) for t in (x, y, z, h, scratch)]
+        parr = (C.c_void_p * max(1, len(props)))(*[t.data_ptr() for t in props])
+        pbytes = (C.c_int * max(1, len(props)))(*[t.element_size() for t in props])
+        rc = self.ctx.lib.cstone_hip_domain_sync(self.h, C.byref(pk), C.byref(ptrs[0]), C.byref(ptrs[1]),
+                                                 C.byref(ptrs[2]), C.byref(ptrs[3]), C.c_size_t(n), C.byref(ptrs[4]),
+                                                 parr, pbytes, C.c_int(len(props)))
+        self.ctx._chk(rc, "domain_sync")
+        v = self.view()
+        m = v.num_particles_with_halos
+        out = [by_ptr[p.value] for p in ptrs]
+        pout = [by_ptr[parr[i]] for i in range(len(props))]
+        return keys[:m], out[0][:m], out[1][:m], out[2][:m], out[3][:m], out[4], [t[:m] for t in pout]
+
+    def view(self):
+        v = DomainView()
+        self.ctx._chk(self.ctx.lib.cstone_hip_domain_view_get(self.h, C.byref(v)), "domain_view_get")
+        return v
+
+    def fetch(self, ptr, count, dtype):
+        """device array behind a view pointer -> numpy"""
+        a = np.empty(count, dtype=dtype)
+        if count:
+            rc = self.ctx.lib.cstone_hip_memcpy_d2h(self.ctx.h, a.ctypes.data_as(C.c_void_p), C.c_void_p(ptr),
+                                                    C.c_size_t(a.nbytes))
+            self.ctx._chk(rc, "memcpy_d2h")
+        return a

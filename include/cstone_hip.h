@@ -201,6 +201,55 @@ extern "C"
                                   const uint32_t* layout, const void* centers, const void* sizes, float ext,
                                   uint32_t ngmax, uint32_t* neighbors, uint32_t* counts);
 
+    /* ---------------------------------------------------------------------------------------------
+     * Domain: device-resident cstone::Domain<KeyType,T,GpuTag> (R/domain/domain.hpp:66-699).
+     * create : Domain(rank, nRanks, bucketSize, bucketSizeFocus, theta, box) (:95-113); CSTONE_E_ARG if
+     *          bucket_size < bucket_size_focus (the reference throws std::runtime_error). This round implements
+     *          num_ranks == 1; other values are refused.
+     * sync   : Domain::sync(keys, x, y, z, h, properties, scratch) (:196-243). Arrays of n elements (n = the
+     *          previous num_particles_with_halos, or the initial particle count on the first call). Like the
+     *          reference, which swaps the caller's vectors with the scratch vectors (layout.hpp:214-219), the call
+     *          EXCHANGES buffers: on return *x, *y, *z, *h, props[i] and *scratch point to (possibly different)
+     *          members of the set of buffers passed in; all must therefore have the same capacity of n elements of
+     *          real_bits (properties: element size <= real_bits/8). *keys is sorted in place. Entries whose key slot
+     *          holds the remove marker 2^(3 maxLevel) on entry are dropped (sfc.hpp:289).
+     *          Post-conditions as domain.hpp:144-179: arrays SFC-sorted, keys consistent with x,y,z under box().
+     * view   : accessors startIndex/endIndex/nParticlesWithHalos/box/globalTree/focusTree/layout and
+     *          octreeProperties() (:388-437) as raw DEVICE pointers, valid until the next sync.
+     * ------------------------------------------------------------------------------------------- */
+    typedef struct cstone_hip_domain cstone_hip_domain;
+
+    typedef struct cstone_hip_domain_view
+    {
+        uint32_t start_index, end_index, num_particles_with_halos; /* Domain::startIndex/endIndex/nParticlesWithHalos */
+        cstone_box box;                                           /* Domain::box() */
+        int32_t num_global_leaves;                                /* Domain::globalTree() */
+        const void* global_leaves;                                /* K[num_global_leaves+1] */
+        const uint32_t* global_counts;
+        int32_t num_focus_leaves, num_focus_nodes; /* Domain::focusTree(), OctreeNsView (R/tree/octree.hpp:297-317) */
+        const void* focus_leaves;                  /* K[L+1] */
+        const uint32_t* focus_leaf_counts;         /* u32[L] */
+        const void* prefixes;                      /* K[M] */
+        const int32_t* child_offsets;
+        const int32_t* parents;
+        const int32_t* level_range;
+        const int32_t* internal_to_leaf;
+        const int32_t* leaf_to_internal;
+        const uint32_t* layout; /* u32[L+1], Domain::layout() */
+        const void* centers;    /* T[M][3] */
+        const void* sizes;      /* T[M][3] */
+        const int32_t* halo_flags;
+        const uint32_t* sfc_order; /* the ordering kept in the last scratch buffer by the reference (:206) */
+    } cstone_hip_domain_view;
+
+    int cstone_hip_domain_create(cstone_hip_ctx* ctx, cstone_hip_domain** out, int curve, int key_bits, int real_bits,
+                                 int rank, int num_ranks, uint32_t bucket_size, uint32_t bucket_size_focus, float theta,
+                                 const cstone_box* box_host);
+    int cstone_hip_domain_destroy(cstone_hip_domain* dom);
+    int cstone_hip_domain_sync(cstone_hip_domain* dom, void** keys, void** x, void** y, void** z, void** h, size_t n,
+                               void** scratch, void** props, const int* prop_bytes, int num_props);
+    int cstone_hip_domain_view_get(cstone_hip_domain* dom, cstone_hip_domain_view* out);
+
 #ifdef __cplusplus
 }
 #endif
