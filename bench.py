@@ -41,17 +41,16 @@ def parse():
 
 
 class SyncPipeline:
-    """Steady-state single-rank domain.sync assembled from the C ABI (device-resident, one context)."""
+    """Steady-state domain.sync through the C ABI: cstone_hip_domain_sync on device-resident arrays."""
 
     def __init__(self, ctx, n, key_bits, real_bits, curve, bucket, bucket_focus, seed):
         import torch
 
         import cstone_amd
+        from cstone_amd.domain import Domain
 
-        self.t, self.cs, self.ctx = torch, cstone_amd, ctx
-        self.n, self.kb, self.rb = n, key_bits, real_bits
-        self.curve = cstone_amd.HILBERT if curve == "hilbert" else cstone_amd.MORTON
-        self.bucket, self.bucket_focus = bucket, bucket_focus
+        self.ctx, self.n, self.kb, self.rb = ctx, n, key_bits, real_bits
+        cv = cstone_amd.HILBERT if curve == "hilbert" else cstone_amd.MORTON
         dev = ctx.device
         rdt = torch.float64 if real_bits == 64 else torch.float32
         g = torch.Generator(device=dev).manual_seed(seed)
@@ -61,77 +60,48 @@ class SyncPipeline:
         # h ~ 1.2 * (3*100/(4 pi N))^(1/3) / 2  (about 100 neighbours inside 2h), SURVEY 8(d)
         h0 = 0.6 * (3.0 * 100 / (4 * 3.141592653589793 * n)) ** (1.0 / 3.0)
         self.h = torch.full((n,), h0, dtype=rdt, device=dev)
-        kdt = cstone_amd.key_torch_dtype(key_bits)
-        self.keys = torch.zeros(n, dtype=kdt, device=dev)
-        self.order = torch.empty(n, dtype=torch.int32, device=dev)
-        # scratch: alt buffers for the sort + one real-typed buffer the gathers swap through
-        self.keys_alt = torch.empty(n, dtype=kdt, device=dev)
-        self.order_alt = torch.empty(n, dtype=torch.int32, device=dev)
-        self.sort_tmp = torch.empty(ctx.sort_temp_bytes(key_bits, n), dtype=torch.uint8, device=dev)
-        self.swap = torch.empty(n, dtype=rdt, device=dev)
-        # trees: global (coarse bucket) and focus (bucket_focus); capacity for the worst case of this cloud
-        self.cap_g = max(4096, 8 * n // max(1, bucket) + 4096)
-        self.cap_f = max(4096, 4 * n // max(1, bucket_focus) + 4096)
-        self.gtree = torch.zeros(self.cap_g + 1, dtype=kdt, device=dev)
-        self.gcounts = torch.zeros(self.cap_g, dtype=torch.int32, device=dev)
-        self.ftree = torch.zeros(self.cap_f + 1, dtype=kdt, device=dev)
-        self.fcounts = torch.zeros(self.cap_f, dtype=torch.int32, device=dev)
-        self.layout = torch.zeros(self.cap_f + 1, dtype=torch.int32, device=dev)
-        self.flags = torch.zeros(self.cap_f, dtype=torch.int32, device=dev)
-        self.g_leaves = self.f_leaves = 0
-        self.box = None
-
-    def _box(self):
-        lim = []
-        for a in (self.x, self.y, self.z):
-            lim += list(self.ctx.minmax(a))
-        return self.cs.make_cbox(lim)
-
-    def first_sync(self):
-        """first call: both trees are built from the root until converged (domain.hpp:220-224)"""
-        ctx = self.ctx
-        self.box = self._box()
-        ctx.compute_sfc_keys(self.curve, self.kb, self.x, self.y, self.z, self.box, self.keys)
-        ctx.sequence(self.order)
-        ctx.sort_pairs(self.keys, self.order, self.keys_alt, self.order_alt, self.sort_tmp)
-        for tree, counts, bucket, attr in ((self.gtree, self.gcounts, self.bucket, "g_leaves"),
-                                           (self.ftree, self.fcounts, self.bucket_focus, "f_leaves")):
-            t, c, _ = ctx.compute_octree(self.keys, bucket, cap_leaves=counts.numel())
-            nl = c.numel()
-            tree[:nl + 1] = t
-            counts[:nl] = c
-            setattr(self, attr, nl)
-        self._finish()
+        self.keys = torch.zeros(n, dtype=cstone_amd.key_torch_dtype(key_bits), device=dev)
+        self.scratch = torch.empty(n, dtype=rdt, device=dev)
+        self.dom = Domain(ctx, cv, key_bits, real_bits, bucket, bucket_focus, 0.5, cstone_amd.make_cbox([0, 1] * 3))
+        self.f_leaves = self.g_leaves = 0
 
     def step(self):
-        ctx = self.ctx
-        self.box = self._box()
-        ctx.compute_sfc_keys(self.curve, self.kb, self.x, self.y, self.z, self.box, self.keys)
-        ctx.sequence(self.order)
-        ctx.sort_pairs(self.keys, self.order, self.keys_alt, self.order_alt, self.sort_tmp)
-        self.g_leaves, _ = ctx.update_octree(self.keys, self.bucket, self.gtree, self.gcounts, self.g_leaves)
-        self.f_leaves, _ = ctx.update_octree(self.keys, self.bucket_focus, self.ftree, self.fcounts, self.f_leaves)
-        assert self.g_leaves > 0 and self.f_leaves > 0
-        self._finish()
+        """one Domain::sync (domain.hpp:196-243); the first call also converges both trees from the root"""
+        self.keys, self.x, self.y, self.z, self.h, self.scratch, _ = self.dom.sync(self.keys, self.x, self.y, self.z,
+                                                                                   self.h, self.scratch)
+        v = self.dom.view()
+        self.f_leaves, self.g_leaves = v.num_focus_leaves, v.num_global_leaves
 
-    def _finish(self):
-        ctx, nl = self.ctx, self.f_leaves
-        # h into SFC order first: halo radii need it (domain.hpp:213-215)
-        ctx.gather(self.order, self.h, self.swap)
-        self.h, self.swap = self.swap, self.h
-        self.octree = ctx.build_octree(self.ftree, num_leaves=nl)
-        self.centers, self.sizes = ctx.node_centers(self.curve, self.octree["prefixes"], self.box, self.rb)
-        # halo discovery over the whole (single-rank) assignment, halos.hpp:128-189
-        self.layout[0] = 0
-        ctx.inclusive_scan(self.fcounts[:nl], self.layout[1:nl + 1])
-        radii = ctx.halo_radii(self.h, self.layout, 0, nl, nl, 1.0)
-        self.flags[:nl].zero_()
-        ctx.find_halos(self.curve, self.octree, self.ftree, radii, self.box, 0, nl, self.rb, self.flags)
-        for name in ("x", "y", "z"):
-            a = getattr(self, name)
-            ctx.gather(self.order, a, self.swap)
-            setattr(self, name, self.swap)
-            self.swap = a
+    first_sync = step
+
+
+def cpu_baseline_domain(n_sample, bucket, bucket_focus, min_seconds=8.0):
+    """the reference's own cstone::Domain<uint64_t,double,CpuTag>::sync on one MPI rank (oracle/_ref, prebuilt)"""
+    import ctypes as C
+
+    import numpy as np
+
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libcstone_ref_domain.so"))
+    lib.cstone_refdom_create.restype = C.c_void_p
+    d = C.c_void_p(lib.cstone_refdom_create(C.c_uint(bucket), C.c_uint(bucket_focus), C.c_float(0.5),
+                                            (C.c_double * 6)(0, 1, 0, 1, 0, 1), (C.c_int * 3)(0, 0, 0)))
+    rng = np.random.default_rng(7)
+    x, y, z = [rng.uniform(0, 1, n_sample) for _ in range(3)]
+    h = np.full(n_sample, 0.01)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    lib.cstone_refdom_set(d, C.c_size_t(n_sample), p(x), p(y), p(z), p(h), None)
+    lib.cstone_refdom_sync(d)  # first call (tree convergence) is not part of the steady state
+    done, t_total = 0, 0.0
+    while t_total < min_seconds and done < 5:
+        t0 = time.perf_counter()
+        lib.cstone_refdom_sync(d)
+        t_total += time.perf_counter() - t0
+        done += 1
+    lib.cstone_refdom_destroy(d)
+    return {"value": n_sample * done / t_total, "unit": "particles/s", "cores": os.cpu_count(), "kind": "reference",
+            "sample": f"{done} steady-state Domain<uint64_t,double,CpuTag>::sync of {n_sample} uniform particles on 1 MPI rank, "
+                      f"bucket {bucket}, bucketFocus {bucket_focus}, OpenMP over all host cores (the sort inside is a serial "
+                      f"std::stable_sort)"}
 
 
 def cpu_baseline(n_sample, key_bits, real_bits, curve, bucket_focus, min_seconds=8.0):
@@ -140,6 +110,11 @@ def cpu_baseline(n_sample, key_bits, real_bits, curve, bucket_focus, min_seconds
 
     from oracle import oracle as orc
 
+    if key_bits == 64 and real_bits == 64 and curve == "hilbert":
+        try:
+            return cpu_baseline_domain(n_sample, max(64, n_sample // 100), bucket_focus, min_seconds)
+        except OSError:
+            pass  # the MPI-linked reference Domain did not travel / load: fall back to the stage-by-stage baseline
     if orc.reference_available():
         impl, kind = orc.Reference(), "reference"
     else:
@@ -165,17 +140,15 @@ def cpu_baseline(n_sample, key_bits, real_bits, curve, bucket_focus, min_seconds
         octree = impl.build_octree(tree)
         hs = h[order]
         nl = tree.size - 1
-        layout = np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)]).astype(np.uint32)
-        if impl.has("halo_radii"):
-            radii = impl.halo_radii(hs, layout, 0, nl, nl, 1.0)
-        else:
-            radii = (np.maximum.reduceat(hs, np.minimum(layout[:-1], n_sample - 1)) * 2).astype(np.float32)
-        impl.find_halos(orc.HILBERT, octree, tree, radii, box, 0, nl, real_bits) if cv == orc.HILBERT else None
+        radii = np.full(nl, 2 * 0.01, dtype=np.float32)
+        if cv == orc.HILBERT:
+            impl.find_halos(orc.HILBERT, octree, tree, radii, box, 0, nl, real_bits)
         x, y, z, h = x[order], y[order], z[order], hs
         t_total += time.perf_counter() - t0
         done += 1
     return {"value": n_sample * done / t_total, "unit": "particles/s", "cores": impl.num_threads(), "kind": kind,
-            "sample": f"{done} sync(s) of {n_sample} uniform particles, same stages, bucket {bucket_focus}"}
+            "sample": f"{done} sync(s) of {n_sample} uniform particles, stage by stage (encode, sort, tree, linked octree, "
+                      f"halo discovery, gathers), bucket {bucket_focus}"}
 
 
 def main():
@@ -253,7 +226,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{n_global:.0e} uniform particles, {args.key_bits}-bit {args.curve} keys, "
                                    f"f{args.real_bits} coordinates, bucketFocus {args.bucket_focus}, "
-                                   f"bucket {bucket_global}, steady-state sync, single-rank stages per GPU",
+                                   f"bucket {bucket_global}, steady-state cstone_hip_domain_sync"
+                                   + ("" if world == 1 else f", {world} independent single-rank domains (no exchange yet)"),
                        "particles_per_gpu": n_local, "focus_leaves": pipe.f_leaves, "global_leaves": pipe.g_leaves},
             "roofline": {"bound": "hbm", "kernel": "onesweepKernel (one 8-bit radix pass over key+index pairs)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

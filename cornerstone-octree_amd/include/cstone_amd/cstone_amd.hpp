@@ -1,0 +1,565 @@
+/*! @file
+ * C++20 host layer over the C ABI of libcstone_hip.so (include/cstone_hip.h).
+ *
+ * Mirrors the names, argument meaning and error behaviour of the reference's GPU interface
+ * (R = /root/reference/include/cstone):
+ *   cstone_amd::DeviceVector<T>          R/cuda/device_vector.h:24-63 (data/size/resize/reserve/capacity/swap)
+ *   memcpyH2D / memcpyD2H / memcpyD2D    R/cuda/cuda_stubs.h:48-57
+ *   computeSfcKeysGpu                    R/sfc/sfc_gpu.h:37-38
+ *   sortByKeyGpu, sortByKeyTempStorage, sequenceGpu, gatherGpu, scatterGpu, MinMaxGpu, exclusiveScanGpu,
+ *   inclusiveScanGpu                     R/primitives/primitives_gpu.h:36-124
+ *   computeNodeCountsGpu, computeNodeOpsGpu, rebalanceTreeGpu     R/tree/csarray_gpu.h:56-88
+ *   updateOctreeGpu                      R/tree/update_gpu.cuh:59-82
+ *   buildOctreeGpu, upsweepSumGpu        R/tree/octree_gpu.h:47-50
+ *   findHalosGpu                         R/traversal/collisions_gpu.h:57-66
+ *   Domain<KeyType, T>                   R/domain/domain.hpp:66-699 (GpuTag flavour, one rank in this round)
+ * Errors: the reference prints and exits (R/cuda/errorcheck.cuh:30-42) or throws std::runtime_error; every failing C
+ * call here throws std::runtime_error carrying cstone_hip_last_error().
+ *
+ * Header-only, no HIP headers needed: a host compiler (g++/clang++ -std=c++20) and -lcstone_hip are enough.
+ */
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "cstone_hip.h"
+
+namespace cstone_amd
+{
+
+using TreeNodeIndex = int;      // R/tree/definitions.h:41
+using LocalIndex    = unsigned; // R/tree/definitions.h:43
+
+enum class BoundaryType : char // R/sfc/box.hpp:97-102
+{
+    open     = 0,
+    periodic = 1,
+    fixed    = 2
+};
+
+//! curve selector; the reference fixes SfcKind = HilbertKey at build time (R/sfc/sfc.hpp:53-55)
+enum class Curve : int
+{
+    morton  = CSTONE_MORTON,
+    hilbert = CSTONE_HILBERT
+};
+
+//! one context per (host thread, device), created on first use
+class Context
+{
+public:
+    static cstone_hip_ctx* get()
+    {
+        thread_local Context instance;
+        return instance.ctx_;
+    }
+
+    static void check(int rc, const char* what)
+    {
+        if (rc != CSTONE_OK)
+        {
+            throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) +
+                                     "): " + cstone_hip_last_error(get()));
+        }
+    }
+
+private:
+    Context()
+    {
+        if (cstone_hip_ctx_create(&ctx_, 0, nullptr, 1) != CSTONE_OK)
+            throw std::runtime_error("cstone_hip_ctx_create failed: no usable MI355X device");
+    }
+    ~Context() { cstone_hip_ctx_destroy(ctx_); }
+    cstone_hip_ctx* ctx_{nullptr};
+};
+
+inline void syncGpu() { Context::check(cstone_hip_ctx_sync(Context::get()), "syncGpu"); }
+
+template<class T>
+void memcpyH2D(const T* src, std::size_t n, T* dest)
+{
+    Context::check(cstone_hip_memcpy_h2d(Context::get(), dest, src, n * sizeof(T)), "memcpyH2D");
+}
+template<class T>
+void memcpyD2H(const T* src, std::size_t n, T* dest)
+{
+    Context::check(cstone_hip_memcpy_d2h(Context::get(), dest, src, n * sizeof(T)), "memcpyD2H");
+}
+template<class T>
+void memcpyD2D(const T* src, std::size_t n, T* dest)
+{
+    Context::check(cstone_hip_memcpy_d2d(Context::get(), dest, src, n * sizeof(T)), "memcpyD2D");
+}
+
+//! uninitialised device array with std::vector-like size management (R/cuda/device_vector.h:24-63)
+template<class T>
+class DeviceVector
+{
+public:
+    using value_type = T;
+
+    DeviceVector() = default;
+    explicit DeviceVector(std::size_t n) { resize(n); }
+    DeviceVector(const T* first, const T* last)
+    {
+        resize(last - first);
+        memcpyH2D(first, size_, data_);
+    }
+    DeviceVector(const DeviceVector& o)
+    {
+        resize(o.size_);
+        memcpyD2D(o.data_, size_, data_);
+    }
+    DeviceVector(DeviceVector&& o) noexcept { swap(o); }
+    DeviceVector& operator=(DeviceVector o)
+    {
+        swap(o);
+        return *this;
+    }
+    ~DeviceVector()
+    {
+        if (data_) cstone_hip_free(Context::get(), data_);
+    }
+
+    T* data() { return data_; }
+    const T* data() const { return data_; }
+    std::size_t size() const { return size_; }
+    bool empty() const { return size_ == 0; }
+    std::size_t capacity() const { return capacity_; }
+
+    void reserve(std::size_t n)
+    {
+        if (n <= capacity_) return;
+        void* p = nullptr;
+        Context::check(cstone_hip_malloc(Context::get(), &p, n * sizeof(T)), "DeviceVector::reserve");
+        if (size_) memcpyD2D(data_, size_, static_cast<T*>(p));
+        if (data_) Context::check(cstone_hip_free(Context::get(), data_), "DeviceVector::reserve");
+        data_     = static_cast<T*>(p);
+        capacity_ = n;
+    }
+    void resize(std::size_t n)
+    {
+        reserve(n);
+        size_ = n;
+    }
+    void swap(DeviceVector& o) noexcept
+    {
+        std::swap(data_, o.data_);
+        std::swap(size_, o.size_);
+        std::swap(capacity_, o.capacity_);
+    }
+
+    //! take over a buffer handed back by cstone_hip_domain_sync (which exchanges buffers like the reference swaps
+    //! vectors); the buffer previously held is NOT freed: it now belongs to another vector of the same call
+    void rebind(void* p, std::size_t size, std::size_t capacityBytes)
+    {
+        data_     = static_cast<T*>(p);
+        size_     = size;
+        capacity_ = capacityBytes / sizeof(T);
+    }
+    std::size_t capacityBytes() const { return capacity_ * sizeof(T); }
+
+private:
+    T* data_{nullptr};
+    std::size_t size_{0}, capacity_{0};
+};
+
+template<class T>
+T* rawPtr(DeviceVector<T>& v)
+{
+    return v.data();
+}
+template<class T>
+const T* rawPtr(const DeviceVector<T>& v)
+{
+    return v.data();
+}
+
+template<class T>
+std::vector<T> toHost(const DeviceVector<T>& v)
+{
+    std::vector<T> h(v.size());
+    if (!h.empty()) memcpyD2H(v.data(), v.size(), h.data());
+    return h;
+}
+
+//! global coordinate bounding box (R/sfc/box.hpp:112-191); inverse lengths are derived by the library like Box<T> does
+template<class T>
+class Box
+{
+public:
+    Box(T xyzMin, T xyzMax, BoundaryType b = BoundaryType::open)
+        : Box(xyzMin, xyzMax, xyzMin, xyzMax, xyzMin, xyzMax, b, b, b)
+    {
+    }
+    Box(T xmin, T xmax, T ymin, T ymax, T zmin, T zmax, BoundaryType bx = BoundaryType::open,
+        BoundaryType by = BoundaryType::open, BoundaryType bz = BoundaryType::open)
+        : pod_{{double(xmin), double(xmax), double(ymin), double(ymax), double(zmin), double(zmax)},
+               {int(bx), int(by), int(bz)},
+               0}
+    {
+    }
+    explicit Box(const cstone_box& pod)
+        : pod_(pod)
+    {
+    }
+
+    T xmin() const { return T(pod_.lim[0]); }
+    T xmax() const { return T(pod_.lim[1]); }
+    T ymin() const { return T(pod_.lim[2]); }
+    T ymax() const { return T(pod_.lim[3]); }
+    T zmin() const { return T(pod_.lim[4]); }
+    T zmax() const { return T(pod_.lim[5]); }
+    T lx() const { return xmax() - xmin(); }
+    T ly() const { return ymax() - ymin(); }
+    T lz() const { return zmax() - zmin(); }
+    BoundaryType boundaryX() const { return BoundaryType(pod_.bc[0]); }
+    BoundaryType boundaryY() const { return BoundaryType(pod_.bc[1]); }
+    BoundaryType boundaryZ() const { return BoundaryType(pod_.bc[2]); }
+    const cstone_box& pod() const { return pod_; }
+
+private:
+    cstone_box pod_;
+};
+
+namespace detail
+{
+template<class K>
+constexpr int keyBits()
+{
+    static_assert(std::is_unsigned_v<K> && (sizeof(K) == 4 || sizeof(K) == 8), "SFC key type: 32- or 64-bit unsigned");
+    return 8 * int(sizeof(K));
+}
+template<class T>
+constexpr int realBits()
+{
+    static_assert(std::is_floating_point_v<T> && (sizeof(T) == 4 || sizeof(T) == 8), "float or double");
+    return 8 * int(sizeof(T));
+}
+} // namespace detail
+
+// ---------------------------------------------------------------------------------------------------------------
+// link-seam functions
+// ---------------------------------------------------------------------------------------------------------------
+
+template<class KeyType, class T>
+void computeSfcKeysGpu(const T* x, const T* y, const T* z, KeyType* keys, std::size_t numKeys, const Box<T>& box,
+                       Curve curve = Curve::hilbert)
+{
+    Context::check(cstone_hip_compute_sfc_keys(Context::get(), int(curve), detail::keyBits<KeyType>(),
+                                               detail::realBits<T>(), x, y, z, keys, numKeys, &box.pod()),
+                   "computeSfcKeysGpu");
+}
+
+template<class KeyType, class ValueType>
+std::uint64_t sortByKeyTempStorage(std::uint64_t numElements)
+{
+    static_assert(sizeof(ValueType) == 4, "the sort payload is a 32-bit LocalIndex");
+    return cstone_hip_sort_pairs_temp_bytes(detail::keyBits<KeyType>(), numElements);
+}
+
+template<class KeyType, class ValueType>
+void sortByKeyGpu(KeyType* first, KeyType* last, ValueType* values, KeyType* keyBuf, ValueType* valueBuf, void* temp,
+                  std::uint64_t tempBytes)
+{
+    static_assert(sizeof(ValueType) == 4, "the sort payload is a 32-bit LocalIndex");
+    Context::check(cstone_hip_sort_pairs(Context::get(), detail::keyBits<KeyType>(), first,
+                                         reinterpret_cast<std::uint32_t*>(values), std::size_t(last - first), keyBuf,
+                                         reinterpret_cast<std::uint32_t*>(valueBuf), temp, tempBytes),
+                   "sortByKeyGpu");
+}
+
+template<class KeyType, class ValueType>
+void sortByKeyGpu(KeyType* first, KeyType* last, ValueType* values)
+{
+    static_assert(sizeof(ValueType) == 4, "the sort payload is a 32-bit LocalIndex");
+    Context::check(cstone_hip_sort_pairs(Context::get(), detail::keyBits<KeyType>(), first,
+                                         reinterpret_cast<std::uint32_t*>(values), std::size_t(last - first), nullptr,
+                                         nullptr, nullptr, 0),
+                   "sortByKeyGpu");
+}
+
+inline void sequenceGpu(LocalIndex* input, std::size_t numElements, LocalIndex init)
+{
+    Context::check(cstone_hip_sequence_u32(Context::get(), input, numElements, init), "sequenceGpu");
+}
+
+template<class T, class IndexType>
+void gatherGpu(const IndexType* ordering, std::size_t numElements, const T* src, T* buffer)
+{
+    static_assert(sizeof(IndexType) == 4);
+    Context::check(cstone_hip_gather(Context::get(), int(sizeof(T)), reinterpret_cast<const std::uint32_t*>(ordering),
+                                     numElements, src, buffer),
+                   "gatherGpu");
+}
+
+template<class T, class IndexType>
+void scatterGpu(const IndexType* ordering, std::size_t numElements, const T* src, T* buffer)
+{
+    static_assert(sizeof(IndexType) == 4);
+    Context::check(cstone_hip_scatter(Context::get(), int(sizeof(T)), reinterpret_cast<const std::uint32_t*>(ordering),
+                                      numElements, src, buffer),
+                   "scatterGpu");
+}
+
+template<class T>
+struct MinMaxGpu
+{
+    std::tuple<T, T> operator()(const T* first, const T* last)
+    {
+        double mm[2];
+        Context::check(cstone_hip_minmax(Context::get(), detail::realBits<T>(), first, std::size_t(last - first), mm),
+                       "MinMaxGpu");
+        return {T(mm[0]), T(mm[1])};
+    }
+};
+
+inline void exclusiveScanGpu(const unsigned* first, const unsigned* last, unsigned* output, unsigned init = 0)
+{
+    Context::check(cstone_hip_exclusive_scan_u32(Context::get(), first, output, std::size_t(last - first), init),
+                   "exclusiveScanGpu");
+}
+
+inline void inclusiveScanGpu(const unsigned* first, const unsigned* last, unsigned* output)
+{
+    Context::check(cstone_hip_inclusive_scan_u32(Context::get(), first, output, std::size_t(last - first)),
+                   "inclusiveScanGpu");
+}
+
+template<class KeyType>
+void computeNodeCountsGpu(const KeyType* tree, unsigned* counts, TreeNodeIndex numNodes, const KeyType* firstKey,
+                          const KeyType* lastKey, unsigned maxCount, bool /*useCountsAsGuess*/ = false)
+{
+    Context::check(cstone_hip_compute_node_counts(Context::get(), detail::keyBits<KeyType>(), tree, counts, numNodes,
+                                                  firstKey, std::size_t(lastKey - firstKey), maxCount),
+                   "computeNodeCountsGpu");
+}
+
+//! returns the new number of nodes; nodeOps holds the exclusive scan of the decisions; *converged as the reference's flag
+template<class KeyType>
+TreeNodeIndex computeNodeOpsGpu(const KeyType* tree, TreeNodeIndex numNodes, const unsigned* counts,
+                                unsigned bucketSize, TreeNodeIndex* nodeOps, bool* converged = nullptr)
+{
+    int newNumNodes = 0, conv = 0;
+    Context::check(cstone_hip_compute_node_ops(Context::get(), detail::keyBits<KeyType>(), tree, numNodes, counts,
+                                               bucketSize, nodeOps, &newNumNodes, &conv),
+                   "computeNodeOpsGpu");
+    if (converged) *converged = conv != 0;
+    return newNumNodes;
+}
+
+template<class KeyType>
+void rebalanceTreeGpu(const KeyType* tree, TreeNodeIndex numNodes, TreeNodeIndex newNumNodes,
+                      const TreeNodeIndex* nodeOps, KeyType* newTree)
+{
+    Context::check(cstone_hip_rebalance_tree(Context::get(), detail::keyBits<KeyType>(), tree, numNodes, newNumNodes,
+                                             nodeOps, newTree),
+                   "rebalanceTreeGpu");
+}
+
+//! one rebalance step + recount on device vectors (R/tree/update_gpu.cuh:59-82); returns the converged flag
+template<class KeyType>
+bool updateOctreeGpu(const KeyType* firstKey, const KeyType* lastKey, unsigned bucketSize,
+                     DeviceVector<KeyType>& tree, DeviceVector<unsigned>& counts,
+                     unsigned maxCount = std::numeric_limits<unsigned>::max())
+{
+    int numLeaves = int(tree.size()) - 1;
+    int converged = 0;
+    while (true)
+    {
+        int cap = int(counts.capacity());
+        if (int(tree.capacity()) - 1 < cap) cap = int(tree.capacity()) - 1;
+        int rc = cstone_hip_update_octree(Context::get(), detail::keyBits<KeyType>(), firstKey,
+                                          std::size_t(lastKey - firstKey), bucketSize, tree.data(), counts.data(),
+                                          &numLeaves, cap, maxCount, &converged);
+        if (rc == CSTONE_E_CAPACITY)
+        {
+            // numLeaves now holds the required size; grow (contents are preserved) and repeat the step
+            std::size_t keep = tree.size();
+            tree.reserve(std::size_t(numLeaves * 1.05) + 2);
+            counts.reserve(std::size_t(numLeaves * 1.05) + 1);
+            numLeaves = int(keep) - 1;
+            continue;
+        }
+        Context::check(rc, "updateOctreeGpu");
+        break;
+    }
+    tree.resize(numLeaves + 1);
+    counts.resize(numLeaves);
+    return converged != 0;
+}
+
+//! R/tree/octree.hpp:280-293
+template<class KeyType>
+struct OctreeView
+{
+    TreeNodeIndex numLeafNodes, numInternalNodes, numNodes;
+    KeyType* prefixes;
+    TreeNodeIndex* childOffsets;
+    TreeNodeIndex* parents;
+    TreeNodeIndex* levelRange;
+    TreeNodeIndex* internalToLeaf;
+    TreeNodeIndex* leafToInternal;
+};
+
+template<class KeyType>
+void buildOctreeGpu(const KeyType* cstoneTree, OctreeView<KeyType> d)
+{
+    Context::check(cstone_hip_build_octree(Context::get(), detail::keyBits<KeyType>(), cstoneTree, d.numLeafNodes,
+                                           d.prefixes, d.childOffsets, d.parents, d.levelRange, d.internalToLeaf,
+                                           d.leafToInternal),
+                   "buildOctreeGpu");
+}
+
+inline void upsweepSumGpu(int numLvl, const TreeNodeIndex* lvlRange, const TreeNodeIndex* childOffsets,
+                          LocalIndex* counts)
+{
+    Context::check(cstone_hip_upsweep_sum(Context::get(), numLvl + 2, lvlRange, childOffsets, counts), "upsweepSumGpu");
+}
+
+template<class KeyType, class T>
+void findHalosGpu(const KeyType* prefixes, const TreeNodeIndex* childOffsets, const TreeNodeIndex* internalToLeaf,
+                  const KeyType* leaves, const float* interactionRadii, const Box<T>& box, TreeNodeIndex firstNode,
+                  TreeNodeIndex lastNode, int* collisionFlags, Curve curve = Curve::hilbert)
+{
+    Context::check(cstone_hip_find_halos(Context::get(), int(curve), detail::keyBits<KeyType>(), detail::realBits<T>(),
+                                         prefixes, childOffsets, internalToLeaf, leaves, interactionRadii, &box.pod(),
+                                         firstNode, lastNode, collisionFlags),
+                   "findHalosGpu");
+}
+
+//! R/tree/octree.hpp:297-317: what Domain::octreeProperties() hands to neighbor-search kernels (device pointers)
+template<class T, class KeyType>
+struct OctreeNsView
+{
+    TreeNodeIndex numLeafNodes;
+    const KeyType* prefixes;
+    const TreeNodeIndex* childOffsets;
+    const TreeNodeIndex* internalToLeaf;
+    const TreeNodeIndex* levelRange;
+    const KeyType* leaves;
+    const LocalIndex* layout;
+    const T* centers; // Vec3<T>[numNodes]
+    const T* sizes;   // Vec3<T>[numNodes]
+    float searchExtFactor{1.0};
+};
+
+/*! cstone::Domain<KeyType, T, GpuTag> (R/domain/domain.hpp:66-699) on one rank.
+ *  sync() keeps the reference's contract: caller-owned device vectors that are resized and SWAPPED with the scratch
+ *  vector; properties need element sizes <= sizeof(T). */
+template<class KeyType, class T>
+class Domain
+{
+public:
+    using RealType = T;
+
+    Domain(int rank, int nRanks, unsigned bucketSize, unsigned bucketSizeFocus, float theta,
+           const Box<T>& box = Box<T>{0, 1}, Curve curve = Curve::hilbert)
+    {
+        int rc = cstone_hip_domain_create(Context::get(), &dom_, int(curve), detail::keyBits<KeyType>(),
+                                          detail::realBits<T>(), rank, nRanks, bucketSize, bucketSizeFocus, theta,
+                                          &box.pod());
+        Context::check(rc, "Domain");
+    }
+    Domain(const Domain&)            = delete;
+    Domain& operator=(const Domain&) = delete;
+    ~Domain()
+    {
+        if (dom_) cstone_hip_domain_destroy(dom_);
+    }
+
+    template<class... Props>
+    void sync(DeviceVector<KeyType>& keys, DeviceVector<T>& x, DeviceVector<T>& y, DeviceVector<T>& z,
+              DeviceVector<T>& h, std::tuple<DeviceVector<Props>&...> properties, DeviceVector<T>& scratch)
+    {
+        static_assert(((sizeof(Props) <= sizeof(T)) && ...), "properties must not be wider than the scratch element");
+        std::size_t n = x.size();
+        if (keys.size() != n || y.size() != n || z.size() != n || h.size() != n)
+            throw std::runtime_error("Domain sync: input array sizes are inconsistent\n");
+        scratch.resize(n);
+        bool tooSmall = false;
+        std::apply([&](auto&... v) { ((tooSmall = tooSmall || v.capacityBytes() < n * sizeof(T)), ...); }, properties);
+        if (tooSmall)
+            throw std::runtime_error("Domain sync: a property buffer is smaller than n * sizeof(T) bytes "
+                                     "(it is exchanged with the scratch buffer)\n");
+        constexpr int np = sizeof...(Props);
+        void* pk = keys.data();
+        void* px = x.data();
+        void* py = y.data();
+        void* pz = z.data();
+        void* ph = h.data();
+        void* ps = scratch.data();
+        void* pp[np + 1] = {};
+        int pb[np + 1]   = {};
+        int i            = 0;
+        std::apply([&](auto&... v) { ((pp[i] = v.data(), pb[i] = int(sizeof(*v.data())), ++i), ...); }, properties);
+        void* before[5 + np + 1] = {px, py, pz, ph, ps};
+        for (int k = 0; k < np; ++k)
+            before[5 + k] = pp[k];
+        Context::check(cstone_hip_domain_sync(dom_, &pk, &px, &py, &pz, &ph, n, &ps, pp, pb, np), "Domain::sync");
+        // the library exchanged buffers among {x, y, z, h, scratch, props...}: rebind the vectors without copying.
+        // Every buffer of the set must offer n elements of sizeof(T); remember each buffer's capacity by address.
+        cstone_hip_domain_view v;
+        Context::check(cstone_hip_domain_view_get(dom_, &v), "Domain::sync");
+        const std::size_t m = v.num_particles_with_halos;
+        std::size_t caps[5 + np + 1] = {x.capacityBytes(), y.capacityBytes(), z.capacityBytes(), h.capacityBytes(),
+                                        scratch.capacityBytes()};
+        i = 0;
+        std::apply([&](auto&... vec) { ((caps[5 + i++] = vec.capacityBytes()), ...); }, properties);
+        auto capOf = [&](void* p)
+        {
+            for (int k = 0; k < 5 + np; ++k)
+                if (before[k] == p) return caps[k];
+            throw std::runtime_error("Domain::sync: library returned a foreign buffer");
+        };
+        x.rebind(px, m, capOf(px));
+        y.rebind(py, m, capOf(py));
+        z.rebind(pz, m, capOf(pz));
+        h.rebind(ph, m, capOf(ph));
+        scratch.rebind(ps, n, capOf(ps));
+        keys.resize(m);
+        i = 0;
+        std::apply([&](auto&... vec) { (vec.rebind(pp[i], m, capOf(pp[i])), ..., void(++i)); }, properties);
+    }
+
+    cstone_hip_domain_view view() const
+    {
+        cstone_hip_domain_view v;
+        Context::check(cstone_hip_domain_view_get(dom_, &v), "Domain::view");
+        return v;
+    }
+    LocalIndex startIndex() const { return view().start_index; }
+    LocalIndex endIndex() const { return view().end_index; }
+    LocalIndex nParticles() const { return endIndex() - startIndex(); }
+    LocalIndex nParticlesWithHalos() const { return view().num_particles_with_halos; }
+    Box<T> box() const { return Box<T>(view().box); }
+    TreeNodeIndex startCell() const { return 0; }
+    TreeNodeIndex endCell() const { return view().num_focus_leaves; }
+
+    OctreeNsView<T, KeyType> octreeProperties() const
+    {
+        auto v = view();
+        return {v.num_focus_leaves,
+                static_cast<const KeyType*>(v.prefixes),
+                v.child_offsets,
+                v.internal_to_leaf,
+                v.level_range,
+                static_cast<const KeyType*>(v.focus_leaves),
+                v.layout,
+                static_cast<const T*>(v.centers),
+                static_cast<const T*>(v.sizes)};
+    }
+
+private:
+    cstone_hip_domain* dom_{nullptr};
+};
+
+} // namespace cstone_amd

@@ -1,0 +1,52 @@
+// Minimal client of the C++20 host layer: the reference README's usage pattern (R/README.md:64-103) on one MI355X.
+//   g++ -std=c++20 -I include -I cornerstone-octree_amd/include examples/domain_example.cpp \
+//       -L cornerstone-octree_amd/lib -lcstone_hip -Wl,-rpath,$PWD/cornerstone-octree_amd/lib -o domain_example
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#include "cstone_amd/cstone_amd.hpp"
+
+using namespace cstone_amd;
+
+int main(int argc, char** argv)
+{
+    using KeyType = std::uint64_t;
+    using T       = double;
+    std::size_t n = argc > 1 ? std::stoul(argv[1]) : 1000000;
+
+    std::mt19937 gen(42);
+    std::uniform_real_distribution<T> dis(0, 1);
+    std::vector<T> hx(n), hy(n), hz(n), hh(n, 0.01);
+    for (auto& v : hx) v = dis(gen);
+    for (auto& v : hy) v = dis(gen);
+    for (auto& v : hz) v = dis(gen);
+    std::vector<float> hmass(n, 1.0f);
+
+    DeviceVector<T> x(hx.data(), hx.data() + n), y(hy.data(), hy.data() + n), z(hz.data(), hz.data() + n),
+        h(hh.data(), hh.data() + n), scratch;
+    // properties share the scratch buffer, which is sized for T: reserve the same byte capacity
+    DeviceVector<float> mass;
+    mass.reserve(n * sizeof(T) / sizeof(float));
+    mass.resize(n);
+    memcpyH2D(hmass.data(), n, mass.data());
+    DeviceVector<KeyType> keys(n);
+    Context::check(cstone_hip_memset(Context::get(), keys.data(), 0, n * sizeof(KeyType)), "memset");
+    x.reserve(n), scratch.reserve(n);
+
+    Domain<KeyType, T> domain(0, 1, /*bucketSize*/ 1024, /*bucketSizeFocus*/ 64, /*theta*/ 0.5f);
+    for (int step = 0; step < 3; ++step)
+    {
+        domain.sync(keys, x, y, z, h, std::tie(mass), scratch);
+        syncGpu();
+        auto v = domain.view();
+        std::printf("step %d: particles [%u, %u) of %u, %d global leaves, %d focus leaves\n", step, v.start_index,
+                    v.end_index, v.num_particles_with_halos, v.num_global_leaves, v.num_focus_leaves);
+    }
+    auto k = toHost(keys);
+    bool sorted = true;
+    for (std::size_t i = 1; i < k.size(); ++i)
+        sorted = sorted && k[i - 1] <= k[i];
+    std::printf("keys sorted: %s\n", sorted ? "yes" : "NO");
+    return sorted ? 0 : 1;
+}
