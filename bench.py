@@ -75,6 +75,53 @@ class SyncPipeline:
     first_sync = step
 
 
+class DistributedPipeline:
+    """N ranks, one per GPU: cstone_amd.distributed.DistributedDomain (global box / global tree all-reduce, SFC
+    assignment, particle all_to_all, owner-side halo discovery + halo all_to_all).  Every rank starts
+    with a random 1/N of the cloud (the first sync moves (N-1)/N of it); before every step a random 1% of the assigned
+    particles is displaced by up to 2h so that the steady-state exchange really moves particles across the boundaries."""
+
+    def __init__(self, ctx, n_local, n_global, key_bits, real_bits, curve, bucket, bucket_focus, seed):
+        import torch
+
+        import cstone_amd
+        from cstone_amd.distributed import Comm, DistributedDomain, HipBackend
+
+        self.torch = torch
+        dev = ctx.device
+        rdt = torch.float64 if real_bits == 64 else torch.float32
+        self.g = torch.Generator(device=dev).manual_seed(seed)
+        self.x, self.y, self.z = [torch.rand(n_local, dtype=rdt, device=dev, generator=self.g) for _ in range(3)]
+        self.h0 = 0.6 * (3.0 * 100 / (4 * 3.141592653589793 * n_global)) ** (1.0 / 3.0)
+        self.h = torch.full((n_local,), self.h0, dtype=rdt, device=dev)
+        cv = cstone_amd.HILBERT if curve == "hilbert" else cstone_amd.MORTON
+        self.dom = DistributedDomain(HipBackend(ctx), Comm(), cv, key_bits, real_bits, bucket, bucket_focus,
+                                     [0, 1] * 3, (0, 0, 0))
+        self.f_leaves = self.g_leaves = 0
+        self.assigned = n_local
+        self.halos = 0
+
+    def jiggle(self):
+        torch = self.torch
+        n = self.x.numel()
+        m = max(1, n // 100)
+        idx = torch.randint(0, n, (m,), device=self.x.device, generator=self.g)
+        for a in (self.x, self.y, self.z):
+            d = (torch.rand(m, dtype=a.dtype, device=a.device, generator=self.g) - 0.5) * (4 * self.h0)
+            a[idx] = (a[idx] + d).clamp_(0.0, 1.0)
+
+    def step(self):
+        self.jiggle()
+        r = self.dom.sync(self.x, self.y, self.z, self.h)
+        s, e = r["start"], r["end"]
+        # the client owns the assigned particles; halos are re-discovered by the next sync
+        self.x, self.y, self.z, self.h = r["x"][s:e], r["y"][s:e], r["z"][s:e], r["h"][s:e]
+        self.assigned, self.halos = e - s, r["x"].numel() - (e - s)
+        self.f_leaves, self.g_leaves = self.dom.f_leaves, self.dom.g_leaves
+
+    first_sync = step
+
+
 def cpu_baseline_domain(n_sample, bucket, bucket_focus, min_seconds=8.0):
     """the reference's own cstone::Domain<uint64_t,double,CpuTag>::sync on one MPI rank (oracle/_ref, prebuilt)"""
     import ctypes as C
@@ -171,11 +218,22 @@ def main():
     n_global = int(args.particles)
     n_local = n_global // world
     bucket_global = max(64, n_global // (100 * world))
-    pipe = SyncPipeline(ctx, n_local, args.key_bits, args.real_bits, args.curve, bucket_global, args.bucket_focus,
-                        seed=42 + rank)
+    distributed = world > 1 or os.environ.get("CSTONE_BENCH_FORCE_DIST") == "1"
+    if distributed:
+        if world == 1:  # rehearsal of the RCCL code path on one GPU
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29555")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        pipe = DistributedPipeline(ctx, n_local, n_global, args.key_bits, args.real_bits, args.curve, bucket_global,
+                                   args.bucket_focus, seed=42 + rank)
+    else:
+        pipe = SyncPipeline(ctx, n_local, args.key_bits, args.real_bits, args.curve, bucket_global, args.bucket_focus,
+                            seed=42 + rank)
 
     def barrier():
-        if world > 1:
+        if distributed:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -190,10 +248,12 @@ def main():
         pipe.step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    n_sorted = n_local
+    if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
+        n_sorted = pipe.assigned
     pass_ms, pass_launches = ctx.profile_get("sort_pass")
     stage_ms = {s: ctx.profile_get(s)[0] / args.steps for s in cstone_amd.STAGES}
     ctx.profile_enable(False)
@@ -206,9 +266,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_onesweep_traffic.json")
         if os.path.exists(tpath) and args.key_bits == 64:
             tj = json.load(open(tpath))
-            traffic = tj["traffic_bytes_per_launch"] / tj["n_pairs"] * n_local
+            traffic = tj["traffic_bytes_per_launch"] / tj["n_pairs"] * n_sorted
         kbytes = args.key_bits // 8
-        per_launch_bytes = 2.0 * (kbytes + 4) * n_local  # read + write of (key, u32 value), SURVEY 8(d)
+        per_launch_bytes = 2.0 * (kbytes + 4) * n_sorted  # read + write of (key, u32 value), SURVEY 8(d)
         avg_s = pass_ms * 1e-3 / max(1, pass_launches)
         achieved = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         out = {
@@ -227,8 +287,12 @@ def main():
             "config": {"workload": f"{n_global:.0e} uniform particles, {args.key_bits}-bit {args.curve} keys, "
                                    f"f{args.real_bits} coordinates, bucketFocus {args.bucket_focus}, "
                                    f"bucket {bucket_global}, steady-state cstone_hip_domain_sync"
-                                   + ("" if world == 1 else f", {world} independent single-rank domains (no exchange yet)"),
-                       "particles_per_gpu": n_local, "focus_leaves": pipe.f_leaves, "global_leaves": pipe.g_leaves},
+                                   + ("" if not distributed else
+                                      f"; {world} rank(s): SFC domain decomposition, particle + halo exchange with "
+                                      f"all_to_all over RCCL, 1% of the particles displaced by <=2h before every sync"),
+                       "particles_per_gpu": n_local, "focus_leaves": pipe.f_leaves, "global_leaves": pipe.g_leaves,
+                       **({"rank0_assigned": pipe.assigned, "rank0_halos": pipe.halos,
+                           "rank0_exchange": dict(pipe.dom.stats)} if distributed else {})},
             "roofline": {"bound": "hbm", "kernel": "onesweepKernel (one 8-bit radix pass over key+index pairs)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3,
@@ -239,7 +303,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample), args.key_bits, args.real_bits, args.curve,
                                                args.bucket_focus)
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         torch.distributed.destroy_process_group()
 
 

@@ -68,11 +68,19 @@ __device__ __forceinline__ int toGridCeil(T x)
     return int(min(r, (1u << nb) - 1u));
 }
 
-template<class K, class T, bool HILBERT>
+/*! MODE 0 (the reference's findHalos): targets are the radius-dilated boxes of leaves [first,last); tree nodes inside
+ *         the own key range [leaves[first], leaves[last]) are skipped, every other overlapped leaf is flagged
+ *  MODE 1 (export): only compute the dilated boxes of leaves [first,last): boxes[k][0..5] = lo/hi per axis,
+ *         boxes[k][6] = 1 if the box is NOT contained in the own key range (it needs halos from other ranks), [7] = 0
+ *  MODE 2 (serve): targets are numTargets foreign boxes (same 8-int records, record[6] == 0 are ignored); only nodes
+ *         that intersect the own key range are visited and own leaves overlapped by a target are flagged: the owner
+ *         of the particles answers "which of my leaves does your halo region touch" on its own, finest tree */
+template<class K, class T, bool HILBERT, int MODE>
 __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
     const K* __restrict__ prefixes, const NodeIdx* __restrict__ childOffsets, const NodeIdx* __restrict__ internalToLeaf,
     const K* __restrict__ leaves, const float* __restrict__ radii, DBox<T> box, NodeIdx first, NodeIdx last,
-    int* __restrict__ flags, const uint16_t* __restrict__ tables, int* __restrict__ errors)
+    int* __restrict__ flags, const uint16_t* __restrict__ tables, int* __restrict__ errors,
+    const int* __restrict__ boxesIn, NodeIdx numTargets, int* __restrict__ boxesOut)
 {
     __shared__ uint16_t enc[24 * 8];
     __shared__ uint16_t dec[24 * 8];
@@ -89,12 +97,24 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
     NodeIdx* stack      = stacks[wave];
     const K lowest = leaves[first], highest = leaves[last];
 
-    NodeIdx leaf = first + NodeIdx(blockIdx.x * (HALO_WAVES * 64) + threadIdx.x);
-    bool active  = leaf < last;
+    const NodeIdx slot0 = NodeIdx(blockIdx.x * (HALO_WAVES * 64) + threadIdx.x);
+    NodeIdx leaf = first + slot0;
+    bool active  = MODE == 2 ? slot0 < numTargets : leaf < last;
 
     // ---- per lane: halo box of my leaf + containment rejection (collisions.hpp:91-98)
     int lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
-    if (active)
+    if (MODE == 2)
+    {
+        if (active)
+        {
+            const int* rec = boxesIn + size_t(slot0) * 8;
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                lo[d] = rec[2 * d], hi[d] = rec[2 * d + 1];
+            active = rec[6] != 0;
+        }
+    }
+    else if (active)
     {
         K start        = leaves[leaf];
         unsigned level = levelOfSpan<K>(leaves[leaf + 1] - start);
@@ -125,7 +145,17 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
             inside          = nodeStart >= lowest && nodeStart + nodeSpan<K>(common) <= highest;
         }
         active = !inside;
+        if (MODE == 1)
+        {
+            int* rec = boxesOut + size_t(slot0) * 8;
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                rec[2 * d] = lo[d], rec[2 * d + 1] = hi[d];
+            rec[6] = active ? 1 : 0;
+            rec[7] = 0;
+        }
     }
+    if (MODE == 1) return;
 
     // ---- cooperative traversal, one surviving leaf at a time
     uint64_t todo = __ballot(active);
@@ -148,7 +178,8 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
             unsigned level = prefixBits(prefix) / 3;
             isLeaf         = childOffsets[n] == 0;
             K end          = start + nodeSpan<K>(level);
-            if (!(start < lowest || end > highest)) return false; // inside my own range: nothing to find there
+            if (MODE == 0 && !(start < lowest || end > highest)) return false; // inside my own range: nothing to find
+            if (MODE == 2 && (end <= lowest || start >= highest)) return false; // not mine: the owner serves it
             int c[3];
             nodeCorner<K, HILBERT>(start, level, dec, c[0], c[1], c[2]);
             int edge = 1 << (maxLevel<K>() - level);
@@ -279,13 +310,13 @@ int cstone_hip_find_halos(cstone_hip_ctx* ctx, int curve, int key_bits, int real
     do                                                                                                                 \
     {                                                                                                                  \
         if (curve == CSTONE_HILBERT)                                                                                   \
-            hipLaunchKernelGGL((findHalosKernel<K, T, true>), grid, HALO_WAVES * 64, 0, ctx->stream,                   \
+            hipLaunchKernelGGL((findHalosKernel<K, T, true, 0>), grid, HALO_WAVES * 64, 0, ctx->stream,                \
                                (const K*)prefixes, child_offsets, internal_to_leaf, (const K*)leaves, radii,           \
-                               makeDBox<T>(*box_host), first, last, flags, tables, errors);                            \
+                               makeDBox<T>(*box_host), first, last, flags, tables, errors, nullptr, 0, nullptr);       \
         else                                                                                                           \
-            hipLaunchKernelGGL((findHalosKernel<K, T, false>), grid, HALO_WAVES * 64, 0, ctx->stream,                  \
+            hipLaunchKernelGGL((findHalosKernel<K, T, false, 0>), grid, HALO_WAVES * 64, 0, ctx->stream,               \
                                (const K*)prefixes, child_offsets, internal_to_leaf, (const K*)leaves, radii,           \
-                               makeDBox<T>(*box_host), first, last, flags, tables, errors);                            \
+                               makeDBox<T>(*box_host), first, last, flags, tables, errors, nullptr, 0, nullptr);       \
     } while (0)
     if (curve != CSTONE_MORTON && curve != CSTONE_HILBERT) return fail(ctx, CSTONE_E_ARG, "find_halos: bad curve");
     if (key_bits == 32 && real_bits == 32) CS_LAUNCH_HALOS(uint32_t, float);
@@ -294,6 +325,75 @@ int cstone_hip_find_halos(cstone_hip_ctx* ctx, int curve, int key_bits, int real
     else if (key_bits == 64 && real_bits == 64) CS_LAUNCH_HALOS(uint64_t, double);
     else return fail(ctx, CSTONE_E_ARG, "find_halos: unsupported type combination");
 #undef CS_LAUNCH_HALOS
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+/* ---- building blocks of the multi-rank halo exchange (owner-side discovery) ---- */
+
+int cstone_hip_halo_boxes(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* leaves,
+                          const float* radii, const cstone_box* box_host, int first, int last, int32_t* boxes)
+{
+    if (!ctx || !leaves || !radii || !box_host || !boxes || first < 0 || last < first)
+        return fail(ctx, CSTONE_E_ARG, "halo_boxes: bad argument");
+    if (last == first) return CSTONE_OK;
+    if (curve != CSTONE_MORTON && curve != CSTONE_HILBERT) return fail(ctx, CSTONE_E_ARG, "halo_boxes: bad curve");
+    StageTimer timer(ctx, CSTONE_STAGE_HALOS);
+    unsigned grid = gridFor(size_t(last - first), HALO_WAVES * 64);
+    auto* tables  = (const uint16_t*)ctx->hilbertTables;
+    int* errors   = ctx->devScalars + 63;
+#define CS_LAUNCH_BOXES(K, T)                                                                                          \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (curve == CSTONE_HILBERT)                                                                                   \
+            hipLaunchKernelGGL((findHalosKernel<K, T, true, 1>), grid, HALO_WAVES * 64, 0, ctx->stream, nullptr,       \
+                               nullptr, nullptr, (const K*)leaves, radii, makeDBox<T>(*box_host), first, last,         \
+                               nullptr, tables, errors, nullptr, 0, boxes);                                            \
+        else                                                                                                           \
+            hipLaunchKernelGGL((findHalosKernel<K, T, false, 1>), grid, HALO_WAVES * 64, 0, ctx->stream, nullptr,      \
+                               nullptr, nullptr, (const K*)leaves, radii, makeDBox<T>(*box_host), first, last,         \
+                               nullptr, tables, errors, nullptr, 0, boxes);                                            \
+    } while (0)
+    if (key_bits == 32 && real_bits == 32) CS_LAUNCH_BOXES(uint32_t, float);
+    else if (key_bits == 32 && real_bits == 64) CS_LAUNCH_BOXES(uint32_t, double);
+    else if (key_bits == 64 && real_bits == 32) CS_LAUNCH_BOXES(uint64_t, float);
+    else if (key_bits == 64 && real_bits == 64) CS_LAUNCH_BOXES(uint64_t, double);
+    else return fail(ctx, CSTONE_E_ARG, "halo_boxes: unsupported type combination");
+#undef CS_LAUNCH_BOXES
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int cstone_hip_find_overlaps(cstone_hip_ctx* ctx, int curve, int key_bits, const void* prefixes,
+                             const int32_t* child_offsets, const int32_t* internal_to_leaf, const void* leaves,
+                             const int32_t* boxes, int num_boxes, int first, int last, int32_t* flags)
+{
+    if (!ctx || !prefixes || !child_offsets || !internal_to_leaf || !leaves || !flags || num_boxes < 0 || first < 0 ||
+        last < first || (num_boxes && !boxes))
+        return fail(ctx, CSTONE_E_ARG, "find_overlaps: bad argument");
+    if (num_boxes == 0 || last == first) return CSTONE_OK;
+    if (curve != CSTONE_MORTON && curve != CSTONE_HILBERT) return fail(ctx, CSTONE_E_ARG, "find_overlaps: bad curve");
+    StageTimer timer(ctx, CSTONE_STAGE_HALOS);
+    unsigned grid = gridFor(size_t(num_boxes), HALO_WAVES * 64);
+    auto* tables  = (const uint16_t*)ctx->hilbertTables;
+    int* errors   = ctx->devScalars + 63;
+    DBox<float> unused{};
+#define CS_LAUNCH_SERVE(K)                                                                                             \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (curve == CSTONE_HILBERT)                                                                                   \
+            hipLaunchKernelGGL((findHalosKernel<K, float, true, 2>), grid, HALO_WAVES * 64, 0, ctx->stream,            \
+                               (const K*)prefixes, child_offsets, internal_to_leaf, (const K*)leaves, nullptr, unused, \
+                               first, last, flags, tables, errors, boxes, num_boxes, nullptr);                         \
+        else                                                                                                           \
+            hipLaunchKernelGGL((findHalosKernel<K, float, false, 2>), grid, HALO_WAVES * 64, 0, ctx->stream,           \
+                               (const K*)prefixes, child_offsets, internal_to_leaf, (const K*)leaves, nullptr, unused, \
+                               first, last, flags, tables, errors, boxes, num_boxes, nullptr);                         \
+    } while (0)
+    if (key_bits == 32) CS_LAUNCH_SERVE(uint32_t);
+    else if (key_bits == 64) CS_LAUNCH_SERVE(uint64_t);
+    else return fail(ctx, CSTONE_E_ARG, "find_overlaps: key_bits %d unsupported", key_bits);
+#undef CS_LAUNCH_SERVE
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

@@ -31,6 +31,7 @@ EXPORTS = [
     "cstone_hip_compute_node_counts", "cstone_hip_compute_node_ops", "cstone_hip_rebalance_tree",
     "cstone_hip_update_octree", "cstone_hip_compute_octree", "cstone_hip_build_octree", "cstone_hip_upsweep_sum",
     "cstone_hip_node_centers", "cstone_hip_halo_radii", "cstone_hip_find_halos", "cstone_hip_find_neighbors",
+    "cstone_hip_halo_boxes", "cstone_hip_find_overlaps",
     "cstone_hip_domain_create", "cstone_hip_domain_destroy", "cstone_hip_domain_sync", "cstone_hip_domain_view_get",
 ]
 
@@ -324,6 +325,27 @@ class Context:
                                                  _ptr(octree["internal_to_leaf"]), _ptr(leaves), _ptr(radii),
                                                  C.byref(box), C.c_int(first), C.c_int(last), _ptr(flags)),
                   "find_halos")
+        return flags
+
+    def halo_boxes(self, curve, leaves, radii, box, first, last, real_bits=64):
+        torch = _torch()
+        kb = leaves.element_size() * 8
+        boxes = torch.zeros((last - first, 8), dtype=torch.int32, device=leaves.device)
+        self._chk(self.lib.cstone_hip_halo_boxes(self.h, C.c_int(curve), C.c_int(kb), C.c_int(real_bits), _ptr(leaves),
+                                                 _ptr(radii), C.byref(box), C.c_int(first), C.c_int(last),
+                                                 _ptr(boxes)), "halo_boxes")
+        return boxes
+
+    def find_overlaps(self, curve, octree, leaves, boxes, first, last, flags=None):
+        torch = _torch()
+        kb = leaves.element_size() * 8
+        if flags is None:
+            flags = torch.zeros(octree["num_leaves"], dtype=torch.int32, device=leaves.device)
+        nb = boxes.shape[0] if boxes.dim() == 2 else boxes.numel() // 8
+        self._chk(self.lib.cstone_hip_find_overlaps(self.h, C.c_int(curve), C.c_int(kb), _ptr(octree["prefixes"]),
+                                                    _ptr(octree["child_offsets"]), _ptr(octree["internal_to_leaf"]),
+                                                    _ptr(leaves), _ptr(boxes), C.c_int(nb), C.c_int(first),
+                                                    C.c_int(last), _ptr(flags)), "find_overlaps")
         return flags
 
     def find_neighbors(self, x, y, z, h, first, last, box, octree, layout, centers, sizes, ngmax, ext=1.0):

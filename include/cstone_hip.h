@@ -188,6 +188,20 @@ extern "C"
                               const int32_t* child_offsets, const int32_t* internal_to_leaf, const void* leaves,
                               const float* radii, const cstone_box* box_host, int first, int last, int32_t* flags);
 
+    /* Building blocks of the multi-rank halo exchange with OWNER-SIDE discovery: instead of
+     * keeping a locally-essential copy of remote tree structure (the R/focus headers), a rank exports the dilated boxes of its
+     * boundary leaves and every owner answers on its own, finest tree.
+     * halo_boxes   : for leaves [first,last): boxes[(i-first)*8 + 0..5] = {xlo,xhi,ylo,yhi,zlo,zhi} of
+     *                makeHaloBox (R/traversal/boxoverlap.hpp:159-182), [6] = 1 if the box is NOT contained in the own
+     *                key range [leaves[first], leaves[last]) (containedIn, :95-115), [7] = 0
+     * find_overlaps: flags[l] = 1 for every leaf l in [first,last) whose box overlaps (periodic-aware, :42-82) one of
+     *                the num_boxes 8-int records with record[6] != 0; flags must be pre-zeroed */
+    int cstone_hip_halo_boxes(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* leaves,
+                              const float* radii, const cstone_box* box_host, int first, int last, int32_t* boxes);
+    int cstone_hip_find_overlaps(cstone_hip_ctx* ctx, int curve, int key_bits, const void* prefixes,
+                                 const int32_t* child_offsets, const int32_t* internal_to_leaf, const void* leaves,
+                                 const int32_t* boxes, int num_boxes, int first, int last, int32_t* flags);
+
     /* ---------------------------------------------------------------------------------------------
      * neighbor search: replaces findNeighbors (R/findneighbors.hpp:160-188) / the traverseNeighbors
      * device function (R/traversal/find_neighbors.cuh:436-506) on an OctreeNsView

@@ -249,6 +249,24 @@ class _CpuImpl:
         assert rc == 0, rc
         return nidx, nc
 
+    def halo_boxes(self, curve, leaves, radii, box, first, last, real_bits=64):
+        kb = leaves.dtype.itemsize * 8
+        boxes = np.zeros((last - first, 8), dtype=np.int32)
+        radii = np.ascontiguousarray(radii, dtype=np.float32)
+        rc = self._f("halo_boxes")(C.c_int(curve), C.c_int(kb), C.c_int(real_bits), _p(leaves), _p(radii),
+                                   _p(box.lim), _p(box.bc), C.c_int(first), C.c_int(last), _p(boxes))
+        assert rc == 0, rc
+        return boxes
+
+    def find_overlaps(self, curve, leaves, boxes, first, last):
+        kb = leaves.dtype.itemsize * 8
+        flags = np.zeros(leaves.size - 1, dtype=np.int32)
+        boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 8)
+        rc = self._f("find_overlaps")(C.c_int(curve), C.c_int(kb), _p(leaves), _p(boxes), C.c_int(boxes.shape[0]),
+                                      C.c_int(first), C.c_int(last), _p(flags))
+        assert rc == 0, rc
+        return flags
+
     def num_threads(self):
         return int(self._f("num_threads")())
 

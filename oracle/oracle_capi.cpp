@@ -284,6 +284,60 @@ int cstone_oracle_find_neighbors(int real_bits, const void* x, const void* y, co
                     });
 }
 
+/* ---- independent (brute-force) checkers for the owner-side halo discovery building blocks of the HIP library
+ *      (cstone_hip_halo_boxes / cstone_hip_find_overlaps); they restate R/traversal/boxoverlap.hpp:42-182 only ---- */
+int cstone_oracle_halo_boxes(int curve, int key_bits, int real_bits, const void* leaves, const float* radii,
+                             const double* lim, const int* bc, int first, int last, int* boxes)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T       = decltype(t);
+                                    const K* lv   = (const K*)leaves;
+                                    Box<T> box    = mkBox<T>(lim, bc);
+                                    K lo = lv[first], hi = lv[last];
+                                    for (int i = first; i < last; ++i)
+                                    {
+                                        unsigned level = levelOfSpan<K>(lv[i + 1] - lv[i]);
+                                        IBox b = haloBox<K, T, float>(nodeIBox<K>(Curve(curve), lv[i], level), radii[i], box);
+                                        int* rec = boxes + size_t(i - first) * 8;
+                                        for (int d = 0; d < 3; ++d)
+                                            rec[2 * d] = b.lo[d], rec[2 * d + 1] = b.hi[d];
+                                        rec[6] = boxInsideKeyRange<K>(Curve(curve), lo, hi, b) ? 0 : 1;
+                                        rec[7] = 0;
+                                    }
+                                });
+                   });
+}
+
+int cstone_oracle_find_overlaps(int curve, int key_bits, const void* leaves, const int* boxes, int num_boxes, int first,
+                                int last, int* flags)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K     = decltype(k);
+                       const K* lv = (const K*)leaves;
+#pragma omp parallel for schedule(dynamic, 16)
+                       for (int l = first; l < last; ++l)
+                       {
+                           unsigned level = levelOfSpan<K>(lv[l + 1] - lv[l]);
+                           IBox nb        = nodeIBox<K>(Curve(curve), lv[l], level);
+                           for (int j = 0; j < num_boxes && !flags[l]; ++j)
+                           {
+                               const int* rec = boxes + size_t(j) * 8;
+                               if (!rec[6]) continue;
+                               IBox tb{{rec[0], rec[2], rec[4]}, {rec[1], rec[3], rec[5]}};
+                               if (boxesOverlap<K>(nb, tb)) flags[l] = 1;
+                           }
+                       }
+                   });
+}
+
 int cstone_oracle_num_threads()
 {
 #ifdef _OPENMP

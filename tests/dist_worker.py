@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Worker of the multi-rank tests (launched with torch.distributed.run, backend gloo).
+--backend cpu : oracle-based CPU backend (no GPU needed)      --backend hip : libcstone_hip on cuda:0 (ranks share it)
+Every rank owns a random 1/P of a global cloud, runs DistributedDomain.sync `steps` times while the particles move and
+checks, like the reference's own multi-rank test (test/integration_mpi/domain_nranks.cpp:80-150):
+  * the assigned particle counts add up to N and every rank's keys are sorted and inside its SFC range,
+  * the sum over ranks of the neighbour counts found with LOCAL + HALO particles equals the neighbour count sum of
+    the undistributed cloud (i.e. every neighbour within 2h of an assigned particle is present)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "cornerstone-octree_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def neighbor_sum(o, x, y, z, h, first, last, lim, bc):
+    """brute-force-free reference count through the oracle's tree search on the given particle set"""
+    from oracle.oracle import HILBERT, Box
+
+    box = Box(lim, bc)
+    keys = o.compute_sfc_keys(HILBERT, 64, x, y, z, box)
+    ks, order = o.sort_pairs(keys, np.arange(x.size))
+    inv = np.empty_like(order)
+    inv[order] = np.arange(x.size, dtype=order.dtype)
+    xs, ys, zs, hs = x[order], y[order], z[order], h[order]
+    tree, counts = o.compute_octree(ks, 32)
+    oc = o.build_octree(tree)
+    layout = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+    cen, siz = o.node_centers(HILBERT, oc["prefixes"], box, 64)
+    _, nc = o.find_neighbors(xs, ys, zs, hs, 0, x.size, box, oc, layout, cen, siz, 1)
+    sel = inv[first:last]
+    return int(nc[sel].astype(np.int64).sum())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="cpu")
+    ap.add_argument("--particles", type=int, default=20000)
+    ap.add_argument("--syncs", type=int, default=3)
+    ap.add_argument("--pbc", type=int, default=0)
+    a = ap.parse_args()
+    dist.init_process_group("gloo")
+    rank, P = dist.get_rank(), dist.get_world_size()
+
+    from cstone_amd.distributed import Comm, DistributedDomain, HipBackend
+    from oracle import oracle as orc
+
+    o = orc.Oracle()
+    if a.backend == "hip":
+        import cstone_amd
+
+        torch.cuda.set_device(0)
+        backend = HipBackend(cstone_amd.Context(0))
+        dev = "cuda"
+    else:
+        from cpu_backend import CpuBackend
+
+        backend = CpuBackend()
+        dev = "cpu"
+
+    N = a.particles
+    rng = np.random.default_rng(2024)
+    lim = [0.0, 1.0, 0.0, 1.0, 0.0, 1.0]
+    bc = (1, 1, 1) if a.pbc else (0, 0, 0)
+    centers = rng.uniform(0.2, 0.8, (4, 3))
+    pos = np.where(rng.uniform(size=(N, 1)) < 0.5, rng.uniform(0, 1, (N, 3)),
+                   centers[rng.integers(0, 4, N)] + rng.normal(0, 0.05, (N, 3)))
+    pos = np.clip(pos, 0.0, 1.0 - 1e-9)
+    hglob = 0.035 * rng.uniform(0.6, 1.2, N)
+    owner = rng.integers(0, P, N)  # random initial ownership: worst-case first exchange
+    vel = rng.normal(0, 0.004, (N, 3))
+
+    mine = np.nonzero(owner == rank)[0]
+    ids = mine.copy()
+    x, y, z = [torch.from_numpy(pos[mine, d].copy()).to(dev) for d in range(3)]
+    h = torch.from_numpy(hglob[mine].copy()).to(dev)
+
+    dom = DistributedDomain(backend, Comm(), orc.HILBERT, 64, 64, bucket=max(64, N // (100 * P)), bucket_focus=16,
+                            box_lim=lim, box_bc=bc)
+    ok = True
+    report = []
+    for s in range(a.syncs):
+        r = dom.sync(x, y, z, h)
+        st, en = r["start"], r["end"]
+        keys = r["keys"].cpu().numpy().view(np.uint64)
+        # invariants: counts add up, keys sorted, assigned keys inside my range
+        tot = torch.tensor([en - st], dtype=torch.int64)
+        dist.all_reduce(tot)
+        ok &= int(tot.item()) == N
+        ok &= bool(np.all(keys[1:] >= keys[:-1]))
+        b = dom.assignment
+        ok &= bool(np.all(keys[st:en] >= np.uint64(b[rank]))) and (en == st or int(keys[en - 1]) < b[rank + 1])
+        # neighbour completeness
+        lx, ly, lz, lh = [r[k].cpu().numpy() for k in "xyzh"]
+        local_sum = neighbor_sum(o, lx, ly, lz, lh, st, en, r["lim"], bc)
+        tsum = torch.tensor([local_sum], dtype=torch.int64)
+        dist.all_reduce(tsum)
+        # the undistributed cloud at this step: gather the assigned particles of every rank
+        parts = [None] * P
+        dist.all_gather_object(parts, np.stack([lx[st:en], ly[st:en], lz[st:en], lh[st:en]]))
+        if rank == 0:
+            allp = np.concatenate(parts, axis=1)
+            ref = neighbor_sum(o, allp[0].copy(), allp[1].copy(), allp[2].copy(), allp[3].copy(), 0, allp.shape[1],
+                               r["lim"], bc)
+            ok &= ref == int(tsum.item())
+            report.append(dict(step=s, neighbors=ref, found=int(tsum.item()), stats=dict(dom.stats)))
+        # move: assigned particles only (halos are discarded by the client before the next sync)
+        m = en - st
+        drift = torch.from_numpy(rng.normal(0, 0.004, (m, 3))).to(dev)
+        x, y, z, h = [r[k][st:en].clone() for k in "xyzh"]
+        x, y, z = x + drift[:, 0], y + drift[:, 1], z + drift[:, 2]
+        if a.pbc:
+            x, y, z = torch.remainder(x, 1.0), torch.remainder(y, 1.0), torch.remainder(z, 1.0)
+        else:
+            x, y, z = x.clamp(0.0, 1.0 - 1e-9), y.clamp(0.0, 1.0 - 1e-9), z.clamp(0.0, 1.0 - 1e-9)
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print("DIST_RESULT " + json.dumps(dict(ok=bool(flag.item()), ranks=P, report=report)))
+    dist.destroy_process_group()
+    sys.exit(0 if flag.item() else 1)
+
+
+if __name__ == "__main__":
+    main()

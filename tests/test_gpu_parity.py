@@ -347,3 +347,31 @@ def test_find_neighbors(hip, oracle, rb, bc):
         stored = np.minimum(c_ref, ngmax)
         mask = np.arange(ngmax)[None, :] < stored[:, None]
         assert np.array_equal(n_got[mask], n_ref[mask])
+
+
+@pytest.mark.parametrize("kb", [32, 64])
+@pytest.mark.parametrize("curve", [MORTON, HILBERT])
+@pytest.mark.parametrize("bc", [(0, 0, 0), (1, 1, 1)])
+def test_owner_side_halo_building_blocks(hip, oracle, kb, curve, bc):
+    """halo_boxes / find_overlaps (multi-rank halo exchange) against the brute-force checker"""
+    box = Box([-1.3, 2.1, 0.2, 0.9, -5, 7], bc)
+    x, y, z, keys = _sorted_keys(oracle, curve, kb, 30000, box, 64, seed=51, kind="clustered")
+    tree, counts = oracle.compute_octree(keys, 16)
+    o = oracle.build_octree(tree)
+    od = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in o.items()}
+    nl = tree.size - 1
+    radii = np.random.default_rng(3).uniform(0.0, 0.08, nl).astype(np.float32)
+    for first, last in ((0, nl // 3), (nl // 3, 2 * nl // 3), (2 * nl // 3, nl)):
+        b_ref = oracle.halo_boxes(curve, tree, radii, box, first, last)
+        b_got = hip.halo_boxes(curve, dev(tree), dev(radii), cbox(box), first, last)
+        assert np.array_equal(host(b_got, False), b_ref)
+        assert b_ref[:, 6].sum() > 0
+        # the boxes exported by one third of the tree are served by the other two thirds
+        for f2, l2 in ((0, nl // 3), (nl // 3, 2 * nl // 3), (2 * nl // 3, nl)):
+            if f2 == first:
+                continue
+            f_ref = oracle.find_overlaps(curve, tree, b_ref, f2, l2)
+            f_got = hip.find_overlaps(curve, od, dev(tree), b_got, f2, l2)
+            hip.sync()
+            assert np.array_equal(host(f_got, False), f_ref), (first, f2, f_ref.sum())
+            assert f_ref[:f2].sum() == 0 and f_ref[l2:].sum() == 0
