@@ -292,7 +292,9 @@ def main():
                                       f"all_to_all over RCCL, 1% of the particles displaced by <=2h before every sync"),
                        "particles_per_gpu": n_local, "focus_leaves": pipe.f_leaves, "global_leaves": pipe.g_leaves,
                        **({"rank0_assigned": pipe.assigned, "rank0_halos": pipe.halos,
-                           "rank0_exchange": dict(pipe.dom.stats)} if distributed else {})},
+                           "rank0_exchange": dict(pipe.dom.stats)} if distributed else {}),
+                       **({"rank0_phase_ms": {k: v * 1e3 for k, v in pipe.dom.timing.items()}}
+                          if distributed and pipe.dom.timing else {})},
             "roofline": {"bound": "hbm", "kernel": "onesweepKernel (one 8-bit radix pass over key+index pairs)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3,

@@ -29,6 +29,29 @@ struct alignas(8) Elem<24>
     unsigned char b[24];
 };
 
+// result[q] = index of the first key >= values[q] (unsigned comparison), one lane per query
+template<class K>
+__global__ __launch_bounds__(256) void lowerBoundKernel(const K* __restrict__ keys, size_t n,
+                                                        const K* __restrict__ values, int numValues,
+                                                        uint64_t* __restrict__ result)
+{
+    int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= numValues) return;
+    K v       = values[q];
+    size_t lo = 0, len = n;
+    while (len > 0)
+    {
+        size_t half = len >> 1;
+        if (keys[lo + half] < v)
+        {
+            lo += half + 1;
+            len -= half + 1;
+        }
+        else { len = half; }
+    }
+    result[q] = lo;
+}
+
 // dst[i] = src[map[i]]: map and dst are streamed, src is a random read (4 + 2E bytes per element)
 template<class E, int PER>
 __global__ __launch_bounds__(256) void gatherKernel(const uint32_t* __restrict__ map, size_t n,
@@ -228,6 +251,24 @@ int cstone_hip_inclusive_scan_u32(cstone_hip_ctx* ctx, const uint32_t* in, uint3
     int rc = scanU32(ctx, in, out, n, 0u, true);
     arenaReset(ctx);
     return rc;
+}
+
+int cstone_hip_lower_bound(cstone_hip_ctx* ctx, int key_bits, const void* keys, size_t n, const void* values,
+                           int num_values, uint64_t* result)
+{
+    if (!ctx || (key_bits != 32 && key_bits != 64) || num_values < 0 || (num_values && (!values || !result)) ||
+        (n && !keys))
+        return fail(ctx, CSTONE_E_ARG, "lower_bound: bad argument");
+    if (num_values == 0) return CSTONE_OK;
+    unsigned grid = (unsigned(num_values) + 255) / 256;
+    if (key_bits == 32)
+        hipLaunchKernelGGL(lowerBoundKernel<uint32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*)keys, n,
+                           (const uint32_t*)values, num_values, result);
+    else
+        hipLaunchKernelGGL(lowerBoundKernel<uint64_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint64_t*)keys, n,
+                           (const uint64_t*)values, num_values, result);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
 }
 
 } // extern "C"

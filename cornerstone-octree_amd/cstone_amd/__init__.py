@@ -27,7 +27,7 @@ EXPORTS = [
     "cstone_hip_memcpy_d2h", "cstone_hip_memcpy_d2d", "cstone_hip_memset", "cstone_hip_profile_enable",
     "cstone_hip_profile_reset", "cstone_hip_profile_get", "cstone_hip_compute_sfc_keys",
     "cstone_hip_sort_pairs_temp_bytes", "cstone_hip_sort_pairs", "cstone_hip_sequence_u32", "cstone_hip_gather",
-    "cstone_hip_scatter", "cstone_hip_minmax", "cstone_hip_exclusive_scan_u32", "cstone_hip_inclusive_scan_u32",
+    "cstone_hip_scatter", "cstone_hip_minmax", "cstone_hip_exclusive_scan_u32", "cstone_hip_inclusive_scan_u32", "cstone_hip_lower_bound",
     "cstone_hip_compute_node_counts", "cstone_hip_compute_node_ops", "cstone_hip_rebalance_tree",
     "cstone_hip_update_octree", "cstone_hip_compute_octree", "cstone_hip_build_octree", "cstone_hip_upsweep_sum",
     "cstone_hip_node_centers", "cstone_hip_halo_radii", "cstone_hip_find_halos", "cstone_hip_find_neighbors",
@@ -201,6 +201,15 @@ class Context:
     def inclusive_scan(self, inp, out):
         self._chk(self.lib.cstone_hip_inclusive_scan_u32(self.h, _ptr(inp), _ptr(out), C.c_size_t(inp.numel())),
                   "inclusive_scan")
+
+    def lower_bound(self, keys, values):
+        """positions (int64 device tensor) of the first key >= values[q], unsigned comparison of the bit patterns"""
+        torch = _torch()
+        out = torch.empty(values.numel(), dtype=torch.int64, device=keys.device)
+        self._chk(self.lib.cstone_hip_lower_bound(self.h, C.c_int(keys.element_size() * 8), _ptr(keys),
+                                                  C.c_size_t(keys.numel()), _ptr(values), C.c_int(values.numel()),
+                                                  _ptr(out)), "lower_bound")
+        return out
 
     # ---- tree
     def compute_node_counts(self, tree, keys, counts=None, max_count=0xFFFFFFFF, num_nodes=None):

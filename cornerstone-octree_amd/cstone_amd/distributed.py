@@ -21,6 +21,9 @@ that tree.  Porting that logic behind the C ABI is the next multi-GPU row (DESIG
 The compute backend is duck-typed (cstone_amd.Context on the GPU; tests drive the same orchestration with a CPU backend
 over gloo), torch.distributed is the only communication layer.
 """
+import os
+import time
+
 import numpy as np
 
 
@@ -42,7 +45,10 @@ class Comm:
         self.stage = dist.get_backend(group) != "nccl"
 
     def _to(self, t):
-        return t.cpu() if (self.stage and t.is_cuda) else t
+        """tensor on the side the backend communicates from: host for gloo, the GPU for RCCL"""
+        if self.stage:
+            return t.cpu() if t.is_cuda else t
+        return t if t.is_cuda else t.cuda()
 
     def all_reduce_min(self, t):
         w = self._to(t).clone()
@@ -50,12 +56,10 @@ class Comm:
         return w.to(t.device)
 
     def all_reduce_sum_(self, t):
-        if self.stage and t.is_cuda:
-            w = t.cpu()
-            self.dist.all_reduce(w, op=self.dist.ReduceOp.SUM, group=self.group)
+        w = self._to(t)
+        self.dist.all_reduce(w, op=self.dist.ReduceOp.SUM, group=self.group)
+        if w is not t:
             t.copy_(w)
-        else:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
     def exchange_counts(self, send_counts):
@@ -145,6 +149,20 @@ class DistributedDomain:
         self.f_leaves = 0
         self.end_key = 1 << (3 * (10 if key_bits == 32 else 21))
         self.stats = {}
+        # CSTONE_DIST_TIMING=1: synchronising wall-clock per phase (diagnostics only; it serialises the stream)
+        self.timing = {} if os.environ.get("CSTONE_DIST_TIMING") == "1" else None
+        self._t0 = None
+
+    def _tick(self, name):
+        if self.timing is None:
+            return
+        torch = _torch()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        now = time.perf_counter()
+        if name is not None and self._t0 is not None:
+            self.timing[name] = self.timing.get(name, 0.0) + (now - self._t0)
+        self._t0 = now
 
     # ---- C1
     def _update_box(self, x, y, z):
@@ -213,7 +231,9 @@ class DistributedDomain:
         torch = _torch()
         b, c = self.b, self.c
         rank, P = c.rank, c.size
+        self._tick(None)
         box = self._update_box(x, y, z)
+        self._tick("box")
 
         # keys + local sort, fields into SFC order so that send ranges are contiguous
         n = x.numel()
@@ -221,9 +241,11 @@ class DistributedDomain:
         order = b.iota(n)
         b.sort_pairs(keys, order)
         fields = [b.gather_new(order, a) for a in (x, y, z, h)]
+        self._tick("encode_sort_gather")
 
         self._update_global_tree(keys)
         bounds = self._assign()
+        self._tick("global_tree_assign")
 
         # C3: particle exchange
         cut = b.searchsorted(keys, bounds, self.kb)  # P+1 positions
@@ -245,6 +267,7 @@ class DistributedDomain:
             keys = keys[cut[rank]:cut[rank + 1]]
             n = x.numel()
         self.stats.update(moved=moved, dropped=dropped, assigned=n)
+        self._tick("particle_exchange_resort")
 
         # local focus tree (finest resolution inside the assignment)
         if self.ftree is None:
@@ -258,6 +281,7 @@ class DistributedDomain:
         layout = b.layout_from_counts(self.fcounts, L)
         start_off = int(b.to_numpy(layout[first:first + 1])[0])
         assert start_off == 0, "particles below the assignment cannot exist after the exchange"
+        self._tick("focus_tree")
 
         halos_lo = halos_hi = None
         if P > 1:
@@ -284,6 +308,7 @@ class DistributedDomain:
             halos_lo = [r[:nlo] for r in recv]
             halos_hi = [r[nlo:] for r in recv]
             self.stats.update(halos=sum(hr_counts), halo_boxes=int(mine.shape[0]), served=sum(hs_counts))
+        self._tick("halo_discovery_exchange")
 
         if halos_lo is not None:
             klo = b.compute_sfc_keys(self.curve, self.kb, halos_lo[0], halos_lo[1], halos_lo[2], box)
@@ -294,6 +319,7 @@ class DistributedDomain:
         else:
             out = [x, y, z, h]
             start = 0
+        self._tick("assemble")
         self.first_call = False
         return dict(keys=keys, x=out[0], y=out[1], z=out[2], h=out[3], start=start, end=start + n, box=box,
                     lim=self.lim.copy())
@@ -388,9 +414,8 @@ class HipBackend:
 
     def searchsorted(self, keys, bounds, kb):
         torch = _torch()
-        q = torch.tensor([min(b, (1 << 63) - 1) if kb == 64 else min(b, (1 << 31) - 1) for b in bounds],
-                         dtype=keys.dtype, device=keys.device)
-        return [int(v) for v in torch.searchsorted(keys, q, right=False).cpu().tolist()]
+        q = torch.tensor([signed_key(b, kb) for b in bounds], dtype=keys.dtype, device=keys.device)
+        return [int(v) for v in self.ctx.lower_bound(keys, q).cpu().tolist()]
 
     def find_leaf(self, tree, nl, key, kb, below):
         torch = _torch()

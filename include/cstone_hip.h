@@ -129,6 +129,12 @@ extern "C"
     int cstone_hip_exclusive_scan_u32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t init);
     int cstone_hip_inclusive_scan_u32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n);
 
+    /* lowerBoundGpu, range form (R/primitives/primitives_gpu.h:70-71): result[q] = index of the first element of
+     * the sorted keys[n] that is >= values[q] (unsigned compare); values and result are device arrays.
+     * Used for createSendRanges (R/domain/domaindecomp.hpp:218-230). */
+    int cstone_hip_lower_bound(cstone_hip_ctx* ctx, int key_bits, const void* keys, size_t n, const void* values,
+                               int num_values, uint64_t* result);
+
     /* ---------------------------------------------------------------------------------------------
      * cornerstone leaf array (R/tree/csarray_gpu.h:56-88, R/tree/update_gpu.cuh:59-82)
      * ------------------------------------------------------------------------------------------- */

@@ -375,3 +375,24 @@ def test_owner_side_halo_building_blocks(hip, oracle, kb, curve, bc):
             hip.sync()
             assert np.array_equal(host(f_got, False), f_ref), (first, f2, f_ref.sum())
             assert f_ref[:f2].sum() == 0 and f_ref[l2:].sum() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kb", [32, 64])
+def test_lower_bound_unsigned(hip, kb):
+    """lowerBoundGpu range form: unsigned comparison, including the removal marker 2^(3*maxLevel) at the tail"""
+    import torch
+
+    rng = np.random.default_rng(5)
+    udt = np.uint64 if kb == 64 else np.uint32
+    end = 1 << (3 * (21 if kb == 64 else 10))
+    keys = np.sort(rng.integers(0, end, 100000, dtype=np.uint64).astype(udt))
+    keys = np.concatenate([keys, np.full(7, end, dtype=udt)])
+    vals = np.concatenate([rng.integers(0, end, 50, dtype=np.uint64).astype(udt), keys[[0, 5, 99999]],
+                           np.array([0, end - 1, end], dtype=udt)])
+    sdt = np.int64 if kb == 64 else np.int32
+    got = hip.lower_bound(torch.from_numpy(keys.view(sdt)).cuda(), torch.from_numpy(vals.view(sdt)).cuda())
+    assert np.array_equal(got.cpu().numpy(), np.searchsorted(keys, vals, side="left"))
+    empty = hip.lower_bound(torch.zeros(0, dtype=torch.int64 if kb == 64 else torch.int32, device="cuda"),
+                            torch.from_numpy(vals.view(sdt)).cuda())
+    assert int(empty.abs().sum()) == 0
