@@ -28,6 +28,9 @@ struct cstone_hip_ctx
     int* hostScalars = nullptr; // [64]
     int* devScalars  = nullptr; // [64]
 
+    // -1 unknown, else result of the one-time LDS atomic ordering probe of the radix sort (sort.hip)
+    int ldsOrderOk = -1;
+
     // Hilbert transducer tables (device_keys.hpp), device copy
     void* hilbertTables = nullptr;
 

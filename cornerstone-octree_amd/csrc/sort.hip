@@ -10,25 +10,25 @@
 //   1. tile index from an atomic ticket (earlier tiles are therefore running or done: the
 //      look-back below cannot deadlock whatever the dispatch order or residency)
 //   2. keys loaded wave-striped (64 consecutive keys per wave instruction)
-//   3. stable rank of every key among equal digits of its wave: 8 ballots build the mask of
-//      lanes holding the same digit (wave64 "match-any"), v_mbcnt below the lane gives the rank;
-//      every lane reads the wave's private LDS digit counter, the first lane of a group adds to it
-//   4. digit threads: prefix over the waves, tile-local exclusive scan over digits; wave 0 publishes
-//      the tile's AGGREGATE row
+//   3. stable rank of every key among equal digits of its wave: a returning LDS atomic on the wave's
+//      private digit counter (ds_add_rtn serves the lanes of one instruction in ascending lane order on
+//      gfx950 -- probed once per context; a wave's LDS instructions execute in order)
+//   4. digit threads: tile totals, tile-local exclusive scan over digits; wave 0 publishes the tile's
+//      AGGREGATE row
 //   5. keys are permuted into tile-sorted order through LDS
-//   6. decoupled look-back by wave 0: lane l owns digits 4l..4l+3 and reads the status rows of the
-//      preceding tiles FOUR ROWS AT A TIME as 16-byte agent-scope (sc1) loads until every digit has
-//      met an INCLUSIVE word, then publishes its own inclusive row.  Status words are 32-bit
-//      {2-bit state, 30-bit count} granules: value and flag travel in one word, so no fence is
-//      needed and tearing between words is harmless; sc1 accesses are coherent across the 8 XCD L2s.
-//      Why rows in bulk and big tiles: with hop latency L and P tiles in flight the look-back depth
-//      settles near L*sqrt(P); fewer, larger tiles and several rows per hop keep it off the critical path.
-//      Spins are bounded.
+//   6. decoupled look-back by 4 waves, one digit quarter each, 16 status rows per round trip (see
+//      quarterLookBack), then the INCLUSIVE row is published
 //   7. keys, then values, are streamed from LDS to their global slots: consecutive lanes write
 //      consecutive addresses within each digit run
 // The last, partial tile is handled by a separate one-workgroup kernel without look-back.
+// Measured phase budget of a 16 Ki tile (CSTONE_SORT_TRACE build, tools/sort_trace.py, 1e8 random 64-bit pairs):
+// ticket 0.7 us, key load 4.6-5.2, rank 3.6-4.1, digit scans 1.2, permute 1.1, look-back 4.5, key store 2.1,
+// value stage + store 2.9: about 23 us per tile and CU, i.e. the kernel is bound by the tile's serial phases with
+// ONE resident workgroup per CU (LDS), not by HBM.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include <utility>
 
 #include "ctx.hpp"
@@ -49,8 +49,23 @@ constexpr uint32_t COUNT_MASK = (1u << 30) - 1;
 
 constexpr int HIST_BLOCK   = 256;
 constexpr int SMALL_BLOCK  = 256;  // 4 Ki pairs per tile
-constexpr int LARGE_BLOCK  = 1024; // 16 Ki pairs per tile
-constexpr int LOOKBACK_ROWS = 4;
+#ifndef CSTONE_LARGE_BLOCK
+#define CSTONE_LARGE_BLOCK 1024
+#endif
+constexpr int LARGE_BLOCK  = CSTONE_LARGE_BLOCK; // 16 Ki pairs per tile
+
+// CSTONE_SORT_TRACE (tuning builds only, tools/sort_trace.py): wave 0 of every tile records wall-clock stamps
+#ifdef CSTONE_SORT_TRACE
+constexpr int TRACE_SLOTS = 16;
+__device__ uint64_t* g_sortTrace;
+#define SORT_TRACE(slot)                                                                                               \
+    if (g_sortTrace && threadIdx.x == 0) g_sortTrace[(size_t(traceRow)) * TRACE_SLOTS + (slot)] = wall_clock64();
+#define SORT_TRACE_VAL(slot, v)                                                                                        \
+    if (g_sortTrace && threadIdx.x == 0) g_sortTrace[(size_t(traceRow)) * TRACE_SLOTS + (slot)] = (v);
+#else
+#define SORT_TRACE(slot)
+#define SORT_TRACE_VAL(slot, v)
+#endif
 
 template<class K, int BLOCK_>
 struct SortCfg
@@ -184,6 +199,39 @@ __device__ __forceinline__ void matchDigit(unsigned d, uint32_t& mlo, uint32_t& 
     }
 }
 
+/*! one-time probe of the property the ranking relies on: returning LDS atomics of one wave instruction are served in
+ *  ascending lane order.  Compares against the ballot-based stable rank for random, few-valued and uniform digits. */
+__global__ __launch_bounds__(1024) void ldsOrderProbeKernel(uint32_t* __restrict__ mismatches)
+{
+    __shared__ uint32_t hist[16 * RADIX];
+    __shared__ uint32_t ref[16 * RADIX];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned bad = 0;
+    for (int mode = 0; mode < 4; ++mode)
+    {
+        for (int i = tid; i < 16 * RADIX; i += 1024)
+            hist[i] = ref[i] = 0;
+        __syncthreads();
+        for (int r = 0; r < 32; ++r)
+        {
+            unsigned hsh = (tid * 2654435761u) ^ ((r + 1) * 40503u * (mode + 7u));
+            hsh ^= hsh >> 13;
+            hsh *= 0x5bd1e995u;
+            hsh ^= hsh >> 15;
+            unsigned d   = mode == 0 ? hsh & 255u : mode == 1 ? hsh & 3u : mode == 2 ? (lane >> 2) + (r & 1) : 9u;
+            unsigned got = atomicAdd(&hist[wave * RADIX + d], 1u);
+            uint32_t mlo = ~0u, mhi = ~0u;
+            matchDigit(d, mlo, mhi);
+            unsigned below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+            unsigned base  = ref[wave * RADIX + d];
+            if (below == 0) ref[wave * RADIX + d] = base + unsigned(__popc(mlo) + __popc(mhi));
+            bad += (got != base + below);
+        }
+        __syncthreads();
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 //! workgroup barrier that orders LDS traffic only: __syncthreads() would also wait for every outstanding global
 //! load and store (vmcnt(0)) and thereby serialise the value loads and the draining stores
 __device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -195,21 +243,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void storeRowSc1(uint32_t* p, u32x4 v)
 {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-
-//! four status rows in flight at once; the wait is part of the statement because the compiler does not track
-//! loads issued from inline asm
-__device__ __forceinline__ void loadRows4Sc1(const uint32_t* p0, const uint32_t* p1, const uint32_t* p2,
-                                             const uint32_t* p3, u32x4 (&w)[LOOKBACK_ROWS])
-{
-    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                 "global_load_dwordx4 %1, %5, off sc1\n\t"
-                 "global_load_dwordx4 %2, %6, off sc1\n\t"
-                 "global_load_dwordx4 %3, %7, off sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
-                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-                 : "memory");
 }
 
 template<class K, int BLOCK>
@@ -225,17 +258,145 @@ struct alignas(16) SortSmem
     K stage[Cfg::TILE];
 };
 
+//! sixteen quarter-rows in flight: 4 instructions, each lane group of 16 lanes addresses its own row.  The wait is
+//! part of the statement because the compiler does not track loads issued from inline asm.
+__device__ __forceinline__ void loadQuarterRows16Sc1(const uint32_t* p0, const uint32_t* p1, const uint32_t* p2,
+                                                     const uint32_t* p3, u32x4 (&w)[4])
+{
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                 "global_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                 : "memory");
+}
+
+constexpr int LB_WAVES = 4;       // look-back waves: wave w owns the digits 64w .. 64w+63
+constexpr int LB_ROWS  = 16;      // status rows per look-back round
+constexpr unsigned LB_NONE = 255; // "no INCLUSIVE word met"
+
+/*! @brief decoupled look-back of one digit quarter by one wave, 16 status rows per round trip
+ *
+ *  Lane l = 16 g + q reads the digits 64 wave + 4q .. +3 (16 bytes, agent scope: sc1 is coherent across the 8 XCD
+ *  L2s) of the rows t-g, t-4-g, t-8-g, t-12-g: one instruction covers 4 rows, 4 instructions the 16 tiles before t.
+ *  Rows are consumed strictly in order up to the first one this quarter of which is not published yet; per digit
+ *  the counts are added up to and including the first INCLUSIVE word.  Status words are 32-bit {2-bit state, 30-bit
+ *  count}: value and flag travel in one word, so no fence is needed and tearing between words is harmless.
+ *  Why 16 rows at once: the tiles in flight start faster (about 10 per microsecond) than one agent-scope round trip
+ *  (about 1.2 us), so the nearest INCLUSIVE row is typically 15-20 tiles back; walking there 4 rows per round trip
+ *  left the CU idle for 5-6 round trips per tile.  The four quarters proceed independently, no barrier inside.
+ *  @return exclusive prefix (count of the digit in all earlier tiles), identical in the 4 lanes that share q */
+__device__ __forceinline__ u32x4 quarterLookBack(const uint32_t* __restrict__ status, uint32_t tile, unsigned wave,
+                                                 unsigned lane, uint32_t* __restrict__ errors
+#ifdef CSTONE_SORT_TRACE
+                                                 , unsigned& rounds, unsigned& rowsUsed
+#endif
+)
+{
+    const unsigned g = lane >> 4, q = lane & 15u;
+    const uint32_t* col = status + 64 * wave + 4 * q;
+    u32x4 excl     = {0, 0, 0, 0};
+    bool done[4]   = {false, false, false, false};
+    int32_t t      = int32_t(tile) - 1;
+    unsigned spins = 0;
+    bool finished  = t < 0;
+    while (!finished)
+    {
+        u32x4 w[4];
+        loadQuarterRows16Sc1(col + size_t(max(t - int32_t(g), 0)) * RADIX, col + size_t(max(t - 4 - int32_t(g), 0)) * RADIX,
+                             col + size_t(max(t - 8 - int32_t(g), 0)) * RADIX,
+                             col + size_t(max(t - 12 - int32_t(g), 0)) * RADIX, w);
+        // first row (0 = tile t) whose quarter is not completely published; rows before tile 0 do not exist and
+        // are never reached (row 0 is INCLUSIVE for every digit)
+        unsigned stop = LB_ROWS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            bool exists = t - 4 * i - int32_t(g) >= 0;
+            bool ready  = true;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                ready = ready && (w[i][c] & ~COUNT_MASK) != 0;
+            uint64_t m = __ballot(ready || !exists);
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+                if (stop == LB_ROWS && ((m >> (16 * gg)) & 0xFFFFull) != 0xFFFFull) stop = 4 * i + gg;
+        }
+        // per digit: nearest usable row holding an INCLUSIVE word
+        unsigned first[4] = {LB_NONE, LB_NONE, LB_NONE, LB_NONE};
+#pragma unroll
+        for (int i = 3; i >= 0; --i)
+        {
+            unsigned rho = 4 * i + g;
+            bool usable  = rho < stop && t - int32_t(rho) >= 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (usable && (w[i][c] & ~COUNT_MASK) == STATE_INC) first[c] = rho;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+        {
+            first[c] = min(first[c], unsigned(__shfl_xor(int(first[c]), 16)));
+            first[c] = min(first[c], unsigned(__shfl_xor(int(first[c]), 32)));
+        }
+        u32x4 sum = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            unsigned rho = 4 * i + g;
+            bool usable  = rho < stop && t - int32_t(rho) >= 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (usable && rho <= first[c]) sum[c] += w[i][c] & COUNT_MASK;
+        }
+        bool allDone = true;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+        {
+            uint32_t v = sum[c];
+            v += uint32_t(__shfl_xor(int(v), 16));
+            v += uint32_t(__shfl_xor(int(v), 32));
+            if (!done[c])
+            {
+                excl[c] += v;
+                done[c] = first[c] != LB_NONE;
+            }
+            allDone = allDone && done[c];
+        }
+#ifdef CSTONE_SORT_TRACE
+        ++rounds;
+        rowsUsed += stop;
+#endif
+        if (__all(allDone)) { finished = true; }
+        else
+        {
+            t -= int32_t(stop);
+            if (t < 0) finished = true; // row 0 is always inclusive: cannot be reached with open digits
+            if (stop == 0)
+            {
+                if (++spins > (1u << 22)) // seconds: something is badly wrong, do not hang the GPU
+                {
+                    if (lane == 0) atomicOr(errors, 1u);
+                    finished = true;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+    }
+    return excl;
+}
+
 /*! @brief rank, permute and scatter one tile whose keys are already in registers
  *
  *  TAIL = false: a full tile of TILE pairs inside the look-back chain (the hot path, no validity predicates)
  *  TAIL = true : the last, partial tile. It sits at the END of every digit bin (it is the last tile in input
  *                order), so its slots follow from the global digit bases alone and it needs no look-back:
- *                first slot of digit d = end(d) - (tail count of d), end(d) = bases[d+1] (n for the last digit)
- *  nextKeys    : if not null, the keys of the workgroup's NEXT tile; they are fetched into key[] as soon as the
- *                current keys sit in LDS, i.e. the loads fly while this tile is looked back and stored */
+ *                first slot of digit d = end(d) - (tail count of d), end(d) = bases[d+1] (n for the last digit) */
 template<class K, int BLOCK, bool TAIL>
 __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCfg<K, BLOCK>::ITEMS],
-                                         const K* __restrict__ nextKeys, uint32_t tile, unsigned tileCount,
+                                         uint32_t tile, unsigned tileCount,
                                          const uint32_t* __restrict__ valsIn,
                                          K* __restrict__ keysOut, uint32_t* __restrict__ valsOut, int shift,
                                          const uint32_t* __restrict__ bases, uint32_t* __restrict__ status,
@@ -247,6 +408,9 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t tileBase = tile * uint32_t(TILE); // n < 2^30: 32-bit index arithmetic throughout
     const unsigned segBase  = wave * (64 * ITEMS);
+#ifdef CSTONE_SORT_TRACE
+    const size_t traceRow = size_t(shift / RADIX_BITS) * (n / TILE + 1) + tile;
+#endif
 
     // values are fetched now so that their latency hides behind the ranking
     uint32_t val[ITEMS];
@@ -256,32 +420,44 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
         unsigned idx = segBase + r * 64 + lane;
         val[r]       = (FULL || idx < tileCount) ? valsIn[tileBase + idx] : 0u;
     }
+#ifdef CSTONE_SORT_TRACE
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); // the keys have arrived, the 16 value loads may still fly
+    SORT_TRACE(2)
+#endif
 
-    // ---- stable in-wave ranking: every lane reads the wave's running count of its digit, the first lane of
-    //      each group of equal digits then adds the group size (LDS executes a wave's accesses in order)
+    // ---- 1. stable in-wave ranking by returning LDS atomics on the wave's private digit counters: ds_add_rtn hands
+    //      the lanes of one instruction that hit the same counter their values in ascending lane order on gfx950
+    //      (probed once per context, ldsOrderProbeKernel), and a wave's LDS instructions execute in order, so
+    //      rank = number of equal digits before this key in (item, lane) order.  A wave-uniform digit (the high
+    //      digits of nearly sorted input) would serialise 64 ways: it takes the arithmetic shortcut instead.
     unsigned rank[ITEMS];
     uint32_t* myHist = sm.waveHist + wave * RADIX;
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r)
     {
-        unsigned d   = unsigned(key[r] >> shift) & (RADIX - 1);
-        uint32_t mlo = ~0u, mhi = ~0u;
-        bool valid   = true;
-        if (!FULL)
+        unsigned d = unsigned(key[r] >> shift) & (RADIX - 1);
+        if (FULL)
         {
-            valid       = segBase + r * 64 + lane < tileCount;
-            uint64_t vm = __ballot(valid);
-            mlo = uint32_t(vm), mhi = uint32_t(vm >> 32);
+            unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+            if (__all(d == d0))
+            {
+                unsigned base = myHist[d0];
+                if (lane == 0) myHist[d0] = base + 64;
+                rank[r] = base + lane;
+            }
+            else { rank[r] = atomicAdd(&myHist[d], 1u); }
         }
-        matchDigit(d, mlo, mhi);
-        unsigned below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-        unsigned base  = myHist[d];
-        if (below == 0 && valid) atomicAdd(&myHist[d], unsigned(__popc(mlo) + __popc(mhi)));
-        rank[r] = base + below;
+        else
+        {
+            bool valid = segBase + r * 64 + lane < tileCount;
+            rank[r]    = valid ? atomicAdd(&myHist[d], 1u) : 0u;
+        }
     }
+    SORT_TRACE(3)
     ldsBarrier();
+    SORT_TRACE(4)
 
-    // ---- digit threads (the first RADIX threads): tile totals and their scan over the digits
+    // ---- 2. digit threads (the first RADIX threads): tile totals and their scan over the digits
     uint32_t total = 0, inc = 0;
     if (tid < RADIX)
     {
@@ -299,14 +475,26 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
         if (lane == 63) sm.scanTmp[wave] = inc;
     }
     ldsBarrier();
-    if (tid < RADIX)
+    SORT_TRACE(5)
+
+    u32x4 base4 = {0, 0, 0, 0};
+    if (!TAIL && wave < unsigned(LB_WAVES))
     {
-        if (!TAIL && wave == 0)
+        // global digit bases of this wave's digit quarter: fetched now, so that no load has to be waited for behind
+        // the INCLUSIVE store below (vmcnt counts stores too: a wait for a younger load would also sit out the
+        // store's round trip)
+        base4 = *reinterpret_cast<const u32x4*>(bases + 64 * wave + 4 * (lane & 15u));
+        if (wave == 0)
         {
             // publish the tile aggregate (tile 0: already the inclusive prefix) as one 1 KiB row
             u32x4 t4 = *reinterpret_cast<const u32x4*>(&sm.total[4 * lane]);
             storeRowSc1(status + size_t(tile) * RADIX + 4 * lane, t4 | (tile == 0 ? STATE_INC : STATE_AGG));
         }
+    }
+
+    // ---- 3. tile-local slot of the first element of every (wave, digit)
+    if (tid < RADIX)
+    {
         uint32_t off = 0;
         for (unsigned w = 0; w < wave; ++w)
             off += sm.scanTmp[w];
@@ -316,13 +504,14 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
         for (int w = 0; w < WAVES; ++w)
         {
             uint32_t c                   = sm.waveHist[w * RADIX + tid];
-            sm.waveHist[w * RADIX + tid] = run; // tile-local slot of the first element of (wave w, digit tid)
+            sm.waveHist[w * RADIX + tid] = run;
             run += c;
         }
     }
     ldsBarrier();
+    SORT_TRACE(6)
 
-    // ---- permute keys into tile-sorted order through LDS
+    // ---- 4. permute keys into tile-sorted order through LDS
     unsigned pos[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r)
@@ -331,16 +520,14 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
         pos[r]     = myHist[d] + rank[r];
         if (FULL || segBase + r * 64 + lane < tileCount) sm.stage[pos[r]] = key[r];
     }
-    // the key registers are free now: start fetching the next tile (wave 0 does so after its look-back, whose
-    // row loads wait on vmcnt(0))
-    if (nextKeys != nullptr && (TAIL || wave != 0))
-    {
+    SORT_TRACE(7)
+    // The value loads are retired HERE, before any store of this tile is issued (the INCLUSIVE row, the keys): vmcnt
+    // counts loads and stores in one queue, a wait for val[] behind a store would sit out its round trip as well.
 #pragma unroll
-        for (int r = 0; r < ITEMS; ++r)
-            key[r] = nextKeys[segBase + r * 64 + lane];
-    }
+    for (int r = 0; r < ITEMS; ++r)
+        asm volatile("" : "+v"(val[r]));
 
-    // ---- global slot of every digit run of this tile
+    // ---- 5. global slot of every digit run of this tile
     if (TAIL)
     {
         if (tid < RADIX)
@@ -349,74 +536,36 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
             sm.binOffset[tid] = end - total - sm.digitStart[tid];
         }
     }
-    else if (wave == 0)
+    else if (wave < unsigned(LB_WAVES))
     {
-        // decoupled look-back by one wave: lane l owns digits 4l..4l+3
-        u32x4 tot  = *reinterpret_cast<const u32x4*>(&sm.total[4 * lane]);
-        u32x4 excl = {0, 0, 0, 0};
-        if (tile > 0)
+#ifdef CSTONE_SORT_TRACE
+        unsigned rounds = 0, rowsUsed = 0;
+        u32x4 excl = quarterLookBack(status, tile, wave, lane, errors, rounds, rowsUsed);
+#else
+        u32x4 excl = quarterLookBack(status, tile, wave, lane, errors);
+#endif
+        asm volatile("" : "+v"(base4)); // pins the wait for base4 here, ahead of the store
+        if (lane < 16)
         {
-            bool done[4]   = {false, false, false, false};
-            int32_t t      = int32_t(tile) - 1;
-            unsigned spins = 0;
-            bool finished  = false;
-            while (!finished)
-            {
-                u32x4 w[LOOKBACK_ROWS];
-                const uint32_t* row = status + 4 * lane;
-                loadRows4Sc1(row + size_t(t) * RADIX, row + size_t(max(t - 1, 0)) * RADIX,
-                             row + size_t(max(t - 2, 0)) * RADIX, row + size_t(max(t - 3, 0)) * RADIX, w);
-                int consumed = 0;
-#pragma unroll
-                for (int r = 0; r < LOOKBACK_ROWS; ++r)
-                {
-                    if (finished || t - r < 0 || consumed != r) continue; // rows are consumed strictly in order
-                    bool ready = true;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        ready = ready && (done[c] || (w[r][c] & ~COUNT_MASK) != 0);
-                    if (!__all(ready)) continue; // this row is not there yet: poll again from here
-                    bool allDone = true;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                    {
-                        if (!done[c])
-                        {
-                            excl[c] += w[r][c] & COUNT_MASK;
-                            done[c] = (w[r][c] & ~COUNT_MASK) == STATE_INC;
-                        }
-                        allDone = allDone && done[c];
-                    }
-                    consumed = r + 1;
-                    if (__all(allDone)) finished = true;
-                }
-                t -= consumed;
-                if (t < 0) finished = true; // row 0 is always inclusive: cannot be reached with open digits
-                if (consumed == 0)
-                {
-                    if (++spins > (1u << 22)) // seconds: something is badly wrong, do not hang the GPU
-                    {
-                        if (lane == 0) atomicOr(errors, 1u);
-                        finished = true;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            storeRowSc1(status + size_t(tile) * RADIX + 4 * lane, ((excl + tot) & COUNT_MASK) | STATE_INC);
+            const unsigned d0 = 64 * wave + 4 * lane;
+            const u32x4 tot   = *reinterpret_cast<const u32x4*>(&sm.total[d0]);
+            if (tile > 0) storeRowSc1(status + size_t(tile) * RADIX + d0, ((excl + tot) & COUNT_MASK) | STATE_INC);
+            const u32x4 start4 = *reinterpret_cast<const u32x4*>(&sm.digitStart[d0]);
+            *reinterpret_cast<u32x4*>(&sm.binOffset[d0]) = base4 + excl - start4;
         }
-        const u32x4 base4  = *reinterpret_cast<const u32x4*>(bases + 4 * lane);
-        const u32x4 start4 = *reinterpret_cast<const u32x4*>(&sm.digitStart[4 * lane]);
-        *reinterpret_cast<u32x4*>(&sm.binOffset[4 * lane]) = base4 + excl - start4;
-        if (nextKeys != nullptr)
+#ifdef CSTONE_SORT_TRACE
+        if (wave == 0)
         {
-#pragma unroll
-            for (int r = 0; r < ITEMS; ++r)
-                key[r] = nextKeys[segBase + r * 64 + lane];
+            SORT_TRACE_VAL(13, rounds)
+            SORT_TRACE_VAL(14, rowsUsed)
+            SORT_TRACE(8)
         }
+#endif
     }
     ldsBarrier();
+    SORT_TRACE(9)
 
-    // ---- stream out keys (remember each slot for the values), then values through the same LDS block
+    // ---- 6. stream out keys (remember each slot for the values), then values through the same LDS block
     uint32_t dst[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k)
@@ -432,6 +581,7 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
             else { atomicOr(errors, 8u); } // cannot happen; turns a would-be wild store into a reported error
         }
     }
+    SORT_TRACE(10)
     ldsBarrier();
     uint32_t* vstage = reinterpret_cast<uint32_t*>(sm.stage);
 #pragma unroll
@@ -440,12 +590,14 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
         if (FULL || segBase + r * 64 + lane < tileCount) vstage[pos[r]] = val[r];
     }
     ldsBarrier();
+    SORT_TRACE(11)
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k)
     {
         unsigned i = k * BLOCK + tid;
         if (dst[k] < n) valsOut[dst[k]] = vstage[i];
     }
+    SORT_TRACE(12)
 }
 
 /*! Full tiles, one per workgroup, tile index by ticket: every lower tile is owned by a workgroup that has started,
@@ -467,6 +619,9 @@ __global__ __launch_bounds__(BLOCK) void onesweepKernel(const K* __restrict__ ke
 
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned segBase = wave * (64 * ITEMS);
+#ifdef CSTONE_SORT_TRACE
+    uint64_t tEntry = wall_clock64();
+#endif
 
     if (tid == 0) sm.tileShared[0] = atomicAdd(ticket, 1u);
     for (int i = tid; i < WAVES * RADIX; i += BLOCK)
@@ -474,11 +629,21 @@ __global__ __launch_bounds__(BLOCK) void onesweepKernel(const K* __restrict__ ke
     __syncthreads();
     const uint32_t tile = sm.tileShared[0];
     if (tile >= numFullTiles) return;
+#ifdef CSTONE_SORT_TRACE
+    const size_t traceRow = size_t(pass) * (n / TILE + 1) + tile;
+    SORT_TRACE_VAL(0, tEntry)
+    SORT_TRACE(1)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    SORT_TRACE_VAL(15, (uint64_t(xcc) << 32) | hwid)
+#endif
     K key[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r)
         key[r] = keysIn[tile * uint32_t(TILE) + segBase + r * 64 + lane];
-    sortTile<K, BLOCK, false>(sm, key, nullptr, tile, unsigned(TILE), valsIn, keysOut, valsOut, pass * RADIX_BITS,
+    sortTile<K, BLOCK, false>(sm, key, tile, unsigned(TILE), valsIn, keysOut, valsOut, pass * RADIX_BITS,
                               bases, status, errors, n);
 }
 
@@ -508,7 +673,7 @@ __global__ __launch_bounds__(BLOCK) void onesweepTailKernel(const K* __restrict_
         key[r]       = idx < tileCount ? keysIn[tileBase + idx] : K(~K(0));
     }
     ldsBarrier();
-    sortTile<K, BLOCK, true>(sm, key, nullptr, numFullTiles, tileCount, valsIn, keysOut, valsOut, pass * RADIX_BITS, bases,
+    sortTile<K, BLOCK, true>(sm, key, numFullTiles, tileCount, valsIn, keysOut, valsOut, pass * RADIX_BITS, bases,
                              nullptr, errors, n);
 }
 
@@ -586,6 +751,20 @@ int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt
     size_t need = sortTempBytes<K>(n);
     if (tempBytes < need) return fail(ctx, CSTONE_E_CAPACITY, "sort_pairs: temp %zu < %zu bytes", tempBytes, need);
 
+    if (ctx->ldsOrderOk < 0)
+    {
+        uint32_t* flag = (uint32_t*)ctx->devScalars + 62;
+        CS_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(ldsOrderProbeKernel, 8, 1024, 0, ctx->stream, flag);
+        ctx->hostScalars[62] = 1;
+        CS_HIP(ctx, hipMemcpyAsync(ctx->hostScalars + 62, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->ldsOrderOk = ctx->hostScalars[62] == 0;
+    }
+    if (!ctx->ldsOrderOk)
+        return fail(ctx, CSTONE_E_INTERNAL, "sort_pairs: LDS atomics of this device are not served in lane order; "
+                                            "the stable ranking of the radix sort cannot be used");
+
     constexpr int P = sizeof(K);
     auto* words     = (uint32_t*)temp;
     SortTemp t;
@@ -606,9 +785,37 @@ int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt
         hipLaunchKernelGGL(histogramKernel<K>, grid, HIST_BLOCK, 0, ctx->stream, keys, n, t.hist);
         hipLaunchKernelGGL(scanHistogramKernel, P, RADIX, 0, ctx->stream, t.hist);
     }
+#ifdef CSTONE_SORT_TRACE
+    const char* traceFile = std::getenv("CSTONE_SORT_TRACE_FILE");
+    uint64_t* traceDev    = nullptr;
+    size_t traceWords     = size_t(P) * (n / tile + 1) * TRACE_SLOTS;
+    if (traceFile)
+    {
+        CS_HIP(ctx, hipMalloc((void**)&traceDev, traceWords * 8));
+        CS_HIP(ctx, hipMemsetAsync(traceDev, 0, traceWords * 8, ctx->stream));
+    }
+    CS_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sortTrace), &traceDev, sizeof(traceDev), 0, hipMemcpyHostToDevice,
+                                       ctx->stream));
+#endif
     if (large) launchPasses<K, LARGE_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt);
     else launchPasses<K, SMALL_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt);
     CS_HIP(ctx, hipGetLastError());
+#ifdef CSTONE_SORT_TRACE
+    if (traceFile)
+    {
+        std::vector<uint64_t> host(traceWords);
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        CS_HIP(ctx, hipMemcpy(host.data(), traceDev, traceWords * 8, hipMemcpyDeviceToHost));
+        CS_HIP(ctx, hipFree(traceDev));
+        if (FILE* f = std::fopen(traceFile, "wb"))
+        {
+            uint64_t hdr[4] = {uint64_t(P), uint64_t(n / tile + 1), uint64_t(TRACE_SLOTS), uint64_t(tile)};
+            std::fwrite(hdr, 8, 4, f);
+            std::fwrite(host.data(), 8, traceWords, f);
+            std::fclose(f);
+        }
+    }
+#endif
     return CSTONE_OK;
 }
 

@@ -1,10 +1,17 @@
 cd $GRAFT_REPO_ROOT
-echo "== full parity" > gpurun_out/variants.log
-timeout -k 10 600 python -m pytest tests -m gpu -q 2>&1 | tail -4 >> gpurun_out/variants.log
-for args in "--n 3e5" "--n 6e4"; do
-  for lm in 1 100000000000; do
-    echo "== $args large_min=$lm" >> gpurun_out/variants.log
-    CSTONE_SORT_LARGE_MIN=$lm timeout -k 10 100 python3 tools/sort_bench.py --reps 2 $args 2>&1 | tail -2 >> gpurun_out/variants.log
-  done
+# usage: runvar.sh [variant ...]   -- parity, sort bench of the default build, then of every named variant, trace report
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; tail -2 gpurun_out/gpu_tests.log
+: > gpurun_out/variants.log
+for args in "" "--sorted" "--key-bits 32"; do
+  echo "== default $args" >> gpurun_out/variants.log
+  timeout -k 10 100 python3 tools/sort_bench.py --reps 3 $args 2>&1 | tail -1 >> gpurun_out/variants.log
 done
-timeout -k 10 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline >> gpurun_out/variants.log 2>&1
+for v in "$@"; do
+  echo "== $v" >> gpurun_out/variants.log
+  CSTONE_HIP_LIB=$PWD/cornerstone-octree_amd/lib/variants/$v.so timeout -k 10 100 python3 tools/sort_bench.py --reps 3 2>&1 | tail -1 >> gpurun_out/variants.log
+done
+cat gpurun_out/variants.log
+if [ -f cornerstone-octree_amd/lib/variants/trace.so ]; then
+  CSTONE_HIP_LIB=$PWD/cornerstone-octree_amd/lib/variants/trace.so CSTONE_SORT_TRACE_FILE=$PWD/gpurun_out/trace.bin timeout -k 10 200 python tools/sort_bench.py --reps 1 > gpurun_out/trace_run.log 2>&1
+  python tools/sort_trace.py gpurun_out/trace.bin > gpurun_out/trace_report.txt; rm -f gpurun_out/trace.bin; head -4 gpurun_out/trace_report.txt
+fi
