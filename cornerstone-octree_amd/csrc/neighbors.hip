@@ -3,11 +3,15 @@
 // |r_i - r_j|^2 < (2 h_i)^2, stored in the order of its depth-first traversal (children 0..7, last
 // pushed popped first), true count returned even beyond ngmax.
 //
-// v0 layout: one lane per target particle, depth-first like the CPU path so the stored lists are
-// identical element for element; the per-lane traversal stack (160 entries >= 7*21+1, the deepest a
-// depth-first octree walk can get) lives in a scratch slice of the context arena and targets are
-// processed in chunks of 2^21 so that scratch stays bounded.  Overflow is reported through the sticky
-// error word.  (A wave-cooperative variant with an LDS particle queue is the planned v1.)
+// Layout: one WAVE per 64 consecutive target particles (neighbours in SFC order, so their search spheres
+// cover almost the same tree nodes) and ONE traversal per wave.  Every stack entry carries the 64-bit mask of
+// the lanes whose own depth-first walk would have reached that node (own overlap test passed on the node and on
+// all its ancestors); a node is visited while any lane is still interested, leaf particles are fetched once
+// per wave through wave-uniform (scalar) loads and tested by the interested lanes.  Each lane therefore sees
+// exactly the leaves, in exactly the order, of the reference's per-particle walk (the relative order of two
+// leaves is decided at their lowest common ancestor and does not depend on what else is visited), so the
+// stored lists are identical element for element.  The traversal stack (160 entries >= 7*21+1, the deepest a
+// depth-first octree walk can get) lives in LDS; overflow is reported through the sticky error word.
 // Compiled with -ffp-contract=off: distances must round like the CPU path (no FMA).
 #include <algorithm>
 
@@ -20,7 +24,8 @@ namespace cship
 namespace
 {
 
-constexpr int NB_BLOCK = 128;
+constexpr int NB_BLOCK = 256;
+constexpr int NB_WAVES = NB_BLOCK / 64;
 constexpr int NB_STACK = 160; // >= 7 * 21 + 1
 
 template<class T, bool PBC>
@@ -31,18 +36,24 @@ __device__ __forceinline__ T foldAxis(T dx, T len, T inv, bool periodic)
     return dx;
 }
 
+__device__ __forceinline__ NodeIdx uniform(NodeIdx v) { return __builtin_amdgcn_readfirstlane(v); }
+
 template<class T>
 __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
     const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, const T* __restrict__ h, uint32_t first,
     uint32_t last, DBox<T> box, const NodeIdx* __restrict__ childOffsets, const NodeIdx* __restrict__ internalToLeaf,
     const uint32_t* __restrict__ layout, const T* __restrict__ centers, const T* __restrict__ sizes, float ext,
-    uint32_t ngmax, uint32_t* __restrict__ neighbors, uint32_t* __restrict__ counts, NodeIdx* __restrict__ stackMem,
-    int* __restrict__ errors)
+    uint32_t ngmax, uint32_t* __restrict__ neighbors, uint32_t* __restrict__ counts, int* __restrict__ errors)
 {
-    uint32_t tid = blockIdx.x * NB_BLOCK + threadIdx.x;
-    uint32_t i   = first + tid;
-    if (i >= last) return;
-    NodeIdx* stack = stackMem + size_t(tid) * NB_STACK;
+    __shared__ NodeIdx stackNode[NB_WAVES][NB_STACK];
+    __shared__ uint64_t stackMask[NB_WAVES][NB_STACK];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    NodeIdx* sNode  = stackNode[wave];
+    uint64_t* sMask = stackMask[wave];
+
+    const uint32_t tid = blockIdx.x * NB_BLOCK + threadIdx.x;
+    const bool valid   = first + tid < last;
+    const uint32_t i   = valid ? first + tid : last - 1;
 
     const T xi = x[i], yi = y[i], zi = z[i];
     const T hi = h[i];
@@ -57,6 +68,7 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
     uint32_t* out = neighbors + size_t(tid) * ngmax;
     uint32_t nn   = 0;
 
+    // n is wave-uniform: centers and sizes come through the scalar cache
     auto overlaps = [&](NodeIdx n) -> bool
     {
         T dx = centers[3 * n] - xi, dy = centers[3 * n + 1] - yi, dz = centers[3 * n + 2] - zi;
@@ -71,12 +83,13 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
         dx *= T(0.5), dy *= T(0.5), dz *= T(0.5);
         return dx * dx + (dy * dy + dz * dz) < cellSq; // right fold, R/util/array.hpp:253-256
     };
-    auto searchLeaf = [&](NodeIdx n)
+    // all particles of leaf node n against the lanes that reached it
+    auto searchLeaf = [&](NodeIdx n, bool mine)
     {
-        NodeIdx leaf = internalToLeaf[n];
-        for (uint32_t j = layout[leaf]; j < layout[leaf + 1]; ++j)
+        NodeIdx leaf      = uniform(internalToLeaf[n]);
+        const uint32_t jb = uniform(layout[leaf]), je = uniform(layout[leaf + 1]);
+        for (uint32_t j = jb; j < je; ++j)
         {
-            if (j == i) continue;
             T dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
             if (usePbc)
             {
@@ -84,7 +97,7 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
                 dy = foldAxis<T, true>(dy, box.len[1], box.inv[1], py);
                 dz = foldAxis<T, true>(dz, box.len[2], box.inv[2], pz);
             }
-            if (dx * dx + dy * dy + dz * dz < radSq)
+            if (mine && j != i && dx * dx + dy * dy + dz * dz < radSq)
             {
                 if (nn < ngmax) out[nn] = j;
                 ++nn;
@@ -92,31 +105,54 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
         }
     };
 
-    // depth-first walk, R/traversal/traversal.hpp:69-110
-    if (overlaps(0))
+    // depth-first walk of R/traversal/traversal.hpp:69-110, once per wave
+    bool ov0      = valid && overlaps(0);
+    uint64_t root = __ballot(ov0);
+    if (root != 0)
     {
-        if (childOffsets[0] == 0) { searchLeaf(0); }
+        if (uniform(childOffsets[0]) == 0) { searchLeaf(0, ov0); }
         else
         {
-            int top    = 1;
-            stack[0]   = 0;
-            NodeIdx node = 0;
+            int top = 1;
+            if (lane == 0)
+            {
+                sNode[0] = 0;
+                sMask[0] = root;
+            }
+            NodeIdx node  = 0;
+            uint64_t mask = root;
             do
             {
-                NodeIdx c0 = childOffsets[node];
+                const NodeIdx c0 = uniform(childOffsets[node]);
+                const bool here  = (mask >> lane) & 1ull;
+#pragma unroll 1
                 for (int oct = 0; oct < 8; ++oct)
                 {
-                    NodeIdx child = c0 + oct;
-                    if (!overlaps(child)) continue;
-                    if (childOffsets[child] == 0) { searchLeaf(child); }
-                    else if (top < NB_STACK) { stack[top++] = child; }
-                    else { atomicOr(errors, 4); }
+                    const NodeIdx child = c0 + oct;
+                    const bool ov       = here && overlaps(child);
+                    const uint64_t cm   = __ballot(ov);
+                    if (cm == 0) continue;
+                    if (uniform(childOffsets[child]) == 0) { searchLeaf(child, ov); }
+                    else if (top < NB_STACK)
+                    {
+                        if (lane == 0)
+                        {
+                            sNode[top] = child;
+                            sMask[top] = cm;
+                        }
+                        ++top;
+                    }
+                    else if (lane == 0) { atomicOr(errors, 4); }
                 }
-                node = stack[--top];
+                --top;
+                node = uniform(sNode[top]);
+                mask = sMask[top];
+                mask = (uint64_t(__builtin_amdgcn_readfirstlane(uint32_t(mask >> 32))) << 32) |
+                       __builtin_amdgcn_readfirstlane(uint32_t(mask));
             } while (node != 0);
         }
     }
-    counts[tid] = nn;
+    if (valid) counts[tid] = nn;
 }
 
 } // namespace
@@ -137,34 +173,22 @@ extern "C" int cstone_hip_find_neighbors(cstone_hip_ctx* ctx, int real_bits, con
         return fail(ctx, CSTONE_E_ARG, "find_neighbors: bad argument");
     if (last == first) return CSTONE_OK;
     if (real_bits != 32 && real_bits != 64) return fail(ctx, CSTONE_E_ARG, "find_neighbors: real_bits %d unsupported", real_bits);
-    size_t nw    = last - first;
-    size_t chunk = std::min<size_t>(nw, size_t(1) << 21);
-    CS_TRY(arenaReserve(ctx, chunk * NB_STACK * sizeof(NodeIdx) + 1024));
-    auto* stackMem = (NodeIdx*)arenaTake(ctx, chunk * NB_STACK * sizeof(NodeIdx));
-    int* errors    = ctx->devScalars + 63;
+    size_t nw   = last - first;
+    int* errors = ctx->devScalars + 63;
     {
         StageTimer timer(ctx, CSTONE_STAGE_NEIGHBORS);
-        for (size_t off = 0; off < nw; off += chunk)
-        {
-            uint32_t f = first + uint32_t(off);
-            uint32_t l = uint32_t(std::min<size_t>(size_t(last), size_t(f) + chunk));
-            unsigned grid = gridFor(l - f, NB_BLOCK);
-            uint32_t* nbOut = neighbors ? neighbors + off * ngmax : nullptr;
-            if (real_bits == 32)
-                hipLaunchKernelGGL(findNeighborsKernel<float>, grid, NB_BLOCK, 0, ctx->stream, (const float*)x,
-                                   (const float*)y, (const float*)z, (const float*)h, f, l,
-                                   makeDBox<float>(*box_host), child_offsets, internal_to_leaf, layout,
-                                   (const float*)centers, (const float*)sizes, ext, ngmax, nbOut, counts + off,
-                                   stackMem, errors);
-            else
-                hipLaunchKernelGGL(findNeighborsKernel<double>, grid, NB_BLOCK, 0, ctx->stream, (const double*)x,
-                                   (const double*)y, (const double*)z, (const double*)h, f, l,
-                                   makeDBox<double>(*box_host), child_offsets, internal_to_leaf, layout,
-                                   (const double*)centers, (const double*)sizes, ext, ngmax, nbOut, counts + off,
-                                   stackMem, errors);
-        }
+        unsigned grid = gridFor(nw, NB_BLOCK);
+        if (real_bits == 32)
+            hipLaunchKernelGGL(findNeighborsKernel<float>, grid, NB_BLOCK, 0, ctx->stream, (const float*)x,
+                               (const float*)y, (const float*)z, (const float*)h, first, last,
+                               makeDBox<float>(*box_host), child_offsets, internal_to_leaf, layout,
+                               (const float*)centers, (const float*)sizes, ext, ngmax, neighbors, counts, errors);
+        else
+            hipLaunchKernelGGL(findNeighborsKernel<double>, grid, NB_BLOCK, 0, ctx->stream, (const double*)x,
+                               (const double*)y, (const double*)z, (const double*)h, first, last,
+                               makeDBox<double>(*box_host), child_offsets, internal_to_leaf, layout,
+                               (const double*)centers, (const double*)sizes, ext, ngmax, neighbors, counts, errors);
     }
-    arenaReset(ctx);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

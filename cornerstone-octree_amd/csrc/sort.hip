@@ -260,6 +260,22 @@ struct alignas(16) SortSmem
 
 //! sixteen quarter-rows in flight: 4 instructions, each lane group of 16 lanes addresses its own row.  The wait is
 //! part of the statement because the compiler does not track loads issued from inline asm.
+__device__ __forceinline__ void loadQuarterRows32Sc1(const uint32_t* const (&p)[8], u32x4 (&w)[8])
+{
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                 "global_load_dwordx4 %1, %9, off sc1\n\t"
+                 "global_load_dwordx4 %2, %10, off sc1\n\t"
+                 "global_load_dwordx4 %3, %11, off sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off sc1\n\t"
+                 "global_load_dwordx4 %5, %13, off sc1\n\t"
+                 "global_load_dwordx4 %6, %14, off sc1\n\t"
+                 "global_load_dwordx4 %7, %15, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+                 : "memory");
+}
+
 __device__ __forceinline__ void loadQuarterRows16Sc1(const uint32_t* p0, const uint32_t* p1, const uint32_t* p2,
                                                      const uint32_t* p3, u32x4 (&w)[4])
 {
@@ -273,9 +289,27 @@ __device__ __forceinline__ void loadQuarterRows16Sc1(const uint32_t* p0, const u
                  : "memory");
 }
 
-constexpr int LB_WAVES = 4;       // look-back waves: wave w owns the digits 64w .. 64w+63
-constexpr int LB_ROWS  = 16;      // status rows per look-back round
-constexpr unsigned LB_NONE = 255; // "no INCLUSIVE word met"
+#ifndef CSTONE_LB_INSTR
+#define CSTONE_LB_INSTR 4
+#endif
+constexpr int LB_WAVES = 4;                   // look-back waves: wave w owns the digits 64w .. 64w+63
+constexpr int LB_INSTR = CSTONE_LB_INSTR;     // 4 or 8 load instructions per round
+constexpr int LB_ROWS  = 4 * LB_INSTR;        // status rows per look-back round
+constexpr unsigned LB_NONE = 255;
+
+__device__ __forceinline__ void loadQuarterRows(const uint32_t* col, int32_t t, int32_t g, u32x4 (&w)[4])
+{
+    loadQuarterRows16Sc1(col + size_t(max(t - g, 0)) * RADIX, col + size_t(max(t - 4 - g, 0)) * RADIX,
+                         col + size_t(max(t - 8 - g, 0)) * RADIX, col + size_t(max(t - 12 - g, 0)) * RADIX, w);
+}
+__device__ __forceinline__ void loadQuarterRows(const uint32_t* col, int32_t t, int32_t g, u32x4 (&w)[8])
+{
+    const uint32_t* p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        p[i] = col + size_t(max(t - 4 * i - g, 0)) * RADIX;
+    loadQuarterRows32Sc1(p, w);
+} // "no INCLUSIVE word met"
 
 /*! @brief decoupled look-back of one digit quarter by one wave, 16 status rows per round trip
  *
@@ -304,15 +338,13 @@ __device__ __forceinline__ u32x4 quarterLookBack(const uint32_t* __restrict__ st
     bool finished  = t < 0;
     while (!finished)
     {
-        u32x4 w[4];
-        loadQuarterRows16Sc1(col + size_t(max(t - int32_t(g), 0)) * RADIX, col + size_t(max(t - 4 - int32_t(g), 0)) * RADIX,
-                             col + size_t(max(t - 8 - int32_t(g), 0)) * RADIX,
-                             col + size_t(max(t - 12 - int32_t(g), 0)) * RADIX, w);
+        u32x4 w[LB_INSTR];
+        loadQuarterRows(col, t, int32_t(g), w);
         // first row (0 = tile t) whose quarter is not completely published; rows before tile 0 do not exist and
         // are never reached (row 0 is INCLUSIVE for every digit)
         unsigned stop = LB_ROWS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < LB_INSTR; ++i)
         {
             bool exists = t - 4 * i - int32_t(g) >= 0;
             bool ready  = true;
@@ -327,7 +359,7 @@ __device__ __forceinline__ u32x4 quarterLookBack(const uint32_t* __restrict__ st
         // per digit: nearest usable row holding an INCLUSIVE word
         unsigned first[4] = {LB_NONE, LB_NONE, LB_NONE, LB_NONE};
 #pragma unroll
-        for (int i = 3; i >= 0; --i)
+        for (int i = LB_INSTR - 1; i >= 0; --i)
         {
             unsigned rho = 4 * i + g;
             bool usable  = rho < stop && t - int32_t(rho) >= 0;
@@ -343,7 +375,7 @@ __device__ __forceinline__ u32x4 quarterLookBack(const uint32_t* __restrict__ st
         }
         u32x4 sum = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < LB_INSTR; ++i)
         {
             unsigned rho = 4 * i + g;
             bool usable  = rho < stop && t - int32_t(rho) >= 0;
