@@ -83,26 +83,40 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
         dx *= T(0.5), dy *= T(0.5), dz *= T(0.5);
         return dx * dx + (dy * dy + dz * dz) < cellSq; // right fold, R/util/array.hpp:253-256
     };
-    // all particles of leaf node n against the lanes that reached it
+    // all particles of leaf node n against the lanes that reached it; coordinates are fetched four particles at a
+    // time so that the scalar loads of a batch are in flight together
+    auto testParticle = [&](uint32_t j, T xj, T yj, T zj, bool mine)
+    {
+        T dx = xj - xi, dy = yj - yi, dz = zj - zi;
+        if (usePbc)
+        {
+            dx = foldAxis<T, true>(dx, box.len[0], box.inv[0], px);
+            dy = foldAxis<T, true>(dy, box.len[1], box.inv[1], py);
+            dz = foldAxis<T, true>(dz, box.len[2], box.inv[2], pz);
+        }
+        if (mine && j != i && dx * dx + dy * dy + dz * dz < radSq)
+        {
+            if (nn < ngmax) out[nn] = j;
+            ++nn;
+        }
+    };
     auto searchLeaf = [&](NodeIdx n, bool mine)
     {
         NodeIdx leaf      = uniform(internalToLeaf[n]);
         const uint32_t jb = uniform(layout[leaf]), je = uniform(layout[leaf + 1]);
-        for (uint32_t j = jb; j < je; ++j)
+        uint32_t j = jb;
+        for (; j + 4 <= je; j += 4)
         {
-            T dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
-            if (usePbc)
-            {
-                dx = foldAxis<T, true>(dx, box.len[0], box.inv[0], px);
-                dy = foldAxis<T, true>(dy, box.len[1], box.inv[1], py);
-                dz = foldAxis<T, true>(dz, box.len[2], box.inv[2], pz);
-            }
-            if (mine && j != i && dx * dx + dy * dy + dz * dz < radSq)
-            {
-                if (nn < ngmax) out[nn] = j;
-                ++nn;
-            }
+            T xa[4], ya[4], za[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                xa[k] = x[j + k], ya[k] = y[j + k], za[k] = z[j + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                testParticle(j + k, xa[k], ya[k], za[k], mine);
         }
+        for (; j < je; ++j)
+            testParticle(j, x[j], y[j], z[j], mine);
     };
 
     // depth-first walk of R/traversal/traversal.hpp:69-110, once per wave
