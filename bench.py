@@ -36,6 +36,8 @@ def parse():
     p.add_argument("--curve", default="hilbert", choices=["hilbert", "morton"])
     p.add_argument("--bucket-focus", type=int, default=64)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--neighbor-targets", type=float, default=1e7,
+                   help="after the timed region: findNeighbors for this many particles of the synced domain (0: skip)")
     p.add_argument("--cpu-sample", type=float, default=4e6, help="particles in the CPU baseline sample")
     return p.parse_args()
 
@@ -73,6 +75,33 @@ class SyncPipeline:
         self.f_leaves, self.g_leaves = v.num_focus_leaves, v.num_global_leaves
 
     first_sync = step
+
+    def find_neighbors(self, targets, ngmax):
+        """cstone_hip_find_neighbors on the synced domain's own tree view (NOT part of the timed metric)"""
+        import ctypes as C
+
+        import torch
+
+        v = self.dom.view()
+        n = v.end_index - v.start_index
+        nt = min(int(targets), n)
+        first = v.start_index + (n - nt) // 2
+        counts = torch.zeros(nt, dtype=torch.int32, device=self.x.device)
+        nidx = torch.zeros(max(1, nt * ngmax), dtype=torch.int32, device=self.x.device)
+        ctx = self.ctx
+        ctx.profile_reset()
+        P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        rc = ctx.lib.cstone_hip_find_neighbors(ctx.h, C.c_int(self.rb), P(self.x), P(self.y), P(self.z), P(self.h),
+                                               C.c_uint32(first), C.c_uint32(first + nt), C.byref(v.box),
+                                               C.c_void_p(v.child_offsets), C.c_void_p(v.internal_to_leaf),
+                                               C.c_void_p(v.layout), C.c_void_p(v.centers), C.c_void_p(v.sizes),
+                                               C.c_float(1.0), C.c_uint32(ngmax), P(nidx) if ngmax else None,
+                                               P(counts))
+        ctx._chk(rc, "find_neighbors")
+        ctx.sync()
+        ms, _ = ctx.profile_get("neighbors")
+        return {"targets": nt, "ngmax": ngmax, "ms": ms, "targets_per_s": nt / (ms * 1e-3) if ms > 0 else None,
+                "mean_neighbors": float(counts.double().mean().item()), "max_neighbors": int(counts.max().item())}
 
 
 class DistributedPipeline:
@@ -256,6 +285,10 @@ def main():
         n_sorted = pipe.assigned
     pass_ms, pass_launches = ctx.profile_get("sort_pass")
     stage_ms = {s: ctx.profile_get(s)[0] / args.steps for s in cstone_amd.STAGES}
+    extras = {}
+    if not distributed and args.neighbor_targets > 0:
+        extras["find_neighbors"] = [pipe.find_neighbors(args.neighbor_targets, 0),
+                                    pipe.find_neighbors(args.neighbor_targets, 128)]
     ctx.profile_enable(False)
     ctx.sync()  # raises if a device-side check tripped
 
@@ -300,6 +333,7 @@ def main():
                          "traffic": traffic, "bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3,
                          "launches": pass_launches},
             "stage_ms_per_step": stage_ms,
+            "extras": extras,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample), args.key_bits, args.real_bits, args.curve,

@@ -234,33 +234,35 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
     }
 }
 
-//! radii[leaf] for leaf in [first,last): float(max(h[layout[k]..layout[k+1])) * 2 * ext); one wave per leaf
+//! radii[leaf] for leaf in [first,last): float(max(h[layout[k]..layout[k+1])) * 2 * ext); 16 lanes per leaf (a leaf
+//! holds a few dozen particles: whole waves per leaf would mostly idle and launch 4x as many waves)
+constexpr int RADII_LEAVES_PER_BLOCK = 16;
 template<class Th>
 __global__ __launch_bounds__(256) void haloRadiiKernel(const Th* __restrict__ h, const uint32_t* __restrict__ layout,
                                                        NodeIdx first, NodeIdx last, float ext, float* __restrict__ radii)
 {
-    const unsigned lane = threadIdx.x & 63u;
-    NodeIdx k = NodeIdx(blockIdx.x) * 4 + NodeIdx(threadIdx.x >> 6);
-    if (first + k >= last) return;
+    const unsigned sub = threadIdx.x & 15u;
+    NodeIdx k = NodeIdx(blockIdx.x) * RADII_LEAVES_PER_BLOCK + NodeIdx(threadIdx.x >> 4);
+    if (first + k >= last) return; // whole 16-lane groups leave together: the shuffles below stay inside a group
     uint32_t a = layout[k], b = layout[k + 1];
     float out = 0.0f;
     if (b > a)
     {
         Th m = h[a];
-        for (uint32_t i = a + lane; i < b; i += 64)
+        for (uint32_t i = a + sub; i < b; i += 16)
         {
             Th v = h[i];
             m    = v > m ? v : m;
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
+        for (int o = 8; o > 0; o >>= 1)
         {
             Th t = __shfl_xor(m, o);
             m    = t > m ? t : m;
         }
         out = float(m * 2 * ext); // Th*int -> Th, then *float in the common type, halos.hpp:176
     }
-    if (lane == 0) radii[first + k] = out;
+    if (sub == 0) radii[first + k] = out;
 }
 
 } // namespace
@@ -281,7 +283,7 @@ int cstone_hip_halo_radii(cstone_hip_ctx* ctx, int h_bits, const void* h, const 
     StageTimer timer(ctx, CSTONE_STAGE_HALOS);
     CS_HIP(ctx, hipMemsetAsync(radii, 0, size_t(num_leaves) * sizeof(float), ctx->stream));
     if (last == first) return CSTONE_OK;
-    unsigned grid = gridFor(size_t(last - first), 4);
+    unsigned grid = gridFor(size_t(last - first), RADII_LEAVES_PER_BLOCK);
     if (h_bits == 32)
         hipLaunchKernelGGL(haloRadiiKernel<float>, grid, 256, 0, ctx->stream, (const float*)h, layout, first, last, ext,
                            radii);

@@ -155,16 +155,61 @@ __device__ __forceinline__ void blockMinMax(T& lo, T& hi, T* smin, T* smax)
     }
 }
 
+//! grid-stride min/max with 16-byte loads, four of them in flight per lane
 template<class T>
 __global__ __launch_bounds__(256) void minMaxPartialKernel(const T* __restrict__ x, size_t n, T* __restrict__ partial)
 {
+    constexpr int VEC = 16 / sizeof(T);
+    struct alignas(16) Pack
+    {
+        T v[VEC];
+    };
     __shared__ T smin[4], smax[4];
     T lo = x[0], hi = x[0];
-    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256)
+    // head up to the first 16-byte boundary and tail beyond the last full pack: first block, scalar
+    size_t head      = (VEC - (reinterpret_cast<uintptr_t>(x) / sizeof(T)) % VEC) % VEC;
+    head             = head < n ? head : n;
+    const size_t nPk = (n - head) / VEC;
+    const Pack* px   = reinterpret_cast<const Pack*>(x + head);
+    const size_t stride = size_t(gridDim.x) * 256;
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    for (; i + 3 * stride < nPk; i += 4 * stride)
     {
-        T v = x[i];
-        lo  = v < lo ? v : lo;
-        hi  = v > hi ? v : hi;
+        Pack p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            p[k] = px[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+            {
+                lo = p[k].v[j] < lo ? p[k].v[j] : lo;
+                hi = p[k].v[j] > hi ? p[k].v[j] : hi;
+            }
+    }
+    for (; i < nPk; i += stride)
+    {
+        Pack p = px[i];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+        {
+            lo = p.v[j] < lo ? p.v[j] : lo;
+            hi = p.v[j] > hi ? p.v[j] : hi;
+        }
+    }
+    if (blockIdx.x == 0)
+    {
+        for (size_t j = threadIdx.x; j < head; j += 256)
+        {
+            lo = x[j] < lo ? x[j] : lo;
+            hi = x[j] > hi ? x[j] : hi;
+        }
+        for (size_t j = head + nPk * VEC + threadIdx.x; j < n; j += 256)
+        {
+            lo = x[j] < lo ? x[j] : lo;
+            hi = x[j] > hi ? x[j] : hi;
+        }
     }
     blockMinMax(lo, hi, smin, smax);
     if (threadIdx.x == 0) partial[2 * blockIdx.x] = lo, partial[2 * blockIdx.x + 1] = hi;
@@ -189,7 +234,7 @@ template<class T>
 int minMax(cstone_hip_ctx* ctx, const T* x, size_t n, double* out2)
 {
     if (n == 0) return fail(ctx, CSTONE_E_ARG, "minmax: empty range");
-    unsigned grid = unsigned(std::min<size_t>(size_t(ctx->numCu) * 4, (n + 255) / 256));
+    unsigned grid = unsigned(std::min<size_t>(size_t(ctx->numCu) * 8, (n + 255) / 256));
     CS_TRY(arenaReserve(ctx, alignUp(size_t(grid) * 2 * sizeof(T)) + 1024));
     T* partial = (T*)arenaTake(ctx, size_t(grid) * 2 * sizeof(T));
     T* out     = (T*)arenaTake(ctx, 2 * sizeof(T));

@@ -159,6 +159,15 @@ def test_minmax_and_scans(hip, rb):
         x = rng.normal(0, 10, n).astype(real_dtype(rb))
         lo, hi = hip.minmax(dev(x))
         assert lo == x.min() and hi == x.max()
+    # unaligned starts (the kernel reads 16-byte packs) with the extremes in the scalar head / tail
+    x = rng.normal(0, 10, 300007).astype(real_dtype(rb))
+    xd = dev(x)
+    for off in (1, 2, 3):
+        sub = x[off:off + 300000].copy()
+        sub[0], sub[-1] = 1e6, -1e6
+        xd[off:off + 300000].copy_(dev(sub))
+        lo, hi = hip.minmax(xd[off:off + 300000])
+        assert lo == -1e6 and hi == 1e6
     for n in (1, 255, 2048, 2049, 100000, 3000001):
         v = rng.integers(0, 100, n, dtype=np.uint32)
         vd = dev(v)
