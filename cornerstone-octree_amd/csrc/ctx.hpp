@@ -93,6 +93,9 @@ struct StageTimer
     ~StageTimer();
 };
 
+//! min/max of up to three equally long coordinate arrays, out = {min0, max0, min1, max1, ...} (primitives.hip)
+int minMaxCoordinates(cstone_hip_ctx* ctx, int real_bits, const void* const* xs, int numArrays, size_t n, double* out);
+
 inline unsigned gridFor(size_t n, unsigned block, unsigned perThread = 1)
 {
     size_t per = size_t(block) * perThread;

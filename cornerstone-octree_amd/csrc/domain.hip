@@ -179,11 +179,23 @@ public:
 
         // ---- GlobalAssignment::assign (assignment.hpp:57-103): box, keys, sort, one global-tree step
         double lim[6];
-        void* coords[3] = {*xPP, *yPP, *zPP};
-        for (int d = 0; d < 3; ++d)
         {
-            if (box_.bc[d] == 1) { lim[2 * d] = box_.lim[2 * d], lim[2 * d + 1] = box_.lim[2 * d + 1]; }
-            else { CS_TRY(cstone_hip_minmax(ctx_, rb, coords[d], n, lim + 2 * d)); }
+            // extents of the open dimensions in one launch and one read-back (MinMaxGpu x3 in the reference)
+            const void* open[3];
+            int dims[3], numOpen = 0;
+            void* coords[3] = {*xPP, *yPP, *zPP};
+            for (int d = 0; d < 3; ++d)
+            {
+                if (box_.bc[d] == 1) { lim[2 * d] = box_.lim[2 * d], lim[2 * d + 1] = box_.lim[2 * d + 1]; }
+                else { open[numOpen] = coords[d], dims[numOpen++] = d; }
+            }
+            if (numOpen)
+            {
+                double ext[6];
+                CS_TRY(minMaxCoordinates(ctx_, rb, open, numOpen, n, ext));
+                for (int i = 0; i < numOpen; ++i)
+                    lim[2 * dims[i]] = ext[2 * i], lim[2 * dims[i] + 1] = ext[2 * i + 1];
+            }
         }
         if (firstCall_) { std::copy(lim, lim + 6, box_.lim); }
         else

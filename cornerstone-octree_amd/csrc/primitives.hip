@@ -157,8 +157,16 @@ __device__ __forceinline__ void blockMinMax(T& lo, T& hi, T* smin, T* smax)
 
 //! grid-stride min/max with 16-byte loads, four of them in flight per lane
 template<class T>
-__global__ __launch_bounds__(256) void minMaxPartialKernel(const T* __restrict__ x, size_t n, T* __restrict__ partial)
+struct MinMaxArrays
 {
+    const T* x[3];
+};
+
+template<class T>
+__global__ __launch_bounds__(256) void minMaxPartialKernel(MinMaxArrays<T> arrays, size_t n, T* __restrict__ partialAll)
+{
+    const T* __restrict__ x = arrays.x[blockIdx.y];
+    T* __restrict__ partial = partialAll + size_t(blockIdx.y) * gridDim.x * 2;
     constexpr int VEC = 16 / sizeof(T);
     struct alignas(16) Pack
     {
@@ -216,8 +224,11 @@ __global__ __launch_bounds__(256) void minMaxPartialKernel(const T* __restrict__
 }
 
 template<class T>
-__global__ __launch_bounds__(256) void minMaxFinalKernel(const T* __restrict__ partial, unsigned m, T* __restrict__ out)
+__global__ __launch_bounds__(256) void minMaxFinalKernel(const T* __restrict__ partialAll, unsigned m,
+                                                         T* __restrict__ outAll)
 {
+    const T* __restrict__ partial = partialAll + size_t(blockIdx.x) * m * 2;
+    T* __restrict__ out           = outAll + 2 * blockIdx.x;
     __shared__ T smin[4], smax[4];
     T lo = partial[0], hi = partial[1];
     for (unsigned b = threadIdx.x; b < m; b += 256)
@@ -230,29 +241,47 @@ __global__ __launch_bounds__(256) void minMaxFinalKernel(const T* __restrict__ p
     if (threadIdx.x == 0) out[0] = lo, out[1] = hi;
 }
 
+//! min and max of up to three arrays of n elements each: one launch pair, one read-back
 template<class T>
-int minMax(cstone_hip_ctx* ctx, const T* x, size_t n, double* out2)
+int minMaxArrays(cstone_hip_ctx* ctx, const T* const* xs, int numArrays, size_t n, double* out)
 {
     if (n == 0) return fail(ctx, CSTONE_E_ARG, "minmax: empty range");
     unsigned grid = unsigned(std::min<size_t>(size_t(ctx->numCu) * 8, (n + 255) / 256));
-    CS_TRY(arenaReserve(ctx, alignUp(size_t(grid) * 2 * sizeof(T)) + 1024));
-    T* partial = (T*)arenaTake(ctx, size_t(grid) * 2 * sizeof(T));
-    T* out     = (T*)arenaTake(ctx, 2 * sizeof(T));
+    CS_TRY(arenaReserve(ctx, alignUp(size_t(grid) * 6 * sizeof(T)) + 1024));
+    T* partial = (T*)arenaTake(ctx, size_t(grid) * 6 * sizeof(T));
+    T* res     = (T*)arenaTake(ctx, 6 * sizeof(T));
+    MinMaxArrays<T> arrays{{xs[0], xs[numArrays > 1 ? 1 : 0], xs[numArrays > 2 ? 2 : 0]}};
     {
         StageTimer timer(ctx, CSTONE_STAGE_MINMAX);
-        hipLaunchKernelGGL(minMaxPartialKernel<T>, grid, 256, 0, ctx->stream, x, n, partial);
-        hipLaunchKernelGGL(minMaxFinalKernel<T>, 1, 256, 0, ctx->stream, partial, grid, out);
+        hipLaunchKernelGGL(minMaxPartialKernel<T>, dim3(grid, numArrays), 256, 0, ctx->stream, arrays, n, partial);
+        hipLaunchKernelGGL(minMaxFinalKernel<T>, numArrays, 256, 0, ctx->stream, partial, grid, res);
     }
-    T host[2];
-    hipError_t e = hipMemcpyAsync(host, out, sizeof host, hipMemcpyDeviceToHost, ctx->stream);
+    T host[6];
+    hipError_t e = hipMemcpyAsync(host, res, size_t(2 * numArrays) * sizeof(T), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     arenaReset(ctx);
     if (e != hipSuccess) return fail(ctx, CSTONE_E_HIP, "minmax: %s", hipGetErrorString(e));
-    out2[0] = host[0];
-    out2[1] = host[1];
+    for (int i = 0; i < 2 * numArrays; ++i)
+        out[i] = host[i];
     return CSTONE_OK;
 }
 
+template<class T>
+int minMax(cstone_hip_ctx* ctx, const T* x, size_t n, double* out2)
+{
+    return minMaxArrays<T>(ctx, &x, 1, n, out2);
+}
+
+} // namespace
+
+int minMaxCoordinates(cstone_hip_ctx* ctx, int real_bits, const void* const* xs, int numArrays, size_t n, double* out)
+{
+    if (real_bits == 32) return minMaxArrays<float>(ctx, (const float* const*)xs, numArrays, n, out);
+    return minMaxArrays<double>(ctx, (const double* const*)xs, numArrays, n, out);
+}
+
+namespace
+{
 } // namespace
 
 } // namespace cship
