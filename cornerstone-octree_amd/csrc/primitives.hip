@@ -309,6 +309,16 @@ int cstone_hip_minmax(cstone_hip_ctx* ctx, int real_bits, const void* x, size_t 
     return fail(ctx, CSTONE_E_ARG, "minmax: real_bits %d unsupported", real_bits);
 }
 
+int cstone_hip_minmax_arrays(cstone_hip_ctx* ctx, int real_bits, const void* const* arrays, int num_arrays, size_t n,
+                             double* out_host)
+{
+    if (!ctx || !arrays || !out_host || num_arrays < 1 || num_arrays > 3 || (real_bits != 32 && real_bits != 64))
+        return fail(ctx, CSTONE_E_ARG, "minmax_arrays: bad argument");
+    for (int i = 0; i < num_arrays; ++i)
+        if (!arrays[i]) return fail(ctx, CSTONE_E_ARG, "minmax_arrays: null array");
+    return minMaxCoordinates(ctx, real_bits, arrays, num_arrays, n, out_host);
+}
+
 int cstone_hip_exclusive_scan_u32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t init)
 {
     if (!ctx || (n && (!in || !out))) return fail(ctx, CSTONE_E_ARG, "exclusive_scan: bad argument");

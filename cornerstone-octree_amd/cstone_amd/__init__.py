@@ -27,7 +27,7 @@ EXPORTS = [
     "cstone_hip_memcpy_d2h", "cstone_hip_memcpy_d2d", "cstone_hip_memset", "cstone_hip_profile_enable",
     "cstone_hip_profile_reset", "cstone_hip_profile_get", "cstone_hip_compute_sfc_keys",
     "cstone_hip_sort_pairs_temp_bytes", "cstone_hip_sort_pairs", "cstone_hip_sequence_u32", "cstone_hip_gather",
-    "cstone_hip_scatter", "cstone_hip_minmax", "cstone_hip_exclusive_scan_u32", "cstone_hip_inclusive_scan_u32", "cstone_hip_lower_bound",
+    "cstone_hip_scatter", "cstone_hip_minmax", "cstone_hip_minmax_arrays", "cstone_hip_exclusive_scan_u32", "cstone_hip_inclusive_scan_u32", "cstone_hip_lower_bound",
     "cstone_hip_compute_node_counts", "cstone_hip_compute_node_ops", "cstone_hip_rebalance_tree",
     "cstone_hip_update_octree", "cstone_hip_compute_octree", "cstone_hip_build_octree", "cstone_hip_upsweep_sum",
     "cstone_hip_node_centers", "cstone_hip_halo_radii", "cstone_hip_find_halos", "cstone_hip_find_neighbors",
@@ -193,6 +193,15 @@ class Context:
         self._chk(self.lib.cstone_hip_minmax(self.h, C.c_int(x.element_size() * 8), _ptr(x), C.c_size_t(x.numel()),
                                              out), "minmax")
         return out[0], out[1]
+
+    def minmax_arrays(self, arrays):
+        """[(min, max), ...] of 1..3 equally long arrays: one launch, one read-back"""
+        k = len(arrays)
+        out = (C.c_double * (2 * k))()
+        ptrs = (C.c_void_p * k)(*[a.data_ptr() for a in arrays])
+        self._chk(self.lib.cstone_hip_minmax_arrays(self.h, C.c_int(arrays[0].element_size() * 8), ptrs, C.c_int(k),
+                                                    C.c_size_t(arrays[0].numel()), out), "minmax_arrays")
+        return [(out[2 * i], out[2 * i + 1]) for i in range(k)]
 
     def exclusive_scan(self, inp, out, init=0):
         self._chk(self.lib.cstone_hip_exclusive_scan_u32(self.h, _ptr(inp), _ptr(out), C.c_size_t(inp.numel()),

@@ -62,6 +62,16 @@ class Comm:
             t.copy_(w)
         return t
 
+    def count_matrix(self, send_counts):
+        """m[src][dst] of every rank's send counts: one all_gather instead of an all_to_all plus reductions"""
+        torch = _torch()
+        s = torch.tensor(send_counts, dtype=torch.int64)
+        if not self.stage:
+            s = s.cuda()
+        out = torch.empty(self.size * self.size, dtype=torch.int64, device=s.device)
+        self.dist.all_gather_into_tensor(out, s, group=self.group)
+        return out.cpu().view(self.size, self.size).tolist()
+
     def exchange_counts(self, send_counts):
         torch = _torch()
         s = torch.tensor(send_counts, dtype=torch.int64)
@@ -169,8 +179,7 @@ class DistributedDomain:
         torch = _torch()
         T = np.float64 if self.rb == 64 else np.float32
         ext = []
-        for a in (x, y, z):
-            lo, hi = self.b.minmax(a) if a.numel() else (float("inf"), float("-inf"))
+        for lo, hi in (self.b.minmax3(x, y, z) if x.numel() else [(float("inf"), float("-inf"))] * 3):
             ext += [lo, -hi]
         g = self.c.all_reduce_min(torch.tensor(ext, dtype=torch.float64)).tolist()
         fit = np.array([g[0], -g[1], g[2], -g[3], g[4], -g[5]], dtype=np.float64)
@@ -251,21 +260,32 @@ class DistributedDomain:
         cut = b.searchsorted(keys, bounds, self.kb)  # P+1 positions
         send_counts = [cut[p + 1] - cut[p] for p in range(P)]
         dropped = n - cut[P]  # particles flagged for removal sort behind the end of the curve
-        recv_counts = c.exchange_counts(send_counts)
+        matrix = c.count_matrix(send_counts) if P > 1 else [[send_counts[0]]]
+        recv_counts = [matrix[p][rank] for p in range(P)]
         moved = sum(send_counts) - send_counts[rank]
-        moved_any = int(c.all_reduce_sum_(torch.tensor([moved], dtype=torch.int64)).item()) if P > 1 else 0
+        moved_any = sum(sum(row) for row in matrix) - sum(matrix[p][p] for p in range(P))
+        kept = [f[cut[rank]:cut[rank + 1]] for f in fields]
+        kept_keys = keys[cut[rank]:cut[rank + 1]]
         if P > 1 and moved_any:
-            fields = [c.all_to_all_v(f[:cut[P]], send_counts, recv_counts) for f in fields]
-            x, y, z, h = fields
-            n = x.numel()
-            keys = b.compute_sfc_keys(self.curve, self.kb, x, y, z, box)
-            order = b.iota(n)
-            b.sort_pairs(keys, order)
-            x, y, z, h = [b.gather_new(order, a) for a in (x, y, z, h)]
+            # only what leaves travels: the range that stays is already sorted and is merged with the newcomers
+            away_send = [0 if p == rank else send_counts[p] for p in range(P)]
+            away_recv = [0 if p == rank else recv_counts[p] for p in range(P)]
+            lo_part, hi_part = slice(cut[0], cut[rank]), slice(cut[rank + 1], cut[P])
+            # x, y, z, h of a particle travel as one row: one collective instead of four
+            packed = torch.stack([torch.cat([f[lo_part], f[hi_part]]) for f in fields], dim=1)
+            recv = list(c.all_to_all_v(packed, away_send, away_recv).unbind(dim=1))
+            if recv[0].numel():
+                recv = [r.contiguous() for r in recv]
+                rk = b.compute_sfc_keys(self.curve, self.kb, recv[0], recv[1], recv[2], box)
+                ro = b.iota(rk.numel())
+                b.sort_pairs(rk, ro)
+                recv = [b.gather_new(ro, a.contiguous()) for a in recv]
+                keys, (x, y, z, h) = b.merge_sorted(kept_keys, kept, rk, recv, self.kb)
+            else:
+                keys, (x, y, z, h) = kept_keys, kept
         else:
-            x, y, z, h = [f[cut[rank]:cut[rank + 1]] for f in fields]
-            keys = keys[cut[rank]:cut[rank + 1]]
-            n = x.numel()
+            keys, (x, y, z, h) = kept_keys, kept
+        n = x.numel()
         self.stats.update(moved=moved, dropped=dropped, assigned=n)
         self._tick("particle_exchange_resort")
 
@@ -298,12 +318,14 @@ class DistributedDomain:
                 idx = b.particles_of_flagged(flags, layout, first, last)
                 send_idx.append(idx)
                 hs_counts.append(int(idx.numel()))
-            hr_counts = c.exchange_counts(hs_counts)
+            hmatrix = c.count_matrix(hs_counts)
+            hr_counts = [hmatrix[p][rank] for p in range(P)]
             if send_idx:
                 sel = torch.cat(send_idx) if len(send_idx) > 1 else send_idx[0]
             else:
                 sel = b.iota(0)
-            recv = [c.all_to_all_v(b.gather_new(sel, a), hs_counts, hr_counts) for a in (x, y, z, h)]
+            packed = torch.stack([b.gather_new(sel, a) for a in (x, y, z, h)], dim=1)
+            recv = [r.contiguous() for r in c.all_to_all_v(packed, hs_counts, hr_counts).unbind(dim=1)]
             nlo = sum(hr_counts[:rank])
             halos_lo = [r[:nlo] for r in recv]
             halos_hi = [r[nlo:] for r in recv]
@@ -352,6 +374,29 @@ class HipBackend:
 
     def minmax(self, a):
         return self.ctx.minmax(a)
+
+    def minmax3(self, x, y, z):
+        return self.ctx.minmax_arrays([x.contiguous(), y.contiguous(), z.contiguous()])
+
+    def merge_sorted(self, keys_a, fields_a, keys_b, fields_b, kb):
+        """stable merge of two sorted runs (ties: run A first); positions by binary search, data by scatter"""
+        torch = _torch()
+        na, nb = keys_a.numel(), keys_b.numel()
+        if na == 0:
+            return keys_b, fields_b
+        # unsigned comparison inside lower_bound; key + 1 cannot wrap for keys below the end of the curve
+        idx_a = (torch.arange(na, device=keys_a.device) + self.ctx.lower_bound(keys_b, keys_a)).to(torch.int32)
+        idx_b = (torch.arange(nb, device=keys_a.device) + self.ctx.lower_bound(keys_a, keys_b + 1)).to(torch.int32)
+        out_keys = torch.empty(na + nb, dtype=keys_a.dtype, device=keys_a.device)
+        self.ctx.scatter(idx_a, keys_a.contiguous(), out_keys)
+        self.ctx.scatter(idx_b, keys_b.contiguous(), out_keys)
+        outs = []
+        for fa, fb in zip(fields_a, fields_b):
+            o = torch.empty(na + nb, dtype=fa.dtype, device=fa.device)
+            self.ctx.scatter(idx_a, fa.contiguous(), o)
+            self.ctx.scatter(idx_b, fb.contiguous(), o)
+            outs.append(o)
+        return out_keys, outs
 
     def compute_sfc_keys(self, curve, kb, x, y, z, box):
         torch = _torch()

@@ -123,6 +123,10 @@ extern "C"
 
     /* MinMaxGpu (R/primitives/primitives_gpu.h:58-62): out_host = {min, max} as doubles (exact for float) */
     int cstone_hip_minmax(cstone_hip_ctx* ctx, int real_bits, const void* x, size_t n, double* out2_host);
+    /* the same for 1..3 equally long arrays (the x, y, z of the bounding box, R/sfc/box_mpi.hpp:40-70) in one launch and
+     * one read-back: out_host = {min0, max0, min1, max1, ...} */
+    int cstone_hip_minmax_arrays(cstone_hip_ctx* ctx, int real_bits, const void* const* arrays, int num_arrays,
+                                 size_t n, double* out_host);
 
     /* exclusiveScanGpu / inclusiveScanGpu on uint32/int32 (R/primitives/primitives_gpu.h:103-115).
      * exclusive: out[i] = init + sum(in[0..i)), n outputs.  in == out allowed. */

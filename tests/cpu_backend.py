@@ -27,6 +27,16 @@ class CpuBackend:
     def minmax(self, a):
         return float(a.min()), float(a.max())
 
+    def minmax3(self, x, y, z):
+        return [(float(a.min()), float(a.max())) for a in (x, y, z)]
+
+    def merge_sorted(self, keys_a, fields_a, keys_b, fields_b, kb):
+        ka, kbb = _k(keys_a.contiguous(), kb), _k(keys_b.contiguous(), kb)
+        allk = np.concatenate([ka, kbb])
+        order = np.argsort(allk, kind="stable")  # stable: run A first on ties
+        fields = [torch.cat([fa, fb])[torch.from_numpy(order)] for fa, fb in zip(fields_a, fields_b)]
+        return _tk(allk[order]), fields
+
     def compute_sfc_keys(self, curve, kb, x, y, z, box):
         if x.numel() == 0:
             return torch.zeros(0, dtype=torch.int64 if kb == 64 else torch.int32)
