@@ -322,6 +322,15 @@ struct MinMaxGpu
     }
 };
 
+//! lowerBoundGpu, range form (cstone/primitives/primitives_gpu.h:70-71): result[q] = first index with keys[i] >= values[q]
+template<class T>
+void lowerBoundGpu(const T* first, const T* last, const T* valueFirst, const T* valueLast, std::uint64_t* result)
+{
+    Context::check(cstone_hip_lower_bound(Context::get(), detail::keyBits<T>(), first, std::size_t(last - first),
+                                          valueFirst, int(valueLast - valueFirst), result),
+                   "lowerBoundGpu");
+}
+
 inline void exclusiveScanGpu(const unsigned* first, const unsigned* last, unsigned* output, unsigned init = 0)
 {
     Context::check(cstone_hip_exclusive_scan_u32(Context::get(), first, output, std::size_t(last - first), init),

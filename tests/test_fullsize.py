@@ -1,0 +1,133 @@
+"""BASELINE.json's full sizes on the GPU through size-independent properties (the oracle would take minutes there):
+sortedness / permutation / stability of the sort, and for Domain::sync: keys sorted and consistent with the
+coordinates they travel with, particle multiset preserved, leaf counts add up and respect the bucket size, idempotence."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cornerstone-octree_amd"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _u64(t):
+    return t.view(np.uint64) if isinstance(t, np.ndarray) else t
+
+
+@pytest.mark.parametrize("kb", [32, 64])
+def test_sort_1e8_pairs_sorted_stable_permutation(hip, kb):
+    import torch
+
+    n = 100_000_000
+    g = torch.Generator(device="cuda").manual_seed(kb)
+    if kb == 64:
+        # 24 random bits spread over the low, middle and high bytes: every digit pass works and every key has ties
+        r = torch.randint(0, 1 << 24, (n,), dtype=torch.int64, device="cuda", generator=g)
+        keys = (r & 0xFF) | ((r & 0xFF00) << 24) | ((r & 0xFF0000) << 39)
+    else:
+        keys = torch.randint(0, 1 << 22, (n,), dtype=torch.int32, device="cuda", generator=g) << 8
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    src = keys.clone()
+    hip.sort_pairs(keys, vals)
+    hip.sync()
+    assert bool((keys[1:] >= keys[:-1]).all())                      # sorted (keys are non-negative as signed, too)
+    assert bool((src[vals.long()] == keys).all())                   # the payload is the permutation that sorts
+    same = keys[1:] == keys[:-1]
+    assert bool((vals[1:][same] > vals[:-1][same]).all())           # stable: ties keep their input order
+    assert int(same.sum()) > n // 2
+    seen = torch.zeros(n, dtype=torch.bool, device="cuda")
+    seen[vals.long()] = True
+    assert bool(seen.all())                                         # a permutation: every index exactly once
+
+
+def test_domain_sync_1e8_uniform_invariants(hip):
+    import torch
+
+    import cstone_amd
+    from cstone_amd.domain import Domain
+
+    n, bucket_focus = 100_000_000, 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x, y, z = [torch.rand(n, dtype=torch.float64, device="cuda", generator=g) for _ in range(3)]
+    h = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 1e-3 + 1e-4
+    sums = [float(a.sum()) for a in (x, y, z, h)]
+    ident = x * 3.0 + y * 5.0 + z * 7.0 + h  # travels as a property: must stay attached to its particle
+    keys = torch.zeros(n, dtype=torch.int64, device="cuda")
+    scratch = torch.empty(n, dtype=torch.float64, device="cuda")
+    dom = Domain(hip, cstone_amd.HILBERT, 64, 64, n // 100, bucket_focus, 0.5, cstone_amd.make_cbox([0, 1] * 3))
+    keys, x, y, z, h, scratch, (ident,) = dom.sync(keys, x, y, z, h, scratch, [ident])
+    hip.sync()
+    v = dom.view()
+    assert (v.start_index, v.end_index, v.num_particles_with_halos) == (0, n, n)
+    assert bool((keys[1:] >= keys[:-1]).all())
+    # keys belong to the coordinates next to them
+    again = hip.compute_sfc_keys(cstone_amd.HILBERT, 64, x, y, z, v.box)
+    assert bool((again == keys).all())
+    del again
+    # the same particles, every field still attached
+    assert bool((ident == x * 3.0 + y * 5.0 + z * 7.0 + h).all())
+    for a, s0 in zip((x, y, z, h), sums):
+        assert abs(float(a.sum()) - s0) <= 1e-9 * abs(s0)
+    # focus tree: counts add up, respect the bucket, match the keys
+    L = v.num_focus_leaves
+    counts = dom.fetch(v.focus_leaf_counts, L, np.uint32)
+    leaves = dom.fetch(v.focus_leaves, L + 1, np.uint64)
+    layout = dom.fetch(v.layout, L + 1, np.uint32)
+    assert int(counts.sum(dtype=np.uint64)) == n and counts.max() <= bucket_focus
+    assert leaves[0] == 0 and leaves[-1] == 1 << 63 and np.all(leaves[1:] > leaves[:-1])
+    assert np.array_equal(layout, np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)]).astype(np.uint32))
+    probe = np.linspace(0, L - 1, 2000).astype(np.int64)
+    kq = torch.from_numpy(leaves[probe].view(np.int64)).cuda()
+    pos = hip.lower_bound(keys, kq).cpu().numpy()
+    assert np.array_equal(pos, layout[probe].astype(np.int64))
+    # a second sync of the unchanged, already sorted particles changes nothing
+    k2, x2, y2, z2, h2, scratch, _ = dom.sync(keys.clone(), x.clone(), y.clone(), z.clone(), h.clone(), scratch)
+    hip.sync()
+    assert bool((k2 == keys).all()) and bool((x2 == x).all()) and bool((z2 == z).all()) and bool((h2 == h).all())
+    v2 = dom.view()
+    assert v2.num_focus_leaves == L
+    assert np.array_equal(dom.fetch(v2.focus_leaves, L + 1, np.uint64), leaves)
+
+
+def test_neighbors_plummer_sample_against_oracle(hip, oracle):
+    """2e6 Plummer particles, bucket 64: the lists of 3000 scattered targets equal the oracle's (bit-exact order)"""
+    import torch
+
+    from oracle.oracle import HILBERT, Box
+
+    n, ngmax = 2_000_000, 160
+    rng = np.random.default_rng(12)
+    u = np.clip(rng.uniform(size=n), 1e-12, 1.0)
+    r = np.minimum(1.0 / np.sqrt(np.maximum(u ** (-2.0 / 3.0) - 1.0, 1e-12)), 10.0)
+    ct, ph = rng.uniform(-1, 1, n), rng.uniform(0, 2 * np.pi, n)
+    st = np.sqrt(1 - ct * ct)
+    x, y, z = r * st * np.cos(ph), r * st * np.sin(ph), r * ct
+    rho = 3.0 * n / (4 * np.pi) * (1 + r * r) ** -2.5
+    h = np.minimum(0.5 * (3.0 * 100 / (4 * np.pi * rho)) ** (1 / 3), 1.0)
+    box = Box([-10.001, 10.001] * 3, (0, 0, 0))
+    keys = oracle.compute_sfc_keys(HILBERT, 64, x, y, z, box)
+    ks, order = oracle.sort_pairs(keys, np.arange(n))
+    x, y, z, h = x[order], y[order], z[order], h[order]
+    tree, counts = oracle.compute_octree(ks, 64)
+    o = oracle.build_octree(tree)
+    layout = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+    cen, siz = oracle.node_centers(HILBERT, o["prefixes"], box, 64)
+
+    import cstone_amd
+
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    od = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in o.items()}
+    cb = cstone_amd.make_cbox(box.lim, box.bc)
+    xd, yd, zd, hd, ld, cd, sd = dev(x), dev(y), dev(z), dev(h), dev(layout), dev(cen), dev(siz)
+    for first in (0, n // 2 - 500, n - 1000):  # centre of the sphere (dense), halo (sparse), both ends of the curve
+        last = first + 1000
+        n_ref, c_ref = oracle.find_neighbors(x, y, z, h, first, last, box, o, layout, cen, siz, ngmax)
+        n_got, c_got = hip.find_neighbors(xd, yd, zd, hd, first, last, cb, od, ld, cd, sd, ngmax)
+        hip.sync()
+        c_got, n_got = c_got.cpu().numpy().view(np.uint32), n_got.cpu().numpy().view(np.uint32)
+        assert np.array_equal(c_got, c_ref)
+        mask = np.arange(ngmax)[None, :] < np.minimum(c_ref, ngmax)[:, None]
+        assert np.array_equal(n_got[mask], n_ref[mask])
