@@ -119,6 +119,38 @@ def signed_key(v, kb):
     return v - (1 << kb) if v >= 1 << (kb - 1) else v
 
 
+def log8ceil(n):
+    """smallest l with 8^l >= n (R/sfc/common.hpp:134-142)"""
+    l = 0
+    while 8 ** l < n:
+        l += 1
+    return l
+
+
+def initial_domain_splits(num_ranks, level, kb):
+    """R/domain/domaindecomp.hpp:242-255: numRanks equal SFC segments, boundaries rounded down to `level` octal digits"""
+    end = 1 << (3 * (10 if kb == 32 else 21))
+    shift = 3 * ((10 if kb == 32 else 21) - level)
+    delta = end // num_ranks
+    return [0] + [((i * delta) >> shift) << shift for i in range(1, num_ranks)] + [end]
+
+
+def spanning_tree(bounds, kb):
+    """computeSpanningTree (R/tree/csarray.hpp:508-531): the coarsest cornerstone leaf array that resolves every boundary;
+    per segment the canonical cover by maximal aligned power-of-8 nodes (spanSfcRange, R/sfc/common.hpp:376-438)"""
+    end = 1 << (3 * (10 if kb == 32 else 21))
+    out = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        while a < b:
+            size = end
+            while size > 1 and (a % size != 0 or size > b - a):
+                size //= 8
+            out.append(a)
+            a += size
+    out.append(bounds[-1])
+    return out
+
+
 def uniform_bins(counts, num_bins):
     """R/domain/domaindecomp.hpp:50-75: leaf indices that split the leaf counts into num_bins equal parts"""
     scan = np.zeros(counts.size + 1, dtype=np.uint64)
@@ -201,11 +233,14 @@ class DistributedDomain:
         torch = _torch()
         b = self.b
         if self.gtree is None:
-            cap = 1 << 16
+            # GlobalAssignment ctor (R/domain/assignment.hpp:42-53): spanning tree of numRanks equal segments at level
+            # log8ceil(100 numRanks), every leaf count = bucketSize - 1
+            init = spanning_tree(initial_domain_splits(self.c.size, log8ceil(100 * self.c.size), self.kb), self.kb)
+            cap = max(1 << 16, 2 * len(init))
             self.gtree = b.zeros_keys(cap + 1, self.kb)
             self.gcounts = b.zeros_i32(cap)
-            b.set_root(self.gtree, self.gcounts, self.kb, self.bucket - 1)
-            self.g_leaves = 1
+            b.set_tree(self.gtree, self.gcounts, init, self.kb, self.bucket - 1)
+            self.g_leaves = len(init) - 1
         steps = 0
         while True:
             # the decisions use the all-reduced counts of the previous step: identical on every rank
@@ -430,10 +465,11 @@ class HipBackend:
         torch = _torch()
         return torch.zeros(n, dtype=torch.int32, device=self.ctx.device)
 
-    def set_root(self, tree, counts, kb, c0):
-        tree[0] = 0
-        tree[1] = signed_key(1 << (3 * (10 if kb == 32 else 21)), kb)
-        counts[0] = c0
+    def set_tree(self, tree, counts, leaves, kb, c0):
+        torch = _torch()
+        t = torch.tensor([signed_key(k, kb) for k in leaves], dtype=tree.dtype)
+        tree[:len(leaves)] = t.to(tree.device)
+        counts[:len(leaves) - 1] = c0
 
     def update_octree(self, keys, bucket, tree, counts, nl):
         return self.ctx.update_octree(keys, bucket, tree, counts, nl)

@@ -61,10 +61,9 @@ class CpuBackend:
     def zeros_i32(self, n):
         return torch.zeros(n, dtype=torch.int32)
 
-    def set_root(self, tree, counts, kb, c0):
-        tree[0] = 0
-        tree[1] = signed_key(1 << (3 * (10 if kb == 32 else 21)), kb)
-        counts[0] = c0
+    def set_tree(self, tree, counts, leaves, kb, c0):
+        tree[:len(leaves)] = torch.tensor([signed_key(k, kb) for k in leaves], dtype=tree.dtype)
+        counts[:len(leaves) - 1] = c0
 
     def update_octree(self, keys, bucket, tree, counts, nl):
         kb = keys.element_size() * 8

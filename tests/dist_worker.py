@@ -40,12 +40,57 @@ def neighbor_sum(o, x, y, z, h, first, last, lim, bc):
     return int(nc[sel].astype(np.int64).sum())
 
 
+def golden(a, backend, dev, rank, P):
+    """the reference's Domain on P MPI ranks (fixture) against DistributedDomain on P torch.distributed ranks: box,
+    SFC ranges, global tree + counts and the assigned particles (keys, x, h) of every rank after every sync, bit for bit"""
+    from cstone_amd.distributed import Comm, DistributedDomain
+    from oracle import oracle as orc
+
+    g = np.load(a.golden)
+    assert int(g["P"]) == P, "launch with the fixture's number of ranks"
+    mine = np.nonzero(g["owner"] == rank)[0]
+    x, y, z, h = [torch.from_numpy(g[k][mine].copy()).to(dev) for k in "xyzh"]
+    dom = DistributedDomain(backend, Comm(), orc.HILBERT, 64, 64, bucket=int(g["bucket"]),
+                            bucket_focus=int(g["bucket_focus"]), box_lim=g["lim"].tolist(),
+                            box_bc=tuple(int(v) for v in g["bc"]))
+    bad = []
+    c, top = 0.01, 1.0 - 2.0**-30
+    for s in range(int(g["syncs"])):
+        r = dom.sync(x, y, z, h)
+        st, en = r["start"], r["end"]
+        keys = r["keys"].cpu().numpy().view(np.uint64)[st:en]
+        L = dom.g_leaves
+        checks = {
+            "lim": np.array_equal(r["lim"], g[f"s{s}_r{rank}_lim"]),
+            "range": [dom.assignment[rank], dom.assignment[rank + 1]] == [int(v) for v in g[f"s{s}_r{rank}_range"]],
+            "leaves": np.array_equal(backend.keys_to_numpy(dom.gtree[:L + 1], 64), g[f"s{s}_leaves"]),
+            "counts": np.array_equal(backend.to_numpy(dom.gcounts[:L]).view(np.uint32), g[f"s{s}_counts"]),
+            "keys": np.array_equal(keys, g[f"s{s}_r{rank}_keys"]),
+            "x": np.array_equal(r["x"][st:en].cpu().numpy(), g[f"s{s}_r{rank}_x"]),
+            "h": np.array_equal(r["h"][st:en].cpu().numpy(), g[f"s{s}_r{rank}_h"]),
+        }
+        bad += [f"sync {s} rank {rank}: {k}" for k, ok in checks.items() if not ok]
+        xo, yo, zo = [r[k][st:en].clone() for k in "xyz"]
+        h = r["h"][st:en].clone()
+        x = torch.clamp(xo + c * (yo - 0.5), 0.0, top)
+        y = torch.clamp(yo + c * (zo - 0.5), 0.0, top)
+        z = torch.clamp(zo + c * (xo - 0.5), 0.0, top)
+    allbad = [None] * P
+    dist.all_gather_object(allbad, bad)
+    flat = [b for part in allbad for b in part]
+    if rank == 0:
+        print("DIST_RESULT " + json.dumps(dict(ok=not flat, ranks=P, mismatches=flat[:20], report=[])))
+    dist.destroy_process_group()
+    return 0 if not flat else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--backend", default="cpu")
     ap.add_argument("--particles", type=int, default=20000)
     ap.add_argument("--syncs", type=int, default=3)
     ap.add_argument("--pbc", type=int, default=0)
+    ap.add_argument("--golden", default="", help="fixture of tests/golden/make_golden_domain_mpi.py to reproduce")
     a = ap.parse_args()
     dist.init_process_group("gloo")
     rank, P = dist.get_rank(), dist.get_world_size()
@@ -65,6 +110,9 @@ def main():
 
         backend = CpuBackend()
         dev = "cpu"
+
+    if a.golden:
+        sys.exit(golden(a, backend, dev, rank, P))
 
     N = a.particles
     rng = np.random.default_rng(2024)

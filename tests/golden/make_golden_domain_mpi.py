@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ref_domain_mpi_P*.npz by running the REFERENCE's cstone::Domain<uint64_t,double,CpuTag> on
+several MPI ranks (oracle/_ref/ref_domain_mpi, built by `make -C oracle refdomain`; needs /root/reference and the MPICH
+under /opt/conda, i.e. it runs in the build container only).  The fixtures hold inputs and, per sync and rank: the box,
+the rank's SFC range, the global tree, and keys / x / h of the assigned particles."""
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+EXE = os.path.join(ROOT, "oracle", "_ref", "ref_domain_mpi")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+def cloud(n, seed, kind):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        pos = rng.uniform(0, 1, (n, 3))
+    else:  # half uniform background, half in four blobs: an imbalanced decomposition
+        centers = rng.uniform(0.2, 0.8, (4, 3))
+        pos = np.where(rng.uniform(size=(n, 1)) < 0.5, rng.uniform(0, 1, (n, 3)),
+                       centers[rng.integers(0, 4, n)] + rng.normal(0, 0.04, (n, 3)))
+    pos = np.clip(pos, 0.0, 1.0 - 2.0**-30)
+    h = 0.02 * rng.uniform(0.5, 1.0, n)
+    owner = rng.integers(0, 1 << 30, n)
+    return pos, h, owner
+
+
+def run(P, n, syncs, bucket, bucket_focus, bc, kind, seed):
+    pos, h, owner = cloud(n, seed, kind)
+    owner = (owner % P).astype(np.int32)
+    lim = np.array([0, 1, 0, 1, 0, 1], dtype=np.float64)
+    with tempfile.TemporaryDirectory() as tmp:
+        inp = os.path.join(tmp, "in.bin")
+        with open(inp, "wb") as f:
+            f.write(struct.pack("8q", n, P, syncs, bucket, bucket_focus, *bc))
+            f.write(lim.tobytes())
+            for d in range(3):
+                f.write(np.ascontiguousarray(pos[:, d]).tobytes())
+            f.write(h.tobytes())
+            f.write(owner.tobytes())
+        subprocess.run([MPIEXEC, "-n", str(P), EXE, inp, os.path.join(tmp, "out")], check=True, timeout=600)
+        out = dict(n=n, P=P, syncs=syncs, bucket=bucket, bucket_focus=bucket_focus, bc=np.array(bc), lim=lim,
+                   x=pos[:, 0].copy(), y=pos[:, 1].copy(), z=pos[:, 2].copy(), h=h, owner=owner)
+        for r in range(P):
+            raw = open(os.path.join(tmp, f"out.rank{r}.bin"), "rb").read()
+            off = 0
+            for s in range(syncs):
+                info = np.frombuffer(raw, np.int64, 5, off); off += 40
+                st, en, wh, L, _ = [int(v) for v in info]
+                out[f"s{s}_r{r}_info"] = info.copy()
+                out[f"s{s}_r{r}_lim"] = np.frombuffer(raw, np.float64, 6, off).copy(); off += 48
+                out[f"s{s}_r{r}_range"] = np.frombuffer(raw, np.uint64, 2, off).copy(); off += 16
+                leaves = np.frombuffer(raw, np.uint64, L + 1, off).copy(); off += 8 * (L + 1)
+                off += 4 * (L + (L & 1))
+                m = en - st
+                out[f"s{s}_r{r}_keys"] = np.frombuffer(raw, np.uint64, m, off).copy(); off += 8 * m
+                out[f"s{s}_r{r}_x"] = np.frombuffer(raw, np.float64, m, off).copy(); off += 8 * m
+                out[f"s{s}_r{r}_h"] = np.frombuffer(raw, np.float64, m, off).copy(); off += 8 * m
+                if r == 0:
+                    out[f"s{s}_leaves"] = leaves
+            assert off == len(raw)
+        # global leaf counts (private to the reference's GlobalAssignment): recount from everybody's assigned keys
+        for s in range(syncs):
+            allk = np.sort(np.concatenate([out[f"s{s}_r{r}_keys"] for r in range(P)]))
+            lv = out[f"s{s}_leaves"]
+            out[f"s{s}_counts"] = np.diff(np.searchsorted(allk, lv, side="left")).astype(np.uint32)
+            assert allk.size == n
+    return out
+
+
+if __name__ == "__main__":
+    if not os.path.exists(EXE):
+        sys.exit("build oracle/_ref/ref_domain_mpi first: make -C oracle refdomain")
+    cases = {
+        "ref_domain_mpi_P2_uniform_open": dict(P=2, n=12000, syncs=3, bucket=64, bucket_focus=8, bc=(0, 0, 0),
+                                               kind="uniform", seed=101),
+        "ref_domain_mpi_P3_blobs_pbc": dict(P=3, n=15000, syncs=3, bucket=64, bucket_focus=8, bc=(1, 1, 1),
+                                            kind="blobs", seed=102),
+        "ref_domain_mpi_P4_blobs_open": dict(P=4, n=16000, syncs=3, bucket=96, bucket_focus=16, bc=(0, 0, 0),
+                                             kind="blobs", seed=103),
+    }
+    for name, kw in cases.items():
+        o = run(**kw)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **o)
+        print(name, {r: o[f"s2_r{r}_info"].tolist() for r in range(kw["P"])}, "global leaves", o["s2_leaves"].size - 1)

@@ -40,15 +40,19 @@ def test_signed_key():
     assert signed_key(1 << 63, 64) == -(1 << 63) and signed_key(5, 64) == 5 and signed_key(1 << 30, 32) == 1 << 30
 
 
-def _launch(nproc, backend, particles, syncs, pbc, port, timeout=900):
+def _launch(nproc, backend, particles, syncs, pbc, port, timeout=900, golden=""):
     env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"),
            "--backend", backend, "--particles", str(particles), "--syncs", str(syncs), "--pbc", str(pbc)]
+    if golden:
+        cmd += ["--golden", os.path.join(ROOT, "tests", "golden", golden)]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("DIST_RESULT ")]
-    assert p.returncode == 0 and lines, p.stdout[-2000:] + p.stderr[-4000:]
-    return json.loads(lines[-1][len("DIST_RESULT "):])
+    assert lines, p.stdout[-2000:] + p.stderr[-4000:]
+    res = json.loads(lines[-1][len("DIST_RESULT "):])
+    assert p.returncode == 0 and res["ok"], str(res)[:2000] + p.stderr[-2000:]
+    return res
 
 
 @pytest.mark.parametrize("nproc,pbc", [(2, 0), (3, 1)])
@@ -70,3 +74,32 @@ def test_gloo_ranks_hip_backend(nproc, pbc):
     assert r["ok"] and r["ranks"] == nproc
     for step in r["report"]:
         assert step["neighbors"] == step["found"] and step["neighbors"] > 0
+
+
+GOLDEN_MPI = [("ref_domain_mpi_P2_uniform_open.npz", 2), ("ref_domain_mpi_P3_blobs_pbc.npz", 3),
+              ("ref_domain_mpi_P4_blobs_open.npz", 4)]
+
+
+def test_host_spanning_tree_against_oracle(oracle):
+    """initial global tree of GlobalAssignment (assignment.hpp:42-53) against the pinned oracle"""
+    from cstone_amd.distributed import initial_domain_splits, log8ceil, spanning_tree
+
+    assert [log8ceil(n) for n in (1, 8, 9, 100, 512, 513)] == [0, 1, 2, 3, 3, 4]
+    for kb in (32, 64):
+        for P in (1, 2, 3, 5, 8, 33):
+            sp = initial_domain_splits(P, log8ceil(100 * P), kb)
+            ref = oracle.spanning_tree(np.array(sp, dtype=np.uint64 if kb == 64 else np.uint32))
+            assert [int(v) for v in ref] == spanning_tree(sp, kb)
+
+
+@pytest.mark.parametrize("fixture,nproc", GOLDEN_MPI)
+def test_reference_decomposition_cpu_backend(fixture, nproc):
+    """fixtures from the REFERENCE Domain on 2-4 MPI ranks: box, SFC ranges, global tree and counts, and every rank's
+    assigned particles after each of 3 syncs with moving particles must be reproduced bit for bit"""
+    _launch(nproc, "cpu", 0, 0, 0, 29660 + nproc, golden=fixture)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,nproc", GOLDEN_MPI)
+def test_reference_decomposition_hip_backend(fixture, nproc):
+    _launch(nproc, "hip", 0, 0, 0, 29680 + nproc, golden=fixture)
