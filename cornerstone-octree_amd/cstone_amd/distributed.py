@@ -329,6 +329,7 @@ class DistributedDomain:
             self.ftree, self.fcounts, self.f_leaves = b.compute_octree_buffers(keys, self.bucket_focus, self.kb)
         else:
             self._update_focus(keys)
+        self._enforce_boundaries(keys, (bounds[rank], bounds[rank + 1]))
         L = self.f_leaves
         octree = b.build_octree(self.ftree, num_leaves=L)
         first = b.find_leaf(self.ftree, L, bounds[rank], self.kb, below=True)
@@ -380,6 +381,36 @@ class DistributedDomain:
         self.first_call = False
         return dict(keys=keys, x=out[0], y=out[1], z=out[2], h=out[3], start=start, end=start + n, box=box,
                     lim=self.lim.copy())
+
+    def _enforce_boundaries(self, keys, mandatory):
+        """The rank's SFC range must start and end on leaf boundaries of its own tree (the job of enforceKeys in the
+        reference's focus tree, R/focus/rebalance.hpp:199-266): a leaf that straddles the range is replaced by the
+        coarsest set of octree nodes that resolves the boundary key.  Such leaves are mostly empty, so the count-driven
+        update merges them again and the split is redone at every sync -- a copy of the leaf array and a recount."""
+        torch = _torch()
+        b = self.b
+        end = self.end_key
+        changed = False
+        for key in mandatory:
+            if key == 0 or key >= end:
+                continue
+            L = self.f_leaves
+            idx = b.find_leaf(self.ftree, L, key, self.kb, below=True)
+            s, e = [int(v) for v in b.keys_to_numpy(self.ftree[idx:idx + 2], self.kb)]
+            if s == key:
+                continue
+            cover = spanning_tree([s, key, e], self.kb)  # starts with s, ends with e
+            ins = torch.tensor([signed_key(k, self.kb) for k in cover], dtype=self.ftree.dtype).to(self.ftree.device)
+            new = torch.cat([self.ftree[:idx], ins, self.ftree[idx + 2:L + 1]])
+            newL = L + len(cover) - 2
+            if newL + 1 > self.ftree.numel():
+                t2, c2 = b.zeros_keys(2 * newL + 1, self.kb), b.zeros_i32(2 * newL)
+                self.ftree, self.fcounts = t2, c2
+            self.ftree[:newL + 1] = new
+            self.f_leaves = newL
+            changed = True
+        if changed:
+            b.compute_node_counts(self.ftree, self.f_leaves, keys, self.fcounts)
 
     def _update_focus(self, keys):
         b = self.b
@@ -486,6 +517,9 @@ class HipBackend:
 
     def build_octree(self, tree, num_leaves):
         return self.ctx.build_octree(tree, num_leaves=num_leaves)
+
+    def compute_node_counts(self, tree, num_leaves, keys, counts):
+        self.ctx.compute_node_counts(tree, keys, counts, num_nodes=num_leaves)
 
     def to_numpy(self, t):
         return t.cpu().numpy()

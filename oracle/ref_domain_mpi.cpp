@@ -12,7 +12,7 @@
 //           clamp to [0, 1 - 2^-30]  (the box is the unit cube in every fixture)
 //   output <prefix>.rank<r>.bin, per sync: int64 {start, end, withHalos, numGlobalLeaves, P+1}, double lim[6],
 //           uint64 assignment[P+1], uint64 globalLeaves[L+1], uint32 globalCounts[L] (padded to 8 bytes),
-//           uint64 keys[end-start], double x[end-start], h[end-start]
+//           uint64 keys[end-start], double x[end-start], h[end-start], double haloX[], haloY[], haloZ[] (withHalos-(end-start) each)
 #include <mpi.h>
 
 #include <cstdio>
@@ -92,6 +92,13 @@ int main(int argc, char** argv)
         put(out, keys.data() + st, size_t(en - st));
         put(out, x.data() + st, size_t(en - st));
         put(out, h.data() + st, size_t(en - st));
+        // halo particles: [0, start) and [end, withHalos)
+        const long wh = long(dom.nParticlesWithHalos());
+        for (auto* a : {&x, &y, &z})
+        {
+            put(out, a->data(), size_t(st));
+            put(out, a->data() + en, size_t(wh - en));
+        }
 
         // the client keeps only its assigned particles and moves them
         std::vector<double> nx(x.begin() + st, x.begin() + en), ny(y.begin() + st, y.begin() + en),

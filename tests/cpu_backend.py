@@ -85,6 +85,11 @@ class CpuBackend:
         cb[:nl] = torch.from_numpy(c.view(np.int32).copy())
         return tb, cb, nl
 
+    def compute_node_counts(self, tree, num_leaves, keys, counts):
+        kb = tree.element_size() * 8
+        c = self.o.node_counts(_k(tree[:num_leaves + 1], kb).copy(), _k(keys.contiguous(), kb))
+        counts[:num_leaves] = torch.from_numpy(c.view(np.int32).copy())
+
     def build_octree(self, tree, num_leaves):
         kb = tree.element_size() * 8
         return self.o.build_octree(_k(tree[:num_leaves + 1], kb).copy())

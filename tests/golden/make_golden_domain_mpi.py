@@ -62,6 +62,8 @@ def run(P, n, syncs, bucket, bucket_focus, bc, kind, seed):
                 out[f"s{s}_r{r}_keys"] = np.frombuffer(raw, np.uint64, m, off).copy(); off += 8 * m
                 out[f"s{s}_r{r}_x"] = np.frombuffer(raw, np.float64, m, off).copy(); off += 8 * m
                 out[f"s{s}_r{r}_h"] = np.frombuffer(raw, np.float64, m, off).copy(); off += 8 * m
+                nh = wh - m
+                out[f"s{s}_r{r}_halos"] = np.frombuffer(raw, np.float64, 3 * nh, off).reshape(3, nh).copy(); off += 24 * nh
                 if r == 0:
                     out[f"s{s}_leaves"] = leaves
             assert off == len(raw)
