@@ -74,7 +74,7 @@ def golden(a, backend, dev, rank, P):
         hx, hy, hz = [np.concatenate([r[k][:st].cpu().numpy(), r[k][en:].cpu().numpy()]) for k in "xyz"]
         got = set(zip(hx.tolist(), hy.tolist(), hz.tolist()))
         ref = set(zip(*[v.tolist() for v in g[f"s{s}_r{rank}_halos"]]))
-        # Identical in 28 of the 31 (rank, sync) cases of the committed fixtures.  The sets may differ by a few particles
+        # Identical in 24 of the 27 (rank, sync) cases of the committed fixtures.  The sets may differ by a few particles
         # where the two trees resolve a cell differently for one step (the reference's focus tree also obeys MAC /
         # peer criteria): finer cells import fewer bystanders.  Completeness is what test_gloo_ranks_* checks.
         extra, missing = len(got - ref), len(ref - got)
