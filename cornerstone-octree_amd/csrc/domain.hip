@@ -152,6 +152,7 @@ struct DomainBase
     virtual int sync(void** keys, void** x, void** y, void** z, void** h, size_t n, void** scratch, void** props,
                      const int* propBytes, int numProps) = 0;
     virtual int view(cstone_hip_domain_view* out)        = 0;
+    virtual void setHaloFactor(float factor)             = 0;
 };
 
 template<class K, class T>
@@ -315,6 +316,8 @@ public:
         firstCall_  = false;
         return CSTONE_OK;
     }
+
+    void setHaloFactor(float factor) override { haloSearchExt_ = factor; }
 
     int view(cstone_hip_domain_view* v) override
     {
@@ -525,6 +528,13 @@ int cstone_hip_domain_view_get(cstone_hip_domain* dom, cstone_hip_domain_view* o
 {
     if (!dom || !out) return CSTONE_E_ARG;
     return dom->impl->view(out);
+}
+
+int cstone_hip_domain_set_halo_factor(cstone_hip_domain* dom, float factor)
+{
+    if (!dom || !(factor > 0.0f)) return CSTONE_E_ARG;
+    dom->impl->setHaloFactor(factor);
+    return CSTONE_OK;
 }
 
 } // extern "C"

@@ -25,6 +25,7 @@
 #include <limits>
 #include <stdexcept>
 #include <string>
+#include <span>
 #include <tuple>
 #include <type_traits>
 #include <utility>
@@ -552,6 +553,23 @@ public:
     Box<T> box() const { return Box<T>(view().box); }
     TreeNodeIndex startCell() const { return 0; }
     TreeNodeIndex endCell() const { return view().num_focus_leaves; }
+    //! particle offsets of each focus tree leaf cell, device pointer (Domain::layout)
+    std::span<const LocalIndex> layout() const
+    {
+        auto v = view();
+        return {v.layout, std::size_t(v.num_focus_leaves) + 1};
+    }
+    void setHaloFactor(float factor)
+    {
+        Context::check(cstone_hip_domain_set_halo_factor(dom_, factor), "Domain::setHaloFactor");
+    }
+    //! kept for source compatibility: the flag has no reader in the reference either (domain.hpp:411,661)
+    void setTreeConv(bool) {}
+    /*! one rank: no halos to exchange.  Several ranks: cstone_amd/distributed.py */
+    template<class... Vectors, class SendBuffer, class ReceiveBuffer>
+    void exchangeHalos(std::tuple<Vectors&...>, SendBuffer&, ReceiveBuffer&) const
+    {
+    }
 
     OctreeNsView<T, KeyType> octreeProperties() const
     {

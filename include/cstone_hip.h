@@ -273,6 +273,9 @@ extern "C"
     int cstone_hip_domain_sync(cstone_hip_domain* dom, void** keys, void** x, void** y, void** z, void** h, size_t n,
                                void** scratch, void** props, const int* prop_bytes, int num_props);
     int cstone_hip_domain_view_get(cstone_hip_domain* dom, cstone_hip_domain_view* out);
+    /* Domain::setHaloFactor (R/domain/domain.hpp:412): extra search factor of the halo discovery (default 1.0), lets a
+     * client take several integration steps between syncs */
+    int cstone_hip_domain_set_halo_factor(cstone_hip_domain* dom, float factor);
 
 #ifdef __cplusplus
 }
