@@ -93,6 +93,72 @@ __global__ __launch_bounds__(256) void scatterKernel(const uint32_t* __restrict_
     }
 }
 
+//! dst[mapOut[i]] = src[mapIn[i]]: a gather and a scatter in one pass (gatherScatter, R/primitives/gather.hpp:120-131)
+template<class E, int PER>
+__global__ __launch_bounds__(256) void gatherScatterKernel(const uint32_t* __restrict__ mapIn,
+                                                           const uint32_t* __restrict__ mapOut, size_t n,
+                                                           const E* __restrict__ src, E* __restrict__ dst)
+{
+    size_t base = size_t(blockIdx.x) * (256 * PER) + threadIdx.x;
+    uint32_t in[PER], out[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+    {
+        size_t i = base + size_t(k) * 256;
+        in[k]    = i < n ? mapIn[i] : 0u;
+        out[k]   = i < n ? mapOut[i] : 0u;
+    }
+    E v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+    {
+        size_t i = base + size_t(k) * 256;
+        if (i < n) v[k] = src[in[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+    {
+        size_t i = base + size_t(k) * 256;
+        if (i < n) dst[out[k]] = v[k];
+    }
+}
+
+//! positions of the elements of two sorted runs in their stable merge (ties: run A first)
+template<class K>
+__global__ __launch_bounds__(256) void mergePositionsKernel(const K* __restrict__ a, size_t na, const K* __restrict__ b,
+                                                            size_t nb, uint32_t offset, uint32_t* __restrict__ posA,
+                                                            uint32_t* __restrict__ posB)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < na)
+    {
+        // elements of B strictly below a[i]
+        K v       = a[i];
+        size_t lo = 0, len = nb;
+        while (len > 0)
+        {
+            size_t half = len >> 1;
+            if (b[lo + half] < v) { lo += half + 1, len -= half + 1; }
+            else { len = half; }
+        }
+        posA[i] = offset + uint32_t(i + lo);
+    }
+    else if (i < na + nb)
+    {
+        // elements of A below or equal to b[j]
+        size_t j  = i - na;
+        K v       = b[j];
+        size_t lo = 0, len = na;
+        while (len > 0)
+        {
+            size_t half = len >> 1;
+            if (!(v < a[lo + half])) { lo += half + 1, len -= half + 1; }
+            else { len = half; }
+        }
+        posB[j] = offset + uint32_t(j + lo);
+    }
+}
+
 template<bool GATHER, int B>
 void launchPermute(cstone_hip_ctx* ctx, const uint32_t* map, size_t n, const void* src, void* dst)
 {
@@ -299,6 +365,47 @@ int cstone_hip_gather(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map, 
 int cstone_hip_scatter(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map, size_t n, const void* src, void* dst)
 {
     return permute<false>(ctx, elem_bytes, map, n, src, dst);
+}
+
+int cstone_hip_gather_scatter(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map_in, const uint32_t* map_out,
+                              size_t n, const void* src, void* dst)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    if (n == 0) return CSTONE_OK;
+    if (!map_in || !map_out || !src || !dst) return fail(ctx, CSTONE_E_ARG, "gather_scatter: null array");
+    StageTimer timer(ctx, CSTONE_STAGE_GATHER);
+    unsigned grid = gridFor(n, 256, 4);
+    switch (elem_bytes)
+    {
+        case 4:
+            hipLaunchKernelGGL((gatherScatterKernel<Elem<4>, 4>), grid, 256, 0, ctx->stream, map_in, map_out, n,
+                               (const Elem<4>*)src, (Elem<4>*)dst);
+            break;
+        case 8:
+            hipLaunchKernelGGL((gatherScatterKernel<Elem<8>, 4>), grid, 256, 0, ctx->stream, map_in, map_out, n,
+                               (const Elem<8>*)src, (Elem<8>*)dst);
+            break;
+        default: return fail(ctx, CSTONE_E_ARG, "gather_scatter: element size %d unsupported", elem_bytes);
+    }
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int cstone_hip_merge_positions(cstone_hip_ctx* ctx, int key_bits, const void* a, size_t na, const void* b, size_t nb,
+                               uint32_t offset, uint32_t* pos_a, uint32_t* pos_b)
+{
+    if (!ctx || (key_bits != 32 && key_bits != 64) || (na && (!a || !pos_a)) || (nb && (!b || !pos_b)))
+        return fail(ctx, CSTONE_E_ARG, "merge_positions: bad argument");
+    if (na + nb == 0) return CSTONE_OK;
+    unsigned grid = gridFor(na + nb, 256);
+    if (key_bits == 32)
+        hipLaunchKernelGGL(mergePositionsKernel<uint32_t>, grid, 256, 0, ctx->stream, (const uint32_t*)a, na,
+                           (const uint32_t*)b, nb, offset, pos_a, pos_b);
+    else
+        hipLaunchKernelGGL(mergePositionsKernel<uint64_t>, grid, 256, 0, ctx->stream, (const uint64_t*)a, na,
+                           (const uint64_t*)b, nb, offset, pos_a, pos_b);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
 }
 
 int cstone_hip_minmax(cstone_hip_ctx* ctx, int real_bits, const void* x, size_t n, double* out2_host)

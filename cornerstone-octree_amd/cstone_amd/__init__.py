@@ -27,7 +27,7 @@ EXPORTS = [
     "cstone_hip_memcpy_d2h", "cstone_hip_memcpy_d2d", "cstone_hip_memset", "cstone_hip_profile_enable",
     "cstone_hip_profile_reset", "cstone_hip_profile_get", "cstone_hip_compute_sfc_keys",
     "cstone_hip_sort_pairs_temp_bytes", "cstone_hip_sort_pairs", "cstone_hip_sequence_u32", "cstone_hip_gather",
-    "cstone_hip_scatter", "cstone_hip_minmax", "cstone_hip_minmax_arrays", "cstone_hip_exclusive_scan_u32", "cstone_hip_inclusive_scan_u32", "cstone_hip_lower_bound",
+    "cstone_hip_scatter", "cstone_hip_gather_scatter", "cstone_hip_merge_positions", "cstone_hip_minmax", "cstone_hip_minmax_arrays", "cstone_hip_exclusive_scan_u32", "cstone_hip_inclusive_scan_u32", "cstone_hip_lower_bound",
     "cstone_hip_compute_node_counts", "cstone_hip_compute_node_ops", "cstone_hip_rebalance_tree",
     "cstone_hip_update_octree", "cstone_hip_compute_octree", "cstone_hip_build_octree", "cstone_hip_upsweep_sum",
     "cstone_hip_node_centers", "cstone_hip_halo_radii", "cstone_hip_find_halos", "cstone_hip_find_neighbors",
@@ -188,6 +188,23 @@ class Context:
         eb = elem_bytes or src.element_size()
         self._chk(self.lib.cstone_hip_scatter(self.h, C.c_int(eb), _ptr(map_), C.c_size_t(map_.numel()), _ptr(src),
                                               _ptr(dst)), "scatter")
+
+    def gather_scatter(self, map_in, map_out, src, dst):
+        """dst[map_out[i]] = src[map_in[i]]"""
+        self._chk(self.lib.cstone_hip_gather_scatter(self.h, C.c_int(src.element_size()), _ptr(map_in), _ptr(map_out),
+                                                     C.c_size_t(map_in.numel()), _ptr(src), _ptr(dst)),
+                  "gather_scatter")
+
+    def merge_positions(self, keys_a, keys_b, offset=0):
+        """positions (int32 storage) of two sorted key runs in their stable merge, ties: run a first"""
+        torch = _torch()
+        pa = torch.empty(keys_a.numel(), dtype=torch.int32, device=keys_a.device)
+        pb = torch.empty(keys_b.numel(), dtype=torch.int32, device=keys_a.device)
+        self._chk(self.lib.cstone_hip_merge_positions(self.h, C.c_int(keys_a.element_size() * 8), _ptr(keys_a),
+                                                      C.c_size_t(keys_a.numel()), _ptr(keys_b),
+                                                      C.c_size_t(keys_b.numel()), C.c_uint32(offset), _ptr(pa),
+                                                      _ptr(pb)), "merge_positions")
+        return pa, pb
 
     def minmax(self, x):
         out = (C.c_double * 2)()

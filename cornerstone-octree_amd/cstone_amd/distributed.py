@@ -271,7 +271,11 @@ class DistributedDomain:
     # ---- the sync
     def sync(self, x, y, z, h):
         """x,y,z,h: this rank's particles (any order).  Returns dict(keys,x,y,z,h,start,end) with arrays holding
-        [halos of lower ranks | assigned particles, SFC sorted | halos of higher ranks]."""
+        [halos of lower ranks | assigned particles, SFC sorted | halos of higher ranks].
+
+        Like the reference (R/domain/assignment.hpp:121-127) the fields are NOT reordered before the exchange: only
+        the SFC ordering is computed, the leaving particles are picked through it, and everything that stays goes
+        from its input position straight to its final slot once the halo counts are known."""
         torch = _torch()
         b, c = self.b, self.c
         rank, P = c.rank, c.size
@@ -279,19 +283,17 @@ class DistributedDomain:
         box = self._update_box(x, y, z)
         self._tick("box")
 
-        # keys + local sort, fields into SFC order so that send ranges are contiguous
         n = x.numel()
         keys = b.compute_sfc_keys(self.curve, self.kb, x, y, z, box)
         order = b.iota(n)
         b.sort_pairs(keys, order)
-        fields = [b.gather_new(order, a) for a in (x, y, z, h)]
-        self._tick("encode_sort_gather")
+        self._tick("encode_sort")
 
         self._update_global_tree(keys)
         bounds = self._assign()
         self._tick("global_tree_assign")
 
-        # C3: particle exchange
+        # C3: particle exchange.  Send ranges are contiguous in the sorted order (createSendRanges)
         cut = b.searchsorted(keys, bounds, self.kb)  # P+1 positions
         send_counts = [cut[p + 1] - cut[p] for p in range(P)]
         dropped = n - cut[P]  # particles flagged for removal sort behind the end of the curve
@@ -299,87 +301,111 @@ class DistributedDomain:
         recv_counts = [matrix[p][rank] for p in range(P)]
         moved = sum(send_counts) - send_counts[rank]
         moved_any = sum(sum(row) for row in matrix) - sum(matrix[p][p] for p in range(P))
-        kept = [f[cut[rank]:cut[rank + 1]] for f in fields]
         kept_keys = keys[cut[rank]:cut[rank + 1]]
+        kept_order = order[cut[rank]:cut[rank + 1]]
+        na = kept_keys.numel()
+        recv, rk = None, None
         if P > 1 and moved_any:
-            # only what leaves travels: the range that stays is already sorted and is merged with the newcomers
             away_send = [0 if p == rank else send_counts[p] for p in range(P)]
             away_recv = [0 if p == rank else recv_counts[p] for p in range(P)]
-            lo_part, hi_part = slice(cut[0], cut[rank]), slice(cut[rank + 1], cut[P])
+            leaving = torch.cat([order[cut[0]:cut[rank]], order[cut[rank + 1]:cut[P]]])
             # x, y, z, h of a particle travel as one row: one collective instead of four
-            packed = torch.stack([torch.cat([f[lo_part], f[hi_part]]) for f in fields], dim=1)
-            recv = list(c.all_to_all_v(packed, away_send, away_recv).unbind(dim=1))
-            if recv[0].numel():
-                recv = [r.contiguous() for r in recv]
+            packed = torch.stack([b.gather_new(leaving, f) for f in (x, y, z, h)], dim=1)
+            got = c.all_to_all_v(packed, away_send, away_recv)
+            if got.shape[0]:
+                recv = [r.contiguous() for r in got.unbind(dim=1)]
                 rk = b.compute_sfc_keys(self.curve, self.kb, recv[0], recv[1], recv[2], box)
                 ro = b.iota(rk.numel())
                 b.sort_pairs(rk, ro)
-                recv = [b.gather_new(ro, a.contiguous()) for a in recv]
-                keys, (x, y, z, h) = b.merge_sorted(kept_keys, kept, rk, recv, self.kb)
-            else:
-                keys, (x, y, z, h) = kept_keys, kept
+                recv = [b.gather_new(ro, a) for a in recv]
+        nb = rk.numel() if rk is not None else 0
+        nm = na + nb
+        # positions of the kept (already sorted) and the received (sorted among themselves) particles in their merge
+        if nb:
+            pos_a, pos_b = b.merge_positions(kept_keys, rk, 0, self.kb)
+            keys_m = b.zeros_keys(nm, self.kb)
+            b.scatter(pos_a, kept_keys, keys_m)
+            b.scatter(pos_b, rk, keys_m)
         else:
-            keys, (x, y, z, h) = kept_keys, kept
-        n = x.numel()
-        self.stats.update(moved=moved, dropped=dropped, assigned=n)
-        self._tick("particle_exchange_resort")
+            pos_a = pos_b = None
+            keys_m = kept_keys
+
+        def place(src, src_recv, dst):
+            """field values of the assigned particles -> dst[0:nm] in SFC order"""
+            if nb:
+                b.gather_scatter(kept_order, pos_a, src, dst)
+                b.scatter(pos_b, src_recv, dst)
+            else:
+                b.gather(kept_order, src, dst)
+
+        h_m = torch.empty(nm, dtype=h.dtype, device=h.device)
+        place(h, recv[3] if nb else None, h_m)
+        self.stats.update(moved=moved, dropped=dropped, assigned=nm)
+        self._tick("particle_exchange_merge")
 
         # local focus tree (finest resolution inside the assignment)
         if self.ftree is None:
-            self.ftree, self.fcounts, self.f_leaves = b.compute_octree_buffers(keys, self.bucket_focus, self.kb)
+            self.ftree, self.fcounts, self.f_leaves = b.compute_octree_buffers(keys_m, self.bucket_focus, self.kb)
         else:
-            self._update_focus(keys)
-        self._enforce_boundaries(keys, (bounds[rank], bounds[rank + 1]))
+            self._update_focus(keys_m)
+        self._enforce_boundaries(keys_m, (bounds[rank], bounds[rank + 1]))
         L = self.f_leaves
         octree = b.build_octree(self.ftree, num_leaves=L)
         first = b.find_leaf(self.ftree, L, bounds[rank], self.kb, below=True)
         last = b.find_leaf(self.ftree, L, bounds[rank + 1], self.kb, below=False)
         layout = b.layout_from_counts(self.fcounts, L)
-        start_off = int(b.to_numpy(layout[first:first + 1])[0])
-        assert start_off == 0, "particles below the assignment cannot exist after the exchange"
         self._tick("focus_tree")
 
-        halos_lo = halos_hi = None
+        # C4: owner-side halo discovery: who needs which of my particles
+        sel, hs_counts, hr_counts = None, [0] * P, [0] * P
         if P > 1:
-            radii = b.halo_radii(h, layout[first:], first, last, L, self.halo_ext)
+            radii = b.halo_radii(h_m, layout[first:], first, last, L, self.halo_ext)
             boxes = b.halo_boxes(self.curve, self.ftree, radii, box, first, last, self.rb)
             mine = boxes[boxes[:, 6] != 0]
             everyone = c.all_gather_v(mine)
-            send_idx, hs_counts = [], []
+            send_idx = []
             for p in range(P):
                 if p == rank or everyone[p].shape[0] == 0:
-                    hs_counts.append(0)
                     continue
                 flags = b.find_overlaps(self.curve, octree, self.ftree, everyone[p], first, last)
                 idx = b.particles_of_flagged(flags, layout, first, last)
                 send_idx.append(idx)
-                hs_counts.append(int(idx.numel()))
+                hs_counts[p] = int(idx.numel())
             hmatrix = c.count_matrix(hs_counts)
             hr_counts = [hmatrix[p][rank] for p in range(P)]
-            if send_idx:
-                sel = torch.cat(send_idx) if len(send_idx) > 1 else send_idx[0]
-            else:
-                sel = b.iota(0)
-            packed = torch.stack([b.gather_new(sel, a) for a in (x, y, z, h)], dim=1)
-            recv = [r.contiguous() for r in c.all_to_all_v(packed, hs_counts, hr_counts).unbind(dim=1)]
-            nlo = sum(hr_counts[:rank])
-            halos_lo = [r[:nlo] for r in recv]
-            halos_hi = [r[nlo:] for r in recv]
+            sel = torch.cat(send_idx) if send_idx else b.iota(0)
             self.stats.update(halos=sum(hr_counts), halo_boxes=int(mine.shape[0]), served=sum(hs_counts))
-        self._tick("halo_discovery_exchange")
+        nlo, nhi = sum(hr_counts[:rank]), sum(hr_counts[rank + 1:])
+        self._tick("halo_discovery")
 
-        if halos_lo is not None:
-            klo = b.compute_sfc_keys(self.curve, self.kb, halos_lo[0], halos_lo[1], halos_lo[2], box)
-            khi = b.compute_sfc_keys(self.curve, self.kb, halos_hi[0], halos_hi[1], halos_hi[2], box)
-            out = [torch.cat([lo, a, hi]) for lo, a, hi in zip(halos_lo, (x, y, z, h), halos_hi)]
-            keys = torch.cat([klo, keys, khi])
-            start = int(klo.numel())
-        else:
-            out = [x, y, z, h]
-            start = 0
+        # final buffers: [halos of lower ranks | assigned | halos of higher ranks]; every assigned value is written once
+        total = nlo + nm + nhi
+        out = [torch.empty(total, dtype=f.dtype, device=f.device) for f in (x, y, z, h)]
+        for f, fr, o in zip((x, y, z), (recv[:3] if nb else (None,) * 3), out[:3]):
+            place(f, fr, o[nlo:nlo + nm])
+        out[3][nlo:nlo + nm].copy_(h_m)
+        keys_out = b.zeros_keys(total, self.kb)
+        keys_out[nlo:nlo + nm].copy_(keys_m)
         self._tick("assemble")
+
+        # C5: halo exchange, one packed collective
+        if P > 1:
+            packed = torch.stack([b.gather_new(sel, o[nlo:nlo + nm]) for o in out], dim=1)
+            got = c.all_to_all_v(packed, hs_counts, hr_counts)
+            for d, o in enumerate(out):
+                col = got[:, d].contiguous()
+                o[:nlo].copy_(col[:nlo])
+                o[nlo + nm:].copy_(col[nlo:])
+            if nlo:
+                keys_out[:nlo].copy_(b.compute_sfc_keys(self.curve, self.kb, out[0][:nlo].contiguous(),
+                                                        out[1][:nlo].contiguous(), out[2][:nlo].contiguous(), box))
+            if nhi:
+                keys_out[nlo + nm:].copy_(b.compute_sfc_keys(self.curve, self.kb, out[0][nlo + nm:].contiguous(),
+                                                             out[1][nlo + nm:].contiguous(),
+                                                             out[2][nlo + nm:].contiguous(), box))
+        self._tick("halo_exchange")
         self.first_call = False
-        return dict(keys=keys, x=out[0], y=out[1], z=out[2], h=out[3], start=start, end=start + n, box=box,
+        return dict(keys=keys_out, x=out[0], y=out[1], z=out[2], h=out[3], start=nlo, end=nlo + nm, box=box,
                     lim=self.lim.copy())
 
     def _enforce_boundaries(self, keys, mandatory):
@@ -444,25 +470,17 @@ class HipBackend:
     def minmax3(self, x, y, z):
         return self.ctx.minmax_arrays([x.contiguous(), y.contiguous(), z.contiguous()])
 
-    def merge_sorted(self, keys_a, fields_a, keys_b, fields_b, kb):
-        """stable merge of two sorted runs (ties: run A first); positions by binary search, data by scatter"""
-        torch = _torch()
-        na, nb = keys_a.numel(), keys_b.numel()
-        if na == 0:
-            return keys_b, fields_b
-        # unsigned comparison inside lower_bound; key + 1 cannot wrap for keys below the end of the curve
-        idx_a = (torch.arange(na, device=keys_a.device) + self.ctx.lower_bound(keys_b, keys_a)).to(torch.int32)
-        idx_b = (torch.arange(nb, device=keys_a.device) + self.ctx.lower_bound(keys_a, keys_b + 1)).to(torch.int32)
-        out_keys = torch.empty(na + nb, dtype=keys_a.dtype, device=keys_a.device)
-        self.ctx.scatter(idx_a, keys_a.contiguous(), out_keys)
-        self.ctx.scatter(idx_b, keys_b.contiguous(), out_keys)
-        outs = []
-        for fa, fb in zip(fields_a, fields_b):
-            o = torch.empty(na + nb, dtype=fa.dtype, device=fa.device)
-            self.ctx.scatter(idx_a, fa.contiguous(), o)
-            self.ctx.scatter(idx_b, fb.contiguous(), o)
-            outs.append(o)
-        return out_keys, outs
+    def merge_positions(self, keys_a, keys_b, offset, kb):
+        return self.ctx.merge_positions(keys_a, keys_b, offset)
+
+    def gather(self, map_, src, dst):
+        self.ctx.gather(map_, src, dst)
+
+    def scatter(self, map_, src, dst):
+        self.ctx.scatter(map_, src.contiguous(), dst)
+
+    def gather_scatter(self, map_in, map_out, src, dst):
+        self.ctx.gather_scatter(map_in, map_out, src, dst)
 
     def compute_sfc_keys(self, curve, kb, x, y, z, box):
         torch = _torch()

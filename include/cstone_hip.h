@@ -121,6 +121,15 @@ extern "C"
     int cstone_hip_scatter(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map, size_t n, const void* src,
                            void* dst);
 
+    /* gatherScatter (R/primitives/gather.hpp:120-131): dst[map_out[i]] = src[map_in[i]], 4- or 8-byte elements */
+    int cstone_hip_gather_scatter(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map_in, const uint32_t* map_out,
+                                  size_t n, const void* src, void* dst);
+    /* positions of the elements of two sorted key runs in their stable merge (ties: run a first), plus offset:
+     * the re-sort of GlobalAssignment::distribute (R/domain/assignment.hpp:139-158) for a kept range that is already
+     * sorted and newcomers that have been sorted among themselves */
+    int cstone_hip_merge_positions(cstone_hip_ctx* ctx, int key_bits, const void* a, size_t na, const void* b,
+                                   size_t nb, uint32_t offset, uint32_t* pos_a, uint32_t* pos_b);
+
     /* MinMaxGpu (R/primitives/primitives_gpu.h:58-62): out_host = {min, max} as doubles (exact for float) */
     int cstone_hip_minmax(cstone_hip_ctx* ctx, int real_bits, const void* x, size_t n, double* out2_host);
     /* the same for 1..3 equally long arrays (the x, y, z of the bounding box, R/sfc/box_mpi.hpp:40-70) in one launch and

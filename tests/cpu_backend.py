@@ -30,12 +30,20 @@ class CpuBackend:
     def minmax3(self, x, y, z):
         return [(float(a.min()), float(a.max())) for a in (x, y, z)]
 
-    def merge_sorted(self, keys_a, fields_a, keys_b, fields_b, kb):
+    def merge_positions(self, keys_a, keys_b, offset, kb):
         ka, kbb = _k(keys_a.contiguous(), kb), _k(keys_b.contiguous(), kb)
-        allk = np.concatenate([ka, kbb])
-        order = np.argsort(allk, kind="stable")  # stable: run A first on ties
-        fields = [torch.cat([fa, fb])[torch.from_numpy(order)] for fa, fb in zip(fields_a, fields_b)]
-        return _tk(allk[order]), fields
+        pa = np.arange(ka.size) + np.searchsorted(kbb, ka, side="left") + offset
+        pb = np.arange(kbb.size) + np.searchsorted(ka, kbb, side="right") + offset
+        return torch.from_numpy(pa.astype(np.int32)), torch.from_numpy(pb.astype(np.int32))
+
+    def gather(self, map_, src, dst):
+        dst.copy_(src[map_.long()])
+
+    def scatter(self, map_, src, dst):
+        dst[map_.long()] = src
+
+    def gather_scatter(self, map_in, map_out, src, dst):
+        dst[map_out.long()] = src[map_in.long()]
 
     def compute_sfc_keys(self, curve, kb, x, y, z, box):
         if x.numel() == 0:
