@@ -405,3 +405,36 @@ def test_lower_bound_unsigned(hip, kb):
     empty = hip.lower_bound(torch.zeros(0, dtype=torch.int64 if kb == 64 else torch.int32, device="cuda"),
                             torch.from_numpy(vals.view(sdt)).cuda())
     assert int(empty.abs().sum()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kb", [32, 64])
+def test_merge_positions_and_gather_scatter(hip, kb):
+    """stable merge of two sorted runs (ties: run a first) = np.sort(kind="stable") of their concatenation;
+    gather_scatter = dst[map_out] = src[map_in]"""
+    import torch
+
+    rng = np.random.default_rng(kb)
+    udt = np.uint64 if kb == 64 else np.uint32
+    sdt = np.int64 if kb == 64 else np.int32
+    end = 1 << (3 * (21 if kb == 64 else 10))
+    for na, nb in ((100000, 3000), (5000, 5000), (1, 0), (0, 7), (70000, 1)):
+        a = np.sort(rng.integers(0, 5000, na).astype(udt) * udt(end // 5000))  # many ties inside and across the runs
+        b = np.sort(rng.integers(0, 5000, nb).astype(udt) * udt(end // 5000))
+        pa, pb = hip.merge_positions(torch.from_numpy(a.view(sdt)).cuda(), torch.from_numpy(b.view(sdt)).cuda(), 11)
+        pa, pb = pa.cpu().numpy(), pb.cpu().numpy()
+        order = np.argsort(np.concatenate([a, b]), kind="stable")
+        ref = np.empty(na + nb, dtype=np.int64)
+        ref[order] = np.arange(na + nb)
+        assert np.array_equal(pa, ref[:na] + 11) and np.array_equal(pb, ref[na:] + 11)
+    n = 200001
+    for dt in (np.float64, np.float32):
+        src = rng.normal(size=n).astype(dt)
+        map_in = rng.permutation(n).astype(np.int32)
+        map_out = rng.permutation(n).astype(np.int32)
+        dst = torch.zeros(n, dtype=torch.float64 if dt == np.float64 else torch.float32, device="cuda")
+        hip.gather_scatter(torch.from_numpy(map_in).cuda(), torch.from_numpy(map_out).cuda(),
+                           torch.from_numpy(src).cuda(), dst)
+        ref = np.zeros(n, dtype=dt)
+        ref[map_out] = src[map_in]
+        assert np.array_equal(dst.cpu().numpy(), ref)
