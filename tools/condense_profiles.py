@@ -18,6 +18,18 @@ os.makedirs("profiles", exist_ok=True)
 stats = glob.glob(os.path.join(src, "bench", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], f"profiles/{tag}_bench_kernel_stats.csv")
+# the pass kernel also runs on the small sorts of the linked-octree build: the --stats average mixes both, so the
+# launches over the full particle set (grid = N / 16384 workgroups of 1024) are averaged separately from the trace
+for trace in glob.glob(os.path.join(src, "bench", "**", "*kernel_trace.csv"), recursive=True):
+    groups = defaultdict(list)
+    for row in csv.DictReader(open(trace)):
+        if "onesweepKernel<" in row["Kernel_Name"]:
+            wgs = int(row["Grid_Size_X"]) // int(row["Workgroup_Size_X"])
+            groups[wgs].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    summary = [{"workgroups": g, "launches": len(v), "avg_us": sum(v) / len(v) / 1e3, "min_us": min(v) / 1e3,
+                "max_us": max(v) / 1e3} for g, v in sorted(groups.items())]
+    json.dump({"kernel": "onesweepKernel", "source": "rocprofv3 --kernel-trace of `python bench.py --steps 5 --warmup 1`",
+               "by_grid": summary}, open(f"profiles/{tag}_onesweep_launches.json", "w"), indent=1)
 means = defaultdict(dict)
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     acc = defaultdict(lambda: [0.0, 0])
