@@ -266,7 +266,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    pipe.first_sync()
+    barrier()
+    t_first = time.perf_counter()
+    pipe.first_sync()  # converges both trees from the root and moves every particle: reported, not part of `value`
+    barrier()
+    first_sync_ms = (time.perf_counter() - t_first) * 1e3
     for _ in range(args.warmup):
         pipe.step()
     ctx.profile_enable(True)
@@ -333,6 +337,7 @@ def main():
                          "traffic": traffic, "bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3,
                          "launches": pass_launches},
             "stage_ms_per_step": stage_ms,
+            "first_sync_ms": first_sync_ms,
             "extras": extras,
         }
         if not args.no_cpu_baseline:
