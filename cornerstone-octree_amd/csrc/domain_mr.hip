@@ -1,0 +1,891 @@
+// cstone::Domain::sync on SEVERAL ranks, one process per GPU (R/domain/domain.hpp:196-243).  Decomposition logic and
+// all device work live here; the three collectives come from the host application through cstone_hip_comm_ops.
+//
+//   C1  global box            makeGlobalBox (R/sfc/box_mpi.hpp:85-121): local min/max, all_reduce(MIN) of (lo, -hi)
+//   C2  global tree           GlobalAssignment (R/domain/assignment.hpp:42-103): spanning tree of numRanks segments,
+//                             updateOctreeGlobal = rebalance + recount + all_reduce(SUM) (R/tree/update_mpi.hpp:71-94)
+//       assignment            uniformBins / makeSfcAssignment / limitBoundaryShifts (R/domain/domaindecomp.hpp:50-172)
+//   C3  particle exchange     createSendRanges (:218-230) on the sorted keys; the fields are NOT reordered first
+//                             (assignment.hpp:121-127): leaving particles are packed through the ordering as
+//                             (x,y,z,h) rows, ONE all_to_all_v; newcomers are sorted among themselves and merged into
+//                             the kept, already sorted range instead of the second full sort of assignment.hpp:156
+//   C4  halo discovery        owner side: every rank exports the radius-dilated boxes of its boundary leaves
+//                             (all_gather), each owner marks the leaves of its own tree that a foreign box touches
+//   C5  halo exchange         ONE all_to_all_v of packed rows
+// Result: [halos of lower ranks | assigned, SFC sorted | halos of higher ranks] in domain-owned arrays.
+// Box, SFC ranges, global tree and the assigned particles are bit-identical to the reference Domain under MPI
+// (tests/golden/ref_domain_mpi_*.npz); the halo set is compared there as well.
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <memory>
+#include <numeric>
+#include <vector>
+
+#include "ctx.hpp"
+#include "devbuf.hpp"
+#include "device_keys.hpp"
+#include "scan.hpp"
+
+namespace cship
+{
+
+namespace
+{
+
+// ---- host-side decomposition rules -------------------------------------------------------------------------------
+
+//! smallest l with 8^l >= n (R/sfc/common.hpp:134-142)
+inline unsigned log8ceilHost(uint64_t n)
+{
+    unsigned l = 0;
+    uint64_t p = 1;
+    while (p < n)
+    {
+        p *= 8;
+        ++l;
+    }
+    return l;
+}
+
+//! computeSpanningTree(initialDomainSplits(numRanks, level)) (R/tree/csarray.hpp:508-531, domaindecomp.hpp:242-255):
+//! per segment the canonical cover by maximal aligned power-of-8 nodes (spanSfcRange, R/sfc/common.hpp:376-438)
+template<class K>
+void appendCover(std::vector<K>& out, uint64_t a, uint64_t b)
+{
+    const uint64_t end = uint64_t(endKey<K>());
+    while (a < b)
+    {
+        uint64_t size = end;
+        while (size > 1 && (a % size != 0 || size > b - a))
+            size /= 8;
+        out.push_back(K(a));
+        a += size;
+    }
+}
+
+template<class K>
+std::vector<K> initialGlobalTree(int numRanks)
+{
+    const uint64_t end   = uint64_t(endKey<K>());
+    const unsigned level = log8ceilHost(100ull * uint64_t(numRanks));
+    const unsigned shift = 3 * (maxLevel<K>() - level);
+    const uint64_t delta = end / uint64_t(numRanks);
+    std::vector<uint64_t> splits(numRanks + 1, 0);
+    for (int i = 1; i < numRanks; ++i)
+        splits[i] = ((uint64_t(i) * delta) >> shift) << shift;
+    splits[numRanks] = end;
+    std::vector<K> tree;
+    for (int i = 0; i < numRanks; ++i)
+        appendCover(tree, splits[i], splits[i + 1]);
+    tree.push_back(K(end));
+    return tree;
+}
+
+//! uniformBins (R/domain/domaindecomp.hpp:50-75)
+inline std::vector<int> uniformBinsHost(const std::vector<uint32_t>& counts, int numBins)
+{
+    std::vector<uint64_t> scan(counts.size() + 1, 0);
+    for (size_t i = 0; i < counts.size(); ++i)
+        scan[i + 1] = scan[i] + counts[i];
+    double binCount = double(scan.back()) / numBins;
+    std::vector<int> bins(numBins + 1, 0);
+    bins[numBins] = int(counts.size());
+    for (int i = 1; i < numBins; ++i)
+    {
+        uint64_t target = uint64_t(i * binCount);
+        bins[i]         = int(std::lower_bound(scan.begin(), scan.end(), target) - scan.begin());
+    }
+    return bins;
+}
+
+// ---- device helpers ------------------------------------------------------------------------------------------------
+
+//! rows[i] = {x, y, z, h}[idx[i]]: the fields of a particle travel as one record
+template<class T>
+__global__ __launch_bounds__(256) void packRowsKernel(const uint32_t* __restrict__ idx, size_t m,
+                                                      const T* __restrict__ x, const T* __restrict__ y,
+                                                      const T* __restrict__ z, const T* __restrict__ h,
+                                                      T* __restrict__ rows)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= m) return;
+    uint32_t j      = idx[i];
+    rows[4 * i]     = x[j];
+    rows[4 * i + 1] = y[j];
+    rows[4 * i + 2] = z[j];
+    rows[4 * i + 3] = h[j];
+}
+
+template<class T>
+__global__ __launch_bounds__(256) void unpackRowsKernel(const T* __restrict__ rows, size_t m, T* __restrict__ x,
+                                                        T* __restrict__ y, T* __restrict__ z, T* __restrict__ h)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= m) return;
+    x[i] = rows[4 * i];
+    y[i] = rows[4 * i + 1];
+    z[i] = rows[4 * i + 2];
+    h[i] = rows[4 * i + 3];
+}
+
+__global__ __launch_bounds__(256) void boxFlagsKernel(const int32_t* __restrict__ boxes, int n,
+                                                      uint32_t* __restrict__ flags)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = boxes[8 * i + 6] != 0;
+}
+
+//! keeps the records with flag != 0; scan = exclusive scan of the flags
+__global__ __launch_bounds__(256) void compactBoxesKernel(const int32_t* __restrict__ boxes,
+                                                          const uint32_t* __restrict__ scan, int n,
+                                                          int32_t* __restrict__ out)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || boxes[8 * i + 6] == 0) return;
+    const int4* src = reinterpret_cast<const int4*>(boxes + 8 * size_t(i));
+    int4* dst       = reinterpret_cast<int4*>(out + 8 * size_t(scan[i]));
+    dst[0]          = src[0];
+    dst[1]          = src[1];
+}
+
+//! cnt[i - first] = number of particles of leaf i if it is flagged, else 0
+__global__ __launch_bounds__(256) void flaggedCountsKernel(const int32_t* __restrict__ flags,
+                                                           const uint32_t* __restrict__ layout, int first, int last,
+                                                           uint32_t* __restrict__ cnt)
+{
+    int i = first + blockIdx.x * 256 + threadIdx.x;
+    if (i < last) cnt[i - first] = flags[i] ? layout[i + 1] - layout[i] : 0u;
+}
+
+//! particle indices (relative to the first assigned particle) of the flagged leaves, 16 lanes per leaf
+__global__ __launch_bounds__(256) void fillIndicesKernel(const int32_t* __restrict__ flags,
+                                                         const uint32_t* __restrict__ layout,
+                                                         const uint32_t* __restrict__ scan, int first, int last,
+                                                         uint32_t* __restrict__ out)
+{
+    const unsigned sub = threadIdx.x & 15u;
+    int i              = first + blockIdx.x * 16 + int(threadIdx.x >> 4);
+    if (i >= last || !flags[i]) return;
+    uint32_t a = layout[i], b = layout[i + 1], o = scan[i - first];
+    uint32_t base = layout[first];
+    for (uint32_t j = a + sub; j < b; j += 16)
+        out[o + (j - a)] = j - base;
+}
+
+//! one set of result arrays
+struct Out
+{
+    DevBuf keys, x, y, z, h;
+};
+
+struct MrBase
+{
+    virtual ~MrBase()                                                                    = default;
+    virtual int sync(const void* x, const void* y, const void* z, const void* h, size_t n) = 0;
+    virtual int view(cstone_hip_domain_mr_view* out)                                     = 0;
+    virtual void setHaloFactor(float f)                                                  = 0;
+};
+
+template<class K, class T>
+class MultiRankDomain final : public MrBase
+{
+    static constexpr int kb = 8 * sizeof(K), rb = 8 * sizeof(T);
+
+public:
+    MultiRankDomain(cstone_hip_ctx* ctx, int curve, int rank, int numRanks, uint32_t bucket, uint32_t bucketFocus,
+                    const cstone_box& box, const cstone_hip_comm_ops& comm)
+        : ctx_(ctx)
+        , curve_(curve)
+        , rank_(rank)
+        , P_(numRanks)
+        , bucket_(bucket)
+        , bucketFocus_(bucketFocus)
+        , box_(box)
+        , comm_(comm)
+    {
+    }
+
+    void setHaloFactor(float f) override { haloExt_ = f; }
+
+    int view(cstone_hip_domain_mr_view* v) override
+    {
+        *v = view_;
+        return CSTONE_OK;
+    }
+
+    int sync(const void* xIn, const void* yIn, const void* zIn, const void* hIn, size_t n) override
+    {
+        const T* x = static_cast<const T*>(xIn);
+        const T* y = static_cast<const T*>(yIn);
+        const T* z = static_cast<const T*>(zIn);
+        const T* h = static_cast<const T*>(hIn);
+        if (n >= (size_t(1) << 30)) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: too many particles per rank");
+        CS_TRY(scal_.ensure(ctx_, 4096 + size_t(P_) * P_ * 8 + size_t(P_ + 1) * 16));
+
+        CS_TRY(updateBox(x, y, z, n));
+
+        // ---- keys + SFC ordering of the present particles
+        const size_t nAlloc = std::max<size_t>(n, 64);
+        CS_TRY(keys_.ensure(ctx_, nAlloc * sizeof(K)));
+        CS_TRY(order_.ensure(ctx_, nAlloc * sizeof(uint32_t)));
+        CS_TRY(ensureSortScratch(nAlloc));
+        CS_HIP(ctx_, hipMemsetAsync(keys_.p, 0, n * sizeof(K), ctx_->stream)); // encode skips entries == removeKey
+        if (n)
+        {
+            CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, x, y, z, keys_.p, n, &box_));
+            CS_TRY(cstone_hip_sequence_u32(ctx_, order_.as<uint32_t>(), n, 0));
+            CS_TRY(cstone_hip_sort_pairs(ctx_, kb, keys_.p, order_.as<uint32_t>(), n, keysAlt_.p,
+                                         orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes));
+        }
+
+        CS_TRY(updateGlobalTree(n));
+        CS_TRY(assign());
+
+        // ---- C3: send ranges on the sorted keys, counts of everybody, exchange of the leaving particles
+        std::vector<uint64_t> cut(P_ + 1);
+        {
+            K* dq      = reinterpret_cast<K*>(scal_.as<char>() + 2048);
+            uint64_t* dr = reinterpret_cast<uint64_t*>(scal_.as<char>() + 2048 + size_t(P_ + 1) * 8);
+            CS_HIP(ctx_, hipMemcpyAsync(dq, assignment_.data(), size_t(P_ + 1) * sizeof(K), hipMemcpyHostToDevice,
+                                        ctx_->stream));
+            CS_TRY(cstone_hip_lower_bound(ctx_, kb, keys_.p, n, dq, P_ + 1, dr));
+            CS_TRY(toHost(cut.data(), dr, size_t(P_ + 1) * 8));
+        }
+        std::vector<uint64_t> sendCounts(P_), matrix;
+        for (int p = 0; p < P_; ++p)
+            sendCounts[p] = cut[p + 1] - cut[p];
+        CS_TRY(countMatrix(sendCounts, matrix));
+        std::vector<size_t> sendBytes(P_, 0), recvBytes(P_, 0);
+        uint64_t movedAny = 0, mSend = 0, nb = 0;
+        for (int p = 0; p < P_; ++p)
+        {
+            for (int q = 0; q < P_; ++q)
+                if (p != q) movedAny += matrix[size_t(p) * P_ + q];
+            if (p == rank_) continue;
+            sendBytes[p] = sendCounts[p] * 4 * sizeof(T);
+            recvBytes[p] = matrix[size_t(p) * P_ + rank_] * 4 * sizeof(T);
+            mSend += sendCounts[p];
+            nb += matrix[size_t(p) * P_ + rank_];
+        }
+        const uint64_t na     = sendCounts[rank_];
+        const K* keptKeys     = keys_.as<K>() + cut[rank_];
+        const uint32_t* keptO = order_.as<uint32_t>() + cut[rank_];
+        const uint64_t nm     = na + nb;
+        if (nm == 0) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: rank %d is left without particles", rank_);
+        if (nm >= (uint64_t(1) << 30)) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: too many particles per rank");
+
+        if (movedAny)
+        {
+            CS_TRY(leaving_.ensure(ctx_, std::max<size_t>(mSend, 1) * sizeof(uint32_t)));
+            CS_TRY(sendRows_.ensure(ctx_, std::max<size_t>(mSend, 1) * 4 * sizeof(T)));
+            CS_TRY(recvRows_.ensure(ctx_, std::max<size_t>(nb, 1) * 4 * sizeof(T)));
+            size_t nLow = cut[rank_] - cut[0], nHigh = cut[P_] - cut[rank_ + 1];
+            if (nLow)
+                CS_HIP(ctx_, hipMemcpyAsync(leaving_.p, order_.as<uint32_t>() + cut[0], nLow * 4,
+                                            hipMemcpyDeviceToDevice, ctx_->stream));
+            if (nHigh)
+                CS_HIP(ctx_, hipMemcpyAsync(leaving_.as<uint32_t>() + nLow, order_.as<uint32_t>() + cut[rank_ + 1],
+                                            nHigh * 4, hipMemcpyDeviceToDevice, ctx_->stream));
+            if (mSend)
+                hipLaunchKernelGGL(packRowsKernel<T>, gridFor(mSend, 256), 256, 0, ctx_->stream,
+                                   leaving_.as<uint32_t>(), size_t(mSend), x, y, z, h, sendRows_.as<T>());
+            CS_TRY(callComm(comm_.all_to_all_v(comm_.user, sendRows_.p, sendBytes.data(), recvRows_.p, recvBytes.data()),
+                            "all_to_all_v (particles)"));
+        }
+
+        // ---- newcomers: sorted among themselves
+        const T* recvSorted[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (nb)
+        {
+            for (int c = 0; c < 4; ++c)
+            {
+                CS_TRY(rcol_[c].ensure(ctx_, nb * sizeof(T)));
+                CS_TRY(rcolS_[c].ensure(ctx_, nb * sizeof(T)));
+            }
+            hipLaunchKernelGGL(unpackRowsKernel<T>, gridFor(nb, 256), 256, 0, ctx_->stream, recvRows_.as<T>(), size_t(nb),
+                               rcol_[0].as<T>(), rcol_[1].as<T>(), rcol_[2].as<T>(), rcol_[3].as<T>());
+            CS_TRY(rk_.ensure(ctx_, nb * sizeof(K)));
+            CS_TRY(ro_.ensure(ctx_, nb * sizeof(uint32_t)));
+            CS_TRY(ensureSortScratch(std::max<size_t>(nAlloc, nb)));
+            CS_HIP(ctx_, hipMemsetAsync(rk_.p, 0, nb * sizeof(K), ctx_->stream));
+            CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, rcol_[0].p, rcol_[1].p, rcol_[2].p, rk_.p, nb,
+                                               &box_));
+            CS_TRY(cstone_hip_sequence_u32(ctx_, ro_.as<uint32_t>(), nb, 0));
+            CS_TRY(cstone_hip_sort_pairs(ctx_, kb, rk_.p, ro_.as<uint32_t>(), nb, keysAlt_.p, orderAlt_.as<uint32_t>(),
+                                         sortTmp_.p, sortTmp_.bytes));
+            for (int c = 0; c < 4; ++c)
+            {
+                CS_TRY(cstone_hip_gather(ctx_, sizeof(T), ro_.as<uint32_t>(), nb, rcol_[c].p, rcolS_[c].p));
+                recvSorted[c] = rcolS_[c].as<T>();
+            }
+        }
+
+        // ---- merge of the kept, already sorted range with the newcomers: positions, keys, h
+        const K* keysM = keptKeys;
+        if (nb)
+        {
+            CS_TRY(posA_.ensure(ctx_, std::max<size_t>(na, 1) * sizeof(uint32_t)));
+            CS_TRY(posB_.ensure(ctx_, nb * sizeof(uint32_t)));
+            CS_TRY(keysM_.ensure(ctx_, nm * sizeof(K)));
+            CS_TRY(cstone_hip_merge_positions(ctx_, kb, keptKeys, na, rk_.p, nb, 0, posA_.as<uint32_t>(),
+                                              posB_.as<uint32_t>()));
+            CS_TRY(cstone_hip_scatter(ctx_, sizeof(K), posA_.as<uint32_t>(), na, keptKeys, keysM_.p));
+            CS_TRY(cstone_hip_scatter(ctx_, sizeof(K), posB_.as<uint32_t>(), nb, rk_.p, keysM_.p));
+            keysM = keysM_.as<K>();
+        }
+        auto place = [&](const T* src, const T* srcRecv, T* dst) -> int
+        {
+            if (nb)
+            {
+                CS_TRY(cstone_hip_gather_scatter(ctx_, sizeof(T), keptO, posA_.as<uint32_t>(), na, src, dst));
+                CS_TRY(cstone_hip_scatter(ctx_, sizeof(T), posB_.as<uint32_t>(), nb, srcRecv, dst));
+            }
+            else { CS_TRY(cstone_hip_gather(ctx_, sizeof(T), keptO, na, src, dst)); }
+            return CSTONE_OK;
+        };
+        CS_TRY(hM_.ensure(ctx_, nm * sizeof(T)));
+        CS_TRY(place(h, recvSorted[3], hM_.as<T>()));
+
+        // ---- this rank's finest tree over its assigned particles; its SFC range must end on leaf boundaries
+        CS_TRY(updateFocusTree(keysM, nm));
+        CS_TRY(enforceBoundaries(keysM, nm));
+        CS_TRY(buildFocusOctree());
+        const int L = fLeaves_;
+        int first = 0, last = L;
+        CS_TRY(findLeaves(&first, &last));
+        CS_TRY(layout_.ensure(ctx_, size_t(L + 1) * sizeof(uint32_t)));
+        CS_HIP(ctx_, hipMemsetAsync(layout_.p, 0, sizeof(uint32_t), ctx_->stream));
+        CS_TRY(cstone_hip_inclusive_scan_u32(ctx_, fCounts_.as<uint32_t>(), layout_.as<uint32_t>() + 1, size_t(L)));
+
+        // ---- C4: owner-side halo discovery
+        std::vector<uint64_t> hsCounts(P_, 0), hmatrix(size_t(P_) * P_, 0);
+        uint64_t numMyBoxes = 0, selTotal = 0;
+        if (P_ > 1)
+        {
+            const int nLocal = last - first;
+            CS_TRY(radii_.ensure(ctx_, size_t(L) * sizeof(float)));
+            CS_TRY(boxes_.ensure(ctx_, size_t(std::max(nLocal, 1)) * 32));
+            CS_TRY(boxFlags_.ensure(ctx_, size_t(nLocal + 1) * sizeof(uint32_t)));
+            CS_TRY(cstone_hip_halo_radii(ctx_, rb, hM_.p, layout_.as<uint32_t>() + first, first, last, L, haloExt_,
+                                         radii_.as<float>()));
+            CS_TRY(cstone_hip_halo_boxes(ctx_, curve_, kb, rb, fTree_.p, radii_.as<float>(), &box_, first, last,
+                                         boxes_.as<int32_t>()));
+            hipLaunchKernelGGL(boxFlagsKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream, boxes_.as<int32_t>(), nLocal,
+                               boxFlags_.as<uint32_t>());
+            uint32_t* total = scal_.as<uint32_t>() + 16;
+            CS_TRY(exclusiveScanWithTotal(boxFlags_.as<uint32_t>(), nLocal, total));
+            uint32_t nbx = 0;
+            CS_TRY(toHost(&nbx, total, 4));
+            numMyBoxes = nbx;
+            CS_TRY(myBoxes_.ensure(ctx_, size_t(std::max<uint32_t>(nbx, 1)) * 32));
+            hipLaunchKernelGGL(compactBoxesKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream, boxes_.as<int32_t>(),
+                               boxFlags_.as<uint32_t>(), nLocal, myBoxes_.as<int32_t>());
+
+            // box counts of everybody, then the boxes themselves padded to the longest list
+            std::vector<uint64_t> boxCounts(P_);
+            CS_TRY(allGatherU64(numMyBoxes, boxCounts));
+            uint64_t maxBoxes = *std::max_element(boxCounts.begin(), boxCounts.end());
+            if (maxBoxes)
+            {
+                CS_TRY(myBoxes_.ensure(ctx_, size_t(maxBoxes) * 32, true));
+                CS_TRY(allBoxes_.ensure(ctx_, size_t(maxBoxes) * 32 * P_));
+                CS_TRY(callComm(comm_.all_gather(comm_.user, myBoxes_.p, allBoxes_.p, size_t(maxBoxes) * 32),
+                                "all_gather (halo boxes)"));
+            }
+            CS_TRY(oflags_.ensure(ctx_, size_t(L) * sizeof(int32_t)));
+            CS_TRY(cnt_.ensure(ctx_, size_t(nLocal + 1) * sizeof(uint32_t)));
+            for (int p = 0; p < P_; ++p)
+            {
+                if (p == rank_ || boxCounts[p] == 0) continue;
+                CS_HIP(ctx_, hipMemsetAsync(oflags_.p, 0, size_t(L) * sizeof(int32_t), ctx_->stream));
+                CS_TRY(cstone_hip_find_overlaps(ctx_, curve_, kb, fPrefixes_.p, fChild_.as<int32_t>(),
+                                                fItl_.as<int32_t>(), fTree_.p,
+                                                allBoxes_.as<int32_t>() + size_t(p) * maxBoxes * 8, int(boxCounts[p]),
+                                                first, last, oflags_.as<int32_t>()));
+                hipLaunchKernelGGL(flaggedCountsKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream,
+                                   oflags_.as<int32_t>(), layout_.as<uint32_t>(), first, last, cnt_.as<uint32_t>());
+                CS_TRY(exclusiveScanWithTotal(cnt_.as<uint32_t>(), nLocal, total));
+                uint32_t tp = 0;
+                CS_TRY(toHost(&tp, total, 4));
+                if (tp)
+                {
+                    CS_TRY(sel_.ensure(ctx_, (selTotal + tp) * sizeof(uint32_t), true));
+                    hipLaunchKernelGGL(fillIndicesKernel, gridFor(nLocal, 16), 256, 0, ctx_->stream,
+                                       oflags_.as<int32_t>(), layout_.as<uint32_t>(), cnt_.as<uint32_t>(), first, last,
+                                       sel_.as<uint32_t>() + selTotal);
+                }
+                hsCounts[p] = tp;
+                selTotal += tp;
+            }
+            CS_TRY(countMatrix(hsCounts, hmatrix));
+        }
+        uint64_t nlo = 0, nhi = 0, haloAny = 0; // haloAny: the same on every rank, it decides about the collective
+        for (uint64_t v : hmatrix)
+            haloAny += v;
+        std::vector<size_t> hSendBytes(P_, 0), hRecvBytes(P_, 0);
+        for (int p = 0; p < P_; ++p)
+        {
+            uint64_t r = hmatrix[size_t(p) * P_ + rank_];
+            (p < rank_ ? nlo : nhi) += (p == rank_ ? 0 : r);
+            hSendBytes[p] = hsCounts[p] * 4 * sizeof(T);
+            hRecvBytes[p] = (p == rank_ ? 0 : r) * 4 * sizeof(T);
+        }
+
+        // ---- final arrays: every assigned value is written once, from its input slot to its final slot
+        const uint64_t total = nlo + nm + nhi;
+        cur_ ^= 1;
+        Out& o = out_[cur_];
+        CS_TRY(o.keys.ensure(ctx_, total * sizeof(K)));
+        for (DevBuf* b : {&o.x, &o.y, &o.z, &o.h})
+            CS_TRY(b->ensure(ctx_, total * sizeof(T)));
+        CS_TRY(place(x, recvSorted[0], o.x.as<T>() + nlo));
+        CS_TRY(place(y, recvSorted[1], o.y.as<T>() + nlo));
+        CS_TRY(place(z, recvSorted[2], o.z.as<T>() + nlo));
+        CS_HIP(ctx_, hipMemcpyAsync(o.h.as<T>() + nlo, hM_.p, nm * sizeof(T), hipMemcpyDeviceToDevice, ctx_->stream));
+        CS_HIP(ctx_, hipMemcpyAsync(o.keys.as<K>() + nlo, keysM, nm * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
+
+        // ---- C5: halo exchange
+        if (P_ > 1 && haloAny)
+        {
+            CS_TRY(sendRows_.ensure(ctx_, std::max<size_t>(selTotal, 1) * 4 * sizeof(T)));
+            CS_TRY(recvRows_.ensure(ctx_, std::max<size_t>(nlo + nhi, 1) * 4 * sizeof(T)));
+            if (selTotal)
+                hipLaunchKernelGGL(packRowsKernel<T>, gridFor(selTotal, 256), 256, 0, ctx_->stream, sel_.as<uint32_t>(),
+                                   size_t(selTotal), o.x.as<T>() + nlo, o.y.as<T>() + nlo, o.z.as<T>() + nlo,
+                                   o.h.as<T>() + nlo, sendRows_.as<T>());
+            CS_TRY(callComm(comm_.all_to_all_v(comm_.user, sendRows_.p, hSendBytes.data(), recvRows_.p,
+                                               hRecvBytes.data()),
+                            "all_to_all_v (halos)"));
+            if (nlo)
+                hipLaunchKernelGGL(unpackRowsKernel<T>, gridFor(nlo, 256), 256, 0, ctx_->stream, recvRows_.as<T>(),
+                                   size_t(nlo), o.x.as<T>(), o.y.as<T>(), o.z.as<T>(), o.h.as<T>());
+            if (nhi)
+                hipLaunchKernelGGL(unpackRowsKernel<T>, gridFor(nhi, 256), 256, 0, ctx_->stream,
+                                   recvRows_.as<T>() + 4 * nlo, size_t(nhi), o.x.as<T>() + nlo + nm,
+                                   o.y.as<T>() + nlo + nm, o.z.as<T>() + nlo + nm, o.h.as<T>() + nlo + nm);
+            // keys of the halo particles (encode skips entries that hold the remove marker: clear first)
+            if (nlo)
+            {
+                CS_HIP(ctx_, hipMemsetAsync(o.keys.p, 0, nlo * sizeof(K), ctx_->stream));
+                CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, o.x.p, o.y.p, o.z.p, o.keys.p, nlo, &box_));
+            }
+            if (nhi)
+            {
+                CS_HIP(ctx_, hipMemsetAsync(o.keys.as<K>() + nlo + nm, 0, nhi * sizeof(K), ctx_->stream));
+                CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, o.x.as<T>() + nlo + nm, o.y.as<T>() + nlo + nm,
+                                                   o.z.as<T>() + nlo + nm, o.keys.as<K>() + nlo + nm, nhi, &box_));
+            }
+        }
+        CS_HIP(ctx_, hipGetLastError());
+
+        firstCall_                     = false;
+        view_.start_index              = uint32_t(nlo);
+        view_.end_index                = uint32_t(nlo + nm);
+        view_.num_particles_with_halos = uint32_t(total);
+        view_.box                      = box_;
+        view_.keys = o.keys.p, view_.x = o.x.p, view_.y = o.y.p, view_.z = o.z.p, view_.h = o.h.p;
+        view_.num_global_leaves = gLeaves_, view_.num_focus_leaves = fLeaves_;
+        view_.global_leaves = gTree_.p, view_.global_counts = gCounts_.as<uint32_t>();
+        view_.focus_leaves = fTree_.p, view_.focus_leaf_counts = fCounts_.as<uint32_t>();
+        view_.range_start = uint64_t(assignment_[rank_]), view_.range_end = uint64_t(assignment_[rank_ + 1]);
+        view_.particles_sent      = mSend;
+        view_.halos_received      = nlo + nhi;
+        view_.halos_sent          = selTotal;
+        view_.halo_boxes_exported = numMyBoxes;
+        return CSTONE_OK;
+    }
+
+private:
+    int callComm(int rc, const char* what)
+    {
+        if (rc != 0) return fail(ctx_, CSTONE_E_INTERNAL, "collective %s failed with code %d", what, rc);
+        return CSTONE_OK;
+    }
+
+    int toHost(void* dst, const void* src, size_t bytes)
+    {
+        CS_HIP(ctx_, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx_->stream));
+        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
+        return CSTONE_OK;
+    }
+
+    int ensureSortScratch(size_t n)
+    {
+        CS_TRY(keysAlt_.ensure(ctx_, n * sizeof(K)));
+        CS_TRY(orderAlt_.ensure(ctx_, n * sizeof(uint32_t)));
+        CS_TRY(sortTmp_.ensure(ctx_, cstone_hip_sort_pairs_temp_bytes(kb, n)));
+        return CSTONE_OK;
+    }
+
+    //! in-place exclusive scan of n values, grand total to *totalDev
+    int exclusiveScanWithTotal(uint32_t* data, int n, uint32_t* totalDev)
+    {
+        if (n == 0)
+        {
+            CS_HIP(ctx_, hipMemsetAsync(totalDev, 0, 4, ctx_->stream));
+            return CSTONE_OK;
+        }
+        CS_TRY(arenaReserve(ctx_, scanArenaBytes(size_t(n))));
+        int rc = scanU32(ctx_, data, data, size_t(n), 0u, false, totalDev);
+        arenaReset(ctx_);
+        return rc;
+    }
+
+    //! m[src * P + dst] of every rank's counts
+    int countMatrix(const std::vector<uint64_t>& mine, std::vector<uint64_t>& matrix)
+    {
+        matrix.assign(size_t(P_) * P_, 0);
+        if (P_ == 1)
+        {
+            matrix[0] = mine[0];
+            return CSTONE_OK;
+        }
+        uint64_t* send = scal_.as<uint64_t>() + 32;
+        uint64_t* recv = reinterpret_cast<uint64_t*>(scal_.as<char>() + 4096);
+        CS_HIP(ctx_, hipMemcpyAsync(send, mine.data(), size_t(P_) * 8, hipMemcpyHostToDevice, ctx_->stream));
+        CS_TRY(callComm(comm_.all_gather(comm_.user, send, recv, size_t(P_) * 8), "all_gather (counts)"));
+        return toHost(matrix.data(), recv, size_t(P_) * P_ * 8);
+    }
+
+    int allGatherU64(uint64_t mine, std::vector<uint64_t>& all)
+    {
+        uint64_t* send = scal_.as<uint64_t>() + 32;
+        uint64_t* recv = reinterpret_cast<uint64_t*>(scal_.as<char>() + 4096);
+        CS_HIP(ctx_, hipMemcpyAsync(send, &mine, 8, hipMemcpyHostToDevice, ctx_->stream));
+        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream)); // `mine` is a stack variable
+        CS_TRY(callComm(comm_.all_gather(comm_.user, send, recv, 8), "all_gather (box counts)"));
+        return toHost(all.data(), recv, size_t(P_) * 8);
+    }
+
+    // ---- C1
+    int updateBox(const T* x, const T* y, const T* z, size_t n)
+    {
+        const double inf = std::numeric_limits<double>::infinity();
+        double ext[6]    = {inf, inf, inf, inf, inf, inf}; // (lo, -hi) per axis
+        if (n)
+        {
+            const void* arrays[3] = {x, y, z};
+            double mm[6];
+            CS_TRY(minMaxCoordinates(ctx_, rb, arrays, 3, n, mm));
+            for (int d = 0; d < 3; ++d)
+                ext[2 * d] = mm[2 * d], ext[2 * d + 1] = -mm[2 * d + 1];
+        }
+        double* dev = scal_.as<double>();
+        CS_HIP(ctx_, hipMemcpyAsync(dev, ext, sizeof ext, hipMemcpyHostToDevice, ctx_->stream));
+        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream)); // `ext` is a stack variable
+        if (P_ > 1) CS_TRY(callComm(comm_.all_reduce(comm_.user, dev, 6, 0, 1), "all_reduce (box)"));
+        CS_TRY(toHost(ext, dev, sizeof ext));
+        double fit[6];
+        for (int d = 0; d < 3; ++d)
+        {
+            fit[2 * d] = ext[2 * d], fit[2 * d + 1] = -ext[2 * d + 1];
+            if (box_.bc[d] == 1) fit[2 * d] = box_.lim[2 * d], fit[2 * d + 1] = box_.lim[2 * d + 1];
+        }
+        if (firstCall_) { std::copy(fit, fit + 6, box_.lim); }
+        else
+        {
+            // limitBoxShrinking (R/sfc/box.hpp:415-431), evaluated in T like the reference
+            const T shrink = T(0.05);
+            for (int d = 0; d < 3; ++d)
+            {
+                T lo = T(box_.lim[2 * d]), hi = T(box_.lim[2 * d + 1]);
+                T len               = hi - lo;
+                box_.lim[2 * d]     = std::min(T(fit[2 * d]), T(lo + shrink * len));
+                box_.lim[2 * d + 1] = std::max(T(fit[2 * d + 1]), T(hi - shrink * len));
+            }
+        }
+        return CSTONE_OK;
+    }
+
+    int ensureTree(DevBuf& tree, DevBuf& counts, int& cap, int need)
+    {
+        if (need <= cap) return CSTONE_OK;
+        int newCap = std::max(need, int(cap * 1.5));
+        CS_TRY(tree.ensure(ctx_, size_t(newCap + 1) * sizeof(K), true));
+        CS_TRY(counts.ensure(ctx_, size_t(newCap) * sizeof(uint32_t), true));
+        cap = newCap;
+        return CSTONE_OK;
+    }
+
+    // ---- C2: GlobalAssignment ctor + assign() tree part
+    int updateGlobalTree(size_t n)
+    {
+        if (gLeaves_ == 0)
+        {
+            std::vector<K> init = initialGlobalTree<K>(P_);
+            int leaves          = int(init.size()) - 1;
+            CS_TRY(ensureTree(gTree_, gCounts_, gCap_, std::max(4096, 2 * leaves)));
+            std::vector<uint32_t> c0(leaves, bucket_ - 1);
+            CS_HIP(ctx_, hipMemcpy(gTree_.p, init.data(), init.size() * sizeof(K), hipMemcpyHostToDevice));
+            CS_HIP(ctx_, hipMemcpy(gCounts_.p, c0.data(), c0.size() * 4, hipMemcpyHostToDevice));
+            gLeaves_ = leaves;
+        }
+        int steps = 0;
+        while (true)
+        {
+            int leaves = gLeaves_, conv = 0;
+            int rc = cstone_hip_update_octree(ctx_, kb, keys_.p, n, bucket_, gTree_.p, gCounts_.as<uint32_t>(), &leaves,
+                                              gCap_, 0xFFFFFFFFu, &conv);
+            if (rc == CSTONE_E_CAPACITY)
+            {
+                CS_TRY(ensureTree(gTree_, gCounts_, gCap_, leaves + 1));
+                continue;
+            }
+            CS_TRY(rc);
+            gLeaves_ = leaves;
+            if (P_ > 1)
+                CS_TRY(callComm(comm_.all_reduce(comm_.user, gCounts_.p, size_t(leaves), 1, 0), "all_reduce (counts)"));
+            ++steps;
+            // later calls: exactly one step; first call: one step, then `while (!update)` (assignment.hpp:92-98)
+            if (!firstCall_ || (steps >= 2 && conv)) break;
+            if (steps > 64) return fail(ctx_, CSTONE_E_INTERNAL, "global tree does not converge");
+        }
+        return CSTONE_OK;
+    }
+
+    int assign()
+    {
+        std::vector<uint32_t> counts(gLeaves_);
+        std::vector<K> leaves(gLeaves_ + 1);
+        CS_HIP(ctx_, hipMemcpyAsync(counts.data(), gCounts_.p, size_t(gLeaves_) * 4, hipMemcpyDeviceToHost,
+                                    ctx_->stream));
+        CS_TRY(toHost(leaves.data(), gTree_.p, size_t(gLeaves_ + 1) * sizeof(K)));
+        std::vector<int> bins = uniformBinsHost(counts, P_);
+        std::vector<K> fresh(P_ + 1);
+        for (int r = 0; r <= P_; ++r)
+            fresh[r] = leaves[bins[r]];
+        if (int(assignment_.size()) == P_ + 1)
+        {
+            // limitBoundaryShifts (domaindecomp.hpp:140-172): a boundary moves at most into a neighbour's old range
+            std::vector<K> old = assignment_;
+            for (int r = 1; r < P_; ++r)
+                fresh[r] = std::min(std::max(fresh[r], old[r - 1]), old[r + 1]);
+        }
+        assignment_ = fresh;
+        return CSTONE_OK;
+    }
+
+    int updateFocusTree(const K* keysM, size_t nm)
+    {
+        if (fLeaves_ == 0)
+        {
+            int cap = std::max<int>(4096, int(4 * nm / std::max(1u, bucketFocus_)) + 4096);
+            while (true)
+            {
+                CS_TRY(ensureTree(fTree_, fCounts_, fCap_, cap));
+                int leaves = 0, iters = 0;
+                int rc = cstone_hip_compute_octree(ctx_, kb, keysM, nm, bucketFocus_, fTree_.p, fCounts_.as<uint32_t>(),
+                                                   &leaves, fCap_, 0xFFFFFFFFu, &iters);
+                if (rc == CSTONE_E_CAPACITY)
+                {
+                    cap = leaves + 1;
+                    continue;
+                }
+                CS_TRY(rc);
+                fLeaves_ = leaves;
+                return CSTONE_OK;
+            }
+        }
+        while (true)
+        {
+            int leaves = fLeaves_, conv = 0;
+            int rc = cstone_hip_update_octree(ctx_, kb, keysM, nm, bucketFocus_, fTree_.p, fCounts_.as<uint32_t>(),
+                                              &leaves, fCap_, 0xFFFFFFFFu, &conv);
+            if (rc == CSTONE_E_CAPACITY)
+            {
+                CS_TRY(ensureTree(fTree_, fCounts_, fCap_, leaves + 1));
+                continue;
+            }
+            CS_TRY(rc);
+            fLeaves_ = leaves;
+            return CSTONE_OK;
+        }
+    }
+
+    //! index of the leaf that contains key (below = true) or of the first leaf starting at or behind key
+    int leafIndex(K key, bool below, int* out)
+    {
+        if (uint64_t(key) >= uint64_t(endKey<K>()))
+        {
+            *out = below ? fLeaves_ - 1 : fLeaves_;
+            return CSTONE_OK;
+        }
+        K* dq        = reinterpret_cast<K*>(scal_.as<char>() + 1024);
+        uint64_t* dr = reinterpret_cast<uint64_t*>(scal_.as<char>() + 1024 + 64);
+        K q          = below ? K(key + 1) : key; // leaf STARTS <= key  <=>  starts < key + 1
+        CS_HIP(ctx_, hipMemcpyAsync(dq, &q, sizeof(K), hipMemcpyHostToDevice, ctx_->stream));
+        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
+        CS_TRY(cstone_hip_lower_bound(ctx_, kb, fTree_.p, size_t(fLeaves_), dq, 1, dr));
+        uint64_t pos = 0;
+        CS_TRY(toHost(&pos, dr, 8));
+        *out = below ? int(pos) - 1 : int(pos);
+        return CSTONE_OK;
+    }
+
+    /*! The rank's SFC range must start and end on leaf boundaries of its own tree (the job of enforceKeys in the
+     *  reference's focus tree, R/focus/rebalance.hpp:199-266): a leaf that straddles the range is replaced by the
+     *  coarsest set of octree nodes that resolves the boundary key.  Such leaves are mostly empty, so the count-driven
+     *  update merges them again and the split is redone at every sync: a copy of the leaf array and a recount. */
+    int enforceBoundaries(const K* keysM, size_t nm)
+    {
+        bool changed = false;
+        for (K key : {assignment_[rank_], assignment_[rank_ + 1]})
+        {
+            if (key == 0 || uint64_t(key) >= uint64_t(endKey<K>())) continue;
+            int idx = 0;
+            CS_TRY(leafIndex(key, true, &idx));
+            K se[2];
+            CS_TRY(toHost(se, fTree_.as<K>() + idx, 2 * sizeof(K)));
+            if (se[0] == key) continue;
+            std::vector<K> cover;
+            appendCover(cover, uint64_t(se[0]), uint64_t(key));
+            appendCover(cover, uint64_t(key), uint64_t(se[1]));
+            const int extra = int(cover.size()) - 1; // the straddling leaf becomes cover.size() leaves
+            const int L     = fLeaves_;
+            CS_TRY(ensureTree(fTree_, fCounts_, fCap_, L + extra));
+            CS_TRY(fTmp_.ensure(ctx_, size_t(L + 1 + extra) * sizeof(K)));
+            K* t = fTmp_.as<K>();
+            CS_HIP(ctx_, hipMemcpyAsync(t, fTree_.p, size_t(idx) * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
+            CS_HIP(ctx_, hipMemcpyAsync(t + idx, cover.data(), cover.size() * sizeof(K), hipMemcpyHostToDevice,
+                                        ctx_->stream));
+            CS_HIP(ctx_, hipMemcpyAsync(t + idx + cover.size(), fTree_.as<K>() + idx + 1,
+                                        size_t(L + 1 - (idx + 1)) * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
+            CS_HIP(ctx_, hipMemcpyAsync(fTree_.p, t, size_t(L + 1 + extra) * sizeof(K), hipMemcpyDeviceToDevice,
+                                        ctx_->stream));
+            CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream)); // `cover` is a local
+            fLeaves_ = L + extra;
+            changed  = true;
+        }
+        if (changed)
+            CS_TRY(cstone_hip_compute_node_counts(ctx_, kb, fTree_.p, fCounts_.as<uint32_t>(), fLeaves_, keysM, nm,
+                                                  0xFFFFFFFFu));
+        return CSTONE_OK;
+    }
+
+    int buildFocusOctree()
+    {
+        const NodeIdx L = fLeaves_, M = L + (L - 1) / 7;
+        CS_TRY(fPrefixes_.ensure(ctx_, size_t(M) * sizeof(K)));
+        CS_TRY(fChild_.ensure(ctx_, size_t(M + 1) * sizeof(NodeIdx)));
+        CS_TRY(fParents_.ensure(ctx_, size_t(std::max(1, (M - 1) / 8)) * sizeof(NodeIdx)));
+        CS_TRY(fLevelRange_.ensure(ctx_, (maxLevel<K>() + 2) * sizeof(NodeIdx)));
+        CS_TRY(fItl_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
+        CS_TRY(fLti_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
+        return cstone_hip_build_octree(ctx_, kb, fTree_.p, L, fPrefixes_.p, fChild_.as<int32_t>(),
+                                       fParents_.as<int32_t>(), fLevelRange_.as<int32_t>(), fItl_.as<int32_t>(),
+                                       fLti_.as<int32_t>());
+    }
+
+    int findLeaves(int* first, int* last)
+    {
+        CS_TRY(leafIndex(assignment_[rank_], true, first));
+        CS_TRY(leafIndex(assignment_[rank_ + 1], false, last));
+        if (*first < 0 || *last > fLeaves_ || *last <= *first)
+            return fail(ctx_, CSTONE_E_INTERNAL, "domain_mr_sync: bad leaf range [%d, %d) of %d", *first, *last, fLeaves_);
+        return CSTONE_OK;
+    }
+
+    cstone_hip_ctx* ctx_;
+    int curve_, rank_, P_;
+    uint32_t bucket_, bucketFocus_;
+    cstone_box box_;
+    cstone_hip_comm_ops comm_;
+    float haloExt_  = 1.0f;
+    bool firstCall_ = true;
+    std::vector<K> assignment_;
+    cstone_hip_domain_mr_view view_{};
+
+    DevBuf scal_;
+    DevBuf keys_, order_, keysAlt_, orderAlt_, sortTmp_;
+    DevBuf gTree_, gCounts_;
+    int gCap_ = 0, gLeaves_ = 0;
+    DevBuf fTree_, fCounts_, fTmp_;
+    int fCap_ = 0, fLeaves_ = 0;
+    DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_;
+    DevBuf leaving_, sendRows_, recvRows_, rcol_[4], rcolS_[4], rk_, ro_, posA_, posB_, keysM_, hM_;
+    DevBuf layout_, radii_, boxes_, boxFlags_, myBoxes_, allBoxes_, oflags_, cnt_, sel_;
+    Out out_[2];
+    int cur_ = 0;
+};
+
+} // namespace
+
+} // namespace cship
+
+using namespace cship;
+
+struct cstone_hip_domain_mr
+{
+    cstone_hip_ctx* ctx;
+    std::unique_ptr<MrBase> impl;
+};
+
+extern "C"
+{
+
+int cstone_hip_domain_mr_create(cstone_hip_ctx* ctx, cstone_hip_domain_mr** out, int curve, int key_bits, int real_bits,
+                                int rank, int num_ranks, uint32_t bucket_size, uint32_t bucket_size_focus,
+                                const cstone_box* box_host, const cstone_hip_comm_ops* comm)
+{
+    if (!ctx || !out || !box_host || !comm) return fail(ctx, CSTONE_E_ARG, "domain_mr_create: null argument");
+    if (num_ranks < 1 || rank < 0 || rank >= num_ranks) return fail(ctx, CSTONE_E_ARG, "domain_mr_create: bad rank");
+    if (num_ranks > 1 && (!comm->all_reduce || !comm->all_gather || !comm->all_to_all_v))
+        return fail(ctx, CSTONE_E_ARG, "domain_mr_create: missing collective");
+    if (curve != CSTONE_MORTON && curve != CSTONE_HILBERT) return fail(ctx, CSTONE_E_ARG, "domain_mr_create: bad curve");
+    // Domain ctor (R/domain/domain.hpp:95-113)
+    if (bucket_size < bucket_size_focus)
+        return fail(ctx, CSTONE_E_ARG, "The bucket size of the global tree must not be smaller than the bucket size of "
+                                       "the focused tree");
+    auto* d = new cstone_hip_domain_mr{ctx, nullptr};
+    if (key_bits == 64 && real_bits == 64)
+        d->impl = std::make_unique<MultiRankDomain<uint64_t, double>>(ctx, curve, rank, num_ranks, bucket_size,
+                                                                      bucket_size_focus, *box_host, *comm);
+    else if (key_bits == 64 && real_bits == 32)
+        d->impl = std::make_unique<MultiRankDomain<uint64_t, float>>(ctx, curve, rank, num_ranks, bucket_size,
+                                                                     bucket_size_focus, *box_host, *comm);
+    else if (key_bits == 32 && real_bits == 64)
+        d->impl = std::make_unique<MultiRankDomain<uint32_t, double>>(ctx, curve, rank, num_ranks, bucket_size,
+                                                                      bucket_size_focus, *box_host, *comm);
+    else if (key_bits == 32 && real_bits == 32)
+        d->impl = std::make_unique<MultiRankDomain<uint32_t, float>>(ctx, curve, rank, num_ranks, bucket_size,
+                                                                     bucket_size_focus, *box_host, *comm);
+    else
+    {
+        delete d;
+        return fail(ctx, CSTONE_E_ARG, "domain_mr_create: unsupported type combination");
+    }
+    *out = d;
+    return CSTONE_OK;
+}
+
+int cstone_hip_domain_mr_destroy(cstone_hip_domain_mr* dom)
+{
+    if (!dom) return CSTONE_E_ARG;
+    (void)hipStreamSynchronize(dom->ctx->stream);
+    delete dom;
+    return CSTONE_OK;
+}
+
+int cstone_hip_domain_mr_sync(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z, const void* h,
+                              size_t n)
+{
+    if (!dom) return CSTONE_E_ARG;
+    if (n && (!x || !y || !z || !h)) return fail(dom->ctx, CSTONE_E_ARG, "domain_mr_sync: null array");
+    return dom->impl->sync(x, y, z, h, n);
+}
+
+int cstone_hip_domain_mr_view_get(cstone_hip_domain_mr* dom, cstone_hip_domain_mr_view* out)
+{
+    if (!dom || !out) return CSTONE_E_ARG;
+    return dom->impl->view(out);
+}
+
+int cstone_hip_domain_mr_set_halo_factor(cstone_hip_domain_mr* dom, float factor)
+{
+    if (!dom || !(factor > 0.0f)) return CSTONE_E_ARG;
+    dom->impl->setHaloFactor(factor);
+    return CSTONE_OK;
+}
+
+} // extern "C"

@@ -582,3 +582,181 @@ class HipBackend:
         counts = (layout[first + 1:last + 1] - layout[first:last]).long()
         mask = torch.repeat_interleave(f, counts)
         return (torch.nonzero(mask, as_tuple=False).flatten() + int(layout[first].item())).to(torch.int32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Native path: the orchestration above re-implemented in C++ inside libcstone_hip (csrc/domain_mr.hip); this module
+# only provides the three collectives through cstone_hip_comm_ops, bridging device pointers to torch.distributed.
+# ---------------------------------------------------------------------------------------------------------------------
+import ctypes as C  # noqa: E402
+
+_ALL_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int)
+_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+_ALL_TO_ALL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t))
+
+
+class CommOps(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_reduce", _ALL_REDUCE), ("all_gather", _ALL_GATHER),
+                ("all_to_all_v", _ALL_TO_ALL)]
+
+
+class MrView(C.Structure):
+    _fields_ = [("start_index", C.c_uint32), ("end_index", C.c_uint32), ("num_particles_with_halos", C.c_uint32),
+                ("pad0_", C.c_uint32), ("box", C.c_byte * 64),
+                ("keys", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("h", C.c_void_p),
+                ("num_global_leaves", C.c_int32), ("num_focus_leaves", C.c_int32),
+                ("global_leaves", C.c_void_p), ("global_counts", C.c_void_p), ("focus_leaves", C.c_void_p),
+                ("focus_leaf_counts", C.c_void_p), ("range_start", C.c_uint64), ("range_end", C.c_uint64),
+                ("particles_sent", C.c_uint64), ("halos_received", C.c_uint64), ("halos_sent", C.c_uint64),
+                ("halo_boxes_exported", C.c_uint64)]
+
+
+class _DevMem:
+    """raw device memory as a __cuda_array_interface__ object (no copy)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class TorchCollectives:
+    """cstone_hip_comm_ops over torch.distributed: RCCL ("nccl") works on the device buffers in place, gloo stages
+    through the host"""
+
+    def __init__(self, ctx, group=None):
+        import torch.distributed as dist
+
+        self.ctx, self.dist, self.group = ctx, dist, group
+        self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
+        self.stage = dist.get_backend(group) != "nccl"
+        self.error = None
+        self._cbs = (_ALL_REDUCE(self._all_reduce), _ALL_GATHER(self._all_gather), _ALL_TO_ALL(self._all_to_all_v))
+        self.ops = CommOps(None, *self._cbs)
+
+    def _tensor(self, ptr, nbytes):
+        torch = _torch()
+        if nbytes == 0:
+            return torch.empty(0, dtype=torch.uint8, device=self.ctx.device)
+        return torch.as_tensor(_DevMem(ptr, nbytes), device=self.ctx.device)
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except Exception as e:  # surfaces as CSTONE_E_INTERNAL in the library; the text is kept for the caller
+            self.error = e
+            return 1
+
+    def _all_reduce(self, user, buf, count, dtype, op):
+        def run():
+            torch = _torch()
+            dt = torch.float64 if dtype == 0 else torch.int32
+            t = self._tensor(buf, count * (8 if dtype == 0 else 4)).view(dt)
+            w = t.cpu() if self.stage else t
+            self.dist.all_reduce(w, op=self.dist.ReduceOp.SUM if op == 0 else self.dist.ReduceOp.MIN, group=self.group)
+            if self.stage:
+                t.copy_(w)
+                torch.cuda.synchronize()
+
+        return self._guard(run)
+
+    def _all_gather(self, user, send, recv, nbytes):
+        def run():
+            torch = _torch()
+            s, r = self._tensor(send, nbytes), self._tensor(recv, nbytes * self.size)
+            if self.stage:
+                sc, rc = s.cpu(), torch.empty(nbytes * self.size, dtype=torch.uint8)
+                self.dist.all_gather_into_tensor(rc, sc, group=self.group)
+                r.copy_(rc)
+                torch.cuda.synchronize()
+            else:
+                self.dist.all_gather_into_tensor(r, s, group=self.group)
+
+        return self._guard(run)
+
+    def _all_to_all_v(self, user, send, send_bytes, recv, recv_bytes):
+        def run():
+            torch = _torch()
+            sb = [int(send_bytes[p]) for p in range(self.size)]
+            rb = [int(recv_bytes[p]) for p in range(self.size)]
+            s, r = self._tensor(send, sum(sb)), self._tensor(recv, sum(rb))
+            if self.stage:
+                sc, rc = s.cpu(), torch.empty(sum(rb), dtype=torch.uint8)
+                self.dist.all_to_all_single(rc, sc, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+                r.copy_(rc)
+                torch.cuda.synchronize()
+            else:
+                self.dist.all_to_all_single(r, s, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+
+        return self._guard(run)
+
+
+class NativeDistributedDomain:
+    """cstone_hip_domain_mr_* (multi-rank Domain::sync inside libcstone_hip) with torch.distributed collectives"""
+
+    def __init__(self, ctx, curve, key_bits, real_bits, bucket, bucket_focus, box_lim, box_bc=(0, 0, 0), group=None):
+        import cstone_amd
+
+        self.ctx, self.kb, self.rb = ctx, key_bits, real_bits
+        self.coll = TorchCollectives(ctx, group)
+        self.h = C.c_void_p()
+        box = cstone_amd.make_cbox(box_lim, box_bc)
+        ctx._chk(ctx.lib.cstone_hip_domain_mr_create(ctx.h, C.byref(self.h), C.c_int(curve), C.c_int(key_bits),
+                                                     C.c_int(real_bits), C.c_int(self.coll.rank),
+                                                     C.c_int(self.coll.size), C.c_uint32(bucket),
+                                                     C.c_uint32(bucket_focus), C.byref(box), C.byref(self.coll.ops)),
+                 "domain_mr_create")
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.cstone_hip_domain_mr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def view(self):
+        v = MrView()
+        self.ctx._chk(self.ctx.lib.cstone_hip_domain_mr_view_get(self.h, C.byref(v)), "domain_mr_view_get")
+        return v
+
+    def sync(self, x, y, z, h):
+        """returns dict(keys, x, y, z, h, start, end) of tensors that alias the domain-owned result arrays (valid until
+        the next but one sync)"""
+        torch = _torch()
+        import cstone_amd
+
+        self._keep = (x, y, z, h)  # inputs must outlive the call
+        rc = self.ctx.lib.cstone_hip_domain_mr_sync(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                    C.c_void_p(z.data_ptr()), C.c_void_p(h.data_ptr()),
+                                                    C.c_size_t(x.numel()))
+        if rc != 0 and self.coll.error is not None:
+            err, self.coll.error = self.coll.error, None
+            raise err
+        self.ctx._chk(rc, "domain_mr_sync")
+        v = self.view()
+        n = v.num_particles_with_halos
+        rdt = torch.float64 if self.rb == 64 else torch.float32
+        kdt = cstone_amd.key_torch_dtype(self.kb)
+        es = self.rb // 8
+
+        def wrap(ptr, dt, nbytes):
+            return torch.as_tensor(_DevMem(ptr, nbytes), device=self.ctx.device).view(dt) if n else \
+                torch.empty(0, dtype=dt, device=self.ctx.device)
+
+        out = dict(keys=wrap(v.keys, kdt, n * self.kb // 8), x=wrap(v.x, rdt, n * es), y=wrap(v.y, rdt, n * es),
+                   z=wrap(v.z, rdt, n * es), h=wrap(v.h, rdt, n * es), start=v.start_index, end=v.end_index)
+        lim = C.cast(C.byref(v.box), C.POINTER(C.c_double))
+        out["lim"] = np.array([lim[i] for i in range(6)])
+        return out
+
+    # the accessors the tests use to compare with DistributedDomain / the reference fixtures
+    def fetch(self, ptr, count, dtype):
+        a = np.empty(count, dtype=dtype)
+        if count:
+            self.ctx._chk(self.ctx.lib.cstone_hip_memcpy_d2h(self.ctx.h, a.ctypes.data_as(C.c_void_p), C.c_void_p(ptr),
+                                                             C.c_size_t(a.nbytes)), "memcpy_d2h")
+        return a

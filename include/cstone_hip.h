@@ -286,6 +286,57 @@ extern "C"
      * client take several integration steps between syncs */
     int cstone_hip_domain_set_halo_factor(cstone_hip_domain* dom, float factor);
 
+    /* ---------------------------------------------------------------------------------------------
+     * Domain::sync on SEVERAL ranks, one process per GPU (R/domain/domain.hpp:196-243 with the exchange steps of
+     * GlobalAssignment R/domain/assignment.hpp:57-158, R/domain/domaindecomp_mpi.hpp:86-174 and of Halos
+     * R/halos/halos.hpp:128-257).  The library does all the device work and the decomposition logic; the three
+     * collectives it needs are provided by the host application through cstone_hip_comm_ops -- RCCL via
+     * torch.distributed in this repository's bench (cstone_amd/distributed.py), MPI or plain RCCL elsewhere.
+     * All buffers handed to the callbacks are DEVICE pointers on the context's device; the callbacks must have
+     * completed (or be ordered on the context's stream) when they return; return 0 for success.
+     * ------------------------------------------------------------------------------------------- */
+    typedef struct cstone_hip_comm_ops
+    {
+        void* user;
+        /* in-place reduction over all ranks; dtype 0 = f64, 1 = u32; op 0 = sum, 1 = min */
+        int (*all_reduce)(void* user, void* buf, size_t count, int dtype, int op);
+        /* every rank contributes `bytes` bytes; recv holds num_ranks * bytes, ordered by rank */
+        int (*all_gather)(void* user, const void* send, void* recv, size_t bytes);
+        /* segments for / from the ranks lie back to back in rank order; sizes in bytes (host arrays, num_ranks long) */
+        int (*all_to_all_v)(void* user, const void* send, const size_t* send_bytes, void* recv,
+                            const size_t* recv_bytes);
+    } cstone_hip_comm_ops;
+
+    typedef struct cstone_hip_domain_mr cstone_hip_domain_mr;
+
+    typedef struct cstone_hip_domain_mr_view
+    {
+        /* [halos of lower ranks | assigned, SFC sorted | halos of higher ranks]; arrays are owned by the domain and
+         * stay valid until the next but one sync (two buffer sets alternate, so the client may update the assigned
+         * range in place and pass it back as the next input) */
+        uint32_t start_index, end_index, num_particles_with_halos, pad0_;
+        cstone_box box;
+        const void *keys, *x, *y, *z, *h;
+        int32_t num_global_leaves, num_focus_leaves;
+        const void* global_leaves;      /* K[num_global_leaves + 1], device */
+        const uint32_t* global_counts;  /* device */
+        const void* focus_leaves;       /* this rank's finest tree, device */
+        const uint32_t* focus_leaf_counts;
+        uint64_t range_start, range_end; /* the rank's SFC key range */
+        uint64_t particles_sent, halos_received, halos_sent, halo_boxes_exported;
+    } cstone_hip_domain_mr_view;
+
+    int cstone_hip_domain_mr_create(cstone_hip_ctx* ctx, cstone_hip_domain_mr** out, int curve, int key_bits,
+                                    int real_bits, int rank, int num_ranks, uint32_t bucket_size,
+                                    uint32_t bucket_size_focus, const cstone_box* box_host,
+                                    const cstone_hip_comm_ops* comm);
+    int cstone_hip_domain_mr_destroy(cstone_hip_domain_mr* dom);
+    /* x, y, z, h: this rank's n particles in any order (device; may point into the previous result) */
+    int cstone_hip_domain_mr_sync(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z,
+                                  const void* h, size_t n);
+    int cstone_hip_domain_mr_view_get(cstone_hip_domain_mr* dom, cstone_hip_domain_mr_view* out);
+    int cstone_hip_domain_mr_set_halo_factor(cstone_hip_domain_mr* dom, float factor);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,13 @@ def neighbor_sum(o, x, y, z, h, first, last, lim, bc):
     return int(nc[sel].astype(np.int64).sum())
 
 
+def make_native(backend, bucket, bucket_focus, lim, bc):
+    from cstone_amd.distributed import NativeDistributedDomain
+    from oracle import oracle as orc
+
+    return NativeDistributedDomain(backend.ctx, orc.HILBERT, 64, 64, bucket, bucket_focus, lim, bc)
+
+
 def golden(a, backend, dev, rank, P):
     """the reference's Domain on P MPI ranks (fixture) against DistributedDomain on P torch.distributed ranks: box,
     SFC ranges, global tree + counts and the assigned particles (keys, x, h) of every rank after every sync, bit for bit"""
@@ -50,21 +57,34 @@ def golden(a, backend, dev, rank, P):
     assert int(g["P"]) == P, "launch with the fixture's number of ranks"
     mine = np.nonzero(g["owner"] == rank)[0]
     x, y, z, h = [torch.from_numpy(g[k][mine].copy()).to(dev) for k in "xyzh"]
-    dom = DistributedDomain(backend, Comm(), orc.HILBERT, 64, 64, bucket=int(g["bucket"]),
-                            bucket_focus=int(g["bucket_focus"]), box_lim=g["lim"].tolist(),
-                            box_bc=tuple(int(v) for v in g["bc"]))
+    if a.impl == "native":
+        dom = make_native(backend, int(g["bucket"]), int(g["bucket_focus"]), g["lim"].tolist(),
+                          tuple(int(v) for v in g["bc"]))
+    else:
+        dom = DistributedDomain(backend, Comm(), orc.HILBERT, 64, 64, bucket=int(g["bucket"]),
+                                bucket_focus=int(g["bucket_focus"]), box_lim=g["lim"].tolist(),
+                                box_bc=tuple(int(v) for v in g["bc"]))
     bad, halo_stats = [], []
     c, top = 0.01, 1.0 - 2.0**-30
     for s in range(int(g["syncs"])):
         r = dom.sync(x, y, z, h)
         st, en = r["start"], r["end"]
         keys = r["keys"].cpu().numpy().view(np.uint64)[st:en]
-        L = dom.g_leaves
+        if a.impl == "native":
+            v = dom.view()
+            rng_ = [v.range_start, v.range_end]
+            gl = dom.fetch(v.global_leaves, v.num_global_leaves + 1, np.uint64)
+            gc = dom.fetch(v.global_counts, v.num_global_leaves, np.uint32)
+        else:
+            L = dom.g_leaves
+            rng_ = [dom.assignment[rank], dom.assignment[rank + 1]]
+            gl = backend.keys_to_numpy(dom.gtree[:L + 1], 64)
+            gc = backend.to_numpy(dom.gcounts[:L]).view(np.uint32)
         checks = {
             "lim": np.array_equal(r["lim"], g[f"s{s}_r{rank}_lim"]),
-            "range": [dom.assignment[rank], dom.assignment[rank + 1]] == [int(v) for v in g[f"s{s}_r{rank}_range"]],
-            "leaves": np.array_equal(backend.keys_to_numpy(dom.gtree[:L + 1], 64), g[f"s{s}_leaves"]),
-            "counts": np.array_equal(backend.to_numpy(dom.gcounts[:L]).view(np.uint32), g[f"s{s}_counts"]),
+            "range": rng_ == [int(v) for v in g[f"s{s}_r{rank}_range"]],
+            "leaves": np.array_equal(gl, g[f"s{s}_leaves"]),
+            "counts": np.array_equal(gc, g[f"s{s}_counts"]),
             "keys": np.array_equal(keys, g[f"s{s}_r{rank}_keys"]),
             "x": np.array_equal(r["x"][st:en].cpu().numpy(), g[f"s{s}_r{rank}_x"]),
             "h": np.array_equal(r["h"][st:en].cpu().numpy(), g[f"s{s}_r{rank}_h"]),
@@ -104,6 +124,8 @@ def main():
     ap.add_argument("--syncs", type=int, default=3)
     ap.add_argument("--pbc", type=int, default=0)
     ap.add_argument("--golden", default="", help="fixture of tests/golden/make_golden_domain_mpi.py to reproduce")
+    ap.add_argument("--impl", default="python", choices=["python", "native"],
+                    help="python: cstone_amd.distributed.DistributedDomain; native: cstone_hip_domain_mr_* (hip only)")
     a = ap.parse_args()
     dist.init_process_group("gloo")
     rank, P = dist.get_rank(), dist.get_world_size()
@@ -144,8 +166,11 @@ def main():
     x, y, z = [torch.from_numpy(pos[mine, d].copy()).to(dev) for d in range(3)]
     h = torch.from_numpy(hglob[mine].copy()).to(dev)
 
-    dom = DistributedDomain(backend, Comm(), orc.HILBERT, 64, 64, bucket=max(64, N // (100 * P)), bucket_focus=16,
-                            box_lim=lim, box_bc=bc)
+    if a.impl == "native":
+        dom = make_native(backend, max(64, N // (100 * P)), 16, lim, bc)
+    else:
+        dom = DistributedDomain(backend, Comm(), orc.HILBERT, 64, 64, bucket=max(64, N // (100 * P)), bucket_focus=16,
+                                box_lim=lim, box_bc=bc)
     ok = True
     report = []
     for s in range(a.syncs):
@@ -157,8 +182,13 @@ def main():
         dist.all_reduce(tot)
         ok &= int(tot.item()) == N
         ok &= bool(np.all(keys[1:] >= keys[:-1]))
-        b = dom.assignment
-        ok &= bool(np.all(keys[st:en] >= np.uint64(b[rank]))) and (en == st or int(keys[en - 1]) < b[rank + 1])
+        if a.impl == "native":
+            v = dom.view()
+            lo_key, hi_key, stats = v.range_start, v.range_end, dict(moved=v.particles_sent, halos=v.halos_received,
+                                                                      served=v.halos_sent, halo_boxes=v.halo_boxes_exported)
+        else:
+            lo_key, hi_key, stats = dom.assignment[rank], dom.assignment[rank + 1], dict(dom.stats)
+        ok &= bool(np.all(keys[st:en] >= np.uint64(lo_key))) and (en == st or int(keys[en - 1]) < hi_key)
         # neighbour completeness
         lx, ly, lz, lh = [r[k].cpu().numpy() for k in "xyzh"]
         local_sum = neighbor_sum(o, lx, ly, lz, lh, st, en, r["lim"], bc)
@@ -172,7 +202,7 @@ def main():
             ref = neighbor_sum(o, allp[0].copy(), allp[1].copy(), allp[2].copy(), allp[3].copy(), 0, allp.shape[1],
                                r["lim"], bc)
             ok &= ref == int(tsum.item())
-            report.append(dict(step=s, neighbors=ref, found=int(tsum.item()), stats=dict(dom.stats)))
+            report.append(dict(step=s, neighbors=ref, found=int(tsum.item()), stats=stats))
         # move: assigned particles only (halos are discarded by the client before the next sync)
         m = en - st
         drift = torch.from_numpy(rng.normal(0, 0.004, (m, 3))).to(dev)

@@ -40,11 +40,12 @@ def test_signed_key():
     assert signed_key(1 << 63, 64) == -(1 << 63) and signed_key(5, 64) == 5 and signed_key(1 << 30, 32) == 1 << 30
 
 
-def _launch(nproc, backend, particles, syncs, pbc, port, timeout=900, golden=""):
+def _launch(nproc, backend, particles, syncs, pbc, port, timeout=900, golden="", impl="python"):
     env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"),
            "--backend", backend, "--particles", str(particles), "--syncs", str(syncs), "--pbc", str(pbc)]
+    cmd += ["--impl", impl]
     if golden:
         cmd += ["--golden", os.path.join(ROOT, "tests", "golden", golden)]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
@@ -103,3 +104,21 @@ def test_reference_decomposition_cpu_backend(fixture, nproc):
 @pytest.mark.parametrize("fixture,nproc", GOLDEN_MPI)
 def test_reference_decomposition_hip_backend(fixture, nproc):
     _launch(nproc, "hip", 0, 0, 0, 29680 + nproc, golden=fixture)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,pbc", [(2, 0), (3, 1)])
+def test_gloo_ranks_native_domain(nproc, pbc):
+    """cstone_hip_domain_mr_sync (the orchestration in C++ inside libcstone_hip, collectives by callback): neighbour
+    completeness and range invariants like test_gloo_ranks_hip_backend"""
+    r = _launch(nproc, "hip", 60000, 3, pbc, 29700 + nproc, impl="native")
+    for step in r["report"]:
+        assert step["neighbors"] == step["found"] and step["neighbors"] > 0
+    assert r["report"][0]["stats"]["moved"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,nproc", GOLDEN_MPI)
+def test_reference_decomposition_native_domain(fixture, nproc):
+    """the C++ multi-rank Domain against the fixtures of the reference Domain under MPI, bit for bit"""
+    _launch(nproc, "hip", 0, 0, 0, 29720 + nproc, golden=fixture, impl="native")
