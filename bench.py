@@ -105,16 +105,18 @@ class SyncPipeline:
 
 
 class DistributedPipeline:
-    """N ranks, one per GPU: cstone_amd.distributed.DistributedDomain (global box / global tree all-reduce, SFC
-    assignment, particle all_to_all, owner-side halo discovery + halo all_to_all).  Every rank starts
-    with a random 1/N of the cloud (the first sync moves (N-1)/N of it); before every step a random 1% of the assigned
-    particles is displaced by up to 2h so that the steady-state exchange really moves particles across the boundaries."""
+    """N ranks, one per GPU: cstone_hip_domain_mr_sync -- the multi-rank Domain::sync inside libcstone_hip (global box /
+    global tree all-reduce, SFC assignment, particle all_to_all + merge, owner-side halo discovery + halo all_to_all;
+    SURVEY.md section 8e) with the collectives served by torch.distributed (RCCL).  Every rank starts with a random 1/N
+    of the cloud (the first sync moves (N-1)/N of it); before every step a random 1% of the assigned particles is
+    displaced by up to 2h so that the steady-state exchange really moves particles across the boundaries.
+    CSTONE_BENCH_PYTHON_DIST=1 selects the Python orchestration of the same algorithm (cstone_amd.distributed)."""
 
     def __init__(self, ctx, n_local, n_global, key_bits, real_bits, curve, bucket, bucket_focus, seed):
         import torch
 
         import cstone_amd
-        from cstone_amd.distributed import Comm, DistributedDomain, HipBackend
+        from cstone_amd.distributed import Comm, DistributedDomain, HipBackend, NativeDistributedDomain
 
         self.torch = torch
         dev = ctx.device
@@ -124,11 +126,16 @@ class DistributedPipeline:
         self.h0 = 0.6 * (3.0 * 100 / (4 * 3.141592653589793 * n_global)) ** (1.0 / 3.0)
         self.h = torch.full((n_local,), self.h0, dtype=rdt, device=dev)
         cv = cstone_amd.HILBERT if curve == "hilbert" else cstone_amd.MORTON
-        self.dom = DistributedDomain(HipBackend(ctx), Comm(), cv, key_bits, real_bits, bucket, bucket_focus,
-                                     [0, 1] * 3, (0, 0, 0))
+        self.native = os.environ.get("CSTONE_BENCH_PYTHON_DIST") != "1"
+        if self.native:
+            self.dom = NativeDistributedDomain(ctx, cv, key_bits, real_bits, bucket, bucket_focus, [0, 1] * 3, (0, 0, 0))
+        else:
+            self.dom = DistributedDomain(HipBackend(ctx), Comm(), cv, key_bits, real_bits, bucket, bucket_focus,
+                                         [0, 1] * 3, (0, 0, 0))
         self.f_leaves = self.g_leaves = 0
         self.assigned = n_local
         self.halos = 0
+        self.stats = {}
 
     def jiggle(self):
         torch = self.torch
@@ -143,10 +150,17 @@ class DistributedPipeline:
         self.jiggle()
         r = self.dom.sync(self.x, self.y, self.z, self.h)
         s, e = r["start"], r["end"]
-        # the client owns the assigned particles; halos are re-discovered by the next sync
+        # the client owns the assigned particles (updated in place); halos are re-discovered by the next sync
         self.x, self.y, self.z, self.h = r["x"][s:e], r["y"][s:e], r["z"][s:e], r["h"][s:e]
         self.assigned, self.halos = e - s, r["x"].numel() - (e - s)
-        self.f_leaves, self.g_leaves = self.dom.f_leaves, self.dom.g_leaves
+        if self.native:
+            v = self.dom.view()
+            self.f_leaves, self.g_leaves = v.num_focus_leaves, v.num_global_leaves
+            self.stats = dict(moved=v.particles_sent, halos=v.halos_received, served=v.halos_sent,
+                              halo_boxes=v.halo_boxes_exported)
+        else:
+            self.f_leaves, self.g_leaves = self.dom.f_leaves, self.dom.g_leaves
+            self.stats = dict(self.dom.stats)
 
     first_sync = step
 
@@ -329,9 +343,11 @@ def main():
                                       f"all_to_all over RCCL, 1% of the particles displaced by <=2h before every sync"),
                        "particles_per_gpu": n_local, "focus_leaves": pipe.f_leaves, "global_leaves": pipe.g_leaves,
                        **({"rank0_assigned": pipe.assigned, "rank0_halos": pipe.halos,
-                           "rank0_exchange": dict(pipe.dom.stats)} if distributed else {}),
+                           "rank0_exchange": dict(pipe.stats),
+                           "orchestration": "libcstone_hip (cstone_hip_domain_mr_sync)" if pipe.native
+                           else "python (cstone_amd.distributed)"} if distributed else {}),
                        **({"rank0_phase_ms": {k: v * 1e3 for k, v in pipe.dom.timing.items()}}
-                          if distributed and pipe.dom.timing else {})},
+                          if distributed and not pipe.native and pipe.dom.timing else {})},
             "roofline": {"bound": "hbm", "kernel": "onesweepKernel (one 8-bit radix pass over key+index pairs)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3,

@@ -462,6 +462,60 @@ struct OctreeNsView
     float searchExtFactor{1.0};
 };
 
+/*! cstone::Domain<KeyType, T, GpuTag> on SEVERAL ranks, one process per GPU (cstone_hip_domain_mr_*).
+ *  The three collectives of a sync (all-reduce, all-gather, all-to-all-v on device buffers) are supplied by the
+ *  application through cstone_hip_comm_ops: RCCL, MPI, or any other transport.  Results live in domain-owned arrays:
+ *  [halos of lower ranks | assigned, SFC sorted | halos of higher ranks], valid until the next but one sync, so a
+ *  client may update x()[startIndex() .. endIndex()) in place and pass that range back as the next input. */
+template<class KeyType, class T>
+class MultiRankDomain
+{
+public:
+    MultiRankDomain(int rank, int nRanks, unsigned bucketSize, unsigned bucketSizeFocus, const Box<T>& box,
+                    const cstone_hip_comm_ops& comm, Curve curve = Curve::hilbert)
+    {
+        int rc = cstone_hip_domain_mr_create(Context::get(), &dom_, int(curve), detail::keyBits<KeyType>(),
+                                             detail::realBits<T>(), rank, nRanks, bucketSize, bucketSizeFocus,
+                                             &box.pod(), &comm);
+        Context::check(rc, "MultiRankDomain");
+    }
+    MultiRankDomain(const MultiRankDomain&)            = delete;
+    MultiRankDomain& operator=(const MultiRankDomain&) = delete;
+    ~MultiRankDomain()
+    {
+        if (dom_) cstone_hip_domain_mr_destroy(dom_);
+    }
+
+    //! x, y, z, h: device pointers to this rank's n particles in any order
+    void sync(const T* x, const T* y, const T* z, const T* h, std::size_t n)
+    {
+        Context::check(cstone_hip_domain_mr_sync(dom_, x, y, z, h, n), "MultiRankDomain::sync");
+        Context::check(cstone_hip_domain_mr_view_get(dom_, &view_), "MultiRankDomain::view");
+    }
+
+    LocalIndex startIndex() const { return view_.start_index; }
+    LocalIndex endIndex() const { return view_.end_index; }
+    LocalIndex nParticles() const { return endIndex() - startIndex(); }
+    LocalIndex nParticlesWithHalos() const { return view_.num_particles_with_halos; }
+    Box<T> box() const { return Box<T>(view_.box); }
+    const KeyType* keys() const { return static_cast<const KeyType*>(view_.keys); }
+    T* x() const { return static_cast<T*>(const_cast<void*>(view_.x)); }
+    T* y() const { return static_cast<T*>(const_cast<void*>(view_.y)); }
+    T* z() const { return static_cast<T*>(const_cast<void*>(view_.z)); }
+    T* h() const { return static_cast<T*>(const_cast<void*>(view_.h)); }
+    //! the rank's SFC key range [first, second)
+    std::pair<KeyType, KeyType> assignedRange() const { return {KeyType(view_.range_start), KeyType(view_.range_end)}; }
+    const cstone_hip_domain_mr_view& view() const { return view_; }
+    void setHaloFactor(float factor)
+    {
+        Context::check(cstone_hip_domain_mr_set_halo_factor(dom_, factor), "MultiRankDomain::setHaloFactor");
+    }
+
+private:
+    cstone_hip_domain_mr* dom_ = nullptr;
+    cstone_hip_domain_mr_view view_{};
+};
+
 /*! cstone::Domain<KeyType, T, GpuTag> (R/domain/domain.hpp:66-699) on one rank.
  *  sync() keeps the reference's contract: caller-owned device vectors that are resized and SWAPPED with the scratch
  *  vector; properties need element sizes <= sizeof(T). */

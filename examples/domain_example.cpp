@@ -48,5 +48,20 @@ int main(int argc, char** argv)
     for (std::size_t i = 1; i < k.size(); ++i)
         sorted = sorted && k[i - 1] <= k[i];
     std::printf("keys sorted: %s\n", sorted ? "yes" : "NO");
-    return sorted ? 0 : 1;
+
+    // The multi-rank Domain with the collectives of a one-rank "communicator" (nothing to exchange).  A real client
+    // fills cstone_hip_comm_ops with RCCL / MPI calls on the device buffers it is handed.
+    cstone_hip_comm_ops self{};
+    self.all_reduce   = [](void*, void*, std::size_t, int, int) { return 0; };
+    self.all_gather   = [](void*, const void* s, void* r, std::size_t bytes)
+    { return cstone_hip_memcpy_d2d(Context::get(), r, s, bytes); };
+    self.all_to_all_v = [](void*, const void*, const std::size_t*, void*, const std::size_t*) { return 0; };
+    MultiRankDomain<KeyType, T> mr(0, 1, 1024, 64, Box<T>{0, 1}, self);
+    mr.sync(x.data(), y.data(), z.data(), h.data(), x.size());
+    syncGpu();
+    std::printf("multi-rank domain on one rank: particles [%u, %u) of %u, range [%llu, %llu)\n", mr.startIndex(),
+                mr.endIndex(), mr.nParticlesWithHalos(), (unsigned long long)mr.assignedRange().first,
+                (unsigned long long)mr.assignedRange().second);
+    bool same = mr.nParticles() == x.size();
+    return sorted && same ? 0 : 1;
 }
