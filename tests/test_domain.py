@@ -8,7 +8,8 @@ import os
 import numpy as np
 import pytest
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_domain_*.npz")))
+GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_domain_*.npz"))
+              if "_mpi_" not in os.path.basename(p))  # the multi-rank fixtures belong to test_distributed.py
 
 
 @pytest.mark.gpu
