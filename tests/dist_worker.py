@@ -40,11 +40,10 @@ def neighbor_sum(o, x, y, z, h, first, last, lim, bc):
     return int(nc[sel].astype(np.int64).sum())
 
 
-def make_native(backend, bucket, bucket_focus, lim, bc):
+def make_native(backend, bucket, bucket_focus, lim, bc, curve=1, key_bits=64):
     from cstone_amd.distributed import NativeDistributedDomain
-    from oracle import oracle as orc
 
-    return NativeDistributedDomain(backend.ctx, orc.HILBERT, 64, 64, bucket, bucket_focus, lim, bc)
+    return NativeDistributedDomain(backend.ctx, curve, key_bits, 64, bucket, bucket_focus, lim, bc)
 
 
 def golden(a, backend, dev, rank, P):
@@ -124,6 +123,8 @@ def main():
     ap.add_argument("--syncs", type=int, default=3)
     ap.add_argument("--pbc", type=int, default=0)
     ap.add_argument("--golden", default="", help="fixture of tests/golden/make_golden_domain_mpi.py to reproduce")
+    ap.add_argument("--key-bits", type=int, default=64)
+    ap.add_argument("--curve", default="hilbert", choices=["hilbert", "morton"])
     ap.add_argument("--impl", default="python", choices=["python", "native"],
                     help="python: cstone_amd.distributed.DistributedDomain; native: cstone_hip_domain_mr_* (hip only)")
     a = ap.parse_args()
@@ -166,17 +167,19 @@ def main():
     x, y, z = [torch.from_numpy(pos[mine, d].copy()).to(dev) for d in range(3)]
     h = torch.from_numpy(hglob[mine].copy()).to(dev)
 
+    curve = orc.HILBERT if a.curve == "hilbert" else orc.MORTON
+    kdt = np.uint64 if a.key_bits == 64 else np.uint32
     if a.impl == "native":
-        dom = make_native(backend, max(64, N // (100 * P)), 16, lim, bc)
+        dom = make_native(backend, max(64, N // (100 * P)), 16, lim, bc, curve, a.key_bits)
     else:
-        dom = DistributedDomain(backend, Comm(), orc.HILBERT, 64, 64, bucket=max(64, N // (100 * P)), bucket_focus=16,
-                                box_lim=lim, box_bc=bc)
+        dom = DistributedDomain(backend, Comm(), curve, a.key_bits, 64, bucket=max(64, N // (100 * P)),
+                                bucket_focus=16, box_lim=lim, box_bc=bc)
     ok = True
     report = []
     for s in range(a.syncs):
         r = dom.sync(x, y, z, h)
         st, en = r["start"], r["end"]
-        keys = r["keys"].cpu().numpy().view(np.uint64)
+        keys = r["keys"].cpu().numpy().view(kdt)
         # invariants: counts add up, keys sorted, assigned keys inside my range
         tot = torch.tensor([en - st], dtype=torch.int64)
         dist.all_reduce(tot)
@@ -188,7 +191,7 @@ def main():
                                                                       served=v.halos_sent, halo_boxes=v.halo_boxes_exported)
         else:
             lo_key, hi_key, stats = dom.assignment[rank], dom.assignment[rank + 1], dict(dom.stats)
-        ok &= bool(np.all(keys[st:en] >= np.uint64(lo_key))) and (en == st or int(keys[en - 1]) < hi_key)
+        ok &= bool(np.all(keys[st:en] >= kdt(lo_key))) and (en == st or int(keys[en - 1]) < hi_key)
         # neighbour completeness
         lx, ly, lz, lh = [r[k].cpu().numpy() for k in "xyzh"]
         local_sum = neighbor_sum(o, lx, ly, lz, lh, st, en, r["lim"], bc)

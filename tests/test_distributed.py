@@ -40,12 +40,12 @@ def test_signed_key():
     assert signed_key(1 << 63, 64) == -(1 << 63) and signed_key(5, 64) == 5 and signed_key(1 << 30, 32) == 1 << 30
 
 
-def _launch(nproc, backend, particles, syncs, pbc, port, timeout=900, golden="", impl="python"):
+def _launch(nproc, backend, particles, syncs, pbc, port, timeout=900, golden="", impl="python", extra=()):
     env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"),
            "--backend", backend, "--particles", str(particles), "--syncs", str(syncs), "--pbc", str(pbc)]
-    cmd += ["--impl", impl]
+    cmd += ["--impl", impl] + list(extra)
     if golden:
         cmd += ["--golden", os.path.join(ROOT, "tests", "golden", golden)]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
@@ -122,3 +122,12 @@ def test_gloo_ranks_native_domain(nproc, pbc):
 def test_reference_decomposition_native_domain(fixture, nproc):
     """the C++ multi-rank Domain against the fixtures of the reference Domain under MPI, bit for bit"""
     _launch(nproc, "hip", 0, 0, 0, 29720 + nproc, golden=fixture, impl="native")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("impl", ["python", "native"])
+def test_gloo_ranks_morton_32bit_keys(impl):
+    """the other key flavour (Morton curve, 32-bit keys: 10 levels) through both orchestrations"""
+    r = _launch(2, "hip", 40000, 2, 1, 29740 + len(impl), impl=impl, extra=["--key-bits", "32", "--curve", "morton"])
+    for step in r["report"]:
+        assert step["neighbors"] == step["found"] and step["neighbors"] > 0
