@@ -16,8 +16,12 @@
 // Box, SFC ranges, global tree and the assigned particles are bit-identical to the reference Domain under MPI
 // (tests/golden/ref_domain_mpi_*.npz); the halo set is compared there as well.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
+#include <map>
+#include <string>
 #include <memory>
 #include <numeric>
 #include <vector>
@@ -208,6 +212,17 @@ public:
 
     void setHaloFactor(float f) override { haloExt_ = f; }
 
+    ~MultiRankDomain() override
+    {
+        if (timing_ && rank_ == 0)
+        {
+            std::fprintf(stderr, "[cstone_hip_domain_mr] phase times per sync over %d syncs (ms, synchronising):", syncs_);
+            for (auto& [name, sec] : phase_)
+                std::fprintf(stderr, "  %s %.3f", name.c_str(), sec * 1e3 / std::max(1, syncs_));
+            std::fprintf(stderr, "\n");
+        }
+    }
+
     int view(cstone_hip_domain_mr_view* v) override
     {
         *v = view_;
@@ -222,8 +237,11 @@ public:
         const T* h = static_cast<const T*>(hIn);
         if (n >= (size_t(1) << 30)) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: too many particles per rank");
         CS_TRY(scal_.ensure(ctx_, 4096 + size_t(P_) * P_ * 8 + size_t(P_ + 1) * 16));
+        ++syncs_;
+        tick(nullptr);
 
         CS_TRY(updateBox(x, y, z, n));
+        tick("1 box");
 
         // ---- keys + SFC ordering of the present particles
         const size_t nAlloc = std::max<size_t>(n, 64);
@@ -239,8 +257,10 @@ public:
                                          orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes));
         }
 
+        tick("2 encode+sort");
         CS_TRY(updateGlobalTree(n));
         CS_TRY(assign());
+        tick("3 global tree+assign");
 
         // ---- C3: send ranges on the sorted keys, counts of everybody, exchange of the leaving particles
         std::vector<uint64_t> cut(P_ + 1);
@@ -321,18 +341,32 @@ public:
             }
         }
 
-        // ---- merge of the kept, already sorted range with the newcomers: positions, keys, h
-        const K* keysM = keptKeys;
+        // ---- Result arrays.  The assigned block is written ONCE, at an offset M that leaves room for the halos of the
+        //      lower ranks (their number is only known after the discovery below; M is generous and follows the
+        //      previous sync).  The arrays handed out start at M - (halos of lower ranks).
+        cur_ ^= 1; // the inputs may live in the other buffer set
+        Out& o           = out_[cur_];
+        const uint64_t M = P_ > 1 ? std::max<uint64_t>(2 * prevLo_ + 4096, firstCall_ ? nm / 4 : 0) : 0;
+        uint64_t cap     = M + nm + (P_ > 1 ? std::max<uint64_t>(2 * prevHi_ + 4096, firstCall_ ? nm / 4 : 0) : 0);
+        CS_TRY(o.keys.ensure(ctx_, cap * sizeof(K)));
+        for (DevBuf* b : {&o.x, &o.y, &o.z, &o.h})
+            CS_TRY(b->ensure(ctx_, cap * sizeof(T)));
+
+        // ---- merge of the kept, already sorted range with the newcomers: positions, then every field from its input
+        //      slot straight to its final slot
+        K* keysM = o.keys.as<K>() + M;
         if (nb)
         {
             CS_TRY(posA_.ensure(ctx_, std::max<size_t>(na, 1) * sizeof(uint32_t)));
             CS_TRY(posB_.ensure(ctx_, nb * sizeof(uint32_t)));
-            CS_TRY(keysM_.ensure(ctx_, nm * sizeof(K)));
             CS_TRY(cstone_hip_merge_positions(ctx_, kb, keptKeys, na, rk_.p, nb, 0, posA_.as<uint32_t>(),
                                               posB_.as<uint32_t>()));
-            CS_TRY(cstone_hip_scatter(ctx_, sizeof(K), posA_.as<uint32_t>(), na, keptKeys, keysM_.p));
-            CS_TRY(cstone_hip_scatter(ctx_, sizeof(K), posB_.as<uint32_t>(), nb, rk_.p, keysM_.p));
-            keysM = keysM_.as<K>();
+            CS_TRY(cstone_hip_scatter(ctx_, sizeof(K), posA_.as<uint32_t>(), na, keptKeys, keysM));
+            CS_TRY(cstone_hip_scatter(ctx_, sizeof(K), posB_.as<uint32_t>(), nb, rk_.p, keysM));
+        }
+        else
+        {
+            CS_HIP(ctx_, hipMemcpyAsync(keysM, keptKeys, na * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
         }
         auto place = [&](const T* src, const T* srcRecv, T* dst) -> int
         {
@@ -344,8 +378,11 @@ public:
             else { CS_TRY(cstone_hip_gather(ctx_, sizeof(T), keptO, na, src, dst)); }
             return CSTONE_OK;
         };
-        CS_TRY(hM_.ensure(ctx_, nm * sizeof(T)));
-        CS_TRY(place(h, recvSorted[3], hM_.as<T>()));
+        CS_TRY(place(x, recvSorted[0], o.x.as<T>() + M));
+        CS_TRY(place(y, recvSorted[1], o.y.as<T>() + M));
+        CS_TRY(place(z, recvSorted[2], o.z.as<T>() + M));
+        CS_TRY(place(h, recvSorted[3], o.h.as<T>() + M));
+        tick("4 exchange+merge+place");
 
         // ---- this rank's finest tree over its assigned particles; its SFC range must end on leaf boundaries
         CS_TRY(updateFocusTree(keysM, nm));
@@ -357,6 +394,7 @@ public:
         CS_TRY(layout_.ensure(ctx_, size_t(L + 1) * sizeof(uint32_t)));
         CS_HIP(ctx_, hipMemsetAsync(layout_.p, 0, sizeof(uint32_t), ctx_->stream));
         CS_TRY(cstone_hip_inclusive_scan_u32(ctx_, fCounts_.as<uint32_t>(), layout_.as<uint32_t>() + 1, size_t(L)));
+        tick("5 focus tree");
 
         // ---- C4: owner-side halo discovery
         std::vector<uint64_t> hsCounts(P_, 0), hmatrix(size_t(P_) * P_, 0);
@@ -367,7 +405,7 @@ public:
             CS_TRY(radii_.ensure(ctx_, size_t(L) * sizeof(float)));
             CS_TRY(boxes_.ensure(ctx_, size_t(std::max(nLocal, 1)) * 32));
             CS_TRY(boxFlags_.ensure(ctx_, size_t(nLocal + 1) * sizeof(uint32_t)));
-            CS_TRY(cstone_hip_halo_radii(ctx_, rb, hM_.p, layout_.as<uint32_t>() + first, first, last, L, haloExt_,
+            CS_TRY(cstone_hip_halo_radii(ctx_, rb, o.h.as<T>() + M, layout_.as<uint32_t>() + first, first, last, L, haloExt_,
                                          radii_.as<float>()));
             CS_TRY(cstone_hip_halo_boxes(ctx_, curve_, kb, rb, fTree_.p, radii_.as<float>(), &box_, first, last,
                                          boxes_.as<int32_t>()));
@@ -432,19 +470,32 @@ public:
             hRecvBytes[p] = (p == rank_ ? 0 : r) * 4 * sizeof(T);
         }
 
-        // ---- final arrays: every assigned value is written once, from its input slot to its final slot
+        tick("6 halo discovery");
+        // ---- room for the halos on both sides of the assigned block
         const uint64_t total = nlo + nm + nhi;
-        cur_ ^= 1;
-        Out& o = out_[cur_];
-        CS_TRY(o.keys.ensure(ctx_, total * sizeof(K)));
-        for (DevBuf* b : {&o.x, &o.y, &o.z, &o.h})
-            CS_TRY(b->ensure(ctx_, total * sizeof(T)));
-        CS_TRY(place(x, recvSorted[0], o.x.as<T>() + nlo));
-        CS_TRY(place(y, recvSorted[1], o.y.as<T>() + nlo));
-        CS_TRY(place(z, recvSorted[2], o.z.as<T>() + nlo));
-        CS_HIP(ctx_, hipMemcpyAsync(o.h.as<T>() + nlo, hM_.p, nm * sizeof(T), hipMemcpyDeviceToDevice, ctx_->stream));
-        CS_HIP(ctx_, hipMemcpyAsync(o.keys.as<K>() + nlo, keysM, nm * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
-
+        uint64_t off = M - std::min(M, nlo); // start of the arrays handed out
+        if (nlo > M || M + nm + nhi > cap)
+        {
+            // the margins were too small (first syncs, abrupt changes): move the block once, through a scratch copy
+            const uint64_t M2 = nlo, cap2 = nlo + nm + nhi;
+            CS_TRY(moveTmp_.ensure(ctx_, nm * std::max(sizeof(K), sizeof(T))));
+            auto shift = [&](DevBuf& buf, size_t elem) -> int
+            {
+                CS_HIP(ctx_, hipMemcpyAsync(moveTmp_.p, buf.as<char>() + M * elem, nm * elem, hipMemcpyDeviceToDevice,
+                                            ctx_->stream));
+                CS_TRY(buf.ensure(ctx_, cap2 * elem));
+                CS_HIP(ctx_, hipMemcpyAsync(buf.as<char>() + M2 * elem, moveTmp_.p, nm * elem, hipMemcpyDeviceToDevice,
+                                            ctx_->stream));
+                return CSTONE_OK;
+            };
+            CS_TRY(shift(o.keys, sizeof(K)));
+            for (DevBuf* b : {&o.x, &o.y, &o.z, &o.h})
+                CS_TRY(shift(*b, sizeof(T)));
+            off = 0;
+        }
+        const uint64_t A = off + nlo; // first assigned slot
+        prevLo_ = nlo, prevHi_ = nhi;
+        tick("7 margins");
         // ---- C5: halo exchange
         if (P_ > 1 && haloAny)
         {
@@ -452,39 +503,42 @@ public:
             CS_TRY(recvRows_.ensure(ctx_, std::max<size_t>(nlo + nhi, 1) * 4 * sizeof(T)));
             if (selTotal)
                 hipLaunchKernelGGL(packRowsKernel<T>, gridFor(selTotal, 256), 256, 0, ctx_->stream, sel_.as<uint32_t>(),
-                                   size_t(selTotal), o.x.as<T>() + nlo, o.y.as<T>() + nlo, o.z.as<T>() + nlo,
-                                   o.h.as<T>() + nlo, sendRows_.as<T>());
+                                   size_t(selTotal), o.x.as<T>() + A, o.y.as<T>() + A, o.z.as<T>() + A,
+                                   o.h.as<T>() + A, sendRows_.as<T>());
             CS_TRY(callComm(comm_.all_to_all_v(comm_.user, sendRows_.p, hSendBytes.data(), recvRows_.p,
                                                hRecvBytes.data()),
                             "all_to_all_v (halos)"));
             if (nlo)
                 hipLaunchKernelGGL(unpackRowsKernel<T>, gridFor(nlo, 256), 256, 0, ctx_->stream, recvRows_.as<T>(),
-                                   size_t(nlo), o.x.as<T>(), o.y.as<T>(), o.z.as<T>(), o.h.as<T>());
+                                   size_t(nlo), o.x.as<T>() + off, o.y.as<T>() + off, o.z.as<T>() + off, o.h.as<T>() + off);
             if (nhi)
                 hipLaunchKernelGGL(unpackRowsKernel<T>, gridFor(nhi, 256), 256, 0, ctx_->stream,
-                                   recvRows_.as<T>() + 4 * nlo, size_t(nhi), o.x.as<T>() + nlo + nm,
-                                   o.y.as<T>() + nlo + nm, o.z.as<T>() + nlo + nm, o.h.as<T>() + nlo + nm);
+                                   recvRows_.as<T>() + 4 * nlo, size_t(nhi), o.x.as<T>() + A + nm,
+                                   o.y.as<T>() + A + nm, o.z.as<T>() + A + nm, o.h.as<T>() + A + nm);
             // keys of the halo particles (encode skips entries that hold the remove marker: clear first)
             if (nlo)
             {
-                CS_HIP(ctx_, hipMemsetAsync(o.keys.p, 0, nlo * sizeof(K), ctx_->stream));
-                CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, o.x.p, o.y.p, o.z.p, o.keys.p, nlo, &box_));
+                CS_HIP(ctx_, hipMemsetAsync(o.keys.as<K>() + off, 0, nlo * sizeof(K), ctx_->stream));
+                CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, o.x.as<T>() + off, o.y.as<T>() + off,
+                                                   o.z.as<T>() + off, o.keys.as<K>() + off, nlo, &box_));
             }
             if (nhi)
             {
-                CS_HIP(ctx_, hipMemsetAsync(o.keys.as<K>() + nlo + nm, 0, nhi * sizeof(K), ctx_->stream));
-                CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, o.x.as<T>() + nlo + nm, o.y.as<T>() + nlo + nm,
-                                                   o.z.as<T>() + nlo + nm, o.keys.as<K>() + nlo + nm, nhi, &box_));
+                CS_HIP(ctx_, hipMemsetAsync(o.keys.as<K>() + A + nm, 0, nhi * sizeof(K), ctx_->stream));
+                CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, o.x.as<T>() + A + nm, o.y.as<T>() + A + nm,
+                                                   o.z.as<T>() + A + nm, o.keys.as<K>() + A + nm, nhi, &box_));
             }
         }
         CS_HIP(ctx_, hipGetLastError());
+        tick("8 halo exchange");
 
         firstCall_                     = false;
         view_.start_index              = uint32_t(nlo);
         view_.end_index                = uint32_t(nlo + nm);
         view_.num_particles_with_halos = uint32_t(total);
         view_.box                      = box_;
-        view_.keys = o.keys.p, view_.x = o.x.p, view_.y = o.y.p, view_.z = o.z.p, view_.h = o.h.p;
+        view_.keys = o.keys.as<K>() + off;
+        view_.x = o.x.as<T>() + off, view_.y = o.y.as<T>() + off, view_.z = o.z.as<T>() + off, view_.h = o.h.as<T>() + off;
         view_.num_global_leaves = gLeaves_, view_.num_focus_leaves = fLeaves_;
         view_.global_leaves = gTree_.p, view_.global_counts = gCounts_.as<uint32_t>();
         view_.focus_leaves = fTree_.p, view_.focus_leaf_counts = fCounts_.as<uint32_t>();
@@ -497,6 +551,16 @@ public:
     }
 
 private:
+    //! CSTONE_MR_TIMING=1: synchronising wall clock per phase, printed by rank 0 when the domain is destroyed
+    void tick(const char* name)
+    {
+        if (!timing_) return;
+        (void)hipStreamSynchronize(ctx_->stream);
+        auto now = std::chrono::steady_clock::now();
+        if (name) phase_[name] += std::chrono::duration<double>(now - t0_).count();
+        t0_ = now;
+    }
+
     int callComm(int rc, const char* what)
     {
         if (rc != 0) return fail(ctx_, CSTONE_E_INTERNAL, "collective %s failed with code %d", what, rc);
@@ -793,6 +857,10 @@ private:
     cstone_hip_comm_ops comm_;
     float haloExt_  = 1.0f;
     bool firstCall_ = true;
+    bool timing_    = std::getenv("CSTONE_MR_TIMING") != nullptr;
+    int syncs_      = 0;
+    std::map<std::string, double> phase_;
+    std::chrono::steady_clock::time_point t0_;
     std::vector<K> assignment_;
     cstone_hip_domain_mr_view view_{};
 
@@ -803,7 +871,8 @@ private:
     DevBuf fTree_, fCounts_, fTmp_;
     int fCap_ = 0, fLeaves_ = 0;
     DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_;
-    DevBuf leaving_, sendRows_, recvRows_, rcol_[4], rcolS_[4], rk_, ro_, posA_, posB_, keysM_, hM_;
+    DevBuf leaving_, sendRows_, recvRows_, rcol_[4], rcolS_[4], rk_, ro_, posA_, posB_, moveTmp_;
+    uint64_t prevLo_ = 0, prevHi_ = 0;
     DevBuf layout_, radii_, boxes_, boxFlags_, myBoxes_, allBoxes_, oflags_, cnt_, sel_;
     Out out_[2];
     int cur_ = 0;
