@@ -142,15 +142,66 @@ __global__ __launch_bounds__(256) void boxFlagsKernel(const int32_t* __restrict_
 
 //! keeps the records with flag != 0; scan = exclusive scan of the flags
 __global__ __launch_bounds__(256) void compactBoxesKernel(const int32_t* __restrict__ boxes,
-                                                          const uint32_t* __restrict__ scan, int n,
+                                                          const uint32_t* __restrict__ scan, int n, int owner,
                                                           int32_t* __restrict__ out)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n || boxes[8 * i + 6] == 0) return;
     const int4* src = reinterpret_cast<const int4*>(boxes + 8 * size_t(i));
     int4* dst       = reinterpret_cast<int4*>(out + 8 * size_t(scan[i]));
+    int4 hi         = src[1];
+    hi.w            = owner; // record[7]: who exports the box (find_overlaps marks bit `owner`)
     dst[0]          = src[0];
-    dst[1]          = src[1];
+    dst[1]          = hi;
+}
+
+//! cnt[q * nLocal + (i - first)] = particles of leaf i if peer q's boxes touch it (bit `peer` of flags), else 0;
+//! q enumerates the peers in rank order without the own rank
+__global__ __launch_bounds__(256) void peerCountsKernel(const int32_t* __restrict__ flags,
+                                                        const uint32_t* __restrict__ layout, int first, int last,
+                                                        int numRanks, int rank, uint32_t* __restrict__ cnt)
+{
+    int k = blockIdx.x * 256 + threadIdx.x;
+    int n = last - first;
+    if (k >= n) return;
+    uint32_t f = uint32_t(flags[first + k]);
+    uint32_t c = layout[first + k + 1] - layout[first + k];
+    for (int p = 0, q = 0; p < numRanks; ++p)
+    {
+        if (p == rank) continue;
+        cnt[size_t(q) * n + k] = ((f >> p) & 1u) ? c : 0u;
+        ++q;
+    }
+}
+
+//! totals[q] = particles served to peer q, from the exclusive scan of cnt (grand total in *total)
+__global__ void peerTotalsKernel(const uint32_t* __restrict__ scan, const uint32_t* __restrict__ total, int n,
+                                 int numPeers, uint32_t* __restrict__ totals)
+{
+    int q = threadIdx.x;
+    if (q >= numPeers) return;
+    uint32_t a = scan[size_t(q) * n];
+    uint32_t b = (q + 1 < numPeers) ? scan[size_t(q + 1) * n] : *total;
+    totals[q]  = b - a;
+}
+
+//! particle indices of the leaves each peer needs, grouped by peer in rank order, 16 lanes per (peer, leaf)
+__global__ __launch_bounds__(256) void peerFillKernel(const int32_t* __restrict__ flags,
+                                                      const uint32_t* __restrict__ layout,
+                                                      const uint32_t* __restrict__ scan, int first, int last,
+                                                      int numRanks, int rank, uint32_t* __restrict__ out)
+{
+    const unsigned sub = threadIdx.x & 15u;
+    const int n        = last - first;
+    size_t item        = size_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
+    if (item >= size_t(numRanks - 1) * n) return;
+    int q = int(item / n), k = int(item % n);
+    int p = q < rank ? q : q + 1;
+    if (!((uint32_t(flags[first + k]) >> p) & 1u)) return;
+    uint32_t a = layout[first + k], b = layout[first + k + 1], o = scan[item];
+    uint32_t base = layout[first];
+    for (uint32_t j = a + sub; j < b; j += 16)
+        out[o + (j - a)] = j - base;
 }
 
 //! cnt[i - first] = number of particles of leaf i if it is flagged, else 0
@@ -418,7 +469,7 @@ public:
             numMyBoxes = nbx;
             CS_TRY(myBoxes_.ensure(ctx_, size_t(std::max<uint32_t>(nbx, 1)) * 32));
             hipLaunchKernelGGL(compactBoxesKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream, boxes_.as<int32_t>(),
-                               boxFlags_.as<uint32_t>(), nLocal, myBoxes_.as<int32_t>());
+                               boxFlags_.as<uint32_t>(), nLocal, rank_, myBoxes_.as<int32_t>());
 
             // box counts of everybody, then the boxes themselves padded to the longest list
             std::vector<uint64_t> boxCounts(P_);
@@ -427,11 +478,56 @@ public:
             if (maxBoxes)
             {
                 CS_TRY(myBoxes_.ensure(ctx_, size_t(maxBoxes) * 32, true));
+                if (maxBoxes > numMyBoxes) // padding records must read "no box"
+                    CS_HIP(ctx_, hipMemsetAsync(myBoxes_.as<char>() + numMyBoxes * 32, 0, (maxBoxes - numMyBoxes) * 32,
+                                                ctx_->stream));
                 CS_TRY(allBoxes_.ensure(ctx_, size_t(maxBoxes) * 32 * P_));
                 CS_TRY(callComm(comm_.all_gather(comm_.user, myBoxes_.p, allBoxes_.p, size_t(maxBoxes) * 32),
                                 "all_gather (halo boxes)"));
             }
             CS_TRY(oflags_.ensure(ctx_, size_t(L) * sizeof(int32_t)));
+            if (maxBoxes && P_ <= 32)
+            {
+                // all peers in one go: the records carry their exporter, find_overlaps sets one bit per exporter
+                // (two calls: the records before and behind my own); then counts, one scan and one fill for all peers
+                const int np = P_ - 1;
+                CS_HIP(ctx_, hipMemsetAsync(oflags_.p, 0, size_t(L) * sizeof(int32_t), ctx_->stream));
+                if (rank_ > 0)
+                    CS_TRY(cstone_hip_find_overlaps(ctx_, curve_, kb, fPrefixes_.p, fChild_.as<int32_t>(),
+                                                    fItl_.as<int32_t>(), fTree_.p, allBoxes_.as<int32_t>(),
+                                                    int(size_t(rank_) * maxBoxes), first, last, oflags_.as<int32_t>()));
+                if (rank_ + 1 < P_)
+                    CS_TRY(cstone_hip_find_overlaps(ctx_, curve_, kb, fPrefixes_.p, fChild_.as<int32_t>(),
+                                                    fItl_.as<int32_t>(), fTree_.p,
+                                                    allBoxes_.as<int32_t>() + size_t(rank_ + 1) * maxBoxes * 8,
+                                                    int(size_t(P_ - rank_ - 1) * maxBoxes), first, last,
+                                                    oflags_.as<int32_t>()));
+                const size_t items = size_t(np) * nLocal;
+                CS_TRY(cnt_.ensure(ctx_, (items + 1) * sizeof(uint32_t)));
+                hipLaunchKernelGGL(peerCountsKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream, oflags_.as<int32_t>(),
+                                   layout_.as<uint32_t>(), first, last, P_, rank_, cnt_.as<uint32_t>());
+                CS_TRY(exclusiveScanWithTotal(cnt_.as<uint32_t>(), int(items), total));
+                uint32_t* totalsDev = scal_.as<uint32_t>() + 128;
+                hipLaunchKernelGGL(peerTotalsKernel, 1, 64, 0, ctx_->stream, cnt_.as<uint32_t>(), total, nLocal, np,
+                                   totalsDev);
+                std::vector<uint32_t> totals(np);
+                CS_TRY(toHost(totals.data(), totalsDev, size_t(np) * 4));
+                for (int p = 0, q = 0; p < P_; ++p)
+                {
+                    if (p == rank_) continue;
+                    hsCounts[p] = totals[q++];
+                    selTotal += hsCounts[p];
+                }
+                if (selTotal)
+                {
+                    CS_TRY(sel_.ensure(ctx_, selTotal * sizeof(uint32_t)));
+                    hipLaunchKernelGGL(peerFillKernel, gridFor(items, 16), 256, 0, ctx_->stream, oflags_.as<int32_t>(),
+                                       layout_.as<uint32_t>(), cnt_.as<uint32_t>(), first, last, P_, rank_,
+                                       sel_.as<uint32_t>());
+                }
+            }
+            else
+            {
             CS_TRY(cnt_.ensure(ctx_, size_t(nLocal + 1) * sizeof(uint32_t)));
             for (int p = 0; p < P_; ++p)
             {
@@ -455,6 +551,7 @@ public:
                 }
                 hsCounts[p] = tp;
                 selTotal += tp;
+            }
             }
             CS_TRY(countMatrix(hsCounts, hmatrix));
         }

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
 
     // ---- per lane: halo box of my leaf + containment rejection (collisions.hpp:91-98)
     int lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
+    int mark  = 1; // MODE 2: the bit a record sets in the flags = 1 << record[7] (the exporting rank, 0 by default)
     if (MODE == 2)
     {
         if (active)
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
             for (int d = 0; d < 3; ++d)
                 lo[d] = rec[2 * d], hi[d] = rec[2 * d + 1];
             active = rec[6] != 0;
+            mark   = 1 << (rec[7] & 31);
         }
     }
     else if (active)
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
             tlo[d] = __shfl(lo[d], src);
             thi[d] = __shfl(hi[d], src);
         }
+        const int tmark = __shfl(mark, src);
 
         auto descend = [&](NodeIdx n, bool& isLeaf) -> bool
         {
@@ -198,7 +201,11 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
             if (!go) continue;
             if (rootLeaf)
             {
-                if (lane == 0) flags[internalToLeaf[0]] = 1;
+                if (lane == 0)
+                {
+                    if (MODE == 2) atomicOr(&flags[internalToLeaf[0]], tmark);
+                    else flags[internalToLeaf[0]] = 1;
+                }
                 continue;
             }
             if (lane == 0) stack[0] = 0;
@@ -218,7 +225,11 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
                 child = childOffsets[par] + NodeIdx(lane & 7u);
                 go    = descend(child, isLeaf);
             }
-            if (go && isLeaf) flags[internalToLeaf[child]] = 1;
+            if (go && isLeaf)
+            {
+                if (MODE == 2) atomicOr(&flags[internalToLeaf[child]], tmark);
+                else flags[internalToLeaf[child]] = 1;
+            }
             bool push     = go && !isLeaf;
             uint64_t pm   = __ballot(push);
             int numPush   = __popcll(pm);

@@ -213,8 +213,10 @@ extern "C"
      * halo_boxes   : for leaves [first,last): boxes[(i-first)*8 + 0..5] = {xlo,xhi,ylo,yhi,zlo,zhi} of
      *                makeHaloBox (R/traversal/boxoverlap.hpp:159-182), [6] = 1 if the box is NOT contained in the own
      *                key range [leaves[first], leaves[last]) (containedIn, :95-115), [7] = 0
-     * find_overlaps: flags[l] = 1 for every leaf l in [first,last) whose box overlaps (periodic-aware, :42-82) one of
-     *                the num_boxes 8-int records with record[6] != 0; flags must be pre-zeroed */
+     * find_overlaps: flags[l] |= 1 << (record[7] & 31) for every leaf l in [first,last) whose box overlaps
+     *                (periodic-aware, :42-82) one of the num_boxes 8-int records with record[6] != 0; flags must be
+     *                pre-zeroed.  record[7] = 0 (what halo_boxes writes) gives plain 0/1 flags; a caller that serves
+     *                the boxes of up to 32 ranks in one traversal stores the exporting rank there */
     int cstone_hip_halo_boxes(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* leaves,
                               const float* radii, const cstone_box* box_host, int first, int last, int32_t* boxes);
     int cstone_hip_find_overlaps(cstone_hip_ctx* ctx, int curve, int key_bits, const void* prefixes,
