@@ -240,6 +240,7 @@ struct MrBase
     virtual int sync(const void* x, const void* y, const void* z, const void* h, size_t n) = 0;
     virtual int view(cstone_hip_domain_mr_view* out)                                     = 0;
     virtual void setHaloFactor(float f)                                                  = 0;
+    virtual int exchangeHalos(void* array, int elemBytes)                                = 0;
 };
 
 template<class K, class T>
@@ -262,6 +263,39 @@ public:
     }
 
     void setHaloFactor(float f) override { haloExt_ = f; }
+
+    /*! Domain::exchangeHalos (R/domain/domain.hpp:381-386, R/halos/halos.hpp:224-257): repeats the halo exchange of the
+     *  last sync for another field.  array: device, laid out like the result arrays (num_particles_with_halos elements
+     *  of elemBytes = 4 or 8); its assigned range is read, its halo ranges are overwritten. */
+    int exchangeHalos(void* array, int elemBytes) override
+    {
+        if (elemBytes != 4 && elemBytes != 8) return fail(ctx_, CSTONE_E_ARG, "exchange_halos: element size %d", elemBytes);
+        if (firstCall_) return fail(ctx_, CSTONE_E_ARG, "exchange_halos: no sync yet");
+        uint64_t any = 0;
+        for (int p = 0; p < P_; ++p)
+            any += haloSend_[p] + haloRecv_[p];
+        // every rank must take part if anybody exchanges: the totals of the last sync's count matrix decide
+        if (P_ == 1 || haloAnyLast_ == 0) return CSTONE_OK;
+        (void)any;
+        char* a = static_cast<char*>(array);
+        std::vector<size_t> sb(P_), rb(P_);
+        for (int p = 0; p < P_; ++p)
+            sb[p] = haloSend_[p] * elemBytes, rb[p] = haloRecv_[p] * elemBytes;
+        CS_TRY(sendRows_.ensure(ctx_, std::max<size_t>(haloSel_, 1) * elemBytes));
+        CS_TRY(recvRows_.ensure(ctx_, std::max<size_t>(haloRecvLo_ + haloRecvHi_, 1) * elemBytes));
+        if (haloSel_)
+            CS_TRY(cstone_hip_gather(ctx_, elemBytes, sel_.as<uint32_t>(), haloSel_, a + haloRecvLo_ * elemBytes,
+                                     sendRows_.p));
+        CS_TRY(callComm(comm_.all_to_all_v(comm_.user, sendRows_.p, sb.data(), recvRows_.p, rb.data()),
+                        "all_to_all_v (exchangeHalos)"));
+        if (haloRecvLo_)
+            CS_HIP(ctx_, hipMemcpyAsync(a, recvRows_.p, haloRecvLo_ * elemBytes, hipMemcpyDeviceToDevice, ctx_->stream));
+        if (haloRecvHi_)
+            CS_HIP(ctx_, hipMemcpyAsync(a + (haloRecvLo_ + haloAssigned_) * elemBytes,
+                                        recvRows_.as<char>() + haloRecvLo_ * elemBytes, haloRecvHi_ * elemBytes,
+                                        hipMemcpyDeviceToDevice, ctx_->stream));
+        return CSTONE_OK;
+    }
 
     ~MultiRankDomain() override
     {
@@ -629,6 +663,12 @@ public:
         CS_HIP(ctx_, hipGetLastError());
         tick("8 halo exchange");
 
+        haloAnyLast_ = haloAny;
+        haloSend_ = hsCounts, haloRecvLo_ = nlo, haloRecvHi_ = nhi, haloAssigned_ = nm, haloSel_ = selTotal;
+        haloRecv_.assign(P_, 0);
+        for (int p = 0; p < P_; ++p)
+            haloRecv_[p] = p == rank_ ? 0 : hmatrix[size_t(p) * P_ + rank_];
+
         firstCall_                     = false;
         view_.start_index              = uint32_t(nlo);
         view_.end_index                = uint32_t(nlo + nm);
@@ -970,6 +1010,9 @@ private:
     DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_;
     DevBuf leaving_, sendRows_, recvRows_, rcol_[4], rcolS_[4], rk_, ro_, posA_, posB_, moveTmp_;
     uint64_t prevLo_ = 0, prevHi_ = 0;
+    // halo exchange pattern of the last sync (exchangeHalos)
+    std::vector<uint64_t> haloSend_, haloRecv_;
+    uint64_t haloRecvLo_ = 0, haloRecvHi_ = 0, haloAssigned_ = 0, haloSel_ = 0, haloAnyLast_ = 0;
     DevBuf layout_, radii_, boxes_, boxFlags_, myBoxes_, allBoxes_, oflags_, cnt_, sel_;
     Out out_[2];
     int cur_ = 0;
@@ -1045,6 +1088,12 @@ int cstone_hip_domain_mr_view_get(cstone_hip_domain_mr* dom, cstone_hip_domain_m
 {
     if (!dom || !out) return CSTONE_E_ARG;
     return dom->impl->view(out);
+}
+
+int cstone_hip_domain_mr_exchange_halos(cstone_hip_domain_mr* dom, void* array, int elem_bytes)
+{
+    if (!dom || !array) return CSTONE_E_ARG;
+    return dom->impl->exchangeHalos(array, elem_bytes);
 }
 
 int cstone_hip_domain_mr_set_halo_factor(cstone_hip_domain_mr* dom, float factor)

@@ -753,6 +753,16 @@ class NativeDistributedDomain:
         out["lim"] = np.array([lim[i] for i in range(6)])
         return out
 
+    def exchange_halos(self, field):
+        """Domain::exchangeHalos: field (tensor of num_particles_with_halos 4- or 8-byte elements, laid out like the
+        result arrays) gets its halo ranges overwritten with the owners' values"""
+        rc = self.ctx.lib.cstone_hip_domain_mr_exchange_halos(self.h, C.c_void_p(field.data_ptr()),
+                                                              C.c_int(field.element_size()))
+        if rc != 0 and self.coll.error is not None:
+            err, self.coll.error = self.coll.error, None
+            raise err
+        self.ctx._chk(rc, "domain_mr_exchange_halos")
+
     # the accessors the tests use to compare with DistributedDomain / the reference fixtures
     def fetch(self, ptr, count, dtype):
         a = np.empty(count, dtype=dtype)

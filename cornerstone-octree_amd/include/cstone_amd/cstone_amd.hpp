@@ -510,6 +510,13 @@ public:
     {
         Context::check(cstone_hip_domain_mr_set_halo_factor(dom_, factor), "MultiRankDomain::setHaloFactor");
     }
+    //! Domain::exchangeHalos for one more field (device array of nParticlesWithHalos elements, 4 or 8 bytes each)
+    template<class V>
+    void exchangeHalos(V* field) const
+    {
+        static_assert(sizeof(V) == 4 || sizeof(V) == 8);
+        Context::check(cstone_hip_domain_mr_exchange_halos(dom_, field, int(sizeof(V))), "MultiRankDomain::exchangeHalos");
+    }
 
 private:
     cstone_hip_domain_mr* dom_ = nullptr;

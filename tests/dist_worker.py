@@ -189,6 +189,12 @@ def main():
             v = dom.view()
             lo_key, hi_key, stats = v.range_start, v.range_end, dict(moved=v.particles_sent, halos=v.halos_received,
                                                                       served=v.halos_sent, halo_boxes=v.halo_boxes_exported)
+            # exchangeHalos: a field that equals 2x + 1 on the assigned range gets the owners' values in the halo ranges
+            for dt in (torch.float64, torch.float32):
+                f = torch.full_like(r["x"], -7.0, dtype=dt)
+                f[st:en] = (2.0 * r["x"][st:en] + 1.0).to(dt)
+                dom.exchange_halos(f)
+                ok &= bool(torch.equal(f, (2.0 * r["x"] + 1.0).to(dt)))
         else:
             lo_key, hi_key, stats = dom.assignment[rank], dom.assignment[rank + 1], dict(dom.stats)
         ok &= bool(np.all(keys[st:en] >= kdt(lo_key))) and (en == st or int(keys[en - 1]) < hi_key)
