@@ -165,7 +165,7 @@ class DistributedPipeline:
     first_sync = step
 
 
-def cpu_baseline_domain(n_sample, bucket, bucket_focus, min_seconds=8.0):
+def cpu_baseline_domain(n_sample, bucket, bucket_focus, min_seconds=10.0):
     """the reference's own cstone::Domain<uint64_t,double,CpuTag>::sync on one MPI rank (oracle/_ref, prebuilt)"""
     import ctypes as C
 
@@ -182,7 +182,7 @@ def cpu_baseline_domain(n_sample, bucket, bucket_focus, min_seconds=8.0):
     lib.cstone_refdom_set(d, C.c_size_t(n_sample), p(x), p(y), p(z), p(h), None)
     lib.cstone_refdom_sync(d)  # first call (tree convergence) is not part of the steady state
     done, t_total = 0, 0.0
-    while t_total < min_seconds and done < 5:
+    while t_total < min_seconds and done < 60:
         t0 = time.perf_counter()
         lib.cstone_refdom_sync(d)
         t_total += time.perf_counter() - t0
