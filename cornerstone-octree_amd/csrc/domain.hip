@@ -188,9 +188,8 @@ public:
         CS_TRY(keysAlt_.ensure(ctx_, n * sizeof(K)));
         size_t tb = cstone_hip_sort_pairs_temp_bytes(kb, n);
         CS_TRY(sortTmp_.ensure(ctx_, tb));
-        CS_TRY(cstone_hip_sequence_u32(ctx_, order_.as<uint32_t>(), n, 0));
-        CS_TRY(cstone_hip_sort_pairs(ctx_, kb, keys, order_.as<uint32_t>(), n, keysAlt_.p, orderAlt_.as<uint32_t>(),
-                                     sortTmp_.p, tb));
+        CS_TRY(cstone_hip_sort_keys_ordering(ctx_, kb, keys, order_.as<uint32_t>(), n, keysAlt_.p,
+                                             orderAlt_.as<uint32_t>(), sortTmp_.p, tb));
 
         if (firstCall_)
         {

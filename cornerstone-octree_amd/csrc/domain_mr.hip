@@ -337,9 +337,8 @@ public:
         if (n)
         {
             CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, x, y, z, keys_.p, n, &box_));
-            CS_TRY(cstone_hip_sequence_u32(ctx_, order_.as<uint32_t>(), n, 0));
-            CS_TRY(cstone_hip_sort_pairs(ctx_, kb, keys_.p, order_.as<uint32_t>(), n, keysAlt_.p,
-                                         orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes));
+            CS_TRY(cstone_hip_sort_keys_ordering(ctx_, kb, keys_.p, order_.as<uint32_t>(), n, keysAlt_.p,
+                                                 orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes));
         }
 
         tick("2 encode+sort");
@@ -416,9 +415,8 @@ public:
             CS_HIP(ctx_, hipMemsetAsync(rk_.p, 0, nb * sizeof(K), ctx_->stream));
             CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, rcol_[0].p, rcol_[1].p, rcol_[2].p, rk_.p, nb,
                                                &box_));
-            CS_TRY(cstone_hip_sequence_u32(ctx_, ro_.as<uint32_t>(), nb, 0));
-            CS_TRY(cstone_hip_sort_pairs(ctx_, kb, rk_.p, ro_.as<uint32_t>(), nb, keysAlt_.p, orderAlt_.as<uint32_t>(),
-                                         sortTmp_.p, sortTmp_.bytes));
+            CS_TRY(cstone_hip_sort_keys_ordering(ctx_, kb, rk_.p, ro_.as<uint32_t>(), nb, keysAlt_.p,
+                                                 orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes));
             for (int c = 0; c < 4; ++c)
             {
                 CS_TRY(cstone_hip_gather(ctx_, sizeof(T), ro_.as<uint32_t>(), nb, rcol_[c].p, rcolS_[c].p));

@@ -450,7 +450,9 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
     for (int r = 0; r < ITEMS; ++r)
     {
         unsigned idx = segBase + r * 64 + lane;
-        val[r]       = (FULL || idx < tileCount) ? valsIn[tileBase + idx] : 0u;
+        // valsIn == nullptr: the values are the positions 0..n-1 (first pass of a sort that starts from the identity
+        // ordering, sequenceGpu + sortByKeyGpu in one): nothing to read
+        val[r] = valsIn == nullptr ? tileBase + idx : ((FULL || idx < tileCount) ? valsIn[tileBase + idx] : 0u);
     }
 #ifdef CSTONE_SORT_TRACE
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); // the keys have arrived, the 16 value loads may still fly
@@ -747,14 +749,14 @@ size_t sortTempBytes(size_t n)
 
 template<class K, int BLOCK>
 void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* vals, size_t n, K* keysAlt,
-                  uint32_t* valsAlt)
+                  uint32_t* valsAlt, bool iotaValues)
 {
     using Cfg             = SortCfg<K, BLOCK>;
     constexpr int P       = Cfg::PASSES;
     uint32_t numFullTiles = uint32_t(n / Cfg::TILE);
     bool haveTail         = (n % Cfg::TILE) != 0;
     K* kIn         = keys;
-    uint32_t* vIn  = vals;
+    uint32_t* vIn  = iotaValues ? nullptr : vals;
     K* kOut        = keysAlt;
     uint32_t* vOut = valsAlt;
     for (int p = 0; p < P; ++p)
@@ -769,14 +771,15 @@ void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* val
             hipLaunchKernelGGL((onesweepTailKernel<K, BLOCK>), 1, BLOCK, 0, ctx->stream, kIn, vIn, kOut, vOut,
                                uint32_t(n), p, numFullTiles, bases, t.errors);
         std::swap(kIn, kOut);
-        std::swap(vIn, vOut);
+        if (p == 0 && iotaValues) { vIn = vOut, vOut = vals; }
+        else { std::swap(vIn, vOut); }
     }
     static_assert(P % 2 == 0, "an even number of passes leaves the result in the caller's buffers");
 }
 
 template<class K>
 int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt, uint32_t* valsAlt, void* temp,
-              size_t tempBytes)
+              size_t tempBytes, bool iotaValues = false)
 {
     if (n == 0) return CSTONE_OK;
     if (n >= (size_t(1) << 30)) return fail(ctx, CSTONE_E_ARG, "sort_pairs: n = %zu exceeds 2^30 - 1", n);
@@ -829,8 +832,8 @@ int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt
     CS_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sortTrace), &traceDev, sizeof(traceDev), 0, hipMemcpyHostToDevice,
                                        ctx->stream));
 #endif
-    if (large) launchPasses<K, LARGE_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt);
-    else launchPasses<K, SMALL_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt);
+    if (large) launchPasses<K, LARGE_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues);
+    else launchPasses<K, SMALL_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues);
     CS_HIP(ctx, hipGetLastError());
 #ifdef CSTONE_SORT_TRACE
     if (traceFile)
@@ -899,6 +902,18 @@ int cstone_hip_sort_pairs(cstone_hip_ctx* ctx, int key_bits, void* keys, uint32_
                ? sortPairs<uint32_t>(ctx, (uint32_t*)keys, values, n, (uint32_t*)keys_alt, values_alt, temp, temp_bytes)
                : sortPairs<uint64_t>(ctx, (uint64_t*)keys, values, n, (uint64_t*)keys_alt, values_alt, temp,
                                      temp_bytes);
+}
+
+int cstone_hip_sort_keys_ordering(cstone_hip_ctx* ctx, int key_bits, void* keys, uint32_t* ordering, size_t n,
+                                  void* keys_alt, uint32_t* values_alt, void* temp, size_t temp_bytes)
+{
+    if (!ctx || (key_bits != 32 && key_bits != 64)) return fail(ctx, CSTONE_E_ARG, "sort_keys_ordering: bad key_bits");
+    if (n && (!keys || !ordering || !keys_alt || !values_alt || !temp))
+        return fail(ctx, CSTONE_E_ARG, "sort_keys_ordering: null array");
+    return key_bits == 32 ? sortPairs<uint32_t>(ctx, (uint32_t*)keys, ordering, n, (uint32_t*)keys_alt, values_alt,
+                                                temp, temp_bytes, true)
+                          : sortPairs<uint64_t>(ctx, (uint64_t*)keys, ordering, n, (uint64_t*)keys_alt, values_alt,
+                                                temp, temp_bytes, true);
 }
 
 int cstone_hip_sequence_u32(cstone_hip_ctx* ctx, uint32_t* out, size_t n, uint32_t init)

@@ -26,7 +26,7 @@ EXPORTS = [
     "cstone_hip_device_info", "cstone_hip_malloc", "cstone_hip_free", "cstone_hip_memcpy_h2d",
     "cstone_hip_memcpy_d2h", "cstone_hip_memcpy_d2d", "cstone_hip_memset", "cstone_hip_profile_enable",
     "cstone_hip_profile_reset", "cstone_hip_profile_get", "cstone_hip_compute_sfc_keys",
-    "cstone_hip_sort_pairs_temp_bytes", "cstone_hip_sort_pairs", "cstone_hip_sequence_u32", "cstone_hip_gather",
+    "cstone_hip_sort_pairs_temp_bytes", "cstone_hip_sort_pairs", "cstone_hip_sort_keys_ordering", "cstone_hip_sequence_u32", "cstone_hip_gather",
     "cstone_hip_scatter", "cstone_hip_gather_scatter", "cstone_hip_merge_positions", "cstone_hip_minmax", "cstone_hip_minmax_arrays", "cstone_hip_exclusive_scan_u32", "cstone_hip_inclusive_scan_u32", "cstone_hip_lower_bound",
     "cstone_hip_compute_node_counts", "cstone_hip_compute_node_ops", "cstone_hip_rebalance_tree",
     "cstone_hip_update_octree", "cstone_hip_compute_octree", "cstone_hip_build_octree", "cstone_hip_upsweep_sum",
@@ -174,6 +174,18 @@ class Context:
         self._chk(self.lib.cstone_hip_sort_pairs(self.h, C.c_int(kb), _ptr(keys), _ptr(vals), C.c_size_t(n),
                                                  _ptr(keys_alt), _ptr(vals_alt), _ptr(temp), C.c_size_t(tb)),
                   "sort_pairs")
+
+    def sort_keys_ordering(self, keys):
+        """sorts keys in place, returns the sorting permutation (int32 storage)"""
+        torch = _torch()
+        kb, n = keys.element_size() * 8, keys.numel()
+        order = torch.empty(n, dtype=torch.int32, device=keys.device)
+        ka, va = torch.empty_like(keys), torch.empty_like(order)
+        tmp = torch.empty(max(1, self.sort_temp_bytes(kb, n)), dtype=torch.uint8, device=keys.device)
+        self._chk(self.lib.cstone_hip_sort_keys_ordering(self.h, C.c_int(kb), _ptr(keys), _ptr(order), C.c_size_t(n),
+                                                         _ptr(ka), _ptr(va), _ptr(tmp),
+                                                         C.c_size_t(tmp.numel())), "sort_keys_ordering")
+        return order
 
     def sequence(self, out, init=0):
         self._chk(self.lib.cstone_hip_sequence_u32(self.h, _ptr(out), C.c_size_t(out.numel()), C.c_uint32(init)),

@@ -110,6 +110,11 @@ extern "C"
      * caller-provided scratch; pass NULL for all three to let the context's arena provide them.
      * ------------------------------------------------------------------------------------------- */
     size_t cstone_hip_sort_pairs_temp_bytes(int key_bits, size_t n);
+    /* GpuSfcSorter::setMapFromCodes (R/primitives/gather.cuh:73-85) = sequenceGpu + sortByKeyGpu in one: sorts keys and
+     * writes the sorting permutation to ordering[n] (its previous content is ignored: the first digit pass produces
+     * the positions instead of reading them).  All scratch arrays are required. */
+    int cstone_hip_sort_keys_ordering(cstone_hip_ctx* ctx, int key_bits, void* keys, uint32_t* ordering, size_t n,
+                                      void* keys_alt, uint32_t* values_alt, void* temp, size_t temp_bytes);
     int cstone_hip_sort_pairs(cstone_hip_ctx* ctx, int key_bits, void* keys, uint32_t* values, size_t n, void* keys_alt,
                               uint32_t* values_alt, void* temp, size_t temp_bytes);
     int cstone_hip_sequence_u32(cstone_hip_ctx* ctx, uint32_t* out, size_t n, uint32_t init);

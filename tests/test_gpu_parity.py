@@ -438,3 +438,21 @@ def test_merge_positions_and_gather_scatter(hip, kb):
         ref = np.zeros(n, dtype=dt)
         ref[map_out] = src[map_in]
         assert np.array_equal(dst.cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kb", [32, 64])
+def test_sort_keys_ordering_equals_sort_pairs_of_iota(hip, kb):
+    """setMapFromCodes = sequenceGpu + sortByKeyGpu: same keys and permutation as sorting (key, position) pairs"""
+    import torch
+
+    rng = np.random.default_rng(kb + 3)
+    for n in (1, 777, 4096, 70001, 3_000_017):
+        src = rng.integers(0, 1 << 20, n, dtype=np.int64) << (10 if kb == 64 else 0)
+        src = torch.from_numpy(src.astype(np.int64 if kb == 64 else np.int32)).cuda()
+        k1, v1 = src.clone(), torch.arange(n, dtype=torch.int32, device="cuda")
+        hip.sort_pairs(k1, v1)
+        k2 = src.clone()
+        v2 = hip.sort_keys_ordering(k2)
+        hip.sync()
+        assert torch.equal(k1, k2) and torch.equal(v1, v2)
