@@ -96,6 +96,10 @@ struct StageTimer
 //! min/max of up to three equally long coordinate arrays, out = {min0, max0, min1, max1, ...} (primitives.hip)
 int minMaxCoordinates(cstone_hip_ctx* ctx, int real_bits, const void* const* xs, int numArrays, size_t n, double* out);
 
+//! encode + the sort's digit histograms in one kernel (sfc.hip); *fused = false: hist untouched (unaligned input)
+int computeKeysAndHistogram(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
+                            const void* z, void* keys, size_t n, const cstone_box& box, uint32_t* hist, bool* fused);
+
 inline unsigned gridFor(size_t n, unsigned block, unsigned perThread = 1)
 {
     size_t per = size_t(block) * perThread;

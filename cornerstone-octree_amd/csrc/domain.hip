@@ -181,15 +181,15 @@ public:
                 box_.lim[2 * d + 1] = std::max(T(lim[2 * d + 1]), b);
             }
         }
-        CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, *xPP, *yPP, *zPP, keys, n, &box_));
-
+        // computeSfcKeys + setMapFromCodes (assignment.hpp:81-86) in one call: the sort's digits are counted while the keys
+        // are still in the encode kernel's registers, its first pass produces the positions instead of reading an iota
         CS_TRY(order_.ensure(ctx_, n * sizeof(uint32_t)));
         CS_TRY(orderAlt_.ensure(ctx_, n * sizeof(uint32_t)));
         CS_TRY(keysAlt_.ensure(ctx_, n * sizeof(K)));
         size_t tb = cstone_hip_sort_pairs_temp_bytes(kb, n);
         CS_TRY(sortTmp_.ensure(ctx_, tb));
-        CS_TRY(cstone_hip_sort_keys_ordering(ctx_, kb, keys, order_.as<uint32_t>(), n, keysAlt_.p,
-                                             orderAlt_.as<uint32_t>(), sortTmp_.p, tb));
+        CS_TRY(cstone_hip_sfc_keys_and_ordering(ctx_, curve_, kb, rb, *xPP, *yPP, *zPP, keys, order_.as<uint32_t>(), n,
+                                                &box_, keysAlt_.p, orderAlt_.as<uint32_t>(), sortTmp_.p, tb));
 
         if (firstCall_)
         {

@@ -336,9 +336,8 @@ public:
         CS_HIP(ctx_, hipMemsetAsync(keys_.p, 0, n * sizeof(K), ctx_->stream)); // encode skips entries == removeKey
         if (n)
         {
-            CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, x, y, z, keys_.p, n, &box_));
-            CS_TRY(cstone_hip_sort_keys_ordering(ctx_, kb, keys_.p, order_.as<uint32_t>(), n, keysAlt_.p,
-                                                 orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes));
+            CS_TRY(cstone_hip_sfc_keys_and_ordering(ctx_, curve_, kb, rb, x, y, z, keys_.p, order_.as<uint32_t>(), n, &box_,
+                                                    keysAlt_.p, orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes));
         }
 
         tick("2 encode+sort");

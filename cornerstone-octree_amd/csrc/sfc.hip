@@ -7,6 +7,8 @@
 //     LDS latency
 // THIS FILE MUST BE COMPILED WITH -ffp-contract=off: int(floor(x*m) - lo*m) is evaluated as two
 // roundings on the reference's CPU path and must not become an FMA.
+#include <algorithm>
+
 #include "ctx.hpp"
 #include "device_keys.hpp"
 
@@ -94,6 +96,130 @@ __global__ __launch_bounds__(256) void encodeKernel(const T* __restrict__ x, con
     }
 }
 
+/*! Encode fused with the digit histograms of the radix sort that follows it in Domain::sync (computeSfcKeys +
+ *  setMapFromCodes, R/domain/assignment.hpp:81-86): the keys are counted while they are still in registers, which
+ *  saves the sort its read of all keys, and the LDS atomics of the counting overlap with the HBM streams of the
+ *  encode.  Grid-stride (few, long-lived workgroups: each flushes its 2 KiB-per-digit LDS histogram once).
+ *  hist: [sizeof(K)][256] counters, zeroed by the caller. */
+template<class K, class T, int VEC, bool HILBERT>
+__global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                             const T* __restrict__ z, K* __restrict__ keys, size_t n,
+                                                             DBox<T> box, const uint16_t* __restrict__ encTable,
+                                                             uint32_t* __restrict__ hist)
+{
+    constexpr int P = int(sizeof(K));
+    __shared__ uint16_t enc[24 * 8];
+    __shared__ uint32_t lh[P * 256];
+    if (threadIdx.x < 24 * 8) enc[threadIdx.x] = encTable[threadIdx.x];
+    for (int i = threadIdx.x; i < P * 256; i += 256)
+        lh[i] = 0;
+    __syncthreads();
+    constexpr unsigned g = 1u << maxLevel<K>();
+    const T mx = g * box.inv[0], my = g * box.inv[1], mz = g * box.inv[2]; // R/sfc/sfc.hpp:188-194
+    const T sx = box.lo[0] * mx, sy = box.lo[1] * my, sz = box.lo[2] * mz;
+    const unsigned lane = threadIdx.x & 63u;
+
+    auto count = [&](K key, bool valid)
+    {
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+        {
+            unsigned d = unsigned(key >> (p * 8)) & 255u;
+            // nearly sorted input makes the high digits wave-uniform: one add instead of a 64-way LDS conflict
+            uint64_t vmask = __ballot(valid);
+            if (vmask == 0) continue;
+            unsigned d0   = __builtin_amdgcn_readfirstlane(__shfl(d, __ffsll((unsigned long long)vmask) - 1));
+            uint64_t same = __ballot(valid && d == d0);
+            if (same == vmask)
+            {
+                if (lane == unsigned(__ffsll((unsigned long long)vmask) - 1))
+                    atomicAdd(&lh[p * 256 + d0], unsigned(__popcll(vmask)));
+            }
+            else if (valid) { atomicAdd(&lh[p * 256 + d], 1u); }
+        }
+    };
+    auto encodeOne = [&](T xv, T yv, T zv, K old) -> K
+    {
+        K m = gridMorton<K, T>(xv, yv, zv, mx, my, mz, sx, sy, sz);
+        if (HILBERT) m = hilbertFromMorton<K>(m, enc);
+        return old == endKey<K>() ? old : m;
+    };
+
+    const size_t nVec   = n / VEC;
+    const size_t stride = size_t(gridDim.x) * 256;
+    const size_t iters  = (nVec + stride - 1) / stride; // whole waves walk the iterations together (ballots above)
+    size_t vi           = size_t(blockIdx.x) * 256 + threadIdx.x;
+    for (size_t it = 0; it < iters; ++it, vi += stride)
+    {
+        const bool valid = vi < nVec;
+        K out[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            out[v] = 0;
+        if (valid)
+        {
+            const size_t base = vi * VEC;
+            T vx[VEC], vy[VEC], vz[VEC];
+            K vk[VEC];
+            __builtin_memcpy(vx, __builtin_assume_aligned(x + base, sizeof(T) * VEC), sizeof vx);
+            __builtin_memcpy(vy, __builtin_assume_aligned(y + base, sizeof(T) * VEC), sizeof vy);
+            __builtin_memcpy(vz, __builtin_assume_aligned(z + base, sizeof(T) * VEC), sizeof vz);
+            __builtin_memcpy(vk, __builtin_assume_aligned(keys + base, sizeof(K) * VEC), sizeof vk);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                out[v] = gridMorton<K, T>(vx[v], vy[v], vz[v], mx, my, mz, sx, sy, sz);
+            if (HILBERT)
+            {
+                K h[VEC];
+                unsigned st[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    h[v] = 0, st[v] = 0;
+#pragma unroll
+                for (int level = int(maxLevel<K>()) - 1; level >= 0; --level)
+                {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                    {
+                        unsigned e = enc[st[v] * 8 + (unsigned(out[v] >> (3 * level)) & 7u)];
+                        h[v]       = (h[v] << 3) | K(e & 7u);
+                        st[v]      = e >> 3;
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    out[v] = h[v];
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                if (vk[v] == endKey<K>()) out[v] = vk[v]; // particles flagged for removal keep their marker
+            __builtin_memcpy(__builtin_assume_aligned(keys + base, sizeof(K) * VEC), out, sizeof out);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            count(out[v], valid);
+    }
+    // elements behind the last full vector: first wave of block 0
+    if (blockIdx.x == 0 && threadIdx.x < 64)
+    {
+        size_t i   = nVec * VEC + threadIdx.x;
+        bool valid = i < n;
+        K key      = 0;
+        if (valid)
+        {
+            key     = encodeOne(x[i], y[i], z[i], keys[i]);
+            keys[i] = key;
+        }
+        count(key, valid);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < P * 256; i += 256)
+    {
+        uint32_t c = lh[i];
+        if (c) atomicAdd(&hist[i], c);
+    }
+}
+
 template<class K, class T>
 int computeKeys(cstone_hip_ctx* ctx, int curve, const T* x, const T* y, const T* z, K* keys, size_t n,
                 const cstone_box& hostBox)
@@ -126,6 +252,48 @@ int computeKeys(cstone_hip_ctx* ctx, int curve, const T* x, const T* y, const T*
     }
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
+}
+
+template<class K, class T>
+int computeKeysHist(cstone_hip_ctx* ctx, int curve, const T* x, const T* y, const T* z, K* keys, size_t n,
+                    const cstone_box& hostBox, uint32_t* hist, bool* fused)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    bool aligned = (uintptr_t(x) % 16 == 0) && (uintptr_t(y) % 16 == 0) && (uintptr_t(z) % 16 == 0) &&
+                   (uintptr_t(keys) % (sizeof(K) * VEC) == 0);
+    *fused = aligned && n > 0;
+    if (!*fused) return computeKeys<K, T>(ctx, curve, x, y, z, keys, n, hostBox); // the sort counts on its own
+    StageTimer timer(ctx, CSTONE_STAGE_ENCODE);
+    DBox<T> box   = makeDBox<T>(hostBox);
+    auto* enc     = (const uint16_t*)ctx->hilbertTables;
+    size_t nVec   = n / VEC;
+    unsigned grid = unsigned(std::max<size_t>(1, std::min<size_t>(size_t(ctx->numCu) * 8, (nVec + 255) / 256)));
+    if (curve == CSTONE_HILBERT)
+        hipLaunchKernelGGL((encodeHistogramKernel<K, T, VEC, true>), grid, 256, 0, ctx->stream, x, y, z, keys, n, box,
+                           enc, hist);
+    else
+        hipLaunchKernelGGL((encodeHistogramKernel<K, T, VEC, false>), grid, 256, 0, ctx->stream, x, y, z, keys, n, box,
+                           enc, hist);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int computeKeysAndHistogram(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
+                            const void* z, void* keys, size_t n, const cstone_box& box, uint32_t* hist, bool* fused)
+{
+    if (key_bits == 32 && real_bits == 32)
+        return computeKeysHist<uint32_t, float>(ctx, curve, (const float*)x, (const float*)y, (const float*)z,
+                                                (uint32_t*)keys, n, box, hist, fused);
+    if (key_bits == 32 && real_bits == 64)
+        return computeKeysHist<uint32_t, double>(ctx, curve, (const double*)x, (const double*)y, (const double*)z,
+                                                 (uint32_t*)keys, n, box, hist, fused);
+    if (key_bits == 64 && real_bits == 32)
+        return computeKeysHist<uint64_t, float>(ctx, curve, (const float*)x, (const float*)y, (const float*)z,
+                                                (uint64_t*)keys, n, box, hist, fused);
+    if (key_bits == 64 && real_bits == 64)
+        return computeKeysHist<uint64_t, double>(ctx, curve, (const double*)x, (const double*)y, (const double*)z,
+                                                 (uint64_t*)keys, n, box, hist, fused);
+    return fail(ctx, CSTONE_E_ARG, "sfc_keys_and_ordering: unsupported type combination");
 }
 
 } // namespace cship

@@ -779,7 +779,8 @@ void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* val
 
 template<class K>
 int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt, uint32_t* valsAlt, void* temp,
-              size_t tempBytes, bool iotaValues = false)
+              size_t tempBytes, bool iotaValues = false, int histogramState = 0 /* 0: do all, 1: only clear the
+              temp (the caller counts into it next), 2: temp cleared and digit counts present */)
 {
     if (n == 0) return CSTONE_OK;
     if (n >= (size_t(1) << 30)) return fail(ctx, CSTONE_E_ARG, "sort_pairs: n = %zu exceeds 2^30 - 1", n);
@@ -811,13 +812,14 @@ int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt
     bool large       = n >= largeTileThreshold();
     size_t tile      = large ? SortCfg<K, LARGE_BLOCK>::TILE : SortCfg<K, SMALL_BLOCK>::TILE;
     size_t usedBytes = (headerWords(P) + size_t(P) * (n / tile) * RADIX) * sizeof(uint32_t);
-    CS_HIP(ctx, hipMemsetAsync(temp, 0, usedBytes, ctx->stream));
+    if (histogramState != 2) CS_HIP(ctx, hipMemsetAsync(temp, 0, usedBytes, ctx->stream));
+    if (histogramState == 1) return CSTONE_OK;
     {
         StageTimer timer(ctx, CSTONE_STAGE_SORT_HIST);
         size_t nVec   = n / (16 / sizeof(K));
         unsigned grid = unsigned(std::min<size_t>(size_t(ctx->numCu) * 8, (nVec + HIST_BLOCK - 1) / HIST_BLOCK));
         grid          = std::max(grid, 1u);
-        hipLaunchKernelGGL(histogramKernel<K>, grid, HIST_BLOCK, 0, ctx->stream, keys, n, t.hist);
+        if (histogramState == 0) hipLaunchKernelGGL(histogramKernel<K>, grid, HIST_BLOCK, 0, ctx->stream, keys, n, t.hist);
         hipLaunchKernelGGL(scanHistogramKernel, P, RADIX, 0, ctx->stream, t.hist);
     }
 #ifdef CSTONE_SORT_TRACE
@@ -914,6 +916,31 @@ int cstone_hip_sort_keys_ordering(cstone_hip_ctx* ctx, int key_bits, void* keys,
                                                 temp, temp_bytes, true)
                           : sortPairs<uint64_t>(ctx, (uint64_t*)keys, ordering, n, (uint64_t*)keys_alt, values_alt,
                                                 temp, temp_bytes, true);
+}
+
+int cstone_hip_sfc_keys_and_ordering(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x,
+                                     const void* y, const void* z, void* keys, uint32_t* ordering, size_t n,
+                                     const cstone_box* box_host, void* keys_alt, uint32_t* values_alt, void* temp,
+                                     size_t temp_bytes)
+{
+    if (!ctx || !box_host || (key_bits != 32 && key_bits != 64) || (curve != CSTONE_MORTON && curve != CSTONE_HILBERT))
+        return fail(ctx, CSTONE_E_ARG, "sfc_keys_and_ordering: bad argument");
+    if (n == 0) return CSTONE_OK;
+    if (!x || !y || !z || !keys || !ordering || !keys_alt || !values_alt || !temp)
+        return fail(ctx, CSTONE_E_ARG, "sfc_keys_and_ordering: null array");
+    // clear the sort's workspace, count the digits while encoding, then the digit passes
+    auto run = [&](int state)
+    {
+        return key_bits == 32 ? sortPairs<uint32_t>(ctx, (uint32_t*)keys, ordering, n, (uint32_t*)keys_alt, values_alt,
+                                                    temp, temp_bytes, true, state)
+                              : sortPairs<uint64_t>(ctx, (uint64_t*)keys, ordering, n, (uint64_t*)keys_alt, values_alt,
+                                                    temp, temp_bytes, true, state);
+    };
+    CS_TRY(run(1));
+    bool fused = false;
+    CS_TRY(computeKeysAndHistogram(ctx, curve, key_bits, real_bits, x, y, z, keys, n, *box_host, (uint32_t*)temp,
+                                   &fused));
+    return run(fused ? 2 : 0);
 }
 
 int cstone_hip_sequence_u32(cstone_hip_ctx* ctx, uint32_t* out, size_t n, uint32_t init)

@@ -26,7 +26,7 @@ EXPORTS = [
     "cstone_hip_device_info", "cstone_hip_malloc", "cstone_hip_free", "cstone_hip_memcpy_h2d",
     "cstone_hip_memcpy_d2h", "cstone_hip_memcpy_d2d", "cstone_hip_memset", "cstone_hip_profile_enable",
     "cstone_hip_profile_reset", "cstone_hip_profile_get", "cstone_hip_compute_sfc_keys",
-    "cstone_hip_sort_pairs_temp_bytes", "cstone_hip_sort_pairs", "cstone_hip_sort_keys_ordering", "cstone_hip_sequence_u32", "cstone_hip_gather",
+    "cstone_hip_sort_pairs_temp_bytes", "cstone_hip_sort_pairs", "cstone_hip_sort_keys_ordering", "cstone_hip_sfc_keys_and_ordering", "cstone_hip_sequence_u32", "cstone_hip_gather",
     "cstone_hip_scatter", "cstone_hip_gather_scatter", "cstone_hip_merge_positions", "cstone_hip_minmax", "cstone_hip_minmax_arrays", "cstone_hip_exclusive_scan_u32", "cstone_hip_inclusive_scan_u32", "cstone_hip_lower_bound",
     "cstone_hip_compute_node_counts", "cstone_hip_compute_node_ops", "cstone_hip_rebalance_tree",
     "cstone_hip_update_octree", "cstone_hip_compute_octree", "cstone_hip_build_octree", "cstone_hip_upsweep_sum",
@@ -186,6 +186,22 @@ class Context:
                                                          _ptr(ka), _ptr(va), _ptr(tmp),
                                                          C.c_size_t(tmp.numel())), "sort_keys_ordering")
         return order
+
+    def sfc_keys_and_ordering(self, curve, key_bits, x, y, z, box, keys=None):
+        """(sorted keys, ordering): compute_sfc_keys + sort_keys_ordering in one call"""
+        torch = _torch()
+        n = x.numel()
+        if keys is None:
+            keys = torch.zeros(n, dtype=key_torch_dtype(key_bits), device=x.device)
+        order = torch.empty(n, dtype=torch.int32, device=x.device)
+        ka, va = torch.empty_like(keys), torch.empty_like(order)
+        tmp = torch.empty(max(1, self.sort_temp_bytes(key_bits, n)), dtype=torch.uint8, device=x.device)
+        self._chk(self.lib.cstone_hip_sfc_keys_and_ordering(self.h, C.c_int(curve), C.c_int(key_bits),
+                                                            C.c_int(x.element_size() * 8), _ptr(x), _ptr(y), _ptr(z),
+                                                            _ptr(keys), _ptr(order), C.c_size_t(n), C.byref(box),
+                                                            _ptr(ka), _ptr(va), _ptr(tmp), C.c_size_t(tmp.numel())),
+                  "sfc_keys_and_ordering")
+        return keys, order
 
     def sequence(self, out, init=0):
         self._chk(self.lib.cstone_hip_sequence_u32(self.h, _ptr(out), C.c_size_t(out.numel()), C.c_uint32(init)),

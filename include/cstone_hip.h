@@ -101,6 +101,14 @@ extern "C"
     int cstone_hip_compute_sfc_keys(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x,
                                     const void* y, const void* z, void* keys, size_t n, const cstone_box* box_host);
 
+    /* computeSfcKeys + setMapFromCodes as GlobalAssignment::assign issues them (R/domain/assignment.hpp:81-86) in one
+     * call: keys[i] as compute_sfc_keys, then keys sorted in place and ordering[n] = the sorting permutation.  The digits
+     * of the sort are counted while the keys are still in the encode kernel's registers. */
+    int cstone_hip_sfc_keys_and_ordering(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x,
+                                         const void* y, const void* z, void* keys, uint32_t* ordering, size_t n,
+                                         const cstone_box* box_host, void* keys_alt, uint32_t* values_alt, void* temp,
+                                         size_t temp_bytes);
+
     /* ---------------------------------------------------------------------------------------------
      * sort: replaces sortByKeyGpu / sortByKeyTempStorage (R/primitives/primitives_gpu.h:93-100,
      * R/primitives/primitives_gpu.cu:328-369,383-386) and sequenceGpu (:286).

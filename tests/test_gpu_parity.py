@@ -456,3 +456,25 @@ def test_sort_keys_ordering_equals_sort_pairs_of_iota(hip, kb):
         v2 = hip.sort_keys_ordering(k2)
         hip.sync()
         assert torch.equal(k1, k2) and torch.equal(v1, v2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kb,rb", [(32, 32), (64, 64), (64, 32)])
+@pytest.mark.parametrize("curve", [MORTON, HILBERT])
+def test_sfc_keys_and_ordering_equals_two_calls(hip, kb, rb, curve):
+    """the fused encode + sort (digits counted inside the encode kernel) against compute_sfc_keys + sort_pairs,
+    including remove markers, an unaligned start and sizes around the vector width"""
+    import torch
+
+    box = Box([-1.0, 2.0, 0.0, 1.0, 3.0, 7.0], (0, 1, 0))
+    for n, off in ((1, 0), (2, 0), (1001, 0), (250003, 0), (250003, 1), (2_000_001, 0)):
+        x, y, z = random_cloud(n + off, box, rb, seed=n, kind="clustered")
+        xd, yd, zd = [dev(a)[off:] for a in (x, y, z)]
+        marked = torch.zeros(n, dtype=torch.int64 if kb == 64 else torch.int32, device="cuda")
+        marked[::97] = -(1 << 63) if kb == 64 else 1 << 30  # remove markers (bit pattern 2^(3 maxLevel)) must survive
+        k1 = hip.compute_sfc_keys(curve, kb, xd, yd, zd, cbox(box), keys=marked.clone())
+        v1 = torch.arange(n, dtype=torch.int32, device="cuda")
+        hip.sort_pairs(k1, v1)
+        k2, v2 = hip.sfc_keys_and_ordering(curve, kb, xd, yd, zd, cbox(box), keys=marked.clone())
+        hip.sync()
+        assert torch.equal(k1, k2) and torch.equal(v1, v2)
