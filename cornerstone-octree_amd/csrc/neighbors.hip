@@ -7,7 +7,7 @@
 // cover almost the same tree nodes) and ONE traversal per wave.  Every stack entry carries the 64-bit mask of
 // the lanes whose own depth-first walk would have reached that node (own overlap test passed on the node and on
 // all its ancestors); a node is visited while any lane is still interested, leaf particles are fetched once
-// per wave through wave-uniform (scalar) loads and tested by the interested lanes.  Each lane therefore sees
+// per wave (one coalesced load, then v_readlane broadcasts) and tested by the interested lanes.  Each lane therefore sees
 // exactly the leaves, in exactly the order, of the reference's per-particle walk (the relative order of two
 // leaves is decided at their lowest common ancestor and does not depend on what else is visited), so the
 // stored lists are identical element for element.  The traversal stack (160 entries >= 7*21+1, the deepest a
@@ -37,6 +37,19 @@ __device__ __forceinline__ T foldAxis(T dx, T len, T inv, bool periodic)
 }
 
 __device__ __forceinline__ NodeIdx uniform(NodeIdx v) { return __builtin_amdgcn_readfirstlane(v); }
+
+//! value of lane k (wave-uniform k) as a wave-uniform scalar
+__device__ __forceinline__ float readLane(float v, unsigned k)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), int(k)));
+}
+__device__ __forceinline__ double readLane(double v, unsigned k)
+{
+    long long b = __double_as_longlong(v);
+    int lo      = __builtin_amdgcn_readlane(int(b), int(k));
+    int hi      = __builtin_amdgcn_readlane(int(b >> 32), int(k));
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
 
 template<class T>
 __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
@@ -83,8 +96,7 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
         dx *= T(0.5), dy *= T(0.5), dz *= T(0.5);
         return dx * dx + (dy * dy + dz * dz) < cellSq; // right fold, R/util/array.hpp:253-256
     };
-    // all particles of leaf node n against the lanes that reached it; coordinates are fetched four particles at a
-    // time so that the scalar loads of a batch are in flight together
+    // all particles of leaf node n against the lanes that reached it
     auto testParticle = [&](uint32_t j, T xj, T yj, T zj, bool mine)
     {
         T dx = xj - xi, dy = yj - yi, dz = zj - zi;
@@ -104,19 +116,17 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
     {
         NodeIdx leaf      = uniform(internalToLeaf[n]);
         const uint32_t jb = uniform(layout[leaf]), je = uniform(layout[leaf + 1]);
-        uint32_t j = jb;
-        for (; j + 4 <= je; j += 4)
+        // the wave fetches up to 64 leaf particles with one coalesced load per coordinate (lane l holds particle
+        // base + l) and hands them round by v_readlane: no memory traffic inside the test loop (wave-uniform scalar
+        // loads of every particle saturated the scalar data cache)
+        for (uint32_t base = jb; base < je; base += 64)
         {
-            T xa[4], ya[4], za[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                xa[k] = x[j + k], ya[k] = y[j + k], za[k] = z[j + k];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                testParticle(j + k, xa[k], ya[k], za[k], mine);
+            const uint32_t cnt = min(64u, je - base);
+            T xl = T(0), yl = T(0), zl = T(0);
+            if (lane < cnt) xl = x[base + lane], yl = y[base + lane], zl = z[base + lane];
+            for (uint32_t k = 0; k < cnt; ++k)
+                testParticle(base + k, readLane(xl, k), readLane(yl, k), readLane(zl, k), mine);
         }
-        for (; j < je; ++j)
-            testParticle(j, x[j], y[j], z[j], mine);
     };
 
     // depth-first walk of R/traversal/traversal.hpp:69-110, once per wave
