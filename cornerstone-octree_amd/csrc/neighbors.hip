@@ -14,6 +14,7 @@
 // depth-first octree walk can get) lives in LDS; overflow is reported through the sticky error word.
 // Compiled with -ffp-contract=off: distances must round like the CPU path (no FMA).
 #include <algorithm>
+#include <type_traits>
 
 #include "ctx.hpp"
 #include "device_keys.hpp"
@@ -96,36 +97,55 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
         dx *= T(0.5), dy *= T(0.5), dz *= T(0.5);
         return dx * dx + (dy * dy + dz * dz) < cellSq; // right fold, R/util/array.hpp:253-256
     };
-    // all particles of leaf node n against the lanes that reached it
-    auto testParticle = [&](uint32_t j, T xj, T yj, T zj, bool mine)
-    {
-        T dx = xj - xi, dy = yj - yi, dz = zj - zi;
-        if (usePbc)
-        {
-            dx = foldAxis<T, true>(dx, box.len[0], box.inv[0], px);
-            dy = foldAxis<T, true>(dy, box.len[1], box.inv[1], py);
-            dz = foldAxis<T, true>(dz, box.len[2], box.inv[2], pz);
-        }
-        if (mine && j != i && dx * dx + dy * dy + dz * dz < radSq)
-        {
-            if (nn < ngmax) out[nn] = j;
-            ++nn;
-        }
-    };
+    // all particles of leaf node n against the lanes that reached it.  The wave fetches up to 64 leaf particles with
+    // one coalesced load per coordinate (lane l holds particle base + l) and hands them round by v_readlane: no memory
+    // traffic inside the test loop (wave-uniform scalar loads of every particle saturated the scalar data cache).
+    // Two copies of the loop: the periodic fold is only compiled into the one taken when some lane needs it.
     auto searchLeaf = [&](NodeIdx n, bool mine)
     {
         NodeIdx leaf      = uniform(internalToLeaf[n]);
         const uint32_t jb = uniform(layout[leaf]), je = uniform(layout[leaf + 1]);
-        // the wave fetches up to 64 leaf particles with one coalesced load per coordinate (lane l holds particle
-        // base + l) and hands them round by v_readlane: no memory traffic inside the test loop (wave-uniform scalar
-        // loads of every particle saturated the scalar data cache)
+        const bool fold   = __any(mine && usePbc);
         for (uint32_t base = jb; base < je; base += 64)
         {
             const uint32_t cnt = min(64u, je - base);
             T xl = T(0), yl = T(0), zl = T(0);
             if (lane < cnt) xl = x[base + lane], yl = y[base + lane], zl = z[base + lane];
-            for (uint32_t k = 0; k < cnt; ++k)
-                testParticle(base + k, readLane(xl, k), readLane(yl, k), readLane(zl, k), mine);
+            auto test = [&](uint32_t k, auto withFold)
+            {
+                const uint32_t j = base + k;
+                T dx = readLane(xl, k) - xi, dy = readLane(yl, k) - yi, dz = readLane(zl, k) - zi;
+                if (decltype(withFold)::value && usePbc)
+                {
+                    dx = foldAxis<T, true>(dx, box.len[0], box.inv[0], px);
+                    dy = foldAxis<T, true>(dy, box.len[1], box.inv[1], py);
+                    dz = foldAxis<T, true>(dz, box.len[2], box.inv[2], pz);
+                }
+                const bool hit = mine && j != i && dx * dx + dy * dy + dz * dz < radSq;
+                if (hit)
+                {
+                    if (nn < ngmax) out[nn] = j;
+                    ++nn;
+                }
+            };
+            if (fold)
+            {
+                for (uint32_t k = 0; k < cnt; ++k)
+                    test(k, std::true_type{});
+            }
+            else
+            {
+                uint32_t k = 0;
+                for (; k + 4 <= cnt; k += 4)
+                {
+                    test(k, std::false_type{});
+                    test(k + 1, std::false_type{});
+                    test(k + 2, std::false_type{});
+                    test(k + 3, std::false_type{});
+                }
+                for (; k < cnt; ++k)
+                    test(k, std::false_type{});
+            }
         }
     };
 
