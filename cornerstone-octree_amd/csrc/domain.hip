@@ -389,13 +389,19 @@ private:
         const NodeIdx newL   = ctx_->hostScalars[1];
         if (newL < 1) return fail(ctx_, CSTONE_E_INTERNAL, "focus rebalance produced %d leaves", newL);
 
-        CS_TRY(newTree_.ensure(ctx_, size_t(newL + 1) * sizeof(K)));
-        CS_TRY(cstone_hip_rebalance_tree(ctx_, 8 * sizeof(K), fTree_.p, L, newL, leafOps_.as<int32_t>(), newTree_.p));
-        CS_TRY(ensureTree(fTree_, fLeafCounts_, fCap_, newL));
-        CS_HIP(ctx_, hipMemcpyAsync(fTree_.p, newTree_.p, size_t(newL + 1) * sizeof(K), hipMemcpyDeviceToDevice,
-                                    ctx_->stream));
-        fLeaves_ = newL;
-        CS_TRY(buildFocusOctree());
+        if (!*converged)
+        {
+            CS_TRY(newTree_.ensure(ctx_, size_t(newL + 1) * sizeof(K)));
+            CS_TRY(cstone_hip_rebalance_tree(ctx_, 8 * sizeof(K), fTree_.p, L, newL, leafOps_.as<int32_t>(),
+                                             newTree_.p));
+            CS_TRY(ensureTree(fTree_, fLeafCounts_, fCap_, newL));
+            CS_HIP(ctx_, hipMemcpyAsync(fTree_.p, newTree_.p, size_t(newL + 1) * sizeof(K), hipMemcpyDeviceToDevice,
+                                        ctx_->stream));
+            fLeaves_ = newL;
+            CS_TRY(buildFocusOctree());
+        }
+        // else: every node op is "keep" -- the leaf array and with it the linked octree are what they were; the reference
+        // rebuilds them regardless (octree_focus.hpp:121-134) because it parks its temporaries in the tree's own arrays
 
         // updateCounts: leaf counts from the particle keys, scattered to the linked layout, summed bottom-up
         const NodeIdx newI = (newL - 1) / 7, newM = newL + newI;
