@@ -255,6 +255,7 @@ public:
         CS_TRY(flags_.ensure(ctx_, size_t(L) * sizeof(int)));
         CS_HIP(ctx_, hipMemsetAsync(layout_.p, 0, sizeof(uint32_t), ctx_->stream));
         CS_TRY(cstone_hip_inclusive_scan_u32(ctx_, fLeafCounts_.as<uint32_t>(), layout_.as<uint32_t>() + 1, size_t(L)));
+        layoutLeaves_ = L;
         CS_TRY(cstone_hip_halo_radii(ctx_, rb, *hPP, layout_.as<uint32_t>(), 0, L, L, haloSearchExt_,
                                      radii_.as<float>()));
         CS_HIP(ctx_, hipMemsetAsync(flags_.p, 0, size_t(L) * sizeof(int), ctx_->stream));
@@ -405,8 +406,10 @@ private:
 
         // updateCounts: leaf counts from the particle keys, scattered to the linked layout, summed bottom-up
         const NodeIdx newI = (newL - 1) / 7, newM = newL + newI;
-        CS_TRY(cstone_hip_compute_node_counts(ctx_, 8 * sizeof(K), fTree_.p, fLeafCounts_.as<uint32_t>(), newL, keys, n,
-                                              0xFFFFFFFFu));
+        // the leaf boundaries of an unchanged tree are searched from where they were at the previous sync (layout_)
+        const uint32_t* guess = (*converged && layoutLeaves_ == newL) ? layout_.as<uint32_t>() : nullptr;
+        CS_TRY(cstone_hip_compute_node_counts_guided(ctx_, 8 * sizeof(K), fTree_.p, fLeafCounts_.as<uint32_t>(), newL,
+                                                     keys, n, 0xFFFFFFFFu, guess));
         CS_TRY(fCounts_.ensure(ctx_, size_t(newM) * sizeof(uint32_t)));
         hipLaunchKernelGGL(scatterLeafCountsKernel, gridFor(newL, 256), 256, 0, ctx_->stream,
                            fLeafCounts_.as<uint32_t>(), fLti_.as<NodeIdx>(), newI, newL, fCounts_.as<uint32_t>());
@@ -434,6 +437,7 @@ private:
     int gCap_ = 0, gLeaves_ = 0;
     DevBuf fTree_, fLeafCounts_, fCounts_, newTree_;
     int fCap_ = 0, fLeaves_ = 0;
+    int layoutLeaves_ = -1; // number of leaves layout_ was computed for
     DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_, fCenters_, fSizes_;
     DevBuf ops_, ops2_, leafOps_, layout_, radii_, flags_;
 };

@@ -34,17 +34,80 @@ __device__ __forceinline__ size_t lowerBound(const K* __restrict__ a, size_t n, 
 }
 
 // ---- counts[i] = min(#keys in [tree[i], tree[i+1]), maxCount)              R/tree/csarray.hpp:94-103
+//      Two steps: the position of every leaf boundary in the sorted keys (numNodes + 1 searches instead of two per
+//      leaf), then the differences.  With a guess per boundary (the positions of the previous step: particles move
+//      little between two syncs -- the reference's useCountsAsGuess, csarray.hpp:117-186) the search gallops away from
+//      the guess and typically ends after two or three probes instead of log2(N) = 27.
 template<class K>
-__global__ __launch_bounds__(256) void nodeCountsKernel(const K* __restrict__ tree, uint32_t* __restrict__ counts,
-                                                        NodeIdx numNodes, const K* __restrict__ keys, size_t n,
-                                                        uint32_t maxCount)
+__global__ __launch_bounds__(256) void boundaryPositionsKernel(const K* __restrict__ tree, NodeIdx numNodes,
+                                                               const K* __restrict__ keys, size_t n,
+                                                               const uint32_t* __restrict__ guess,
+                                                               uint32_t* __restrict__ pos)
+{
+    NodeIdx i = blockIdx.x * 256 + threadIdx.x;
+    if (i > numNodes) return;
+    const K key = tree[i];
+    size_t lo = 0, hi = n; // the answer (first index with keys[idx] >= key) lies in [lo, hi]
+    if (guess != nullptr)
+    {
+        size_t g = guess[i] < n ? guess[i] : n;
+        if (g < n && keys[g] < key)
+        {
+            lo          = g + 1;
+            size_t step = 1, p = lo;
+            while (p < n && keys[p] < key)
+            {
+                lo = p + 1;
+                step *= 2;
+                p = lo + step - 1;
+            }
+            hi = p < n ? p : n;
+        }
+        else
+        {
+            hi          = g;
+            size_t step = 1;
+            while (hi >= step && !(keys[hi - step] < key))
+            {
+                hi -= step;
+                step *= 2;
+            }
+            lo = hi >= step ? hi - step + 1 : 0;
+        }
+    }
+    size_t len = hi - lo;
+    while (len > 0)
+    {
+        size_t half = len >> 1;
+        if (keys[lo + half] < key) { lo += half + 1, len -= half + 1; }
+        else { len = half; }
+    }
+    pos[i] = uint32_t(lo);
+}
+
+__global__ __launch_bounds__(256) void countsFromPositionsKernel(const uint32_t* __restrict__ pos, NodeIdx numNodes,
+                                                                 uint32_t maxCount, uint32_t* __restrict__ counts)
 {
     NodeIdx i = blockIdx.x * 256 + threadIdx.x;
     if (i >= numNodes) return;
-    size_t a  = lowerBound(keys, n, tree[i]);
-    size_t b  = lowerBound(keys, n, tree[i + 1]);
-    size_t c  = b - a;
-    counts[i] = uint32_t(c < size_t(maxCount) ? c : size_t(maxCount));
+    uint32_t c = pos[i + 1] - pos[i];
+    counts[i]  = c < maxCount ? c : maxCount;
+}
+
+template<class K>
+int nodeCounts(cstone_hip_ctx* ctx, const K* tree, uint32_t* counts, NodeIdx numNodes, const K* keys, size_t n,
+               uint32_t maxCount, const uint32_t* guess)
+{
+    if (numNodes == 0) return CSTONE_OK;
+    CS_TRY(arenaReserve(ctx, alignUp(size_t(numNodes + 1) * sizeof(uint32_t)) + 1024));
+    auto* pos = (uint32_t*)arenaTake(ctx, size_t(numNodes + 1) * sizeof(uint32_t));
+    hipLaunchKernelGGL(boundaryPositionsKernel<K>, gridFor(numNodes + 1, 256), 256, 0, ctx->stream, tree, numNodes, keys,
+                       n, guess, pos);
+    hipLaunchKernelGGL(countsFromPositionsKernel, gridFor(numNodes, 256), 256, 0, ctx->stream, pos, numNodes, maxCount,
+                       counts);
+    arenaReset(ctx);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
 }
 
 // ---- rebalance decision                                                     R/tree/csarray.hpp:270-310
@@ -313,8 +376,7 @@ int updateOctree(cstone_hip_ctx* ctx, const K* keys, size_t n, uint32_t bucket, 
     CS_TRY(rc);
     {
         StageTimer timer(ctx, CSTONE_STAGE_NODE_COUNTS);
-        hipLaunchKernelGGL(nodeCountsKernel<K>, gridFor(newNumNodes, 256), 256, 0, ctx->stream, tree, counts,
-                           newNumNodes, keys, n, maxCount);
+        CS_TRY(nodeCounts<K>(ctx, tree, counts, newNumNodes, keys, n, maxCount, nullptr));
     }
     *numLeavesHost = newNumNodes;
     CS_HIP(ctx, hipGetLastError());
@@ -360,23 +422,28 @@ using namespace cship;
 extern "C"
 {
 
-int cstone_hip_compute_node_counts(cstone_hip_ctx* ctx, int key_bits, const void* tree, uint32_t* counts,
-                                   int num_nodes, const void* keys, size_t n, uint32_t max_count)
+int cstone_hip_compute_node_counts_guided(cstone_hip_ctx* ctx, int key_bits, const void* tree, uint32_t* counts,
+                                          int num_nodes, const void* keys, size_t n, uint32_t max_count,
+                                          const uint32_t* guess_positions)
 {
     if (!ctx || !tree || !counts || num_nodes < 0 || (n && !keys))
         return fail(ctx, CSTONE_E_ARG, "compute_node_counts: bad argument");
     if (num_nodes == 0) return CSTONE_OK;
+    if (n >= (size_t(1) << 32)) return fail(ctx, CSTONE_E_ARG, "compute_node_counts: more than 2^32 - 1 keys");
     StageTimer timer(ctx, CSTONE_STAGE_NODE_COUNTS);
     if (key_bits == 32)
-        hipLaunchKernelGGL(nodeCountsKernel<uint32_t>, gridFor(num_nodes, 256), 256, 0, ctx->stream,
-                           (const uint32_t*)tree, counts, num_nodes, (const uint32_t*)keys, n, max_count);
-    else if (key_bits == 64)
-        hipLaunchKernelGGL(nodeCountsKernel<uint64_t>, gridFor(num_nodes, 256), 256, 0, ctx->stream,
-                           (const uint64_t*)tree, counts, num_nodes, (const uint64_t*)keys, n, max_count);
-    else
-        return fail(ctx, CSTONE_E_ARG, "compute_node_counts: key_bits %d unsupported", key_bits);
-    CS_HIP(ctx, hipGetLastError());
-    return CSTONE_OK;
+        return nodeCounts<uint32_t>(ctx, (const uint32_t*)tree, counts, num_nodes, (const uint32_t*)keys, n, max_count,
+                                    guess_positions);
+    if (key_bits == 64)
+        return nodeCounts<uint64_t>(ctx, (const uint64_t*)tree, counts, num_nodes, (const uint64_t*)keys, n, max_count,
+                                    guess_positions);
+    return fail(ctx, CSTONE_E_ARG, "compute_node_counts: key_bits %d unsupported", key_bits);
+}
+
+int cstone_hip_compute_node_counts(cstone_hip_ctx* ctx, int key_bits, const void* tree, uint32_t* counts,
+                                   int num_nodes, const void* keys, size_t n, uint32_t max_count)
+{
+    return cstone_hip_compute_node_counts_guided(ctx, key_bits, tree, counts, num_nodes, keys, n, max_count, nullptr);
 }
 
 int cstone_hip_compute_node_ops(cstone_hip_ctx* ctx, int key_bits, const void* tree, int num_nodes,

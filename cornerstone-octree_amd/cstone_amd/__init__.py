@@ -28,7 +28,7 @@ EXPORTS = [
     "cstone_hip_profile_reset", "cstone_hip_profile_get", "cstone_hip_compute_sfc_keys",
     "cstone_hip_sort_pairs_temp_bytes", "cstone_hip_sort_pairs", "cstone_hip_sort_keys_ordering", "cstone_hip_sfc_keys_and_ordering", "cstone_hip_sequence_u32", "cstone_hip_gather",
     "cstone_hip_scatter", "cstone_hip_gather_scatter", "cstone_hip_merge_positions", "cstone_hip_minmax", "cstone_hip_minmax_arrays", "cstone_hip_exclusive_scan_u32", "cstone_hip_inclusive_scan_u32", "cstone_hip_lower_bound",
-    "cstone_hip_compute_node_counts", "cstone_hip_compute_node_ops", "cstone_hip_rebalance_tree",
+    "cstone_hip_compute_node_counts", "cstone_hip_compute_node_counts_guided", "cstone_hip_compute_node_ops", "cstone_hip_rebalance_tree",
     "cstone_hip_update_octree", "cstone_hip_compute_octree", "cstone_hip_build_octree", "cstone_hip_upsweep_sum",
     "cstone_hip_node_centers", "cstone_hip_halo_radii", "cstone_hip_find_halos", "cstone_hip_find_neighbors",
     "cstone_hip_halo_boxes", "cstone_hip_find_overlaps",
@@ -277,6 +277,16 @@ class Context:
         self._chk(self.lib.cstone_hip_compute_node_counts(self.h, C.c_int(kb), _ptr(tree), _ptr(counts), C.c_int(nn),
                                                           _ptr(keys), C.c_size_t(keys.numel()),
                                                           C.c_uint32(max_count)), "compute_node_counts")
+        return counts
+
+    def compute_node_counts_guided(self, tree, keys, guess, max_count=0xFFFFFFFF):
+        torch = _torch()
+        nn = tree.numel() - 1
+        counts = torch.zeros(nn, dtype=torch.int32, device=tree.device)
+        self._chk(self.lib.cstone_hip_compute_node_counts_guided(self.h, C.c_int(keys.element_size() * 8), _ptr(tree),
+                                                                 _ptr(counts), C.c_int(nn), _ptr(keys),
+                                                                 C.c_size_t(keys.numel()), C.c_uint32(max_count),
+                                                                 _ptr(guess)), "compute_node_counts_guided")
         return counts
 
     def compute_node_ops(self, tree, counts, bucket, num_nodes=None):

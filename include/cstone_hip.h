@@ -167,6 +167,12 @@ extern "C"
     /* computeNodeCountsGpu: counts[i] = min(#keys in [tree[i],tree[i+1]), max_count); keys sorted */
     int cstone_hip_compute_node_counts(cstone_hip_ctx* ctx, int key_bits, const void* tree, uint32_t* counts,
                                        int num_nodes, const void* keys, size_t n, uint32_t max_count);
+    /* the same with a starting point per leaf boundary (useCountsAsGuess, R/tree/csarray.hpp:117-186):
+     * guess_positions[num_nodes + 1] = where tree[i] was found last time (e.g. the previous layout); any values are
+     * allowed, good ones end the search after two or three probes instead of log2(n); NULL = plain binary search */
+    int cstone_hip_compute_node_counts_guided(cstone_hip_ctx* ctx, int key_bits, const void* tree, uint32_t* counts,
+                                              int num_nodes, const void* keys, size_t n, uint32_t max_count,
+                                              const uint32_t* guess_positions);
     /* computeNodeOpsGpu: node_ops[num_nodes+1] <- exclusive scan of the rebalance decisions
      * (R/tree/csarray.hpp:288-310); *new_num_nodes_host = node_ops[num_nodes];
      * *converged_host = 1 iff every decision was "keep" */

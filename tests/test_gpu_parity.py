@@ -478,3 +478,28 @@ def test_sfc_keys_and_ordering_equals_two_calls(hip, kb, rb, curve):
         k2, v2 = hip.sfc_keys_and_ordering(curve, kb, xd, yd, zd, cbox(box), keys=marked.clone())
         hip.sync()
         assert torch.equal(k1, k2) and torch.equal(v1, v2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kb", [32, 64])
+def test_node_counts_guided_any_guess(hip, oracle, kb):
+    """useCountsAsGuess: the result never depends on the guess (exact, shifted, zero, beyond the end, random)"""
+    import torch
+
+    box = Box([0, 1, 0, 1, 0, 1])
+    x, y, z, keys = _sorted_keys(oracle, HILBERT, kb, 300000, box, 64, seed=77, kind="clustered")
+    tree, counts = oracle.compute_octree(keys, 32)
+    nl = counts.size
+    exact = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+    rng = np.random.default_rng(1)
+    kd, td = dev(keys), dev(tree)
+    for guess in (exact, np.clip(exact.astype(np.int64) + rng.integers(-40, 40, nl + 1), 0, keys.size).astype(np.uint32),
+                  np.zeros(nl + 1, np.uint32), np.full(nl + 1, 0xFFFFFFFF, np.uint32),
+                  rng.integers(0, keys.size, nl + 1).astype(np.uint32)):
+        got = hip.compute_node_counts_guided(td, kd, dev(guess))
+        assert np.array_equal(host(got), counts)
+    # keys confined to the middle of the tree: leaves left and right of the populated range count zero
+    sub = keys[keys.size // 3: keys.size // 2]
+    ref = oracle.node_counts(tree, sub)
+    got = hip.compute_node_counts_guided(td, dev(sub), dev(exact))
+    assert np.array_equal(host(got), ref)
