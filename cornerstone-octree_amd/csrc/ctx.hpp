@@ -106,4 +106,8 @@ inline unsigned gridFor(size_t n, unsigned block, unsigned perThread = 1)
     return unsigned((n + per - 1) / per);
 }
 
+//! bottom-up saturating sum over the linked octree, launching only the levels that exist (tree.hip)
+int upsweepSumLevels(cstone_hip_ctx* ctx, int numLevelsPlus2, const int32_t* levelRangeHost, const int32_t* levelRange,
+                     const int32_t* childOffsets, uint32_t* counts);
+
 } // namespace cship

@@ -356,9 +356,15 @@ private:
         CS_TRY(fLevelRange_.ensure(ctx_, (maxLevel<K>() + 2) * sizeof(NodeIdx)));
         CS_TRY(fItl_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
         CS_TRY(fLti_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
-        return cstone_hip_build_octree(ctx_, 8 * sizeof(K), fTree_.p, L, fPrefixes_.p, fChild_.as<int32_t>(),
+        CS_TRY(cstone_hip_build_octree(ctx_, 8 * sizeof(K), fTree_.p, L, fPrefixes_.p, fChild_.as<int32_t>(),
                                        fParents_.as<int32_t>(), fLevelRange_.as<int32_t>(), fItl_.as<int32_t>(),
-                                       fLti_.as<int32_t>());
+                                       fLti_.as<int32_t>()));
+        // the level ranges also on the host (the tree is rebuilt rarely): the upsweep then launches existing levels only
+        levelRangeHost_.resize(maxLevel<K>() + 2);
+        CS_HIP(ctx_, hipMemcpyAsync(levelRangeHost_.data(), fLevelRange_.p, levelRangeHost_.size() * sizeof(NodeIdx),
+                                    hipMemcpyDeviceToHost, ctx_->stream));
+        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
+        return CSTONE_OK;
     }
 
     /*! one FocusedOctree::updateTree + updateCounts + updateGeoCenters step on one rank
@@ -413,8 +419,8 @@ private:
         CS_TRY(fCounts_.ensure(ctx_, size_t(newM) * sizeof(uint32_t)));
         hipLaunchKernelGGL(scatterLeafCountsKernel, gridFor(newL, 256), 256, 0, ctx_->stream,
                            fLeafCounts_.as<uint32_t>(), fLti_.as<NodeIdx>(), newI, newL, fCounts_.as<uint32_t>());
-        CS_TRY(cstone_hip_upsweep_sum(ctx_, int(maxLevel<K>()) + 2, fLevelRange_.as<int32_t>(), fChild_.as<int32_t>(),
-                                      fCounts_.as<uint32_t>()));
+        CS_TRY(upsweepSumLevels(ctx_, int(maxLevel<K>()) + 2, levelRangeHost_.data(), fLevelRange_.as<int32_t>(),
+                                fChild_.as<int32_t>(), fCounts_.as<uint32_t>()));
         // updateGeoCenters
         CS_TRY(fCenters_.ensure(ctx_, size_t(newM) * 3 * sizeof(T)));
         CS_TRY(fSizes_.ensure(ctx_, size_t(newM) * 3 * sizeof(T)));
@@ -438,6 +444,7 @@ private:
     DevBuf fTree_, fLeafCounts_, fCounts_, newTree_;
     int fCap_ = 0, fLeaves_ = 0;
     int layoutLeaves_ = -1; // number of leaves layout_ was computed for
+    std::vector<NodeIdx> levelRangeHost_;
     DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_, fCenters_, fSizes_;
     DevBuf ops_, ops2_, leafOps_, layout_, radii_, flags_;
 };

@@ -412,6 +412,24 @@ int buildOctree(cstone_hip_ctx* ctx, const K* leaves, NodeIdx numLeaves, K* pref
 
 } // namespace cship
 
+namespace cship
+{
+//! upsweep with the level ranges known on the host as well: empty levels are not launched
+int upsweepSumLevels(cstone_hip_ctx* ctx, int numLevelsPlus2, const int32_t* levelRangeHost, const int32_t* levelRange,
+                     const int32_t* childOffsets, uint32_t* counts)
+{
+    for (int level = numLevelsPlus2 - 2; level >= 0; --level)
+    {
+        int size = levelRangeHost[level + 1] - levelRangeHost[level];
+        if (size <= 0) continue;
+        unsigned grid = std::min(unsigned(ctx->numCu) * 4, gridFor(size_t(size), 256));
+        hipLaunchKernelGGL(upsweepLevelKernel, grid, 256, 0, ctx->stream, level, levelRange, childOffsets, counts);
+    }
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+} // namespace cship
+
 using namespace cship;
 
 #define CS_KEY_DISPATCH(key_bits, CALL32, CALL64)                                                                      \
