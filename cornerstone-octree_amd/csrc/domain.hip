@@ -199,6 +199,11 @@ public:
                                bucket_ - 1);
             gLeaves_ = 1;
         }
+        // particles flagged with the remove marker sort behind the end of the curve and leave the domain: their number
+        // is on its way to the host while the global tree is updated (whose own read-back completes the stream)
+        hipLaunchKernelGGL(countValidKernel<K>, 1, 1, 0, ctx_->stream, keys, n, ctx_->devScalars + 2);
+        CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars + 2, ctx_->devScalars + 2, sizeof(int), hipMemcpyDeviceToHost,
+                                    ctx_->stream));
         int converged = 0;
         CS_TRY(updateGlobal(keys, n, &converged));
         if (firstCall_)
@@ -211,12 +216,7 @@ public:
                 if (++guard > 64) return fail(ctx_, CSTONE_E_INTERNAL, "global tree does not converge");
             } while (!converged);
         }
-
-        // particles flagged with the remove marker sort behind the end of the curve and leave the domain
-        hipLaunchKernelGGL(countValidKernel<K>, 1, 1, 0, ctx_->stream, keys, n, ctx_->devScalars + 2);
-        CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars + 2, ctx_->devScalars + 2, sizeof(int), hipMemcpyDeviceToHost,
-                                    ctx_->stream));
-        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
+        // the copy was queued ahead of the update's own read-back (update_octree synchronises for the new leaf count)
         const uint32_t numAssigned = uint32_t(ctx_->hostScalars[2]);
         if (numAssigned == 0) return fail(ctx_, CSTONE_E_ARG, "domain_sync: all particles removed");
 
