@@ -106,6 +106,12 @@ inline unsigned gridFor(size_t n, unsigned block, unsigned perThread = 1)
     return unsigned((n + per - 1) / per);
 }
 
+//! encode + SFC ordering with only the digits at or above bit 8 * startPass radix-sorted (sort.hip)
+int sfcKeysAndOrderingHint(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
+                           const void* z, void* keys, uint32_t* ordering, size_t n, const cstone_box& box,
+                           void* keys_alt, uint32_t* values_alt, void* temp, size_t temp_bytes, int startPass,
+                           int* tooLongDev);
+
 //! bottom-up saturating sum over the linked octree, launching only the levels that exist (tree.hip)
 int upsweepSumLevels(cstone_hip_ctx* ctx, int numLevelsPlus2, const int32_t* levelRangeHost, const int32_t* levelRange,
                      const int32_t* childOffsets, uint32_t* counts);

@@ -8,6 +8,7 @@
 // row to build; the object refuses num_ranks > 1 instead of silently running something else.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <vector>
 
@@ -188,8 +189,23 @@ public:
         CS_TRY(keysAlt_.ensure(ctx_, n * sizeof(K)));
         size_t tb = cstone_hip_sort_pairs_temp_bytes(kb, n);
         CS_TRY(sortTmp_.ensure(ctx_, tb));
-        CS_TRY(cstone_hip_sfc_keys_and_ordering(ctx_, curve_, kb, rb, *xPP, *yPP, *zPP, keys, order_.as<uint32_t>(), n,
-                                                &box_, keysAlt_.p, orderAlt_.as<uint32_t>(), sortTmp_.p, tb));
+        // Which digits need the radix passes: two particles whose keys agree in the digits above the deepest leaf level
+        // (+1) of the previous focus tree sit in the same leaf cell, i.e. such runs hold at most a bucket of particles
+        // and are ordered by a fix-up pass instead (sort.hip, fixupRunsKernel).  If a run turns out longer (the
+        // particles have clustered since), the flag read back below triggers a regular sort of the rest.
+        int startPass = 0;
+        if (!firstCall_ && !levelRangeHost_.empty() && std::getenv("CSTONE_FULL_SORT") == nullptr)
+        {
+            int lmax = 0;
+            for (int l = 0; l <= int(maxLevel<K>()); ++l)
+                if (levelRangeHost_[l + 1] > levelRangeHost_[l]) lmax = l;
+            int lowBits = 3 * int(maxLevel<K>()) - 3 * (lmax + 1);
+            startPass   = std::max(0, lowBits / 8) & ~1;
+        }
+        CS_TRY(sfcKeysAndOrderingHint(ctx_, curve_, kb, rb, *xPP, *yPP, *zPP, keys, order_.as<uint32_t>(), n, box_,
+                                      keysAlt_.p, orderAlt_.as<uint32_t>(), sortTmp_.p, tb, startPass,
+                                      ctx_->devScalars + 3));
+        if (startPass == 0) CS_HIP(ctx_, hipMemsetAsync(ctx_->devScalars + 3, 0, sizeof(int), ctx_->stream));
 
         if (firstCall_)
         {
@@ -202,7 +218,7 @@ public:
         // particles flagged with the remove marker sort behind the end of the curve and leave the domain: their number
         // is on its way to the host while the global tree is updated (whose own read-back completes the stream)
         hipLaunchKernelGGL(countValidKernel<K>, 1, 1, 0, ctx_->stream, keys, n, ctx_->devScalars + 2);
-        CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars + 2, ctx_->devScalars + 2, sizeof(int), hipMemcpyDeviceToHost,
+        CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars + 2, ctx_->devScalars + 2, 2 * sizeof(int), hipMemcpyDeviceToHost,
                                     ctx_->stream));
         int converged = 0;
         CS_TRY(updateGlobal(keys, n, &converged));
@@ -219,6 +235,14 @@ public:
         // the copy was queued ahead of the update's own read-back (update_octree synchronises for the new leaf count)
         const uint32_t numAssigned = uint32_t(ctx_->hostScalars[2]);
         if (numAssigned == 0) return fail(ctx_, CSTONE_E_ARG, "domain_sync: all particles removed");
+        if (ctx_->hostScalars[3] != 0)
+        {
+            // a run of equal high digits was too long for the fix-up: sort the rest the regular way.  (The global tree
+            // above is not affected: its leaf boundaries cannot fall inside such a run.)
+            CS_TRY(cstone_hip_sort_pairs(ctx_, kb, keys, order_.as<uint32_t>(), n, keysAlt_.p, orderAlt_.as<uint32_t>(),
+                                         sortTmp_.p, tb));
+            ++fullSortFallbacks_;
+        }
 
         // ---- GlobalAssignment::distribute on one rank: nothing to exchange; the second sort (assignment.hpp:156) of an
         //      already sorted range is the identity and is skipped.
@@ -445,6 +469,7 @@ private:
     int fCap_ = 0, fLeaves_ = 0;
     int layoutLeaves_ = -1; // number of leaves layout_ was computed for
     std::vector<NodeIdx> levelRangeHost_;
+    int fullSortFallbacks_ = 0;
     DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_, fCenters_, fSizes_;
     DevBuf ops_, ops2_, leafOps_, layout_, radii_, flags_;
 };

@@ -711,6 +711,59 @@ __global__ __launch_bounds__(BLOCK) void onesweepTailKernel(const K* __restrict_
                              nullptr, errors, n);
 }
 
+/*! @brief orders the low key bits inside runs of equal high bits (keys >> shift), stably
+ *
+ *  After a sort on the digits above `shift` only, the elements of a run sit in input order.  The thread of a run's first
+ *  element insertion-sorts the run in place (strict comparison: equal keys keep their order), so the result equals the
+ *  full stable sort.  Meant for keys whose high bits almost identify them (SFC keys with the digits above the leaf
+ *  level of the octree sorted: a run lies inside one leaf cell); runs longer than RUN_LIMIT raise *tooLong instead and
+ *  the caller sorts the remaining digits the regular way.  Remove markers (all equal) are left alone. */
+constexpr uint32_t RUN_LIMIT = 192;
+template<class K>
+__global__ __launch_bounds__(256) void fixupRunsKernel(K* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n,
+                                                       int shift, int* __restrict__ tooLong)
+{
+    const uint32_t i    = blockIdx.x * 256u + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
+    // one coalesced load per lane; the neighbours' keys come from the neighbouring lanes (the wave's edge lanes fetch
+    // theirs): this kernel is a plain stream over the keys unless a run needs work
+    const bool inside = i < n;
+    const K k0        = inside ? keys[i] : K(0);
+    K prev            = __shfl_up(k0, 1);
+    K next            = __shfl_down(k0, 1);
+    if (lane == 0 && inside && i > 0) prev = keys[i - 1];
+    if (lane == 63 && i + 1 < n) next = keys[i + 1];
+    if (!inside || i + 1 >= n || k0 == endKey<K>()) return;
+    const K top = k0 >> shift;
+    if (i > 0 && (prev >> shift) == top) return; // not the first of its run
+    if ((next >> shift) != top) return;           // a run of one
+    uint32_t end = i + 2;
+    while (end < n && (keys[end] >> shift) == top && end - i <= RUN_LIMIT)
+        ++end;
+    if (end - i > RUN_LIMIT)
+    {
+        atomicOr(tooLong, 1);
+        return;
+    }
+    for (uint32_t a = i + 1; a < end; ++a)
+    {
+        const K ka        = keys[a];
+        const uint32_t va = vals[a];
+        uint32_t b        = a;
+        while (b > i && keys[b - 1] > ka)
+        {
+            keys[b] = keys[b - 1];
+            vals[b] = vals[b - 1];
+            --b;
+        }
+        if (b != a)
+        {
+            keys[b] = ka;
+            vals[b] = va;
+        }
+    }
+}
+
 __global__ void sequenceKernel(uint32_t* out, size_t n, uint32_t init)
 {
     size_t i = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
@@ -749,7 +802,7 @@ size_t sortTempBytes(size_t n)
 
 template<class K, int BLOCK>
 void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* vals, size_t n, K* keysAlt,
-                  uint32_t* valsAlt, bool iotaValues)
+                  uint32_t* valsAlt, bool iotaValues, int startPass)
 {
     using Cfg             = SortCfg<K, BLOCK>;
     constexpr int P       = Cfg::PASSES;
@@ -759,7 +812,7 @@ void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* val
     uint32_t* vIn  = iotaValues ? nullptr : vals;
     K* kOut        = keysAlt;
     uint32_t* vOut = valsAlt;
-    for (int p = 0; p < P; ++p)
+    for (int p = startPass; p < P; ++p)
     {
         StageTimer timer(ctx, CSTONE_STAGE_SORT_PASS);
         const uint32_t* bases = t.hist + size_t(p) * RADIX;
@@ -771,7 +824,7 @@ void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* val
             hipLaunchKernelGGL((onesweepTailKernel<K, BLOCK>), 1, BLOCK, 0, ctx->stream, kIn, vIn, kOut, vOut,
                                uint32_t(n), p, numFullTiles, bases, t.errors);
         std::swap(kIn, kOut);
-        if (p == 0 && iotaValues) { vIn = vOut, vOut = vals; }
+        if (p == startPass && iotaValues) { vIn = vOut, vOut = vals; }
         else { std::swap(vIn, vOut); }
     }
     static_assert(P % 2 == 0, "an even number of passes leaves the result in the caller's buffers");
@@ -780,7 +833,8 @@ void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* val
 template<class K>
 int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt, uint32_t* valsAlt, void* temp,
               size_t tempBytes, bool iotaValues = false, int histogramState = 0 /* 0: do all, 1: only clear the
-              temp (the caller counts into it next), 2: temp cleared and digit counts present */)
+              temp (the caller counts into it next), 2: temp cleared and digit counts present */,
+              int startPass = 0 /* even: digits below 8 * startPass bits are left to the caller (fixupRuns) */)
 {
     if (n == 0) return CSTONE_OK;
     if (n >= (size_t(1) << 30)) return fail(ctx, CSTONE_E_ARG, "sort_pairs: n = %zu exceeds 2^30 - 1", n);
@@ -834,8 +888,8 @@ int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt
     CS_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sortTrace), &traceDev, sizeof(traceDev), 0, hipMemcpyHostToDevice,
                                        ctx->stream));
 #endif
-    if (large) launchPasses<K, LARGE_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues);
-    else launchPasses<K, SMALL_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues);
+    if (large) launchPasses<K, LARGE_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass);
+    else launchPasses<K, SMALL_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass);
     CS_HIP(ctx, hipGetLastError());
 #ifdef CSTONE_SORT_TRACE
     if (traceFile)
@@ -873,6 +927,46 @@ int sortPairsArena(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n)
 template int sortPairsArena<uint32_t>(cstone_hip_ctx*, uint32_t*, uint32_t*, size_t);
 template int sortPairsArena<uint64_t>(cstone_hip_ctx*, uint64_t*, uint32_t*, size_t);
 
+} // namespace cship
+
+namespace cship
+{
+/*! computeSfcKeys + setMapFromCodes with a hint on the key structure: only the digits at or above bit 8 * startPass
+ *  go through the radix passes, the order inside runs of equal high bits is finished by fixupRunsKernel.
+ *  *tooLongDev (device int, zeroed here) != 0 afterwards means a run was too long for that: the caller then completes
+ *  the job with a regular sort of (keys, ordering), which yields the same result as if nothing had been skipped. */
+int sfcKeysAndOrderingHint(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
+                           const void* z, void* keys, uint32_t* ordering, size_t n, const cstone_box& box,
+                           void* keys_alt, uint32_t* values_alt, void* temp, size_t temp_bytes, int startPass,
+                           int* tooLongDev)
+{
+    if (n == 0) return CSTONE_OK;
+    startPass &= ~1; // an even number of passes leaves the result in the caller's buffers
+    auto run = [&](int state)
+    {
+        return key_bits == 32 ? sortPairs<uint32_t>(ctx, (uint32_t*)keys, ordering, n, (uint32_t*)keys_alt, values_alt,
+                                                    temp, temp_bytes, true, state, startPass)
+                              : sortPairs<uint64_t>(ctx, (uint64_t*)keys, ordering, n, (uint64_t*)keys_alt, values_alt,
+                                                    temp, temp_bytes, true, state, startPass);
+    };
+    CS_TRY(run(1));
+    bool fused = false;
+    CS_TRY(computeKeysAndHistogram(ctx, curve, key_bits, real_bits, x, y, z, keys, n, box, (uint32_t*)temp, &fused));
+    CS_TRY(run(fused ? 2 : 0));
+    if (startPass > 0)
+    {
+        StageTimer timer(ctx, CSTONE_STAGE_SORT_HIST);
+        CS_HIP(ctx, hipMemsetAsync(tooLongDev, 0, sizeof(int), ctx->stream));
+        if (key_bits == 32)
+            hipLaunchKernelGGL(fixupRunsKernel<uint32_t>, gridFor(n, 256), 256, 0, ctx->stream, (uint32_t*)keys, ordering,
+                               uint32_t(n), 8 * startPass, tooLongDev);
+        else
+            hipLaunchKernelGGL(fixupRunsKernel<uint64_t>, gridFor(n, 256), 256, 0, ctx->stream, (uint64_t*)keys, ordering,
+                               uint32_t(n), 8 * startPass, tooLongDev);
+        CS_HIP(ctx, hipGetLastError());
+    }
+    return CSTONE_OK;
+}
 } // namespace cship
 
 using namespace cship;

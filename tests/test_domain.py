@@ -62,3 +62,41 @@ def test_domain_argument_errors(hip):
         Domain(hip, cstone_amd.HILBERT, 64, 64, 8, 64)  # domain.hpp:108-112
     with pytest.raises(cstone_amd.CstoneError, match="single-rank"):
         Domain(hip, cstone_amd.HILBERT, 64, 64, 64, 8, rank=0, nranks=2)
+
+
+@pytest.mark.gpu
+def test_partial_sort_fallback_when_particles_collapse(hip, oracle):
+    """Domain::sync radix-sorts only the key digits above the previous tree's depth and orders the rest inside runs of
+    equal high digits; when the particles suddenly collapse into a tiny region those runs become too long and the
+    regular sort must take over.  Keys, ordering and attached fields must equal the oracle's full stable sort."""
+    import torch
+
+    import cstone_amd
+    from cstone_amd.domain import Domain
+    from oracle.oracle import HILBERT, Box
+
+    n = 400000
+    rng = np.random.default_rng(3)
+    x, y, z = [rng.uniform(0, 1, n) for _ in range(3)]
+    h = np.full(n, 0.005)
+    dom = Domain(hip, cstone_amd.HILBERT, 64, 64, 4096, 64, 0.5, cstone_amd.make_cbox([0, 1] * 3, (1, 1, 1)))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    xd, yd, zd, hd = dev(x), dev(y), dev(z), dev(h)
+    keys = torch.zeros(n, dtype=torch.int64, device="cuda")
+    scratch = torch.empty(n, dtype=torch.float64, device="cuda")
+    ident = torch.arange(n, dtype=torch.float64, device="cuda")
+    box = Box([0, 1] * 3, (1, 1, 1))
+    for step in range(4):
+        if step == 2:
+            # collapse: everything within 1e-7 of one point, thousands of particles share 40+ key bits
+            xd = 0.3 + (xd - 0.5) * 2e-7
+            yd = 0.6 + (yd - 0.5) * 2e-7
+            zd = 0.2 + (zd - 0.5) * 2e-7
+        xin, yin, zin, idin = [t.cpu().numpy().copy() for t in (xd, yd, zd, ident)]
+        keys, xd, yd, zd, hd, scratch, (ident,) = dom.sync(keys, xd, yd, zd, hd, scratch, [ident])
+        hip.sync()
+        kref = oracle.compute_sfc_keys(HILBERT, 64, xin, yin, zin, box)
+        ks, order = oracle.sort_pairs(kref, np.arange(n))
+        assert np.array_equal(keys.cpu().numpy().view(np.uint64), ks), step
+        assert np.array_equal(ident.cpu().numpy(), idin[order]), step   # the same stable permutation
+        assert np.array_equal(xd.cpu().numpy(), xin[order]), step
