@@ -304,6 +304,20 @@ def main():
     pass_ms, pass_launches = ctx.profile_get("sort_pass")
     stage_ms = {s: ctx.profile_get(s)[0] / args.steps for s in cstone_amd.STAGES}
     extras = {}
+    if not distributed:
+        # the same syncs with the radix sort forced over ALL key digits (what the reference's GPU path does every time;
+        # by default Domain::sync sorts the digits above the previous tree's leaf level and finishes the rest in runs)
+        os.environ["CSTONE_FULL_SORT"] = "1"
+        pipe.step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.step()
+        barrier()
+        full = (time.perf_counter() - t1) / args.steps
+        del os.environ["CSTONE_FULL_SORT"]
+        pipe.step()
+        extras["all_digits_sorted"] = {"ms_per_step": full * 1e3, "value": n_local / full, "unit": "particles/s"}
     if not distributed and args.neighbor_targets > 0:
         extras["find_neighbors"] = [pipe.find_neighbors(args.neighbor_targets, 0),
                                     pipe.find_neighbors(args.neighbor_targets, 128)]
@@ -337,7 +351,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{n_global:.0e} uniform particles, {args.key_bits}-bit {args.curve} keys, "
                                    f"f{args.real_bits} coordinates, bucketFocus {args.bucket_focus}, "
-                                   f"bucket {bucket_global}, steady-state cstone_hip_domain_sync"
+                                   f"bucket {bucket_global}, steady-state cstone_hip_domain_sync (radix passes over the "
+                                   f"key digits above the previous tree's leaf level + run fix-up: same order as "
+                                   f"sorting all digits, see extras.all_digits_sorted)"
                                    + ("" if not distributed else
                                       f"; {world} rank(s): SFC domain decomposition, particle + halo exchange with "
                                       f"all_to_all over RCCL, 1% of the particles displaced by <=2h before every sync"),

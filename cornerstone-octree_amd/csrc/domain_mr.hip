@@ -336,8 +336,23 @@ public:
         CS_HIP(ctx_, hipMemsetAsync(keys_.p, 0, n * sizeof(K), ctx_->stream)); // encode skips entries == removeKey
         if (n)
         {
-            CS_TRY(cstone_hip_sfc_keys_and_ordering(ctx_, curve_, kb, rb, x, y, z, keys_.p, order_.as<uint32_t>(), n, &box_,
-                                                    keysAlt_.p, orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes));
+            // radix passes only over the digits above the leaf level (+1) of the previous tree, runs of equal high digits
+            // are finished by a fix-up pass; a run that is too long raises a flag and the regular sort completes the job
+            int startPass = 0;
+            if (!firstCall_ && prevMaxLeafLevel_ >= 0 && std::getenv("CSTONE_FULL_SORT") == nullptr)
+                startPass = std::max(0, (3 * int(maxLevel<K>()) - 3 * (prevMaxLeafLevel_ + 1)) / 8) & ~1;
+            int* tooLong = reinterpret_cast<int*>(scal_.as<char>() + 128);
+            CS_TRY(sfcKeysAndOrderingHint(ctx_, curve_, kb, rb, x, y, z, keys_.p, order_.as<uint32_t>(), n, box_,
+                                          keysAlt_.p, orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes, startPass,
+                                          tooLong));
+            if (startPass > 0)
+            {
+                int flag = 0;
+                CS_TRY(toHost(&flag, tooLong, sizeof(int)));
+                if (flag)
+                    CS_TRY(cstone_hip_sort_pairs(ctx_, kb, keys_.p, order_.as<uint32_t>(), n, keysAlt_.p,
+                                                 orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes));
+            }
         }
 
         tick("2 encode+sort");
@@ -470,6 +485,13 @@ public:
         CS_TRY(updateFocusTree(keysM, nm));
         CS_TRY(enforceBoundaries(keysM, nm));
         CS_TRY(buildFocusOctree());
+        {
+            NodeIdx lr[32];
+            CS_TRY(toHost(lr, fLevelRange_.p, (maxLevel<K>() + 2) * sizeof(NodeIdx)));
+            prevMaxLeafLevel_ = 0;
+            for (int l = 0; l <= int(maxLevel<K>()); ++l)
+                if (lr[l + 1] > lr[l]) prevMaxLeafLevel_ = l;
+        }
         const int L = fLeaves_;
         int first = 0, last = L;
         CS_TRY(findLeaves(&first, &last));
@@ -1007,6 +1029,7 @@ private:
     DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_;
     DevBuf leaving_, sendRows_, recvRows_, rcol_[4], rcolS_[4], rk_, ro_, posA_, posB_, moveTmp_;
     uint64_t prevLo_ = 0, prevHi_ = 0;
+    int prevMaxLeafLevel_ = -1; // deepest level of this rank's tree at the previous sync
     // halo exchange pattern of the last sync (exchangeHalos)
     std::vector<uint64_t> haloSend_, haloRecv_;
     uint64_t haloRecvLo_ = 0, haloRecvHi_ = 0, haloAssigned_ = 0, haloSel_ = 0, haloAnyLast_ = 0;
