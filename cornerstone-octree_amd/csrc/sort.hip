@@ -733,10 +733,22 @@ __global__ __launch_bounds__(256) void fixupRunsKernel(K* __restrict__ keys, uin
     K next            = __shfl_down(k0, 1);
     if (lane == 0 && inside && i > 0) prev = keys[i - 1];
     if (lane == 63 && i + 1 < n) next = keys[i + 1];
+    K next2 = __shfl_down(k0, 2);
     if (!inside || i + 1 >= n || k0 == endKey<K>()) return;
     const K top = k0 >> shift;
     if (i > 0 && (prev >> shift) == top) return; // not the first of its run
     if ((next >> shift) != top) return;           // a run of one
+    // by far the most frequent case, a run of two whose keys are already in this wave's registers: at most one swap
+    if (lane < 62 && (i + 2 >= n || (next2 >> shift) != top))
+    {
+        if (k0 > next)
+        {
+            uint32_t v0 = vals[i], v1 = vals[i + 1];
+            keys[i] = next, keys[i + 1] = k0;
+            vals[i] = v1, vals[i + 1] = v0;
+        }
+        return;
+    }
     uint32_t end = i + 2;
     while (end < n && (keys[end] >> shift) == top && end - i <= RUN_LIMIT)
         ++end;
