@@ -98,7 +98,8 @@ int minMaxCoordinates(cstone_hip_ctx* ctx, int real_bits, const void* const* xs,
 
 //! encode + the sort's digit histograms in one kernel (sfc.hip); *fused = false: hist untouched (unaligned input)
 int computeKeysAndHistogram(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
-                            const void* z, void* keys, size_t n, const cstone_box& box, uint32_t* hist, bool* fused);
+                            const void* z, void* keys, size_t n, const cstone_box& box, uint32_t* hist, bool* fused,
+                            int firstDigit = 0);
 
 inline unsigned gridFor(size_t n, unsigned block, unsigned perThread = 1)
 {

@@ -8,6 +8,7 @@
 // THIS FILE MUST BE COMPILED WITH -ffp-contract=off: int(floor(x*m) - lo*m) is evaluated as two
 // roundings on the reference's CPU path and must not become an FMA.
 #include <algorithm>
+#include <cstdlib>
 
 #include "ctx.hpp"
 #include "device_keys.hpp"
@@ -105,7 +106,7 @@ template<class K, class T, int VEC, bool HILBERT>
 __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict__ x, const T* __restrict__ y,
                                                              const T* __restrict__ z, K* __restrict__ keys, size_t n,
                                                              DBox<T> box, const uint16_t* __restrict__ encTable,
-                                                             uint32_t* __restrict__ hist)
+                                                             uint32_t* __restrict__ hist, int firstDigit)
 {
     constexpr int P = int(sizeof(K));
     __shared__ uint16_t enc[24 * 8];
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict
 #pragma unroll
         for (int p = 0; p < P; ++p)
         {
+            if (p < firstDigit) continue; // digits the sort will not pass over need no counts
             unsigned d = unsigned(key >> (p * 8)) & 255u;
             // nearly sorted input makes the high digits wave-uniform: one add instead of a 64-way LDS conflict
             uint64_t vmask = __ballot(valid);
@@ -254,9 +256,20 @@ int computeKeys(cstone_hip_ctx* ctx, int curve, const T* x, const T* y, const T*
     return CSTONE_OK;
 }
 
+//! workgroups per CU of the grid-stride encode (CSTONE_ENCODE_BLOCKS overrides, for tuning runs)
+inline size_t encodeBlocksPerCu()
+{
+    static const size_t v = []
+    {
+        const char* e = std::getenv("CSTONE_ENCODE_BLOCKS");
+        return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(8);
+    }();
+    return v;
+}
+
 template<class K, class T>
 int computeKeysHist(cstone_hip_ctx* ctx, int curve, const T* x, const T* y, const T* z, K* keys, size_t n,
-                    const cstone_box& hostBox, uint32_t* hist, bool* fused)
+                    const cstone_box& hostBox, uint32_t* hist, bool* fused, int firstDigit)
 {
     constexpr int VEC = 16 / sizeof(T);
     bool aligned = (uintptr_t(x) % 16 == 0) && (uintptr_t(y) % 16 == 0) && (uintptr_t(z) % 16 == 0) &&
@@ -267,32 +280,33 @@ int computeKeysHist(cstone_hip_ctx* ctx, int curve, const T* x, const T* y, cons
     DBox<T> box   = makeDBox<T>(hostBox);
     auto* enc     = (const uint16_t*)ctx->hilbertTables;
     size_t nVec   = n / VEC;
-    unsigned grid = unsigned(std::max<size_t>(1, std::min<size_t>(size_t(ctx->numCu) * 8, (nVec + 255) / 256)));
+    unsigned grid = unsigned(std::max<size_t>(1, std::min<size_t>(size_t(ctx->numCu) * encodeBlocksPerCu(), (nVec + 255) / 256)));
     if (curve == CSTONE_HILBERT)
         hipLaunchKernelGGL((encodeHistogramKernel<K, T, VEC, true>), grid, 256, 0, ctx->stream, x, y, z, keys, n, box,
-                           enc, hist);
+                           enc, hist, firstDigit);
     else
         hipLaunchKernelGGL((encodeHistogramKernel<K, T, VEC, false>), grid, 256, 0, ctx->stream, x, y, z, keys, n, box,
-                           enc, hist);
+                           enc, hist, firstDigit);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }
 
 int computeKeysAndHistogram(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
-                            const void* z, void* keys, size_t n, const cstone_box& box, uint32_t* hist, bool* fused)
+                            const void* z, void* keys, size_t n, const cstone_box& box, uint32_t* hist, bool* fused,
+                            int firstDigit)
 {
     if (key_bits == 32 && real_bits == 32)
         return computeKeysHist<uint32_t, float>(ctx, curve, (const float*)x, (const float*)y, (const float*)z,
-                                                (uint32_t*)keys, n, box, hist, fused);
+                                                (uint32_t*)keys, n, box, hist, fused, firstDigit);
     if (key_bits == 32 && real_bits == 64)
         return computeKeysHist<uint32_t, double>(ctx, curve, (const double*)x, (const double*)y, (const double*)z,
-                                                 (uint32_t*)keys, n, box, hist, fused);
+                                                 (uint32_t*)keys, n, box, hist, fused, firstDigit);
     if (key_bits == 64 && real_bits == 32)
         return computeKeysHist<uint64_t, float>(ctx, curve, (const float*)x, (const float*)y, (const float*)z,
-                                                (uint64_t*)keys, n, box, hist, fused);
+                                                (uint64_t*)keys, n, box, hist, fused, firstDigit);
     if (key_bits == 64 && real_bits == 64)
         return computeKeysHist<uint64_t, double>(ctx, curve, (const double*)x, (const double*)y, (const double*)z,
-                                                 (uint64_t*)keys, n, box, hist, fused);
+                                                 (uint64_t*)keys, n, box, hist, fused, firstDigit);
     return fail(ctx, CSTONE_E_ARG, "sfc_keys_and_ordering: unsupported type combination");
 }
 

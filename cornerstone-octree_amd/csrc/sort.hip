@@ -963,7 +963,8 @@ int sfcKeysAndOrderingHint(cstone_hip_ctx* ctx, int curve, int key_bits, int rea
     };
     CS_TRY(run(1));
     bool fused = false;
-    CS_TRY(computeKeysAndHistogram(ctx, curve, key_bits, real_bits, x, y, z, keys, n, box, (uint32_t*)temp, &fused));
+    CS_TRY(computeKeysAndHistogram(ctx, curve, key_bits, real_bits, x, y, z, keys, n, box, (uint32_t*)temp, &fused,
+                                   startPass));
     CS_TRY(run(fused ? 2 : 0));
     if (startPass > 0)
     {
