@@ -266,10 +266,13 @@ public:
 
     /*! Domain::exchangeHalos (R/domain/domain.hpp:381-386, R/halos/halos.hpp:224-257): repeats the halo exchange of the
      *  last sync for another field.  array: device, laid out like the result arrays (num_particles_with_halos elements
-     *  of elemBytes = 4 or 8); its assigned range is read, its halo ranges are overwritten. */
+     *  of 1, 2, 4, 8, 12, 16, 24 or 32 bytes); its assigned range is read, its halo ranges are overwritten. */
     int exchangeHalos(void* array, int elemBytes) override
     {
-        if (elemBytes != 4 && elemBytes != 8) return fail(ctx_, CSTONE_E_ARG, "exchange_halos: element size %d", elemBytes);
+        // the element sizes gatherGpu is instantiated for (R/primitives/primitives_gpu.cu:126-148)
+        if (elemBytes != 1 && elemBytes != 2 && elemBytes != 4 && elemBytes != 8 && elemBytes != 12 && elemBytes != 16 &&
+            elemBytes != 24 && elemBytes != 32)
+            return fail(ctx_, CSTONE_E_ARG, "exchange_halos: element size %d", elemBytes);
         if (firstCall_) return fail(ctx_, CSTONE_E_ARG, "exchange_halos: no sync yet");
         uint64_t any = 0;
         for (int p = 0; p < P_; ++p)

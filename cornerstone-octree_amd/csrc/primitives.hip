@@ -179,8 +179,9 @@ int permute(cstone_hip_ctx* ctx, int elemBytes, const uint32_t* map, size_t n, c
     if (n == 0) return CSTONE_OK;
     if (!map || !src || !dst) return fail(ctx, CSTONE_E_ARG, "gather/scatter: null array");
     StageTimer timer(ctx, CSTONE_STAGE_GATHER);
-    int natural = elemBytes >= 16 ? 16 : (elemBytes == 12 ? 4 : (elemBytes == 24 ? 8 : elemBytes));
-    if (elemBytes == 32) natural = 16;
+    // alignment the element type is accessed with: Vec3<float> = 12 bytes at 4, Vec3<double> = 24 bytes at 8
+    // (R/util/array.hpp:42-58), 16- and 32-byte elements as 16-byte vectors
+    int natural = elemBytes == 12 ? 4 : (elemBytes == 24 ? 8 : (elemBytes >= 16 ? 16 : elemBytes));
     if ((uintptr_t(src) % natural) || (uintptr_t(dst) % natural))
         return fail(ctx, CSTONE_E_ARG, "gather/scatter: arrays must be aligned to %d bytes", natural);
     switch (elemBytes)

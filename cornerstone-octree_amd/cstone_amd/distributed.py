@@ -756,8 +756,8 @@ class NativeDistributedDomain:
     def exchange_halos(self, field):
         """Domain::exchangeHalos: field (tensor of num_particles_with_halos 4- or 8-byte elements, laid out like the
         result arrays) gets its halo ranges overwritten with the owners' values"""
-        rc = self.ctx.lib.cstone_hip_domain_mr_exchange_halos(self.h, C.c_void_p(field.data_ptr()),
-                                                              C.c_int(field.element_size()))
+        elem = field.element_size() * (field[0].numel() if field.dim() > 1 and field.shape[0] else 1)
+        rc = self.ctx.lib.cstone_hip_domain_mr_exchange_halos(self.h, C.c_void_p(field.data_ptr()), C.c_int(elem))
         if rc != 0 and self.coll.error is not None:
             err, self.coll.error = self.coll.error, None
             raise err

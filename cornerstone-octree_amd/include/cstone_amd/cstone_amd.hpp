@@ -510,11 +510,12 @@ public:
     {
         Context::check(cstone_hip_domain_mr_set_halo_factor(dom_, factor), "MultiRankDomain::setHaloFactor");
     }
-    //! Domain::exchangeHalos for one more field (device array of nParticlesWithHalos elements, 4 or 8 bytes each)
+    //! Domain::exchangeHalos for one more field (device array of nParticlesWithHalos elements of 1..32 bytes)
     template<class V>
     void exchangeHalos(V* field) const
     {
-        static_assert(sizeof(V) == 4 || sizeof(V) == 8);
+        static_assert(sizeof(V) == 1 || sizeof(V) == 2 || sizeof(V) == 4 || sizeof(V) == 8 || sizeof(V) == 12 ||
+                      sizeof(V) == 16 || sizeof(V) == 24 || sizeof(V) == 32);
         Context::check(cstone_hip_domain_mr_exchange_halos(dom_, field, int(sizeof(V))), "MultiRankDomain::exchangeHalos");
     }
 

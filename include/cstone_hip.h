@@ -357,7 +357,8 @@ extern "C"
                                   const void* h, size_t n);
     int cstone_hip_domain_mr_view_get(cstone_hip_domain_mr* dom, cstone_hip_domain_mr_view* out);
     /* Domain::exchangeHalos (R/domain/domain.hpp:381-386): repeats the halo exchange of the last sync for one more
-     * field; array (device, 4- or 8-byte elements) is laid out like the result arrays: its assigned range is read,
+     * field; array (device; elements of 1, 2, 4, 8, 12, 16, 24 or 32 bytes, e.g. Vec3<float>, Vec4<double>) is laid out
+     * like the result arrays: its assigned range is read,
      * its halo ranges are overwritten with the owners' values */
     int cstone_hip_domain_mr_exchange_halos(cstone_hip_domain_mr* dom, void* array, int elem_bytes);
     int cstone_hip_domain_mr_set_halo_factor(cstone_hip_domain_mr* dom, float factor);

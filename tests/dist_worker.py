@@ -195,6 +195,12 @@ def main():
                 f[st:en] = (2.0 * r["x"][st:en] + 1.0).to(dt)
                 dom.exchange_halos(f)
                 ok &= bool(torch.equal(f, (2.0 * r["x"] + 1.0).to(dt)))
+            # a Vec3<double> field (24-byte elements)
+            ref3 = torch.stack([r["x"], r["y"], r["z"]], dim=1).contiguous()
+            f3 = torch.full_like(ref3, -7.0)
+            f3[st:en] = ref3[st:en]
+            dom.exchange_halos(f3)
+            ok &= bool(torch.equal(f3, ref3))
         else:
             lo_key, hi_key, stats = dom.assignment[rank], dom.assignment[rank + 1], dict(dom.stats)
         ok &= bool(np.all(keys[st:en] >= kdt(lo_key))) and (en == st or int(keys[en - 1]) < hi_key)

@@ -503,3 +503,21 @@ def test_node_counts_guided_any_guess(hip, oracle, kb):
     ref = oracle.node_counts(tree, sub)
     got = hip.compute_node_counts_guided(td, dev(sub), dev(exact))
     assert np.array_equal(host(got), ref)
+
+
+@pytest.mark.gpu
+def test_gather_vec3_double_at_8_byte_alignment(hip):
+    """Vec3<double> (24-byte elements, alignas 8 in the reference, util/array.hpp:42-58): arrays that are only 8-byte
+    aligned must be accepted"""
+    import torch
+
+    n = 50000
+    rng = np.random.default_rng(8)
+    src = torch.from_numpy(rng.normal(size=(n + 1, 3))).cuda()
+    perm = torch.from_numpy(rng.permutation(n).astype(np.int32)).cuda()
+    s = src[1:]                      # base + 24 bytes: 8-byte aligned, not 16
+    assert s.data_ptr() % 16 == 8
+    dst = torch.zeros(n + 1, 3, dtype=torch.float64, device="cuda")[1:]
+    hip.gather(perm, s, dst, elem_bytes=24)
+    hip.sync()
+    assert torch.equal(dst, s[perm.long()])
