@@ -229,15 +229,18 @@ __global__ __launch_bounds__(256) void fillIndicesKernel(const int32_t* __restri
 }
 
 //! one set of result arrays
+constexpr int MAX_PROPS = 16;
 struct Out
 {
     DevBuf keys, x, y, z, h;
+    DevBuf props[MAX_PROPS];
 };
 
 struct MrBase
 {
     virtual ~MrBase()                                                                    = default;
-    virtual int sync(const void* x, const void* y, const void* z, const void* h, size_t n) = 0;
+    virtual int sync(const void* x, const void* y, const void* z, const void* h, size_t n, const void* const* props,
+                     const int* propBytes, int numProps) = 0;
     virtual int view(cstone_hip_domain_mr_view* out)                                     = 0;
     virtual void setHaloFactor(float f)                                                  = 0;
     virtual int exchangeHalos(void* array, int elemBytes)                                = 0;
@@ -317,8 +320,13 @@ public:
         return CSTONE_OK;
     }
 
-    int sync(const void* xIn, const void* yIn, const void* zIn, const void* hIn, size_t n) override
+    int sync(const void* xIn, const void* yIn, const void* zIn, const void* hIn, size_t n, const void* const* props,
+             const int* propBytes, int numProps) override
     {
+        if (numProps < 0 || numProps > MAX_PROPS) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: at most %d properties", MAX_PROPS);
+        for (int q = 0; q < numProps; ++q)
+            if (!props[q] || (propBytes[q] != 4 && propBytes[q] != 8))
+                return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: property %d must be a 4- or 8-byte array", q);
         const T* x = static_cast<const T*>(xIn);
         const T* y = static_cast<const T*>(yIn);
         const T* z = static_cast<const T*>(zIn);
@@ -441,6 +449,29 @@ public:
             }
         }
 
+        // ---- further conserved fields travel the same way, one collective per field (the volume is small in the steady
+        //      state); received values are brought into the newcomers' sorted order
+        DevBuf* propRecvSorted[MAX_PROPS] = {};
+        for (int q = 0; q < numProps && movedAny; ++q)
+        {
+            const size_t e = size_t(propBytes[q]);
+            std::vector<size_t> sb(P_, 0), rbv(P_, 0);
+            for (int p = 0; p < P_; ++p)
+            {
+                if (p == rank_) continue;
+                sb[p]  = sendCounts[p] * e;
+                rbv[p] = matrix[size_t(p) * P_ + rank_] * e;
+            }
+            CS_TRY(sendRows_.ensure(ctx_, std::max<size_t>(mSend, 1) * e));
+            CS_TRY(propRecv_[q].ensure(ctx_, std::max<size_t>(nb, 1) * e));
+            CS_TRY(propRecvS_[q].ensure(ctx_, std::max<size_t>(nb, 1) * e));
+            if (mSend) CS_TRY(cstone_hip_gather(ctx_, int(e), leaving_.as<uint32_t>(), mSend, props[q], sendRows_.p));
+            CS_TRY(callComm(comm_.all_to_all_v(comm_.user, sendRows_.p, sb.data(), propRecv_[q].p, rbv.data()),
+                            "all_to_all_v (property)"));
+            if (nb) CS_TRY(cstone_hip_gather(ctx_, int(e), ro_.as<uint32_t>(), nb, propRecv_[q].p, propRecvS_[q].p));
+            propRecvSorted[q] = &propRecvS_[q];
+        }
+
         // ---- Result arrays.  The assigned block is written ONCE, at an offset M that leaves room for the halos of the
         //      lower ranks (their number is only known after the discovery below; M is generous and follows the
         //      previous sync).  The arrays handed out start at M - (halos of lower ranks).
@@ -451,6 +482,8 @@ public:
         CS_TRY(o.keys.ensure(ctx_, cap * sizeof(K)));
         for (DevBuf* b : {&o.x, &o.y, &o.z, &o.h})
             CS_TRY(b->ensure(ctx_, cap * sizeof(T)));
+        for (int q = 0; q < numProps; ++q)
+            CS_TRY(o.props[q].ensure(ctx_, cap * size_t(propBytes[q])));
 
         // ---- merge of the kept, already sorted range with the newcomers: positions, then every field from its input
         //      slot straight to its final slot
@@ -482,6 +515,17 @@ public:
         CS_TRY(place(y, recvSorted[1], o.y.as<T>() + M));
         CS_TRY(place(z, recvSorted[2], o.z.as<T>() + M));
         CS_TRY(place(h, recvSorted[3], o.h.as<T>() + M));
+        for (int q = 0; q < numProps; ++q)
+        {
+            const int e = propBytes[q];
+            char* dst   = o.props[q].as<char>() + M * e;
+            if (nb)
+            {
+                CS_TRY(cstone_hip_gather_scatter(ctx_, e, keptO, posA_.as<uint32_t>(), na, props[q], dst));
+                CS_TRY(cstone_hip_scatter(ctx_, e, posB_.as<uint32_t>(), nb, propRecvSorted[q]->p, dst));
+            }
+            else { CS_TRY(cstone_hip_gather(ctx_, e, keptO, na, props[q], dst)); }
+        }
         tick("4 exchange+merge+place");
 
         // ---- this rank's finest tree over its assigned particles; its SFC range must end on leaf boundaries
@@ -631,7 +675,7 @@ public:
         {
             // the margins were too small (first syncs, abrupt changes): move the block once, through a scratch copy
             const uint64_t M2 = nlo, cap2 = nlo + nm + nhi;
-            CS_TRY(moveTmp_.ensure(ctx_, nm * std::max(sizeof(K), sizeof(T))));
+            CS_TRY(moveTmp_.ensure(ctx_, nm * 8));
             auto shift = [&](DevBuf& buf, size_t elem) -> int
             {
                 CS_HIP(ctx_, hipMemcpyAsync(moveTmp_.p, buf.as<char>() + M * elem, nm * elem, hipMemcpyDeviceToDevice,
@@ -644,6 +688,8 @@ public:
             CS_TRY(shift(o.keys, sizeof(K)));
             for (DevBuf* b : {&o.x, &o.y, &o.z, &o.h})
                 CS_TRY(shift(*b, sizeof(T)));
+            for (int q = 0; q < numProps; ++q)
+                CS_TRY(shift(o.props[q], size_t(propBytes[q])));
             off = 0;
         }
         const uint64_t A = off + nlo; // first assigned slot
@@ -698,6 +744,8 @@ public:
         view_.box                      = box_;
         view_.keys = o.keys.as<K>() + off;
         view_.x = o.x.as<T>() + off, view_.y = o.y.as<T>() + off, view_.z = o.z.as<T>() + off, view_.h = o.h.as<T>() + off;
+        for (int q = 0; q < MAX_PROPS; ++q)
+            view_.props[q] = q < numProps ? static_cast<const void*>(o.props[q].as<char>() + off * propBytes[q]) : nullptr;
         view_.num_global_leaves = gLeaves_, view_.num_focus_leaves = fLeaves_;
         view_.global_leaves = gTree_.p, view_.global_counts = gCounts_.as<uint32_t>();
         view_.focus_leaves = fTree_.p, view_.focus_leaf_counts = fCounts_.as<uint32_t>();
@@ -1031,6 +1079,7 @@ private:
     int fCap_ = 0, fLeaves_ = 0;
     DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_;
     DevBuf leaving_, sendRows_, recvRows_, rcol_[4], rcolS_[4], rk_, ro_, posA_, posB_, moveTmp_;
+    DevBuf propRecv_[MAX_PROPS], propRecvS_[MAX_PROPS];
     uint64_t prevLo_ = 0, prevHi_ = 0;
     int prevMaxLeafLevel_ = -1; // deepest level of this rank's tree at the previous sync
     // halo exchange pattern of the last sync (exchangeHalos)
@@ -1099,12 +1148,20 @@ int cstone_hip_domain_mr_destroy(cstone_hip_domain_mr* dom)
     return CSTONE_OK;
 }
 
-int cstone_hip_domain_mr_sync(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z, const void* h,
-                              size_t n)
+int cstone_hip_domain_mr_sync_props(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z,
+                                    const void* h, size_t n, const void* const* props, const int* prop_bytes,
+                                    int num_props)
 {
     if (!dom) return CSTONE_E_ARG;
     if (n && (!x || !y || !z || !h)) return fail(dom->ctx, CSTONE_E_ARG, "domain_mr_sync: null array");
-    return dom->impl->sync(x, y, z, h, n);
+    if (num_props && (!props || !prop_bytes)) return fail(dom->ctx, CSTONE_E_ARG, "domain_mr_sync: null property list");
+    return dom->impl->sync(x, y, z, h, n, props, prop_bytes, num_props);
+}
+
+int cstone_hip_domain_mr_sync(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z, const void* h,
+                              size_t n)
+{
+    return cstone_hip_domain_mr_sync_props(dom, x, y, z, h, n, nullptr, nullptr, 0);
 }
 
 int cstone_hip_domain_mr_view_get(cstone_hip_domain_mr* dom, cstone_hip_domain_mr_view* out)

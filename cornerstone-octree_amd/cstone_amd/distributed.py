@@ -608,7 +608,7 @@ class MrView(C.Structure):
                 ("global_leaves", C.c_void_p), ("global_counts", C.c_void_p), ("focus_leaves", C.c_void_p),
                 ("focus_leaf_counts", C.c_void_p), ("range_start", C.c_uint64), ("range_end", C.c_uint64),
                 ("particles_sent", C.c_uint64), ("halos_received", C.c_uint64), ("halos_sent", C.c_uint64),
-                ("halo_boxes_exported", C.c_uint64)]
+                ("halo_boxes_exported", C.c_uint64), ("props", C.c_void_p * 16)]
 
 
 class _DevMem:
@@ -723,16 +723,19 @@ class NativeDistributedDomain:
         self.ctx._chk(self.ctx.lib.cstone_hip_domain_mr_view_get(self.h, C.byref(v)), "domain_mr_view_get")
         return v
 
-    def sync(self, x, y, z, h):
-        """returns dict(keys, x, y, z, h, start, end) of tensors that alias the domain-owned result arrays (valid until
-        the next but one sync)"""
+    def sync(self, x, y, z, h, props=()):
+        """returns dict(keys, x, y, z, h, start, end[, props]) of tensors that alias the domain-owned result arrays (valid
+        until the next but one sync); props: further 4- or 8-byte fields that follow their particles"""
         torch = _torch()
         import cstone_amd
 
-        self._keep = (x, y, z, h)  # inputs must outlive the call
-        rc = self.ctx.lib.cstone_hip_domain_mr_sync(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
-                                                    C.c_void_p(z.data_ptr()), C.c_void_p(h.data_ptr()),
-                                                    C.c_size_t(x.numel()))
+        self._keep = (x, y, z, h, props)  # inputs must outlive the call
+        k = len(props)
+        parr = (C.c_void_p * max(1, k))(*[t.data_ptr() for t in props])
+        pbytes = (C.c_int * max(1, k))(*[t.element_size() for t in props])
+        rc = self.ctx.lib.cstone_hip_domain_mr_sync_props(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                          C.c_void_p(z.data_ptr()), C.c_void_p(h.data_ptr()),
+                                                          C.c_size_t(x.numel()), parr, pbytes, C.c_int(k))
         if rc != 0 and self.coll.error is not None:
             err, self.coll.error = self.coll.error, None
             raise err
@@ -751,6 +754,7 @@ class NativeDistributedDomain:
                    z=wrap(v.z, rdt, n * es), h=wrap(v.h, rdt, n * es), start=v.start_index, end=v.end_index)
         lim = C.cast(C.byref(v.box), C.POINTER(C.c_double))
         out["lim"] = np.array([lim[i] for i in range(6)])
+        out["props"] = [wrap(v.props[q], props[q].dtype, n * props[q].element_size()) for q in range(len(props))]
         return out
 
     def exchange_halos(self, field):

@@ -486,11 +486,22 @@ public:
         if (dom_) cstone_hip_domain_mr_destroy(dom_);
     }
 
-    //! x, y, z, h: device pointers to this rank's n particles in any order
-    void sync(const T* x, const T* y, const T* z, const T* h, std::size_t n)
+    //! x, y, z, h: device pointers to this rank's n particles in any order; properties: further conserved 4- or
+    //! 8-byte fields that follow their particles (results in view().props[i], halo ranges via exchangeHalos)
+    template<class... Props>
+    void sync(const T* x, const T* y, const T* z, const T* h, std::size_t n, const Props*... properties)
     {
-        Context::check(cstone_hip_domain_mr_sync(dom_, x, y, z, h, n), "MultiRankDomain::sync");
+        static_assert(((sizeof(Props) == 4 || sizeof(Props) == 8) && ...));
+        constexpr int np = sizeof...(Props);
+        const void* pp[np + 1] = {static_cast<const void*>(properties)..., nullptr};
+        const int pb[np + 1]   = {int(sizeof(Props))..., 0};
+        Context::check(cstone_hip_domain_mr_sync_props(dom_, x, y, z, h, n, pp, pb, np), "MultiRankDomain::sync");
         Context::check(cstone_hip_domain_mr_view_get(dom_, &view_), "MultiRankDomain::view");
+    }
+    template<class V>
+    V* property(int i) const
+    {
+        return static_cast<V*>(const_cast<void*>(view_.props[i]));
     }
 
     LocalIndex startIndex() const { return view_.start_index; }

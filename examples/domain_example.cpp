@@ -57,7 +57,7 @@ int main(int argc, char** argv)
     { return cstone_hip_memcpy_d2d(Context::get(), r, s, bytes); };
     self.all_to_all_v = [](void*, const void*, const std::size_t*, void*, const std::size_t*) { return 0; };
     MultiRankDomain<KeyType, T> mr(0, 1, 1024, 64, Box<T>{0, 1}, self);
-    mr.sync(x.data(), y.data(), z.data(), h.data(), x.size());
+    mr.sync(x.data(), y.data(), z.data(), h.data(), x.size(), mass.data());
     syncGpu();
     std::printf("multi-rank domain on one rank: particles [%u, %u) of %u, range [%llu, %llu)\n", mr.startIndex(),
                 mr.endIndex(), mr.nParticlesWithHalos(), (unsigned long long)mr.assignedRange().first,

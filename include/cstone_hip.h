@@ -345,6 +345,8 @@ extern "C"
         const uint32_t* focus_leaf_counts;
         uint64_t range_start, range_end; /* the rank's SFC key range */
         uint64_t particles_sent, halos_received, halos_sent, halo_boxes_exported;
+        const void* props[16];           /* the conserved properties of the last sync_props call, same layout; their
+                                            halo ranges are NOT filled (exchange_halos does that on request) */
     } cstone_hip_domain_mr_view;
 
     int cstone_hip_domain_mr_create(cstone_hip_ctx* ctx, cstone_hip_domain_mr** out, int curve, int key_bits,
@@ -355,6 +357,12 @@ extern "C"
     /* x, y, z, h: this rank's n particles in any order (device; may point into the previous result) */
     int cstone_hip_domain_mr_sync(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z,
                                   const void* h, size_t n);
+    /* the same with further conserved per-particle fields (the `properties` of Domain::sync, R/domain/domain.hpp:196-203:
+     * masses, velocities, ...; up to 16 arrays of 4- or 8-byte elements) that follow their particles to the new owner
+     * and into SFC order */
+    int cstone_hip_domain_mr_sync_props(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z,
+                                        const void* h, size_t n, const void* const* props, const int* prop_bytes,
+                                        int num_props);
     int cstone_hip_domain_mr_view_get(cstone_hip_domain_mr* dom, cstone_hip_domain_mr_view* out);
     /* Domain::exchangeHalos (R/domain/domain.hpp:381-386): repeats the halo exchange of the last sync for one more
      * field; array (device; elements of 1, 2, 4, 8, 12, 16, 24 or 32 bytes, e.g. Vec3<float>, Vec4<double>) is laid out

@@ -21,6 +21,10 @@ sys.path.insert(0, os.path.join(ROOT, "cornerstone-octree_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def tag64_of(r, st, en):
+    return r["x"][st:en] * 3.0 + r["y"][st:en] * 5.0 + r["z"][st:en] * 7.0 + r["h"][st:en]
+
+
 def neighbor_sum(o, x, y, z, h, first, last, lim, bc):
     """brute-force-free reference count through the oracle's tree search on the given particle set"""
     from oracle.oracle import HILBERT, Box
@@ -176,9 +180,18 @@ def main():
                                 bucket_focus=16, box_lim=lim, box_bc=bc)
     ok = True
     report = []
+    tag64 = x * 3.0 + y * 5.0 + z * 7.0 + h          # conserved fields that must stay attached to their particles
+    tag32 = (x + 2.0 * y).to(torch.float32)
     for s in range(a.syncs):
-        r = dom.sync(x, y, z, h)
+        if a.impl == "native":
+            r = dom.sync(x, y, z, h, props=[tag64, tag32])
+        else:
+            r = dom.sync(x, y, z, h)
         st, en = r["start"], r["end"]
+        if a.impl == "native":
+            p64, p32 = r["props"]
+            ok &= bool(torch.equal(p64[st:en], tag64_of(r, st, en)))
+            ok &= bool(torch.equal(p32[st:en], (r["x"][st:en] + 2.0 * r["y"][st:en]).to(torch.float32)))
         keys = r["keys"].cpu().numpy().view(kdt)
         # invariants: counts add up, keys sorted, assigned keys inside my range
         tot = torch.tensor([en - st], dtype=torch.int64)
@@ -227,6 +240,8 @@ def main():
             x, y, z = torch.remainder(x, 1.0), torch.remainder(y, 1.0), torch.remainder(z, 1.0)
         else:
             x, y, z = x.clamp(0.0, 1.0 - 1e-9), y.clamp(0.0, 1.0 - 1e-9), z.clamp(0.0, 1.0 - 1e-9)
+        tag64 = x * 3.0 + y * 5.0 + z * 7.0 + h
+        tag32 = (x + 2.0 * y).to(torch.float32)
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
