@@ -254,7 +254,14 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # CSTONE_BENCH_BACKEND=gloo: rehearsal of the N-rank bench logic with several processes on ONE GPU (the numbers
+        # mean nothing then: host-staged collectives, shared device)
+        backend = os.environ.get("CSTONE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+            local_rank = 0
     torch.cuda.set_device(local_rank)
     ctx = cstone_amd.Context(local_rank)
 
@@ -297,7 +304,8 @@ def main():
     elapsed = time.perf_counter() - t0
     n_sorted = n_local
     if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
         n_sorted = pipe.assigned
