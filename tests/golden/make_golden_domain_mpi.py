@@ -86,7 +86,13 @@ if __name__ == "__main__":
                                             kind="blobs", seed=102),
         "ref_domain_mpi_P4_blobs_open": dict(P=4, n=16000, syncs=3, bucket=96, bucket_focus=16, bc=(0, 0, 0),
                                              kind="blobs", seed=103),
+        "ref_domain_mpi_P6_uniform_pbc": dict(P=6, n=9000, syncs=3, bucket=32, bucket_focus=8, bc=(1, 0, 1),
+                                              kind="uniform", seed=104),
+        "ref_domain_mpi_P8_blobs_open": dict(P=8, n=9600, syncs=3, bucket=32, bucket_focus=8, bc=(0, 0, 0),
+                                             kind="blobs", seed=105),
     }
+    only = sys.argv[1:]
+    cases = {k: v for k, v in cases.items() if not only or k in only}
     for name, kw in cases.items():
         o = run(**kw)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **o)

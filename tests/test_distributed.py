@@ -79,6 +79,8 @@ def test_gloo_ranks_hip_backend(nproc, pbc):
 
 GOLDEN_MPI = [("ref_domain_mpi_P2_uniform_open.npz", 2), ("ref_domain_mpi_P3_blobs_pbc.npz", 3),
               ("ref_domain_mpi_P4_blobs_open.npz", 4)]
+# 6 and 8 ranks: CPU suite only (a GPU box admits 6 processes on its card, the test runner included)
+GOLDEN_MPI_CPU = GOLDEN_MPI + [("ref_domain_mpi_P6_uniform_pbc.npz", 6), ("ref_domain_mpi_P8_blobs_open.npz", 8)]
 
 
 def test_host_spanning_tree_against_oracle(oracle):
@@ -93,7 +95,7 @@ def test_host_spanning_tree_against_oracle(oracle):
             assert [int(v) for v in ref] == spanning_tree(sp, kb)
 
 
-@pytest.mark.parametrize("fixture,nproc", GOLDEN_MPI)
+@pytest.mark.parametrize("fixture,nproc", GOLDEN_MPI_CPU)
 def test_reference_decomposition_cpu_backend(fixture, nproc):
     """fixtures from the REFERENCE Domain on 2-4 MPI ranks: box, SFC ranges, global tree and counts, and every rank's
     assigned particles after each of 3 syncs with moving particles must be reproduced bit for bit"""
