@@ -8,4 +8,8 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCL
   n=$(echo $c | tr " " "_" | cut -c1-24)
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$n -o p --output-format csv -- python3 $R/tools/sort_bench.py --reps 1 > /dev/null 2>&1
 done
+# HBM traffic of every kernel of the sync itself (bench.py, 3 timed syncs), again one counter per run
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $O/benchpmc_$c -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --neighbor-targets 0 > /dev/null 2>&1
+done
 ls $O
