@@ -719,59 +719,75 @@ __global__ __launch_bounds__(BLOCK) void onesweepTailKernel(const K* __restrict_
  *  level of the octree sorted: a run lies inside one leaf cell); runs longer than RUN_LIMIT raise *tooLong instead and
  *  the caller sorts the remaining digits the regular way.  Remove markers (all equal) are left alone. */
 constexpr uint32_t RUN_LIMIT = 192;
+constexpr int FIX_VEC = 4; // consecutive keys per lane: a stream this light is otherwise bound by wave launches
 template<class K>
 __global__ __launch_bounds__(256) void fixupRunsKernel(K* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n,
                                                        int shift, int* __restrict__ tooLong)
 {
-    const uint32_t i    = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t base = (blockIdx.x * 256u + threadIdx.x) * FIX_VEC;
     const unsigned lane = threadIdx.x & 63u;
-    // one coalesced load per lane; the neighbours' keys come from the neighbouring lanes (the wave's edge lanes fetch
-    // theirs): this kernel is a plain stream over the keys unless a run needs work
-    const bool inside = i < n;
-    const K k0        = inside ? keys[i] : K(0);
-    K prev            = __shfl_up(k0, 1);
-    K next            = __shfl_down(k0, 1);
-    if (lane == 0 && inside && i > 0) prev = keys[i - 1];
-    if (lane == 63 && i + 1 < n) next = keys[i + 1];
-    K next2 = __shfl_down(k0, 2);
-    if (!inside || i + 1 >= n || k0 == endKey<K>()) return;
-    const K top = k0 >> shift;
-    if (i > 0 && (prev >> shift) == top) return; // not the first of its run
-    if ((next >> shift) != top) return;           // a run of one
-    // by far the most frequent case, a run of two whose keys are already in this wave's registers: at most one swap
-    if (lane < 62 && (i + 2 >= n || (next2 >> shift) != top))
+    // FIX_VEC + 3 keys around my slots: k[1 + e] = keys[base + e]; k[0] = the key before, k[FIX_VEC + 1], k[FIX_VEC + 2]
+    // the two behind (runs of two are decided and swapped from registers).  Neighbouring lanes supply the edges, the
+    // wave's edge lanes fetch theirs.
+    K k[FIX_VEC + 3];
+#pragma unroll
+    for (int e = 0; e < FIX_VEC; ++e)
+        k[1 + e] = base + e < n ? keys[base + e] : endKey<K>();
+    k[0]           = __shfl_up(k[FIX_VEC], 1);
+    k[FIX_VEC + 1] = __shfl_down(k[1], 1);
+    k[FIX_VEC + 2] = __shfl_down(k[2], 1);
+    if (lane == 0) k[0] = base > 0 && base - 1 < n ? keys[base - 1] : endKey<K>();
+    if (lane == 63)
     {
-        if (k0 > next)
-        {
-            uint32_t v0 = vals[i], v1 = vals[i + 1];
-            keys[i] = next, keys[i + 1] = k0;
-            vals[i] = v1, vals[i + 1] = v0;
-        }
-        return;
+        k[FIX_VEC + 1] = base + FIX_VEC < n ? keys[base + FIX_VEC] : endKey<K>();
+        k[FIX_VEC + 2] = base + FIX_VEC + 1 < n ? keys[base + FIX_VEC + 1] : endKey<K>();
     }
-    uint32_t end = i + 2;
-    while (end < n && (keys[end] >> shift) == top && end - i <= RUN_LIMIT)
-        ++end;
-    if (end - i > RUN_LIMIT)
+#pragma unroll
+    for (int e = 0; e < FIX_VEC; ++e)
     {
-        atomicOr(tooLong, 1);
-        return;
-    }
-    for (uint32_t a = i + 1; a < end; ++a)
-    {
-        const K ka        = keys[a];
-        const uint32_t va = vals[a];
-        uint32_t b        = a;
-        while (b > i && keys[b - 1] > ka)
+        const uint32_t i = base + e;
+        const K k0       = k[1 + e];
+        if (i + 1 >= n || k0 == endKey<K>()) continue;
+        const K top = k0 >> shift;
+        if (i > 0 && k[e] != endKey<K>() && (k[e] >> shift) == top) continue; // not the first of its run
+        const K next = k[2 + e];
+        if (next == endKey<K>() || (next >> shift) != top) continue;           // a run of one
+        const K next2 = k[3 + e];
+        if (i + 2 >= n || next2 == endKey<K>() || (next2 >> shift) != top)
         {
-            keys[b] = keys[b - 1];
-            vals[b] = vals[b - 1];
-            --b;
+            // by far the most frequent case, a run of two: at most one swap, decided from registers
+            if (k0 > next)
+            {
+                uint32_t v0 = vals[i], v1 = vals[i + 1];
+                keys[i] = next, keys[i + 1] = k0;
+                vals[i] = v1, vals[i + 1] = v0;
+            }
+            continue;
         }
-        if (b != a)
+        uint32_t end = i + 3;
+        while (end < n && (keys[end] >> shift) == top && end - i <= RUN_LIMIT)
+            ++end;
+        if (end - i > RUN_LIMIT)
         {
-            keys[b] = ka;
-            vals[b] = va;
+            atomicOr(tooLong, 1);
+            continue;
+        }
+        for (uint32_t a = i + 1; a < end; ++a)
+        {
+            const K ka        = keys[a];
+            const uint32_t va = vals[a];
+            uint32_t b        = a;
+            while (b > i && keys[b - 1] > ka)
+            {
+                keys[b] = keys[b - 1];
+                vals[b] = vals[b - 1];
+                --b;
+            }
+            if (b != a)
+            {
+                keys[b] = ka;
+                vals[b] = va;
+            }
         }
     }
 }
@@ -971,10 +987,10 @@ int sfcKeysAndOrderingHint(cstone_hip_ctx* ctx, int curve, int key_bits, int rea
         StageTimer timer(ctx, CSTONE_STAGE_SORT_HIST);
         CS_HIP(ctx, hipMemsetAsync(tooLongDev, 0, sizeof(int), ctx->stream));
         if (key_bits == 32)
-            hipLaunchKernelGGL(fixupRunsKernel<uint32_t>, gridFor(n, 256), 256, 0, ctx->stream, (uint32_t*)keys, ordering,
+            hipLaunchKernelGGL(fixupRunsKernel<uint32_t>, gridFor(n, 256, FIX_VEC), 256, 0, ctx->stream, (uint32_t*)keys, ordering,
                                uint32_t(n), 8 * startPass, tooLongDev);
         else
-            hipLaunchKernelGGL(fixupRunsKernel<uint64_t>, gridFor(n, 256), 256, 0, ctx->stream, (uint64_t*)keys, ordering,
+            hipLaunchKernelGGL(fixupRunsKernel<uint64_t>, gridFor(n, 256, FIX_VEC), 256, 0, ctx->stream, (uint64_t*)keys, ordering,
                                uint32_t(n), 8 * startPass, tooLongDev);
         CS_HIP(ctx, hipGetLastError());
     }
