@@ -407,7 +407,7 @@ def main():
             "first_sync_ms": first_sync_ms,
             "extras": extras,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample), args.key_bits, args.real_bits, args.curve,
                                                args.bucket_focus)
         print(json.dumps(out))
