@@ -240,7 +240,7 @@ struct MrBase
 {
     virtual ~MrBase()                                                                    = default;
     virtual int sync(const void* x, const void* y, const void* z, const void* h, size_t n, const void* const* props,
-                     const int* propBytes, int numProps) = 0;
+                     const int* propBytes, int numProps, const void* keysIn) = 0;
     virtual int view(cstone_hip_domain_mr_view* out)                                     = 0;
     virtual void setHaloFactor(float f)                                                  = 0;
     virtual int exchangeHalos(void* array, int elemBytes)                                = 0;
@@ -321,7 +321,7 @@ public:
     }
 
     int sync(const void* xIn, const void* yIn, const void* zIn, const void* hIn, size_t n, const void* const* props,
-             const int* propBytes, int numProps) override
+             const int* propBytes, int numProps, const void* keysIn) override
     {
         if (numProps < 0 || numProps > MAX_PROPS) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: at most %d properties", MAX_PROPS);
         for (int q = 0; q < numProps; ++q)
@@ -344,7 +344,12 @@ public:
         CS_TRY(keys_.ensure(ctx_, nAlloc * sizeof(K)));
         CS_TRY(order_.ensure(ctx_, nAlloc * sizeof(uint32_t)));
         CS_TRY(ensureSortScratch(nAlloc));
-        CS_HIP(ctx_, hipMemsetAsync(keys_.p, 0, n * sizeof(K), ctx_->stream)); // encode skips entries == removeKey
+        // encode leaves entries that hold the remove marker 2^(3 maxLevel) alone (R/sfc/sfc.hpp:284-291): such particles
+        // sort behind the end of the curve and leave the domain
+        if (keysIn && n)
+            CS_HIP(ctx_, hipMemcpyAsync(keys_.p, keysIn, n * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
+        else
+            CS_HIP(ctx_, hipMemsetAsync(keys_.p, 0, n * sizeof(K), ctx_->stream));
         if (n)
         {
             // radix passes only over the digits above the leaf level (+1) of the previous tree, runs of equal high digits
@@ -1155,7 +1160,17 @@ int cstone_hip_domain_mr_sync_props(cstone_hip_domain_mr* dom, const void* x, co
     if (!dom) return CSTONE_E_ARG;
     if (n && (!x || !y || !z || !h)) return fail(dom->ctx, CSTONE_E_ARG, "domain_mr_sync: null array");
     if (num_props && (!props || !prop_bytes)) return fail(dom->ctx, CSTONE_E_ARG, "domain_mr_sync: null property list");
-    return dom->impl->sync(x, y, z, h, n, props, prop_bytes, num_props);
+    return dom->impl->sync(x, y, z, h, n, props, prop_bytes, num_props, nullptr);
+}
+
+int cstone_hip_domain_mr_sync_keys(cstone_hip_domain_mr* dom, const void* keys, const void* x, const void* y,
+                                   const void* z, const void* h, size_t n, const void* const* props,
+                                   const int* prop_bytes, int num_props)
+{
+    if (!dom) return CSTONE_E_ARG;
+    if (n && (!x || !y || !z || !h)) return fail(dom->ctx, CSTONE_E_ARG, "domain_mr_sync: null array");
+    if (num_props && (!props || !prop_bytes)) return fail(dom->ctx, CSTONE_E_ARG, "domain_mr_sync: null property list");
+    return dom->impl->sync(x, y, z, h, n, props, prop_bytes, num_props, keys);
 }
 
 int cstone_hip_domain_mr_sync(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z, const void* h,

@@ -723,9 +723,10 @@ class NativeDistributedDomain:
         self.ctx._chk(self.ctx.lib.cstone_hip_domain_mr_view_get(self.h, C.byref(v)), "domain_mr_view_get")
         return v
 
-    def sync(self, x, y, z, h, props=()):
+    def sync(self, x, y, z, h, props=(), keys=None):
         """returns dict(keys, x, y, z, h, start, end[, props]) of tensors that alias the domain-owned result arrays (valid
-        until the next but one sync); props: further 4- or 8-byte fields that follow their particles"""
+        until the next but one sync); props: further 4- or 8-byte fields that follow their particles; keys: optional
+        key array whose remove markers flag particles that leave the domain"""
         torch = _torch()
         import cstone_amd
 
@@ -733,9 +734,11 @@ class NativeDistributedDomain:
         k = len(props)
         parr = (C.c_void_p * max(1, k))(*[t.data_ptr() for t in props])
         pbytes = (C.c_int * max(1, k))(*[t.element_size() for t in props])
-        rc = self.ctx.lib.cstone_hip_domain_mr_sync_props(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
-                                                          C.c_void_p(z.data_ptr()), C.c_void_p(h.data_ptr()),
-                                                          C.c_size_t(x.numel()), parr, pbytes, C.c_int(k))
+        self._keep = (x, y, z, h, props, keys)
+        rc = self.ctx.lib.cstone_hip_domain_mr_sync_keys(self.h, C.c_void_p(keys.data_ptr() if keys is not None else 0),
+                                                         C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                         C.c_void_p(z.data_ptr()), C.c_void_p(h.data_ptr()),
+                                                         C.c_size_t(x.numel()), parr, pbytes, C.c_int(k))
         if rc != 0 and self.coll.error is not None:
             err, self.coll.error = self.coll.error, None
             raise err

@@ -363,6 +363,12 @@ extern "C"
     int cstone_hip_domain_mr_sync_props(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z,
                                         const void* h, size_t n, const void* const* props, const int* prop_bytes,
                                         int num_props);
+    /* the same with the caller's key array (n keys, device, or NULL): entries that hold the remove marker
+     * 2^(3*maxLevel) flag their particle for removal (R/sfc/sfc.hpp:284-291, R/tree/definitions.h:87-91), all other
+     * entries are ignored */
+    int cstone_hip_domain_mr_sync_keys(cstone_hip_domain_mr* dom, const void* keys, const void* x, const void* y,
+                                       const void* z, const void* h, size_t n, const void* const* props,
+                                       const int* prop_bytes, int num_props);
     int cstone_hip_domain_mr_view_get(cstone_hip_domain_mr* dom, cstone_hip_domain_mr_view* out);
     /* Domain::exchangeHalos (R/domain/domain.hpp:381-386): repeats the halo exchange of the last sync for one more
      * field; array (device; elements of 1, 2, 4, 8, 12, 16, 24 or 32 bytes, e.g. Vec3<float>, Vec4<double>) is laid out

@@ -242,6 +242,20 @@ def main():
             x, y, z = x.clamp(0.0, 1.0 - 1e-9), y.clamp(0.0, 1.0 - 1e-9), z.clamp(0.0, 1.0 - 1e-9)
         tag64 = x * 3.0 + y * 5.0 + z * 7.0 + h
         tag32 = (x + 2.0 * y).to(torch.float32)
+    if a.impl == "native" and a.key_bits == 64:
+        # particles flagged with the remove marker leave the domain: every 10th of what each rank holds
+        marks = torch.zeros(x.numel(), dtype=torch.int64, device=x.device)
+        marks[::10] = -(1 << 63)
+        gone = torch.tensor([int((marks != 0).sum())], dtype=torch.int64)
+        before = torch.tensor([x.numel()], dtype=torch.int64)
+        r = dom.sync(x, y, z, h, props=[tag64, tag32], keys=marks)
+        after = torch.tensor([r["end"] - r["start"]], dtype=torch.int64)
+        for t in (gone, before, after):
+            dist.all_reduce(t)
+        ok &= int(after.item()) == int(before.item()) - int(gone.item())
+        kk = r["keys"].cpu().numpy().view(np.uint64)[r["start"]:r["end"]]
+        ok &= bool(np.all(kk < np.uint64(1 << 63))) and bool(np.all(kk[1:] >= kk[:-1]))
+        ok &= bool(torch.equal(r["props"][0][r["start"]:r["end"]], tag64_of(r, r["start"], r["end"])))
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
