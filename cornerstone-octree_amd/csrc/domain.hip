@@ -199,7 +199,10 @@ public:
             int lmax = 0;
             for (int l = 0; l <= int(maxLevel<K>()); ++l)
                 if (levelRangeHost_[l + 1] > levelRangeHost_[l]) lmax = l;
-            int lowBits = 3 * int(maxLevel<K>()) - 3 * (lmax + 1);
+            // one level below the deepest leaves a run holds about bucket / 8 particles; larger buckets get more margin
+            // (the fix-up handles runs of up to 192)
+            int margin  = 1 + (bucketFocus_ > 128) + (bucketFocus_ > 1024);
+            int lowBits = 3 * int(maxLevel<K>()) - 3 * (lmax + margin);
             startPass   = std::max(0, lowBits / 8) & ~1;
         }
         CS_TRY(sfcKeysAndOrderingHint(ctx_, curve_, kb, rb, *xPP, *yPP, *zPP, keys, order_.as<uint32_t>(), n, box_,

@@ -356,7 +356,8 @@ public:
             // are finished by a fix-up pass; a run that is too long raises a flag and the regular sort completes the job
             int startPass = 0;
             if (!firstCall_ && prevMaxLeafLevel_ >= 0 && std::getenv("CSTONE_FULL_SORT") == nullptr)
-                startPass = std::max(0, (3 * int(maxLevel<K>()) - 3 * (prevMaxLeafLevel_ + 1)) / 8) & ~1;
+                startPass = std::max(0, (3 * int(maxLevel<K>()) -
+                                         3 * (prevMaxLeafLevel_ + 1 + (bucketFocus_ > 128) + (bucketFocus_ > 1024))) / 8) & ~1;
             int* tooLong = reinterpret_cast<int*>(scal_.as<char>() + 128);
             CS_TRY(sfcKeysAndOrderingHint(ctx_, curve_, kb, rb, x, y, z, keys_.p, order_.as<uint32_t>(), n, box_,
                                           keysAlt_.p, orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes, startPass,
