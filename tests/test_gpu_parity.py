@@ -521,3 +521,36 @@ def test_gather_vec3_double_at_8_byte_alignment(hip):
     hip.gather(perm, s, dst, elem_bytes=24)
     hip.sync()
     assert torch.equal(dst, s[perm.long()])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kb", [32, 64])
+def test_sort_adversarial_digit_patterns_large_tiles(hip, kb):
+    """the 16 Ki-pair tile kernel (n >= 2^20) on inputs that stress the rank by LDS atomics: two alternating values, runs of
+    32 and 64 equal digits, a single value, few values in every byte, descending order; checked against torch's stable sort"""
+    import torch
+
+    n = 1_100_003  # 67 full tiles + a tail
+    dt = torch.int64 if kb == 64 else torch.int32
+    i = torch.arange(n, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(kb)
+    top = (1 << 62) if kb == 64 else (1 << 30)
+    nbytes = 8 if kb == 64 else 4
+    rep = lambda v: sum(int(v) << (8 * b) for b in range(nbytes - 1))  # the same byte in every digit position  # noqa: E731
+    patterns = {
+        "alternating": torch.where(i % 2 == 0, rep(0x11), rep(0xEE)),
+        "runs32": ((i // 32) % 5) * rep(0x21),
+        "runs64": ((i // 64) % 3) * rep(0x7F) + (i % 2),
+        "constant": torch.full((n,), rep(0x5A)),
+        "few_values": torch.randint(0, 4, (n,), device="cuda", generator=g) * rep(0x33),
+        "descending": top - 1 - i * ((top - 1) // n),
+        "lane_pattern": ((i % 64) // 16) * rep(0x40) + ((i // 64) % 2),
+    }
+    for name, k in patterns.items():
+        keys = k.to(device="cuda", dtype=dt).contiguous()
+        ref_k, ref_v = torch.sort(keys, stable=True)
+        vals = torch.arange(n, dtype=torch.int32, device="cuda")
+        hip.sort_pairs(keys, vals)
+        hip.sync()
+        assert torch.equal(keys, ref_k), name
+        assert torch.equal(vals.long(), ref_v), name
