@@ -52,10 +52,11 @@ __device__ __forceinline__ double readLane(double v, unsigned k)
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
-template<class T>
+template<class T, bool GROUPS>
 __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
     const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, const T* __restrict__ h, uint32_t first,
-    uint32_t last, DBox<T> box, const NodeIdx* __restrict__ childOffsets, const NodeIdx* __restrict__ internalToLeaf,
+    uint32_t last, const uint32_t* __restrict__ groupStart, const uint32_t* __restrict__ groupEnd, uint32_t numGroups,
+    DBox<T> box, const NodeIdx* __restrict__ childOffsets, const NodeIdx* __restrict__ internalToLeaf,
     const uint32_t* __restrict__ layout, const T* __restrict__ centers, const T* __restrict__ sizes, float ext,
     uint32_t ngmax, uint32_t* __restrict__ neighbors, uint32_t* __restrict__ counts, int* __restrict__ errors)
 {
@@ -65,9 +66,21 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
     NodeIdx* sNode  = stackNode[wave];
     uint64_t* sMask = stackMask[wave];
 
-    const uint32_t tid = blockIdx.x * NB_BLOCK + threadIdx.x;
-    const bool valid   = first + tid < last;
-    const uint32_t i   = valid ? first + tid : last - 1;
+    // targets of this wave: 64 consecutive particles, or (GROUPS) the particles of one target group, 64 at a time
+    uint32_t chunk = first + (blockIdx.x * NB_WAVES + wave) * 64u, chunkEnd = last;
+    if (GROUPS)
+    {
+        const uint32_t g = blockIdx.x * NB_WAVES + wave;
+        if (g >= numGroups) return;
+        chunk    = max(first, uniform(NodeIdx(groupStart[g])));
+        chunkEnd = min(last, uint32_t(uniform(NodeIdx(groupEnd[g]))));
+    }
+    if (chunk >= chunkEnd) return;
+    do
+    {
+    const bool valid   = chunk + lane < chunkEnd;
+    const uint32_t i   = valid ? chunk + lane : chunkEnd - 1;
+    const uint32_t tid = i - first;
 
     const T xi = x[i], yi = y[i], zi = z[i];
     const T hi = h[i];
@@ -197,6 +210,8 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
         }
     }
     if (valid) counts[tid] = nn;
+    chunk += 64;
+    } while (GROUPS && chunk < chunkEnd);
 }
 
 } // namespace
@@ -205,6 +220,42 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
 
 using namespace cship;
 
+namespace
+{
+
+template<bool GROUPS>
+int launchFindNeighbors(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y, const void* z, const void* h,
+                        uint32_t first, uint32_t last, const uint32_t* groupStart, const uint32_t* groupEnd,
+                        uint32_t numGroups, const cstone_box* box_host, const int32_t* child_offsets,
+                        const int32_t* internal_to_leaf, const uint32_t* layout, const void* centers, const void* sizes,
+                        float ext, uint32_t ngmax, uint32_t* neighbors, uint32_t* counts)
+{
+    if (!ctx || !x || !y || !z || !h || !box_host || !child_offsets || !internal_to_leaf || !layout || !centers ||
+        !sizes || !counts || (ngmax && !neighbors) || last < first || (GROUPS && numGroups && (!groupStart || !groupEnd)))
+        return fail(ctx, CSTONE_E_ARG, "find_neighbors: bad argument");
+    if (last == first || (GROUPS && numGroups == 0)) return CSTONE_OK;
+    if (real_bits != 32 && real_bits != 64) return fail(ctx, CSTONE_E_ARG, "find_neighbors: real_bits %d unsupported", real_bits);
+    int* errors = ctx->devScalars + 63;
+    {
+        StageTimer timer(ctx, CSTONE_STAGE_NEIGHBORS);
+        unsigned grid = GROUPS ? gridFor(numGroups, NB_WAVES) : gridFor(size_t(last - first), NB_BLOCK);
+        if (real_bits == 32)
+            hipLaunchKernelGGL((findNeighborsKernel<float, GROUPS>), grid, NB_BLOCK, 0, ctx->stream, (const float*)x,
+                               (const float*)y, (const float*)z, (const float*)h, first, last, groupStart, groupEnd,
+                               numGroups, makeDBox<float>(*box_host), child_offsets, internal_to_leaf, layout,
+                               (const float*)centers, (const float*)sizes, ext, ngmax, neighbors, counts, errors);
+        else
+            hipLaunchKernelGGL((findNeighborsKernel<double, GROUPS>), grid, NB_BLOCK, 0, ctx->stream, (const double*)x,
+                               (const double*)y, (const double*)z, (const double*)h, first, last, groupStart, groupEnd,
+                               numGroups, makeDBox<double>(*box_host), child_offsets, internal_to_leaf, layout,
+                               (const double*)centers, (const double*)sizes, ext, ngmax, neighbors, counts, errors);
+    }
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+} // namespace
+
 extern "C" int cstone_hip_find_neighbors(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y,
                                          const void* z, const void* h, uint32_t first, uint32_t last,
                                          const cstone_box* box_host, const int32_t* child_offsets,
@@ -212,27 +263,20 @@ extern "C" int cstone_hip_find_neighbors(cstone_hip_ctx* ctx, int real_bits, con
                                          const void* sizes, float ext, uint32_t ngmax, uint32_t* neighbors,
                                          uint32_t* counts)
 {
-    if (!ctx || !x || !y || !z || !h || !box_host || !child_offsets || !internal_to_leaf || !layout || !centers ||
-        !sizes || !counts || (ngmax && !neighbors) || last < first)
-        return fail(ctx, CSTONE_E_ARG, "find_neighbors: bad argument");
-    if (last == first) return CSTONE_OK;
-    if (real_bits != 32 && real_bits != 64) return fail(ctx, CSTONE_E_ARG, "find_neighbors: real_bits %d unsupported", real_bits);
-    size_t nw   = last - first;
-    int* errors = ctx->devScalars + 63;
-    {
-        StageTimer timer(ctx, CSTONE_STAGE_NEIGHBORS);
-        unsigned grid = gridFor(nw, NB_BLOCK);
-        if (real_bits == 32)
-            hipLaunchKernelGGL(findNeighborsKernel<float>, grid, NB_BLOCK, 0, ctx->stream, (const float*)x,
-                               (const float*)y, (const float*)z, (const float*)h, first, last,
-                               makeDBox<float>(*box_host), child_offsets, internal_to_leaf, layout,
-                               (const float*)centers, (const float*)sizes, ext, ngmax, neighbors, counts, errors);
-        else
-            hipLaunchKernelGGL(findNeighborsKernel<double>, grid, NB_BLOCK, 0, ctx->stream, (const double*)x,
-                               (const double*)y, (const double*)z, (const double*)h, first, last,
-                               makeDBox<double>(*box_host), child_offsets, internal_to_leaf, layout,
-                               (const double*)centers, (const double*)sizes, ext, ngmax, neighbors, counts, errors);
-    }
-    CS_HIP(ctx, hipGetLastError());
-    return CSTONE_OK;
+    return launchFindNeighbors<false>(ctx, real_bits, x, y, z, h, first, last, nullptr, nullptr, 0, box_host,
+                                      child_offsets, internal_to_leaf, layout, centers, sizes, ext, ngmax, neighbors,
+                                      counts);
+}
+
+extern "C" int cstone_hip_find_neighbors_groups(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y,
+                                                const void* z, const void* h, uint32_t first, uint32_t last,
+                                                const uint32_t* group_start, const uint32_t* group_end,
+                                                uint32_t num_groups, const cstone_box* box_host,
+                                                const int32_t* child_offsets, const int32_t* internal_to_leaf,
+                                                const uint32_t* layout, const void* centers, const void* sizes,
+                                                float ext, uint32_t ngmax, uint32_t* neighbors, uint32_t* counts)
+{
+    return launchFindNeighbors<true>(ctx, real_bits, x, y, z, h, first, last, group_start, group_end, num_groups,
+                                     box_host, child_offsets, internal_to_leaf, layout, centers, sizes, ext, ngmax,
+                                     neighbors, counts);
 }

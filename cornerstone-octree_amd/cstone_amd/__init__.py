@@ -31,7 +31,8 @@ EXPORTS = [
     "cstone_hip_compute_node_counts", "cstone_hip_compute_node_counts_guided", "cstone_hip_compute_node_ops", "cstone_hip_rebalance_tree",
     "cstone_hip_update_octree", "cstone_hip_compute_octree", "cstone_hip_build_octree", "cstone_hip_upsweep_sum",
     "cstone_hip_node_centers", "cstone_hip_halo_radii", "cstone_hip_find_halos", "cstone_hip_find_neighbors",
-    "cstone_hip_halo_boxes", "cstone_hip_find_overlaps",
+    "cstone_hip_halo_boxes", "cstone_hip_find_overlaps", "cstone_hip_compute_fixed_groups",
+    "cstone_hip_compute_group_splits", "cstone_hip_find_neighbors_groups",
     "cstone_hip_domain_create", "cstone_hip_domain_destroy", "cstone_hip_domain_sync", "cstone_hip_domain_view_get",
     "cstone_hip_domain_set_halo_factor", "cstone_hip_domain_mr_create", "cstone_hip_domain_mr_destroy",
     "cstone_hip_domain_mr_sync", "cstone_hip_domain_mr_sync_props", "cstone_hip_domain_mr_sync_keys", "cstone_hip_domain_mr_view_get", "cstone_hip_domain_mr_set_halo_factor", "cstone_hip_domain_mr_exchange_halos",
@@ -433,6 +434,43 @@ class Context:
                                                      _ptr(octree["child_offsets"]), _ptr(octree["internal_to_leaf"]),
                                                      _ptr(layout), _ptr(centers), _ptr(sizes), C.c_float(ext),
                                                      C.c_uint32(ngmax), _ptr(nidx), _ptr(nc)), "find_neighbors")
+        return nidx, nc
+
+    def compute_fixed_groups(self, first, last, group_size):
+        torch = _torch()
+        cap = (last - first + group_size - 1) // max(group_size, 1) + 1
+        groups = torch.zeros(cap, dtype=torch.int32, device=self.device)
+        ng = C.c_uint32(0)
+        self._chk(self.lib.cstone_hip_compute_fixed_groups(self.h, C.c_uint32(first), C.c_uint32(last),
+                                                           C.c_uint32(group_size), _ptr(groups), C.byref(ng)),
+                  "compute_fixed_groups")
+        return groups[:ng.value + 1]
+
+    def compute_group_splits(self, first, last, x, y, z, leaves, layout, box, group_size, tol_factor, capacity=None):
+        """groups[num_groups + 1]: groupStart = groups[:-1], groupEnd = groups[1:]"""
+        torch = _torch()
+        cap = last - first + 1 if capacity is None else capacity
+        groups = torch.zeros(max(cap, 1), dtype=torch.int32, device=self.device)
+        ng = C.c_uint32(0)
+        self._chk(self.lib.cstone_hip_compute_group_splits(
+            self.h, C.c_int(leaves.element_size() * 8), C.c_int(x.element_size() * 8), C.c_uint32(first),
+            C.c_uint32(last), _ptr(x), _ptr(y), _ptr(z), _ptr(leaves), C.c_int(leaves.numel() - 1), _ptr(layout),
+            C.byref(box), C.c_uint32(group_size), C.c_float(tol_factor), _ptr(groups), C.c_size_t(cap), C.byref(ng)),
+            "compute_group_splits")
+        return groups[:ng.value + 1]
+
+    def find_neighbors_groups(self, x, y, z, h, first, last, groups, box, octree, layout, centers, sizes, ngmax,
+                              ext=1.0):
+        torch = _torch()
+        nw = last - first
+        nidx = torch.zeros((nw, ngmax), dtype=torch.int32, device=x.device)
+        nc = torch.zeros(nw, dtype=torch.int32, device=x.device)
+        ng = groups.numel() - 1
+        self._chk(self.lib.cstone_hip_find_neighbors_groups(
+            self.h, C.c_int(x.element_size() * 8), _ptr(x), _ptr(y), _ptr(z), _ptr(h), C.c_uint32(first),
+            C.c_uint32(last), _ptr(groups), C.c_void_p(groups.data_ptr() + 4), C.c_uint32(ng), C.byref(box),
+            _ptr(octree["child_offsets"]), _ptr(octree["internal_to_leaf"]), _ptr(layout), _ptr(centers), _ptr(sizes),
+            C.c_float(ext), C.c_uint32(ngmax), _ptr(nidx), _ptr(nc)), "find_neighbors_groups")
         return nidx, nc
 
 

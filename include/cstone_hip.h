@@ -256,6 +256,40 @@ extern "C"
                                   uint32_t ngmax, uint32_t* neighbors, uint32_t* counts);
 
     /* ---------------------------------------------------------------------------------------------
+     * target particle groups: replace computeFixedGroups (R/traversal/groups_gpu.h:46, groups_gpu.cu:41-71) and
+     * computeGroupSplits (R/traversal/groups_gpu.h:73-87, groups_gpu.cu:74-151); the result is what a
+     * GroupView (R/traversal/groups.hpp:20-26) points at: groupStart = groups, groupEnd = groups + 1.
+     * fixed_groups : groups[g] = first + g * group_size for g < *num_groups = ceil((last-first)/group_size),
+     *                groups[*num_groups] = last; groups holds *num_groups + 1 entries.
+     * group_splits : runs of group_size (64 or 128 = one or two wavefronts; anything else is CSTONE_E_ARG where the
+     *                reference throws) consecutive particles of [first,last), each cut again behind every particle
+     *                whose successor in the run is farther away, in coordinates scaled by the box's inverse lengths,
+     *                than tol_factor x 2^-level of the deepest leaf among the run's first 64 particles.  leaves /
+     *                layout: cornerstone leaf keys [num_leaves + 1] and the index of each leaf's first particle.
+     *                Writes *num_groups + 1 <= capacity ascending indices (first ... last); CSTONE_E_CAPACITY with
+     *                *num_groups set when capacity is too small (last - first + 1 always suffices).  The smoothing
+     *                lengths of the reference's signature do not enter the result and are not passed.
+     * find_neighbors_groups : find_neighbors with the 64 targets of a wavefront taken from one group
+     *                [group_start[g], group_end[g]) (clipped to [first,last); longer groups are walked 64 at a time) instead of 64
+     *                consecutive indices; particles outside every group keep counts/neighbors untouched.  Same
+     *                result rows as find_neighbors: counts[i-first], neighbors[(i-first)*ngmax + k].
+     * ------------------------------------------------------------------------------------------- */
+    int cstone_hip_compute_fixed_groups(cstone_hip_ctx* ctx, uint32_t first, uint32_t last, uint32_t group_size,
+                                        uint32_t* groups, uint32_t* num_groups);
+    int cstone_hip_compute_group_splits(cstone_hip_ctx* ctx, int key_bits, int real_bits, uint32_t first, uint32_t last,
+                                        const void* x, const void* y, const void* z, const void* leaves,
+                                        int num_leaves, const uint32_t* layout, const cstone_box* box_host,
+                                        uint32_t group_size, float tol_factor, uint32_t* groups, size_t capacity,
+                                        uint32_t* num_groups);
+    int cstone_hip_find_neighbors_groups(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y,
+                                         const void* z, const void* h, uint32_t first, uint32_t last,
+                                         const uint32_t* group_start, const uint32_t* group_end, uint32_t num_groups,
+                                         const cstone_box* box_host, const int32_t* child_offsets,
+                                         const int32_t* internal_to_leaf, const uint32_t* layout, const void* centers,
+                                         const void* sizes, float ext, uint32_t ngmax, uint32_t* neighbors,
+                                         uint32_t* counts);
+
+    /* ---------------------------------------------------------------------------------------------
      * Domain: device-resident cstone::Domain<KeyType,T,GpuTag> (R/domain/domain.hpp:66-699).
      * create : Domain(rank, nRanks, bucketSize, bucketSizeFocus, theta, box) (:95-113); CSTONE_E_ARG if
      *          bucket_size < bucket_size_focus (the reference throws std::runtime_error). This round implements

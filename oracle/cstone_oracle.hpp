@@ -15,6 +15,7 @@
 #pragma once
 
 #include <algorithm>
+#include <array>
 #include <cassert>
 #include <cmath>
 #include <cstddef>
@@ -906,6 +907,110 @@ void findNeighbors(const T* x, const T* y, const T* z, const Th* h, LocalIdx fir
 #pragma omp parallel for schedule(dynamic, 256)
     for (LocalIdx i = first; i < last; ++i)
         counts[i - first] = findNeighborsOf(i, x, y, z, h, tree, box, ngmax, neighbors + size_t(i - first) * ngmax);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// target particle groups (GPU-only code in the reference: restated for a wavefront of W lanes, W = 64 on AMD hardware,
+// R/cuda/gpu_config.cuh:41-49)
+// ---------------------------------------------------------------------------------------------------------------------
+
+//! R/traversal/groups_gpu.cu:41-71
+inline std::vector<LocalIdx> fixedGroups(LocalIdx first, LocalIdx last, unsigned groupSize)
+{
+    LocalIdx numGroups = (last - first + groupSize - 1) / groupSize;
+    std::vector<LocalIdx> groups(numGroups + 1);
+    for (LocalIdx g = 0; g < numGroups; ++g)
+        groups[g] = first + g * groupSize;
+    groups[numGroups] = last;
+    return groups;
+}
+
+//! split bits of one run of N*W positions, R/traversal/groups_gpu.cuh:57-93: bit l of word k is set when the particle
+//! behind position k*W + l is farther than sqrt(distCritSq) away; the last position of the run compares with itself
+template<class T>
+inline std::vector<uint64_t> findSplits(const std::vector<std::array<T, 3>>& pos, T distCritSq, int W = 64)
+{
+    const int N = int(pos.size()) / W;
+    std::vector<uint64_t> splits(N, 0);
+    for (int k = 0; k < N; ++k)
+        for (int l = 0; l < W; ++l)
+        {
+            const auto& a = pos[k * W + l];
+            // shuffle down by one inside word k; lane W-1 takes lane 0 of word k+1, in the last word it keeps its own
+            const auto& b = (l + 1 < W) ? pos[k * W + l + 1] : (k + 1 < N ? pos[(k + 1) * W] : a);
+            T dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+            T distSq = dx * dx + (dy * dy + dz * dz); // right fold, R/util/array.hpp:253-256
+            if (distSq > distCritSq) splits[k] |= uint64_t(1) << l;
+        }
+    return splits;
+}
+
+//! lengths of the zero runs between set bits, R/traversal/groups_gpu.cuh:107-130; popcount(all words) + 1 entries
+inline std::vector<LocalIdx> makeSplits(const std::vector<uint64_t>& split, int W = 64)
+{
+    std::vector<LocalIdx> lengths;
+    int carry = 0;
+    for (uint64_t mask : split)
+    {
+        int bitsRemaining = W;
+        while (mask)
+        {
+            int length = ctz(mask) + 1;
+            bitsRemaining -= length;
+            lengths.push_back(LocalIdx(length + carry));
+            carry = 0;
+            mask  = length < 64 ? mask >> length : 0;
+        }
+        carry += bitsRemaining;
+    }
+    lengths.push_back(LocalIdx(carry));
+    return lengths;
+}
+
+//! computeGroupSplits, R/traversal/groups_gpu.cu:74-151 with the kernel of R/traversal/groups_gpu.cuh:165-232
+template<class K, class T>
+std::vector<LocalIdx> groupSplits(LocalIdx first, LocalIdx last, const T* x, const T* y, const T* z, const K* leaves,
+                                  NodeIdx numLeaves, const LocalIdx* layout, const Box<T>& box, unsigned groupSize,
+                                  float tolFactor, int W = 64)
+{
+    const int nwt            = int(groupSize) / W;
+    const LocalIdx numFixed  = (last - first + groupSize - 1) / groupSize;
+    std::vector<LocalIdx> newGroupSizes;
+    for (LocalIdx w = 0; w < numFixed; ++w)
+    {
+        std::vector<LocalIdx> body(groupSize);
+        for (unsigned p = 0; p < groupSize; ++p)
+            body[p] = std::min(first + w * groupSize + p, last - 1);
+        // :194-201: the volume loop runs nwt times over leafIdx[0], i.e. over the leaves of the first W bodies
+        T nodeVolume = 1;
+        for (int l = 0; l < W; ++l)
+        {
+            NodeIdx leaf = NodeIdx(std::upper_bound(layout, layout + numLeaves, body[l]) - layout) - 1;
+            unsigned level = levelOfSpan<K>(leaves[leaf + 1] - leaves[leaf]);
+            // centerAndSize in the unit box (R/sfc/box.hpp:334-351): half edge = (2^(maxLevel-level)) * 0.5 / 2^maxLevel
+            T halfUnit = T(0.5) * (T(1.) / T(1u << maxLevel<K>()));
+            T s        = T(int(1u << (maxLevel<K>() - level))) * halfUnit;
+            T vol      = 8 * s * s * s;
+            nodeVolume = std::min(vol, nodeVolume);
+        }
+        T distCrit = std::cbrt(nodeVolume) * tolFactor;
+        std::vector<std::array<T, 3>> pos(groupSize);
+        for (unsigned p = 0; p < groupSize; ++p)
+            pos[p] = {x[body[p]] * box.inv[0], y[body[p]] * box.inv[1], z[body[p]] * box.inv[2]};
+        auto lengths = makeSplits(findSplits(pos, T(distCrit * distCrit), W), W);
+        newGroupSizes.insert(newGroupSizes.end(), lengths.begin(), lengths.end());
+    }
+    // exclusive scan of the lengths from `first`; the last entry is overwritten with `last` (:117-121)
+    std::vector<LocalIdx> groups(newGroupSizes.size() + 1);
+    LocalIdx run = first;
+    for (size_t g = 0; g < newGroupSizes.size(); ++g)
+    {
+        groups[g] = run;
+        run += newGroupSizes[g];
+    }
+    groups.back() = last;
+    (void)nwt;
+    return groups;
 }
 
 } // namespace orc

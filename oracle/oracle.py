@@ -249,6 +249,38 @@ class _CpuImpl:
         assert rc == 0, rc
         return nidx, nc
 
+    # ---- target particle groups (oracle only: the reference's code for them is GPU-only) ----
+    def fixed_groups(self, first, last, group_size):
+        cap = (last - first + group_size - 1) // group_size + 1
+        groups = np.zeros(cap, dtype=np.uint32)
+        n = self._f("fixed_groups")(C.c_uint(first), C.c_uint(last), C.c_uint(group_size), _p(groups), C.c_int(cap))
+        assert n >= 0, n
+        return groups[:n + 1]
+
+    def group_splits(self, first, last, x, y, z, leaves, layout, box, group_size, tol_factor):
+        cap = last - first + 2
+        groups = np.zeros(cap, dtype=np.uint32)
+        lay = np.ascontiguousarray(layout, dtype=np.uint32)
+        n = self._f("group_splits")(C.c_int(leaves.dtype.itemsize * 8), C.c_int(x.dtype.itemsize * 8), C.c_uint(first),
+                                    C.c_uint(last), _p(x), _p(y), _p(z), _p(leaves), C.c_int(leaves.size - 1), _p(lay),
+                                    _p(box.lim), _p(box.bc), C.c_uint(group_size), C.c_float(tol_factor), _p(groups),
+                                    C.c_int(cap))
+        assert n >= 0, n
+        return groups[:n + 1]
+
+    def find_splits(self, pos, dist_crit_sq):
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        words = pos.shape[0] // 64
+        out = np.zeros(words, dtype=np.uint64)
+        self._f("find_splits")(_p(pos), C.c_int(words), C.c_double(dist_crit_sq), _p(out))
+        return out
+
+    def make_splits(self, masks, width=64):
+        masks = np.ascontiguousarray(masks, dtype=np.uint64)
+        out = np.zeros(masks.size * width + 1, dtype=np.uint32)
+        n = self._f("make_splits")(_p(masks), C.c_int(masks.size), C.c_int(width), _p(out))
+        return out[:n]
+
     def halo_boxes(self, curve, leaves, radii, box, first, last, real_bits=64):
         kb = leaves.dtype.itemsize * 8
         boxes = np.zeros((last - first, 8), dtype=np.int32)

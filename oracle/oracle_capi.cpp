@@ -338,6 +338,63 @@ int cstone_oracle_find_overlaps(int curve, int key_bits, const void* leaves, con
                    });
 }
 
+/* ---- target particle groups, R/traversal/groups_gpu.cu:41-151 ---- */
+int cstone_oracle_fixed_groups(unsigned first, unsigned last, unsigned group_size, unsigned* groups, int capacity)
+{
+    auto g = fixedGroups(first, last, group_size);
+    if (int(g.size()) > capacity) return -int(g.size());
+    std::copy(g.begin(), g.end(), groups);
+    return int(g.size()) - 1;
+}
+
+/*! returns the number of groups (groups holds one entry more) or -(entries needed) if capacity is too small */
+int cstone_oracle_group_splits(int key_bits, int real_bits, unsigned first, unsigned last, const void* x, const void* y,
+                               const void* z, const void* leaves, int num_leaves, const unsigned* layout,
+                               const double* lim, const int* bc, unsigned group_size, float tol_factor,
+                               unsigned* groups, int capacity)
+{
+    int ret = 0;
+    int rc  = withKey(key_bits,
+                     [&](auto k)
+                     {
+                         using K = decltype(k);
+                         return withReal(real_bits,
+                                         [&](auto t)
+                                         {
+                                             using T = decltype(t);
+                                             auto g  = groupSplits<K, T>(first, last, (const T*)x, (const T*)y,
+                                                                        (const T*)z, (const K*)leaves, num_leaves,
+                                                                        layout, mkBox<T>(lim, bc), group_size,
+                                                                        tol_factor);
+                                             if (int(g.size()) > capacity) { ret = -int(g.size()); }
+                                             else
+                                             {
+                                                 std::copy(g.begin(), g.end(), groups);
+                                                 ret = int(g.size()) - 1;
+                                             }
+                                         });
+                     });
+    return rc ? -1 : ret;
+}
+
+/*! split bits of n = 64 * words positions (x,y,z interleaved), R/traversal/groups_gpu.cuh:57-93 */
+void cstone_oracle_find_splits(const double* pos3, int words, double dist_crit_sq, uint64_t* splits)
+{
+    std::vector<std::array<double, 3>> pos(size_t(words) * 64);
+    for (size_t i = 0; i < pos.size(); ++i)
+        pos[i] = {pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2]};
+    auto s = findSplits(pos, dist_crit_sq, 64);
+    std::copy(s.begin(), s.end(), splits);
+}
+
+/*! R/traversal/groups_gpu.cuh:107-130 for a stream of `words` masks of `width` (32 or 64) bits; returns the count */
+int cstone_oracle_make_splits(const uint64_t* masks, int words, int width, unsigned* lengths)
+{
+    auto l = makeSplits(std::vector<uint64_t>(masks, masks + words), width);
+    std::copy(l.begin(), l.end(), lengths);
+    return int(l.size());
+}
+
 int cstone_oracle_num_threads()
 {
 #ifdef _OPENMP
