@@ -123,6 +123,7 @@ struct DomainBase
                      const int* propBytes, int numProps) = 0;
     virtual int view(cstone_hip_domain_view* out)        = 0;
     virtual void setHaloFactor(float factor)             = 0;
+    virtual int reapplySync(const void* in, size_t n, int elemBytes, void* out) = 0;
 };
 
 template<class K, class T>
@@ -308,6 +309,7 @@ public:
 
         startIndex_ = 0;
         endIndex_   = numAssigned;
+        lastN_      = n;
         bufSize_    = numAssigned;
         firstCall_  = false;
         return CSTONE_OK;
@@ -342,9 +344,20 @@ public:
         return CSTONE_OK;
     }
 
+    /*! Domain::reapplySync (R/domain/domain.hpp:334-378) without an exchange: the kept particles in SFC order */
+    int reapplySync(const void* in, size_t n, int elemBytes, void* out) override
+    {
+        if (lastN_ == 0) return fail(ctx_, CSTONE_E_ARG, "reapply_sync: no sync yet");
+        if (n != lastN_)
+            return fail(ctx_, CSTONE_E_ARG, "reapply_sync: array of %zu elements, the last sync took %zu", n, lastN_);
+        if (!in || !out || in == out) return fail(ctx_, CSTONE_E_ARG, "reapply_sync: bad array");
+        return cstone_hip_gather(ctx_, elemBytes, order_.as<uint32_t>(), endIndex_, in, out);
+    }
+
     float haloSearchExt_ = 1.0f;
 
 private:
+    size_t lastN_ = 0; // input size of the last sync
     int ensureTree(DevBuf& tree, DevBuf& counts, int& cap, int need)
     {
         if (need <= cap) return CSTONE_OK;
@@ -541,6 +554,12 @@ int cstone_hip_domain_view_get(cstone_hip_domain* dom, cstone_hip_domain_view* o
 {
     if (!dom || !out) return CSTONE_E_ARG;
     return dom->impl->view(out);
+}
+
+int cstone_hip_domain_reapply_sync(cstone_hip_domain* dom, const void* in, size_t n, int elem_bytes, void* out)
+{
+    if (!dom) return CSTONE_E_ARG;
+    return dom->impl->reapplySync(in, n, elem_bytes, out);
 }
 
 int cstone_hip_domain_set_halo_factor(cstone_hip_domain* dom, float factor)

@@ -244,6 +244,7 @@ struct MrBase
     virtual int view(cstone_hip_domain_mr_view* out)                                     = 0;
     virtual void setHaloFactor(float f)                                                  = 0;
     virtual int exchangeHalos(void* array, int elemBytes)                                = 0;
+    virtual int reapplySync(const void* in, size_t n, int elemBytes, void* out)          = 0;
 };
 
 template<class K, class T>
@@ -300,6 +301,54 @@ public:
             CS_HIP(ctx_, hipMemcpyAsync(a + (haloRecvLo_ + haloAssigned_) * elemBytes,
                                         recvRows_.as<char>() + haloRecvLo_ * elemBytes, haloRecvHi_ * elemBytes,
                                         hipMemcpyDeviceToDevice, ctx_->stream));
+        return CSTONE_OK;
+    }
+
+    /*! Domain::reapplySync (R/domain/domain.hpp:334-378): sends one more per-particle field along the routes of the last
+     *  sync -- the same particles leave to the same ranks, the kept ones and the newcomers land in the same slots.
+     *  in: n elements laid out like the INPUT arrays of the last sync; out: laid out like the result arrays
+     *  (num_particles_with_halos elements), only its assigned range is written (exchangeHalos fills the rest). */
+    int reapplySync(const void* in, size_t n, int elemBytes, void* out) override
+    {
+        if (elemBytes != 1 && elemBytes != 2 && elemBytes != 4 && elemBytes != 8 && elemBytes != 12 && elemBytes != 16 &&
+            elemBytes != 24 && elemBytes != 32)
+            return fail(ctx_, CSTONE_E_ARG, "reapply_sync: element size %d", elemBytes);
+        if (firstCall_) return fail(ctx_, CSTONE_E_ARG, "reapply_sync: no sync yet");
+        if (n != rsN_) // checkSizesEqual(prevBufDesc_.size, arrays...), R/domain/domain.hpp:341
+            return fail(ctx_, CSTONE_E_ARG, "reapply_sync: array of %zu elements, the last sync took %zu", n, size_t(rsN_));
+        if (!in || !out) return fail(ctx_, CSTONE_E_ARG, "reapply_sync: null array");
+        const size_t e        = size_t(elemBytes);
+        const uint32_t* keptO = order_.as<uint32_t>() + rsKeptOffset_;
+        char* dst             = static_cast<char*>(out) + size_t(view_.start_index) * e;
+        const void* recvSorted = nullptr;
+        if (rsMoved_)
+        {
+            std::vector<size_t> sb(P_, 0), rbv(P_, 0);
+            for (int p = 0; p < P_; ++p)
+            {
+                if (p == rank_) continue;
+                sb[p]  = rsSendCounts_[p] * e;
+                rbv[p] = rsRecvCounts_[p] * e;
+            }
+            // 32-byte elements are moved as 16-byte vectors: keep every staging buffer 16-byte aligned (DevBuf is)
+            CS_TRY(sendRows_.ensure(ctx_, std::max<size_t>(rsSend_, 1) * e));
+            CS_TRY(recvRows_.ensure(ctx_, std::max<size_t>(rsNb_, 1) * e));
+            CS_TRY(moveTmp_.ensure(ctx_, std::max<size_t>(rsNb_, 1) * e));
+            if (rsSend_) CS_TRY(cstone_hip_gather(ctx_, elemBytes, leaving_.as<uint32_t>(), rsSend_, in, sendRows_.p));
+            CS_TRY(callComm(comm_.all_to_all_v(comm_.user, sendRows_.p, sb.data(), recvRows_.p, rbv.data()),
+                            "all_to_all_v (reapplySync)"));
+            if (rsNb_)
+            {
+                CS_TRY(cstone_hip_gather(ctx_, elemBytes, ro_.as<uint32_t>(), rsNb_, recvRows_.p, moveTmp_.p));
+                recvSorted = moveTmp_.p;
+            }
+        }
+        if (rsNb_)
+        {
+            CS_TRY(cstone_hip_gather_scatter(ctx_, elemBytes, keptO, posA_.as<uint32_t>(), rsNa_, in, dst));
+            CS_TRY(cstone_hip_scatter(ctx_, elemBytes, posB_.as<uint32_t>(), rsNb_, recvSorted, dst));
+        }
+        else { CS_TRY(cstone_hip_gather(ctx_, elemBytes, keptO, rsNa_, in, dst)); }
         return CSTONE_OK;
     }
 
@@ -737,6 +786,12 @@ public:
         CS_HIP(ctx_, hipGetLastError());
         tick("8 halo exchange");
 
+        // the particle routes of this sync (reapplySync)
+        rsN_ = n, rsNa_ = na, rsNb_ = nb, rsSend_ = mSend, rsMoved_ = movedAny, rsKeptOffset_ = cut[rank_];
+        rsSendCounts_ = sendCounts;
+        rsRecvCounts_.assign(P_, 0);
+        for (int p = 0; p < P_; ++p)
+            rsRecvCounts_[p] = p == rank_ ? 0 : matrix[size_t(p) * P_ + rank_];
         haloAnyLast_ = haloAny;
         haloSend_ = hsCounts, haloRecvLo_ = nlo, haloRecvHi_ = nhi, haloAssigned_ = nm, haloSel_ = selTotal;
         haloRecv_.assign(P_, 0);
@@ -1087,6 +1142,9 @@ private:
     DevBuf leaving_, sendRows_, recvRows_, rcol_[4], rcolS_[4], rk_, ro_, posA_, posB_, moveTmp_;
     DevBuf propRecv_[MAX_PROPS], propRecvS_[MAX_PROPS];
     uint64_t prevLo_ = 0, prevHi_ = 0;
+    // particle routes of the last sync (reapplySync): input size, kept / received / sent counts, start of the kept range
+    uint64_t rsN_ = 0, rsNa_ = 0, rsNb_ = 0, rsSend_ = 0, rsMoved_ = 0, rsKeptOffset_ = 0;
+    std::vector<uint64_t> rsSendCounts_, rsRecvCounts_;
     int prevMaxLeafLevel_ = -1; // deepest level of this rank's tree at the previous sync
     // halo exchange pattern of the last sync (exchangeHalos)
     std::vector<uint64_t> haloSend_, haloRecv_;
@@ -1190,6 +1248,12 @@ int cstone_hip_domain_mr_exchange_halos(cstone_hip_domain_mr* dom, void* array, 
 {
     if (!dom || !array) return CSTONE_E_ARG;
     return dom->impl->exchangeHalos(array, elem_bytes);
+}
+
+int cstone_hip_domain_mr_reapply_sync(cstone_hip_domain_mr* dom, const void* in, size_t n, int elem_bytes, void* out)
+{
+    if (!dom) return CSTONE_E_ARG;
+    return dom->impl->reapplySync(in, n, elem_bytes, out);
 }
 
 int cstone_hip_domain_mr_set_halo_factor(cstone_hip_domain_mr* dom, float factor)

@@ -376,18 +376,27 @@ int cstone_hip_gather_scatter(cstone_hip_ctx* ctx, int elem_bytes, const uint32_
     if (!map_in || !map_out || !src || !dst) return fail(ctx, CSTONE_E_ARG, "gather_scatter: null array");
     StageTimer timer(ctx, CSTONE_STAGE_GATHER);
     unsigned grid = gridFor(n, 256, 4);
+    int natural   = elem_bytes == 12 ? 4 : (elem_bytes == 24 ? 8 : (elem_bytes >= 16 ? 16 : elem_bytes));
+    if (natural > 0 && ((uintptr_t(src) % natural) || (uintptr_t(dst) % natural)))
+        return fail(ctx, CSTONE_E_ARG, "gather_scatter: arrays must be aligned to %d bytes", natural);
+#define CSTONE_GS_CASE(B)                                                                                              \
+    case B:                                                                                                            \
+        hipLaunchKernelGGL((gatherScatterKernel<Elem<B>, 4>), grid, 256, 0, ctx->stream, map_in, map_out, n,           \
+                           (const Elem<B>*)src, (Elem<B>*)dst);                                                        \
+        break
     switch (elem_bytes)
     {
-        case 4:
-            hipLaunchKernelGGL((gatherScatterKernel<Elem<4>, 4>), grid, 256, 0, ctx->stream, map_in, map_out, n,
-                               (const Elem<4>*)src, (Elem<4>*)dst);
-            break;
-        case 8:
-            hipLaunchKernelGGL((gatherScatterKernel<Elem<8>, 4>), grid, 256, 0, ctx->stream, map_in, map_out, n,
-                               (const Elem<8>*)src, (Elem<8>*)dst);
-            break;
+        CSTONE_GS_CASE(1);
+        CSTONE_GS_CASE(2);
+        CSTONE_GS_CASE(4);
+        CSTONE_GS_CASE(8);
+        CSTONE_GS_CASE(12);
+        CSTONE_GS_CASE(16);
+        CSTONE_GS_CASE(24);
+        CSTONE_GS_CASE(32);
         default: return fail(ctx, CSTONE_E_ARG, "gather_scatter: element size %d unsupported", elem_bytes);
     }
+#undef CSTONE_GS_CASE
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

@@ -770,6 +770,23 @@ class NativeDistributedDomain:
             raise err
         self.ctx._chk(rc, "domain_mr_exchange_halos")
 
+    def reapply_sync(self, field):
+        """Domain::reapplySync: field (laid out like the INPUT arrays of the last sync, rows of 1..32 bytes) follows its
+        particles; returns a tensor laid out like the result arrays whose assigned range is filled"""
+        torch = _torch()
+        row = field[0].numel() if field.dim() > 1 and field.shape[0] else 1
+        elem = field.element_size() * row
+        v = self.view()
+        out = torch.zeros((v.num_particles_with_halos,) + tuple(field.shape[1:]), dtype=field.dtype, device=field.device)
+        rc = self.ctx.lib.cstone_hip_domain_mr_reapply_sync(self.h, C.c_void_p(field.data_ptr()),
+                                                            C.c_size_t(field.shape[0]), C.c_int(elem),
+                                                            C.c_void_p(out.data_ptr()))
+        if rc != 0 and self.coll.error is not None:
+            err, self.coll.error = self.coll.error, None
+            raise err
+        self.ctx._chk(rc, "domain_mr_reapply_sync")
+        return out
+
     # the accessors the tests use to compare with DistributedDomain / the reference fixtures
     def fetch(self, ptr, count, dtype):
         a = np.empty(count, dtype=dtype)

@@ -61,6 +61,18 @@ class Domain:
         pout = [by_ptr[parr[i]] for i in range(len(props))]
         return keys[:m], out[0][:m], out[1][:m], out[2][:m], out[3][:m], out[4], [t[:m] for t in pout]
 
+    def reapply_sync(self, field):
+        """Domain::reapplySync: field (n rows of the last sync's input, 1..32 bytes each) in the order of the result"""
+        import torch
+
+        row = field[0].numel() if field.dim() > 1 and field.shape[0] else 1
+        v = self.view()
+        out = torch.zeros((v.num_particles_with_halos,) + tuple(field.shape[1:]), dtype=field.dtype, device=field.device)
+        rc = self.ctx.lib.cstone_hip_domain_reapply_sync(self.h, C.c_void_p(field.data_ptr()), C.c_size_t(field.shape[0]),
+                                                         C.c_int(field.element_size() * row), C.c_void_p(out.data_ptr()))
+        self.ctx._chk(rc, "domain_reapply_sync")
+        return out
+
     def view(self):
         v = DomainView()
         self.ctx._chk(self.ctx.lib.cstone_hip_domain_view_get(self.h, C.byref(v)), "domain_view_get")

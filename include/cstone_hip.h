@@ -134,7 +134,7 @@ extern "C"
     int cstone_hip_scatter(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map, size_t n, const void* src,
                            void* dst);
 
-    /* gatherScatter (R/primitives/gather.hpp:120-131): dst[map_out[i]] = src[map_in[i]], 4- or 8-byte elements */
+    /* gatherScatter (R/primitives/gather.hpp:120-131): dst[map_out[i]] = src[map_in[i]], element sizes as gather */
     int cstone_hip_gather_scatter(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map_in, const uint32_t* map_out,
                                   size_t n, const void* src, void* dst);
     /* positions of the elements of two sorted key runs in their stable merge (ties: run a first), plus offset:
@@ -340,6 +340,10 @@ extern "C"
     /* Domain::setHaloFactor (R/domain/domain.hpp:412): extra search factor of the halo discovery (default 1.0), lets a
      * client take several integration steps between syncs */
     int cstone_hip_domain_set_halo_factor(cstone_hip_domain* dom, float factor);
+    /* Domain::reapplySync (R/domain/domain.hpp:334-378) on one rank: out[i] = in[sfc_order[i]] for the end_index
+     * particles the last sync kept; in has the n elements (elem_bytes in {1,2,4,8,12,16,24,32}) of that call's arrays,
+     * out must not alias in */
+    int cstone_hip_domain_reapply_sync(cstone_hip_domain* dom, const void* in, size_t n, int elem_bytes, void* out);
 
     /* ---------------------------------------------------------------------------------------------
      * Domain::sync on SEVERAL ranks, one process per GPU (R/domain/domain.hpp:196-243 with the exchange steps of
@@ -409,6 +413,14 @@ extern "C"
      * like the result arrays: its assigned range is read,
      * its halo ranges are overwritten with the owners' values */
     int cstone_hip_domain_mr_exchange_halos(cstone_hip_domain_mr* dom, void* array, int elem_bytes);
+    /* Domain::reapplySync (R/domain/domain.hpp:334-378): moves one more per-particle field along the routes of the last
+     * sync (same particles to the same ranks, same final slots), for fields that were not passed to sync itself.
+     * in: device, n elements laid out like the INPUT arrays of the last sync (n must be that call's n, the reference's
+     * checkSizesEqual); out: device, laid out like the result arrays (num_particles_with_halos elements of elem_bytes in
+     * {1,2,4,8,12,16,24,32}); only the assigned range [start_index, end_index) is written.  Collective: every rank
+     * calls it. */
+    int cstone_hip_domain_mr_reapply_sync(cstone_hip_domain_mr* dom, const void* in, size_t n, int elem_bytes,
+                                          void* out);
     int cstone_hip_domain_mr_set_halo_factor(cstone_hip_domain_mr* dom, float factor);
 
 #ifdef __cplusplus

@@ -44,6 +44,30 @@ def neighbor_sum(o, x, y, z, h, first, last, lim, bc):
     return int(nc[sel].astype(np.int64).sum())
 
 
+def late_fields(x, y, z, h):
+    """fields of 8, 12, 1 and 32 bytes per particle that are NOT passed to sync: reapplySync must route them afterwards"""
+    return [x * 11.0 - z, torch.stack([x, y, z], dim=1).to(torch.float32).contiguous(),
+            (x * 200.0).to(torch.uint8), torch.stack([x, y, z, h], dim=1).contiguous()]
+
+
+def check_reapply(dom, late, r):
+    """Domain::reapplySync (R/domain/domain.hpp:334-378): the assigned range holds the values of its particles"""
+    st, en = r["start"], r["end"]
+    want = late_fields(*[r[k][st:en] for k in "xyzh"])
+    ok = True
+    for f, w in zip(late, want):
+        out = dom.reapply_sync(f)
+        ok &= out.shape[0] == r["x"].numel() and bool(torch.equal(out[st:en], w))
+    if late[0].shape[0] == 0:
+        return ok
+    try:
+        dom.reapply_sync(late[0][:-1])  # checkSizesEqual: an array that does not match the last sync's input
+        ok = False
+    except Exception:
+        pass
+    return ok
+
+
 def make_native(backend, bucket, bucket_focus, lim, bc, curve=1, key_bits=64):
     from cstone_amd.distributed import NativeDistributedDomain
 
@@ -184,11 +208,13 @@ def main():
     tag32 = (x + 2.0 * y).to(torch.float32)
     for s in range(a.syncs):
         if a.impl == "native":
+            late = late_fields(x, y, z, h)
             r = dom.sync(x, y, z, h, props=[tag64, tag32])
         else:
             r = dom.sync(x, y, z, h)
         st, en = r["start"], r["end"]
         if a.impl == "native":
+            ok &= check_reapply(dom, late, r)
             p64, p32 = r["props"]
             ok &= bool(torch.equal(p64[st:en], tag64_of(r, st, en)))
             ok &= bool(torch.equal(p32[st:en], (r["x"][st:en] + 2.0 * r["y"][st:en]).to(torch.float32)))
@@ -248,7 +274,9 @@ def main():
         marks[::10] = -(1 << 63)
         gone = torch.tensor([int((marks != 0).sum())], dtype=torch.int64)
         before = torch.tensor([x.numel()], dtype=torch.int64)
+        late = late_fields(x, y, z, h)
         r = dom.sync(x, y, z, h, props=[tag64, tag32], keys=marks)
+        ok &= check_reapply(dom, late, r)
         after = torch.tensor([r["end"] - r["start"]], dtype=torch.int64)
         for t in (gone, before, after):
             dist.all_reduce(t)

@@ -30,7 +30,13 @@ def test_domain_sync_matches_reference(hip, path):
         keys = torch.from_numpy(kin.view(np.int64).copy()).cuda()
         scratch = torch.empty_like(x)
         tag = torch.arange(n, dtype=torch.float64, device="cuda")  # a conserved property travelling along
+        late = [torch.stack([x, y, z], dim=1).to(torch.float32).contiguous(), (h * 1e3).to(torch.int16)]
         keys, x, y, z, h, scratch, props = dom.sync(keys, x, y, z, h, scratch, [tag])
+        # reapplySync (domain.hpp:334-378): fields that were not part of the sync are brought into the new order later
+        for f, w in zip(late, [torch.stack([x, y, z], dim=1).to(torch.float32), (h * 1e3).to(torch.int16)]):
+            assert torch.equal(dom.reapply_sync(f), w), s
+        with pytest.raises(cstone_amd.CstoneError, match="last sync took"):
+            dom.reapply_sync(late[1][:-1])
         hip.sync()
         v = dom.view()
         info = d[f"out{s}_info"]

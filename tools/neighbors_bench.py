@@ -23,6 +23,7 @@ p.add_argument("--targets", type=float, default=0, help="number of target partic
 p.add_argument("--real-bits", type=int, default=64)
 p.add_argument("--ng0", type=float, default=100.0)
 p.add_argument("--reps", type=int, default=2)
+p.add_argument("--groups", type=float, default=0, help="> 0: targets come from compute_group_splits(64, tol = this)")
 a = p.parse_args()
 n = int(a.n)
 dev = "cuda"
@@ -62,13 +63,31 @@ layout = torch.zeros(nl + 1, dtype=torch.int32, device=dev)
 ctx.inclusive_scan(counts, layout[1:])
 nt = int(a.targets) or n
 first = (n - nt) // 2
+groups = None
+if a.groups > 0:
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    groups = ctx.compute_group_splits(first, first + nt, xs, ys, zs, tree, layout, box, 64, a.groups)
+    torch.cuda.synchronize()
+    dtg = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    groups = ctx.compute_group_splits(first, first + nt, xs, ys, zs, tree, layout, box, 64, a.groups)
+    torch.cuda.synchronize()
+    dtg = time.perf_counter() - t0
+    sz = (groups[1:] - groups[:-1]).double()
+    print(f"group splits tol {a.groups}: {groups.numel() - 1} groups (fixed: {(nt + 63) // 64}), mean size "
+          f"{sz.mean().item():.1f}, {dtg*1e3:.2f} ms", flush=True)
 ctx.profile_enable(True)
 for rep in range(a.reps + 1):
     if rep == 1:
         ctx.profile_reset()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    nidx, nc = ctx.find_neighbors(xs, ys, zs, hs, first, first + nt, box, oc, layout, cen, siz, a.ngmax)
+    if groups is None:
+        nidx, nc = ctx.find_neighbors(xs, ys, zs, hs, first, first + nt, box, oc, layout, cen, siz, a.ngmax)
+    else:
+        nidx, nc = ctx.find_neighbors_groups(xs, ys, zs, hs, first, first + nt, groups, box, oc, layout, cen, siz,
+                                             a.ngmax)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rep:
