@@ -462,6 +462,69 @@ struct OctreeNsView
     float searchExtFactor{1.0};
 };
 
+//! R/traversal/groups.hpp:20-26: groups of target particles, device pointers
+struct GroupView
+{
+    LocalIndex firstBody, lastBody;
+    LocalIndex numGroups;
+    const LocalIndex* groupStart;
+    const LocalIndex* groupEnd;
+};
+
+//! R/traversal/groups.hpp:29-57 (the GpuTag flavour: the offsets live in device memory)
+class GroupData
+{
+public:
+    GroupData()                 = default;
+    GroupData(const GroupView&) = delete;
+    GroupView view() const { return {firstBody, lastBody, numGroups, groupStart, groupEnd}; }
+
+    DeviceVector<LocalIndex> data;
+    LocalIndex firstBody{0}, lastBody{0};
+    LocalIndex numGroups{0};
+    LocalIndex* groupStart{nullptr};
+    LocalIndex* groupEnd{nullptr};
+};
+
+//! R/traversal/groups_gpu.h:46: groups of groupSize consecutive particles
+inline void computeFixedGroups(LocalIndex first, LocalIndex last, unsigned groupSize, GroupData& groups)
+{
+    if (groupSize == 0) throw std::runtime_error("Unsupported spatial group size\n");
+    groups.data.resize((last - first + groupSize - 1) / groupSize + 1);
+    LocalIndex numGroups = 0;
+    Context::check(cstone_hip_compute_fixed_groups(Context::get(), first, last, groupSize, groups.data.data(), &numGroups),
+                   "computeFixedGroups");
+    groups.firstBody = first, groups.lastBody = last, groups.numGroups = numGroups;
+    groups.groupStart = groups.data.data(), groups.groupEnd = groups.data.data() + 1;
+}
+
+/*! R/traversal/groups_gpu.h:73-87: groups of at most groupSize particles, split where consecutive particles are farther
+ *  apart than tolFactor x the edge of the group's smallest leaf.  h and the scratch vector of the reference's signature
+ *  are accepted and not used (the smoothing lengths do not enter the reference's result either). */
+template<class Tc, class T, class KeyType>
+void computeGroupSplits(LocalIndex first, LocalIndex last, const Tc* x, const Tc* y, const Tc* z, const T* /*h*/,
+                        const KeyType* leaves, TreeNodeIndex numLeaves, const LocalIndex* layout, const Box<Tc>& box,
+                        unsigned groupSize, float tolFactor, DeviceVector<LocalIndex>& /*numSplitsPerGroup*/,
+                        DeviceVector<LocalIndex>& groups)
+{
+    if (groupSize != 64 && groupSize != 128) throw std::runtime_error("Unsupported spatial group size\n");
+    LocalIndex numFixed = (last - first + groupSize - 1) / groupSize;
+    groups.resize(std::size_t(numFixed) + numFixed / 8 + 2); // the reference reserves 1.1 x; grow on demand
+    LocalIndex numGroups = 0;
+    int rc = cstone_hip_compute_group_splits(Context::get(), detail::keyBits<KeyType>(), detail::realBits<Tc>(), first,
+                                             last, x, y, z, leaves, numLeaves, layout, &box.pod(), groupSize, tolFactor,
+                                             groups.data(), groups.size(), &numGroups);
+    if (rc == CSTONE_E_CAPACITY)
+    {
+        groups.resize(std::size_t(numGroups) + 1);
+        rc = cstone_hip_compute_group_splits(Context::get(), detail::keyBits<KeyType>(), detail::realBits<Tc>(), first,
+                                             last, x, y, z, leaves, numLeaves, layout, &box.pod(), groupSize, tolFactor,
+                                             groups.data(), groups.size(), &numGroups);
+    }
+    Context::check(rc, "computeGroupSplits");
+    groups.resize(std::size_t(numGroups) + 1);
+}
+
 /*! cstone::Domain<KeyType, T, GpuTag> on SEVERAL ranks, one process per GPU (cstone_hip_domain_mr_*).
  *  The three collectives of a sync (all-reduce, all-gather, all-to-all-v on device buffers) are supplied by the
  *  application through cstone_hip_comm_ops: RCCL, MPI, or any other transport.  Results live in domain-owned arrays:
@@ -528,6 +591,16 @@ public:
         static_assert(sizeof(V) == 1 || sizeof(V) == 2 || sizeof(V) == 4 || sizeof(V) == 8 || sizeof(V) == 12 ||
                       sizeof(V) == 16 || sizeof(V) == 24 || sizeof(V) == 32);
         Context::check(cstone_hip_domain_mr_exchange_halos(dom_, field, int(sizeof(V))), "MultiRankDomain::exchangeHalos");
+    }
+
+    /*! Domain::reapplySync (R/domain/domain.hpp:334-378) for one more field: in holds the n elements of the last sync's
+     *  input arrays, out nParticlesWithHalos() elements; the assigned range of out is written (collective call) */
+    template<class V>
+    void reapplySync(const V* in, std::size_t n, V* out) const
+    {
+        static_assert(sizeof(V) == 1 || sizeof(V) == 2 || sizeof(V) == 4 || sizeof(V) == 8 || sizeof(V) == 12 ||
+                      sizeof(V) == 16 || sizeof(V) == 24 || sizeof(V) == 32);
+        Context::check(cstone_hip_domain_mr_reapply_sync(dom_, in, n, int(sizeof(V)), out), "MultiRankDomain::reapplySync");
     }
 
 private:
@@ -642,6 +715,27 @@ public:
     template<class... Vectors, class SendBuffer, class ReceiveBuffer>
     void exchangeHalos(std::tuple<Vectors&...>, SendBuffer&, ReceiveBuffer&) const
     {
+    }
+
+    /*! R/domain/domain.hpp:334-378 with device vectors (the reference restricts its version to host vectors, :340):
+     *  every array of the last sync's input size is brought into the order of the result through the scratch vector,
+     *  which it is swapped with; the ordering argument of the reference lives inside the domain */
+    template<class... Vectors, class Scratch>
+    void reapplySync(std::tuple<Vectors&...> arrays, Scratch& scratch) const
+    {
+        auto one = [&](auto& a)
+        {
+            using V = std::decay_t<decltype(*a.data())>;
+            static_assert(std::is_same_v<V, std::decay_t<decltype(*scratch.data())>>,
+                          "the scratch vector must have the arrays' element type");
+            const std::size_t m = nParticlesWithHalos();
+            scratch.resize(std::max(m, a.size()));
+            Context::check(cstone_hip_domain_reapply_sync(dom_, a.data(), a.size(), int(sizeof(V)), scratch.data()),
+                           "Domain::reapplySync");
+            scratch.resize(m);
+            a.swap(scratch);
+        };
+        std::apply([&](auto&... a) { (one(a), ...); }, arrays);
     }
 
     OctreeNsView<T, KeyType> octreeProperties() const

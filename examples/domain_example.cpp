@@ -43,6 +43,37 @@ int main(int argc, char** argv)
         std::printf("step %d: particles [%u, %u) of %u, %d global leaves, %d focus leaves\n", step, v.start_index,
                     v.end_index, v.num_particles_with_halos, v.num_global_leaves, v.num_focus_leaves);
     }
+    // a field that was not part of the sync follows later (Domain::reapplySync): one more sync with "id" left out,
+    // then id is brought into the new order and must name the particle that now sits in each slot
+    std::vector<T> hid(x.size());
+    for (std::size_t i = 0; i < hid.size(); ++i)
+        hid[i] = T(i);
+    DeviceVector<T> id(hid.data(), hid.data() + hid.size()), idScratch;
+    auto xBefore = toHost(x);
+    domain.sync(keys, x, y, z, h, std::tie(mass), scratch);
+    domain.reapplySync(std::tie(id), idScratch);
+    auto xAfter = toHost(x);
+    auto idAfter = toHost(id);
+    bool followed = idAfter.size() == xAfter.size();
+    for (std::size_t i = 0; followed && i < idAfter.size(); ++i)
+        followed = xBefore[std::size_t(idAfter[i])] == xAfter[i];
+    std::printf("reapplySync: field followed its particles: %s\n", followed ? "yes" : "NO");
+
+    // target groups for neighbor kernels (computeGroupSplits) on the domain's tree
+    auto v = domain.view();
+    DeviceVector<LocalIndex> splitScratch, groupOffsets;
+    computeGroupSplits(domain.startIndex(), domain.endIndex(), x.data(), y.data(), z.data(), h.data(),
+                       static_cast<const KeyType*>(v.focus_leaves), v.num_focus_leaves, v.layout, domain.box(), 64, 1.5f,
+                       splitScratch, groupOffsets);
+    GroupData fixed;
+    computeFixedGroups(domain.startIndex(), domain.endIndex(), 64, fixed);
+    auto go = toHost(groupOffsets);
+    bool groupsOk = go.front() == domain.startIndex() && go.back() == domain.endIndex() &&
+                    go.size() - 1 >= fixed.numGroups;
+    for (std::size_t g = 1; g < go.size(); ++g)
+        groupsOk = groupsOk && go[g] > go[g - 1] && go[g] - go[g - 1] <= 64;
+    std::printf("target groups: %zu (fixed: %u): %s\n", go.size() - 1, fixed.numGroups, groupsOk ? "ok" : "BAD");
+
     auto k = toHost(keys);
     bool sorted = true;
     for (std::size_t i = 1; i < k.size(); ++i)
@@ -63,5 +94,5 @@ int main(int argc, char** argv)
                 mr.endIndex(), mr.nParticlesWithHalos(), (unsigned long long)mr.assignedRange().first,
                 (unsigned long long)mr.assignedRange().second);
     bool same = mr.nParticles() == x.size();
-    return sorted && same ? 0 : 1;
+    return sorted && same && followed && groupsOk ? 0 : 1;
 }

@@ -30,3 +30,5 @@ def test_cpp_domain_example_runs():
     out = subprocess.run([EXE, "300000"], check=True, capture_output=True, text=True, timeout=120).stdout
     assert "keys sorted: yes" in out
     assert out.count("focus leaves") == 3
+    assert "field followed its particles: yes" in out
+    assert "target groups:" in out and "BAD" not in out
