@@ -245,6 +245,7 @@ struct MrBase
     virtual void setHaloFactor(float f)                                                  = 0;
     virtual int exchangeHalos(void* array, int elemBytes)                                = 0;
     virtual int reapplySync(const void* in, size_t n, int elemBytes, void* out)          = 0;
+    virtual int octree(cstone_hip_domain_mr_octree* out)                                 = 0;
 };
 
 template<class K, class T>
@@ -349,6 +350,30 @@ public:
             CS_TRY(cstone_hip_scatter(ctx_, elemBytes, posB_.as<uint32_t>(), rsNb_, recvSorted, dst));
         }
         else { CS_TRY(cstone_hip_gather(ctx_, elemBytes, keptO, rsNa_, in, dst)); }
+        return CSTONE_OK;
+    }
+
+    /*! Domain::octreeProperties() / layout() (R/domain/domain.hpp:388-437) for the result arrays of the last sync: a
+     *  cornerstone tree (bucketFocus) over ALL local particles, halos included -- the keys of
+     *  [halos of lower ranks | assigned | halos of higher ranks] ascend over the whole array, so the tree machinery of
+     *  the single-rank path applies as it is.  Built on the first request after a sync, from the tree of the previous
+     *  request; a sync that nobody asks a tree for does not pay for one. */
+    int octree(cstone_hip_domain_mr_octree* out) override
+    {
+        if (firstCall_) return fail(ctx_, CSTONE_E_ARG, "domain_mr_octree: no sync yet");
+        if (nsSync_ != syncs_)
+        {
+            CS_TRY(buildNsTree());
+            nsSync_ = syncs_;
+        }
+        const NodeIdx L = nsLeaves_, M = L + (L - 1) / 7;
+        out->num_leaves = L, out->num_nodes = M;
+        out->leaves = nsTree_.p, out->leaf_counts = nsCounts_.as<uint32_t>();
+        out->prefixes = nsPrefixes_.p, out->child_offsets = nsChild_.as<int32_t>();
+        out->parents = nsParents_.as<int32_t>(), out->level_range = nsLevelRange_.as<int32_t>();
+        out->internal_to_leaf = nsItl_.as<int32_t>(), out->leaf_to_internal = nsLti_.as<int32_t>();
+        out->layout = nsLayout_.as<uint32_t>();
+        out->centers = nsCenters_.p, out->sizes = nsSizes_.p;
         return CSTONE_OK;
     }
 
@@ -1109,6 +1134,66 @@ private:
                                        fLti_.as<int32_t>());
     }
 
+    int buildNsTree()
+    {
+        const K* keysAll = static_cast<const K*>(view_.keys);
+        const size_t n   = view_.num_particles_with_halos;
+        if (nsLeaves_ == 0)
+        {
+            int cap = std::max<int>(4096, int(4 * n / std::max(1u, bucketFocus_)) + 4096);
+            while (true)
+            {
+                CS_TRY(ensureTree(nsTree_, nsCounts_, nsCap_, cap));
+                int leaves = 0, iters = 0;
+                int rc = cstone_hip_compute_octree(ctx_, kb, keysAll, n, bucketFocus_, nsTree_.p,
+                                                   nsCounts_.as<uint32_t>(), &leaves, nsCap_, 0xFFFFFFFFu, &iters);
+                if (rc == CSTONE_E_CAPACITY)
+                {
+                    cap = leaves + 1;
+                    continue;
+                }
+                CS_TRY(rc);
+                nsLeaves_ = leaves;
+                break;
+            }
+        }
+        else
+        {
+            // the particles moved a little since the last request: a few update steps (each one level of splits or
+            // merges, R/tree/csarray.hpp:430-448); the search stays correct if the last one still changed something
+            for (int it = 0, conv = 0; it < 4 && !conv;)
+            {
+                int leaves = nsLeaves_;
+                int rc = cstone_hip_update_octree(ctx_, kb, keysAll, n, bucketFocus_, nsTree_.p, nsCounts_.as<uint32_t>(),
+                                                  &leaves, nsCap_, 0xFFFFFFFFu, &conv);
+                if (rc == CSTONE_E_CAPACITY)
+                {
+                    CS_TRY(ensureTree(nsTree_, nsCounts_, nsCap_, leaves + 1));
+                    continue;
+                }
+                CS_TRY(rc);
+                nsLeaves_ = leaves;
+                ++it;
+            }
+        }
+        const NodeIdx L = nsLeaves_, M = L + (L - 1) / 7;
+        CS_TRY(nsLayout_.ensure(ctx_, size_t(L + 1) * sizeof(uint32_t)));
+        CS_HIP(ctx_, hipMemsetAsync(nsLayout_.p, 0, sizeof(uint32_t), ctx_->stream));
+        CS_TRY(cstone_hip_inclusive_scan_u32(ctx_, nsCounts_.as<uint32_t>(), nsLayout_.as<uint32_t>() + 1, size_t(L)));
+        CS_TRY(nsPrefixes_.ensure(ctx_, size_t(M) * sizeof(K)));
+        CS_TRY(nsChild_.ensure(ctx_, size_t(M + 1) * sizeof(NodeIdx)));
+        CS_TRY(nsParents_.ensure(ctx_, size_t(std::max(1, (M - 1) / 8)) * sizeof(NodeIdx)));
+        CS_TRY(nsLevelRange_.ensure(ctx_, (maxLevel<K>() + 2) * sizeof(NodeIdx)));
+        CS_TRY(nsItl_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
+        CS_TRY(nsLti_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
+        CS_TRY(cstone_hip_build_octree(ctx_, kb, nsTree_.p, L, nsPrefixes_.p, nsChild_.as<int32_t>(),
+                                       nsParents_.as<int32_t>(), nsLevelRange_.as<int32_t>(), nsItl_.as<int32_t>(),
+                                       nsLti_.as<int32_t>()));
+        CS_TRY(nsCenters_.ensure(ctx_, size_t(M) * 3 * sizeof(T)));
+        CS_TRY(nsSizes_.ensure(ctx_, size_t(M) * 3 * sizeof(T)));
+        return cstone_hip_node_centers(ctx_, curve_, kb, rb, nsPrefixes_.p, M, &box_, nsCenters_.p, nsSizes_.p);
+    }
+
     int findLeaves(int* first, int* last)
     {
         CS_TRY(leafIndex(assignment_[rank_], true, first));
@@ -1142,6 +1227,10 @@ private:
     DevBuf leaving_, sendRows_, recvRows_, rcol_[4], rcolS_[4], rk_, ro_, posA_, posB_, moveTmp_;
     DevBuf propRecv_[MAX_PROPS], propRecvS_[MAX_PROPS];
     uint64_t prevLo_ = 0, prevHi_ = 0;
+    // tree over all local particles incl. halos (octree()), built on request
+    DevBuf nsTree_, nsCounts_, nsLayout_, nsPrefixes_, nsChild_, nsParents_, nsLevelRange_, nsItl_, nsLti_, nsCenters_,
+        nsSizes_;
+    int nsCap_ = 0, nsLeaves_ = 0, nsSync_ = -1;
     // particle routes of the last sync (reapplySync): input size, kept / received / sent counts, start of the kept range
     uint64_t rsN_ = 0, rsNa_ = 0, rsNb_ = 0, rsSend_ = 0, rsMoved_ = 0, rsKeptOffset_ = 0;
     std::vector<uint64_t> rsSendCounts_, rsRecvCounts_;
@@ -1248,6 +1337,12 @@ int cstone_hip_domain_mr_exchange_halos(cstone_hip_domain_mr* dom, void* array, 
 {
     if (!dom || !array) return CSTONE_E_ARG;
     return dom->impl->exchangeHalos(array, elem_bytes);
+}
+
+int cstone_hip_domain_mr_octree_get(cstone_hip_domain_mr* dom, cstone_hip_domain_mr_octree* out)
+{
+    if (!dom || !out) return CSTONE_E_ARG;
+    return dom->impl->octree(out);
 }
 
 int cstone_hip_domain_mr_reapply_sync(cstone_hip_domain_mr* dom, const void* in, size_t n, int elem_bytes, void* out)

@@ -36,7 +36,7 @@ EXPORTS = [
     "cstone_hip_domain_create", "cstone_hip_domain_destroy", "cstone_hip_domain_sync", "cstone_hip_domain_view_get",
     "cstone_hip_domain_set_halo_factor", "cstone_hip_domain_mr_create", "cstone_hip_domain_mr_destroy",
     "cstone_hip_domain_mr_sync", "cstone_hip_domain_mr_sync_props", "cstone_hip_domain_mr_sync_keys", "cstone_hip_domain_mr_view_get", "cstone_hip_domain_mr_set_halo_factor", "cstone_hip_domain_mr_exchange_halos", "cstone_hip_domain_mr_reapply_sync",
-    "cstone_hip_domain_reapply_sync",
+    "cstone_hip_domain_reapply_sync", "cstone_hip_domain_mr_octree_get",
 ]
 
 

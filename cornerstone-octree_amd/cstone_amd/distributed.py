@@ -611,6 +611,14 @@ class MrView(C.Structure):
                 ("halo_boxes_exported", C.c_uint64), ("props", C.c_void_p * 16)]
 
 
+class MrOctree(C.Structure):
+    _fields_ = [("num_leaves", C.c_int32), ("num_nodes", C.c_int32), ("leaves", C.c_void_p),
+                ("leaf_counts", C.c_void_p), ("prefixes", C.c_void_p), ("child_offsets", C.c_void_p),
+                ("parents", C.c_void_p), ("level_range", C.c_void_p), ("internal_to_leaf", C.c_void_p),
+                ("leaf_to_internal", C.c_void_p), ("layout", C.c_void_p), ("centers", C.c_void_p),
+                ("sizes", C.c_void_p)]
+
+
 class _DevMem:
     """raw device memory as a __cuda_array_interface__ object (no copy)"""
 
@@ -769,6 +777,30 @@ class NativeDistributedDomain:
             err, self.coll.error = self.coll.error, None
             raise err
         self.ctx._chk(rc, "domain_mr_exchange_halos")
+
+    def octree(self):
+        """Domain::octreeProperties() + layout(): the tree over all local particles (halos included) of the last sync as
+        tensors that alias the domain's arrays; the dict is what Context.find_neighbors takes as `octree`"""
+        torch = _torch()
+        import cstone_amd
+
+        o = MrOctree()
+        self.ctx._chk(self.ctx.lib.cstone_hip_domain_mr_octree_get(self.h, C.byref(o)), "domain_mr_octree_get")
+        L, M = o.num_leaves, o.num_nodes
+        rdt = torch.float64 if self.rb == 64 else torch.float32
+        kdt = cstone_amd.key_torch_dtype(self.kb)
+
+        def wrap(ptr, dt, count):
+            nbytes = count * torch.empty(0, dtype=dt).element_size()
+            return torch.as_tensor(_DevMem(ptr, nbytes), device=self.ctx.device).view(dt)
+
+        return dict(num_leaves=L, num_nodes=M, leaves=wrap(o.leaves, kdt, L + 1),
+                    leaf_counts=wrap(o.leaf_counts, torch.int32, L), prefixes=wrap(o.prefixes, kdt, M),
+                    child_offsets=wrap(o.child_offsets, torch.int32, M + 1),
+                    level_range=wrap(o.level_range, torch.int32, cstone_amd.max_level(self.kb) + 2),
+                    internal_to_leaf=wrap(o.internal_to_leaf, torch.int32, M),
+                    leaf_to_internal=wrap(o.leaf_to_internal, torch.int32, M), layout=wrap(o.layout, torch.int32, L + 1),
+                    centers=wrap(o.centers, rdt, 3 * M).view(M, 3), sizes=wrap(o.sizes, rdt, 3 * M).view(M, 3))
 
     def reapply_sync(self, field):
         """Domain::reapplySync: field (laid out like the INPUT arrays of the last sync, rows of 1..32 bytes) follows its

@@ -593,6 +593,29 @@ public:
         Context::check(cstone_hip_domain_mr_exchange_halos(dom_, field, int(sizeof(V))), "MultiRankDomain::exchangeHalos");
     }
 
+    /*! Domain::octreeProperties() (R/domain/domain.hpp:424-437): the tree over all local particles, halos included, for
+     *  neighbor searches on the result arrays; built on the first request after a sync */
+    OctreeNsView<T, KeyType> octreeProperties() const
+    {
+        cstone_hip_domain_mr_octree o;
+        Context::check(cstone_hip_domain_mr_octree_get(dom_, &o), "MultiRankDomain::octreeProperties");
+        return {o.num_leaves,
+                static_cast<const KeyType*>(o.prefixes),
+                o.child_offsets,
+                o.internal_to_leaf,
+                o.level_range,
+                static_cast<const KeyType*>(o.leaves),
+                o.layout,
+                static_cast<const T*>(o.centers),
+                static_cast<const T*>(o.sizes)};
+    }
+    //! Domain::layout(): particle offsets of the leaf cells of octreeProperties(), device pointer
+    std::span<const LocalIndex> layout() const
+    {
+        auto o = octreeProperties();
+        return {o.layout, std::size_t(o.numLeafNodes) + 1};
+    }
+
     /*! Domain::reapplySync (R/domain/domain.hpp:334-378) for one more field: in holds the n elements of the last sync's
      *  input arrays, out nParticlesWithHalos() elements; the assigned range of out is written (collective call) */
     template<class V>

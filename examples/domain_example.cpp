@@ -93,6 +93,8 @@ int main(int argc, char** argv)
     std::printf("multi-rank domain on one rank: particles [%u, %u) of %u, range [%llu, %llu)\n", mr.startIndex(),
                 mr.endIndex(), mr.nParticlesWithHalos(), (unsigned long long)mr.assignedRange().first,
                 (unsigned long long)mr.assignedRange().second);
-    bool same = mr.nParticles() == x.size();
+    auto nsView = mr.octreeProperties();
+    std::printf("its tree over local + halo particles: %d leaves\n", nsView.numLeafNodes);
+    bool same = mr.nParticles() == x.size() && nsView.numLeafNodes > 0;
     return sorted && same && followed && groupsOk ? 0 : 1;
 }

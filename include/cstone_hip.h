@@ -423,6 +423,28 @@ extern "C"
                                           void* out);
     int cstone_hip_domain_mr_set_halo_factor(cstone_hip_domain_mr* dom, float factor);
 
+    /* Domain::octreeProperties() and Domain::layout() (R/domain/domain.hpp:388-437) for the result arrays of the last
+     * sync: a cornerstone tree with bucket_size_focus over ALL local particles, halos included, as an OctreeNsView
+     * (R/tree/octree.hpp:297-317) -- what cstone_hip_find_neighbors / find_neighbors_groups / compute_group_splits
+     * take.  layout[i] = index in the result arrays of the first particle of leaf i.  Built on the first request after
+     * a sync (device pointers, valid until the next sync); local call, no collective. */
+    typedef struct cstone_hip_domain_mr_octree
+    {
+        int32_t num_leaves, num_nodes;
+        const void* leaves;          /* K[num_leaves + 1] */
+        const uint32_t* leaf_counts; /* u32[num_leaves] */
+        const void* prefixes;        /* K[num_nodes] */
+        const int32_t* child_offsets;
+        const int32_t* parents;
+        const int32_t* level_range;
+        const int32_t* internal_to_leaf;
+        const int32_t* leaf_to_internal;
+        const uint32_t* layout; /* u32[num_leaves + 1] */
+        const void* centers;    /* T[num_nodes][3] */
+        const void* sizes;      /* T[num_nodes][3] */
+    } cstone_hip_domain_mr_octree;
+    int cstone_hip_domain_mr_octree_get(cstone_hip_domain_mr* dom, cstone_hip_domain_mr_octree* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -246,6 +246,17 @@ def main():
         # neighbour completeness
         lx, ly, lz, lh = [r[k].cpu().numpy() for k in "xyzh"]
         local_sum = neighbor_sum(o, lx, ly, lz, lh, st, en, r["lim"], bc)
+        if a.impl == "native":
+            # Domain::octreeProperties(): the domain's own tree over local + halo particles feeds the neighbor search
+            import cstone_amd
+
+            oc = dom.octree()
+            lay = oc["layout"]
+            ok &= int(lay[0]) == 0 and int(lay[-1]) == r["x"].numel() and oc["num_leaves"] == lay.numel() - 1
+            _, nc = backend.ctx.find_neighbors(r["x"], r["y"], r["z"], r["h"], st, en, cstone_amd.make_cbox(r["lim"], bc),
+                                               oc, lay, oc["centers"], oc["sizes"], 0)
+            ok &= int(nc.long().sum().item()) == local_sum
+            ok &= int(oc["leaf_counts"].max().item()) <= 16 or s > 0  # bucketFocus 16: converged on the first request
         tsum = torch.tensor([local_sum], dtype=torch.int64)
         dist.all_reduce(tsum)
         # the undistributed cloud at this step: gather the assigned particles of every rank
