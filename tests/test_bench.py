@@ -1,0 +1,57 @@
+"""bench.py keeps its contract (GPU): one JSON line with the agreed keys on one rank, and the N-rank code path
+(cstone_hip_domain_mr_sync under torch.distributed.run) runs end to end -- rehearsed here with two gloo ranks that share
+the one GPU of the test box (numbers meaningless, control flow identical to the RCCL run)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def _json_line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_contract():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--particles", "2e6", "--steps", "2", "--warmup", "1",
+           "--cpu-sample", "2e5", "--neighbor-targets", "1e5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    for k in KEYS + ["cpu_baseline"]:
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["vs_baseline"] is None
+    assert j["value"] > 0 and abs(j["value"] - 2e6 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+    assert "workload" in j["config"] and "model" not in j["config"]
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = j["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal():
+    env = dict(os.environ, CSTONE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29790", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--particles", "2e6",
+           "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    for k in KEYS:
+        assert k in j, k
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and "cpu_baseline" not in j
+    assert j["config"]["particles_per_gpu"] == 1000000
+    assert j["config"]["orchestration"].startswith("libcstone_hip")
+    # both exchanges moved data: particles changed owner and halos were served
+    ex = j["config"]["rank0_exchange"]
+    assert ex["halos"] > 0 and j["config"]["rank0_assigned"] > 0
