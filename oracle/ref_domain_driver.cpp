@@ -13,8 +13,19 @@ using namespace cstone;
 
 namespace
 {
+//! type-erased access to Domain<K, T, CpuTag>; arrays cross the C boundary as raw bytes of K resp. T
+struct HolderBase
+{
+    virtual ~HolderBase() = default;
+    virtual void set(size_t n, const void* x, const void* y, const void* z, const void* h, const void* keysIn) = 0;
+    virtual void sync()                                                                                        = 0;
+    virtual void info(long* out)                                                                               = 0;
+    virtual void get(void* keys, void* x, void* y, void* z, void* h, void* globalLeaves, void* focusLeaves,
+                     unsigned* focusCounts, unsigned* layout)                                                  = 0;
+};
+
 template<class K, class T>
-struct Holder
+struct Holder final : HolderBase
 {
     Domain<K, T, CpuTag> dom;
     std::vector<K> keys;
@@ -24,8 +35,47 @@ struct Holder
         : dom(0, 1, bucket, bucketFocus, theta, box)
     {
     }
+    void set(size_t n, const void* xi, const void* yi, const void* zi, const void* hi, const void* keysIn) override
+    {
+        auto* px = (const T*)xi;
+        auto* py = (const T*)yi;
+        auto* pz = (const T*)zi;
+        auto* ph = (const T*)hi;
+        x.assign(px, px + n), y.assign(py, py + n), z.assign(pz, pz + n), h.assign(ph, ph + n);
+        if (keysIn) keys.assign((const K*)keysIn, (const K*)keysIn + n);
+        else keys.assign(n, 0);
+    }
+    void sync() override { dom.sync(keys, x, y, z, h, std::tuple{}, std::tie(s1, s2, s3)); }
+    void info(long* out) override
+    {
+        out[0] = dom.startIndex();
+        out[1] = dom.endIndex();
+        out[2] = dom.nParticlesWithHalos();
+        out[3] = dom.globalTree().numLeafNodes();
+        out[4] = dom.focusTree().treeLeaves().size() - 1;
+        auto b = dom.box();
+        double lim[6] = {double(b.xmin()), double(b.xmax()), double(b.ymin()),
+                         double(b.ymax()), double(b.zmin()), double(b.zmax())};
+        std::memcpy(out + 8, lim, sizeof lim);
+    }
+    void get(void* ko, void* xo, void* yo, void* zo, void* ho, void* globalLeaves, void* focusLeaves,
+             unsigned* focusCounts, unsigned* layout) override
+    {
+        std::copy(keys.begin(), keys.end(), (K*)ko);
+        std::copy(x.begin(), x.end(), (T*)xo);
+        std::copy(y.begin(), y.end(), (T*)yo);
+        std::copy(z.begin(), z.end(), (T*)zo);
+        std::copy(h.begin(), h.end(), (T*)ho);
+        auto gl = dom.globalTree().treeLeaves();
+        std::copy(gl.begin(), gl.end(), (K*)globalLeaves);
+        auto fl = dom.focusTree().treeLeaves();
+        std::copy(fl.begin(), fl.end(), (K*)focusLeaves);
+        auto fc = dom.focusTree().leafCounts();
+        std::copy(fc.begin(), fc.end(), focusCounts);
+        auto lo = dom.layout();
+        std::copy(lo.begin(), lo.end(), layout);
+    }
 };
-using H64 = Holder<uint64_t, double>;
 
 void ensureMpi()
 {
@@ -33,68 +83,56 @@ void ensureMpi()
     MPI_Initialized(&init);
     if (!init) MPI_Init(nullptr, nullptr);
 }
+
+template<class K, class T>
+HolderBase* make(unsigned bucket, unsigned bucketFocus, float theta, const double* lim, const int* bc)
+{
+    Box<T> box(static_cast<T>(lim[0]), static_cast<T>(lim[1]), static_cast<T>(lim[2]), static_cast<T>(lim[3]),
+               static_cast<T>(lim[4]), static_cast<T>(lim[5]), static_cast<BoundaryType>(bc[0]),
+               static_cast<BoundaryType>(bc[1]), static_cast<BoundaryType>(bc[2]));
+    return new Holder<K, T>(bucket, bucketFocus, theta, box);
+}
 } // namespace
 
 extern "C"
 {
 
-void* cstone_refdom_create(unsigned bucket, unsigned bucketFocus, float theta, const double* lim, const int* bc)
+//! key_bits in {32, 64}, real_bits in {32, 64}: the instantiation of cstone::Domain to run
+void* cstone_refdom_create_typed(int key_bits, int real_bits, unsigned bucket, unsigned bucketFocus, float theta,
+                                 const double* lim, const int* bc)
 {
     ensureMpi();
-    Box<double> box(lim[0], lim[1], lim[2], lim[3], lim[4], lim[5], BoundaryType(bc[0]), BoundaryType(bc[1]),
-                    BoundaryType(bc[2]));
-    return new H64(bucket, bucketFocus, theta, box);
+    if (key_bits == 64 && real_bits == 64) return make<uint64_t, double>(bucket, bucketFocus, theta, lim, bc);
+    if (key_bits == 64 && real_bits == 32) return make<uint64_t, float>(bucket, bucketFocus, theta, lim, bc);
+    if (key_bits == 32 && real_bits == 64) return make<unsigned, double>(bucket, bucketFocus, theta, lim, bc);
+    if (key_bits == 32 && real_bits == 32) return make<unsigned, float>(bucket, bucketFocus, theta, lim, bc);
+    return nullptr;
 }
 
-void cstone_refdom_destroy(void* p) { delete (H64*)p; }
-
-//! set the particle arrays (size n); keys_in may carry remove markers (nullptr = all zero)
-void cstone_refdom_set(void* p, size_t n, const double* x, const double* y, const double* z, const double* h,
-                       const uint64_t* keys_in)
+void* cstone_refdom_create(unsigned bucket, unsigned bucketFocus, float theta, const double* lim, const int* bc)
 {
-    auto* d = (H64*)p;
-    d->x.assign(x, x + n), d->y.assign(y, y + n), d->z.assign(z, z + n), d->h.assign(h, h + n);
-    if (keys_in) d->keys.assign(keys_in, keys_in + n);
-    else d->keys.assign(n, 0);
+    return cstone_refdom_create_typed(64, 64, bucket, bucketFocus, theta, lim, bc);
 }
 
-void cstone_refdom_sync(void* p)
+void cstone_refdom_destroy(void* p) { delete (HolderBase*)p; }
+
+//! set the particle arrays (size n, elements of the domain's real type); keys_in may carry remove markers (nullptr =
+//! all zero)
+void cstone_refdom_set(void* p, size_t n, const void* x, const void* y, const void* z, const void* h,
+                       const void* keys_in)
 {
-    auto* d = (H64*)p;
-    d->dom.sync(d->keys, d->x, d->y, d->z, d->h, std::tuple{}, std::tie(d->s1, d->s2, d->s3));
+    ((HolderBase*)p)->set(n, x, y, z, h, keys_in);
 }
 
-//! out[0..] = startIndex, endIndex, nParticlesWithHalos, numGlobalLeaves, numFocusLeaves
-void cstone_refdom_info(void* p, long* out)
-{
-    auto* d = (H64*)p;
-    out[0]  = d->dom.startIndex();
-    out[1]  = d->dom.endIndex();
-    out[2]  = d->dom.nParticlesWithHalos();
-    out[3]  = d->dom.globalTree().numLeafNodes();
-    out[4]  = d->dom.focusTree().treeLeaves().size() - 1;
-    auto b  = d->dom.box();
-    double lim[6] = {b.xmin(), b.xmax(), b.ymin(), b.ymax(), b.zmin(), b.zmax()};
-    std::memcpy(out + 8, lim, sizeof lim);
-}
+void cstone_refdom_sync(void* p) { ((HolderBase*)p)->sync(); }
 
-void cstone_refdom_get(void* p, uint64_t* keys, double* x, double* y, double* z, double* h, uint64_t* globalLeaves,
-                       uint64_t* focusLeaves, unsigned* focusCounts, unsigned* layout)
+//! out[0..] = startIndex, endIndex, nParticlesWithHalos, numGlobalLeaves, numFocusLeaves; out[8..13] = box as doubles
+void cstone_refdom_info(void* p, long* out) { ((HolderBase*)p)->info(out); }
+
+void cstone_refdom_get(void* p, void* keys, void* x, void* y, void* z, void* h, void* globalLeaves, void* focusLeaves,
+                       unsigned* focusCounts, unsigned* layout)
 {
-    auto* d = (H64*)p;
-    std::copy(d->keys.begin(), d->keys.end(), keys);
-    std::copy(d->x.begin(), d->x.end(), x);
-    std::copy(d->y.begin(), d->y.end(), y);
-    std::copy(d->z.begin(), d->z.end(), z);
-    std::copy(d->h.begin(), d->h.end(), h);
-    auto gl = d->dom.globalTree().treeLeaves();
-    std::copy(gl.begin(), gl.end(), globalLeaves);
-    auto fl = d->dom.focusTree().treeLeaves();
-    std::copy(fl.begin(), fl.end(), focusLeaves);
-    auto fc = d->dom.focusTree().leafCounts();
-    std::copy(fc.begin(), fc.end(), focusCounts);
-    auto lo = d->dom.layout();
-    std::copy(lo.begin(), lo.end(), layout);
+    ((HolderBase*)p)->get(keys, x, y, z, h, globalLeaves, focusLeaves, focusCounts, layout);
 }
 
 } // extern "C"

@@ -1,5 +1,5 @@
 """Domain::sync parity (GPU): cstone_hip_domain_* against fixtures produced by the reference's own
-cstone::Domain<uint64_t,double,CpuTag> on one rank (tests/golden/make_golden_domain.py), step by step with moving
+cstone::Domain<KeyType,T,CpuTag> (all four combinations of 32-/64-bit keys and float/double) on one rank (tests/golden/make_golden_domain.py), step by step with moving
 particles, shrinking boxes, periodic axes and particle removal.  Everything is compared bit-for-bit, exactly as the
 reference's own GPU-vs-CPU integration test does (test/integration_mpi/domain_gpu.cpp:117-136)."""
 import glob
@@ -21,15 +21,20 @@ def test_domain_sync_matches_reference(hip, path):
     from cstone_amd.domain import Domain
 
     d = np.load(path)
+    kb = int(d["key_bits"]) if "key_bits" in d else 64
+    rb = int(d["real_bits"]) if "real_bits" in d else 64
+    kdt, ksigned = (np.uint64, np.int64) if kb == 64 else (np.uint32, np.int32)
     box = cstone_amd.make_cbox(d["lim"], d["bc"])
-    dom = Domain(hip, cstone_amd.HILBERT, 64, 64, int(d["bucket"]), int(d["bucket_focus"]), 0.5, box)
+    dom = Domain(hip, cstone_amd.HILBERT, kb, rb, int(d["bucket"]), int(d["bucket_focus"]), 0.5, box)
     for s in range(int(d["steps"])):
         x, y, z, h = [torch.from_numpy(d[f"in{s}_{c}"].copy()).cuda() for c in "xyzh"]
+        assert x.element_size() * 8 == rb
         n = x.numel()
-        kin = d[f"in{s}_keys"] if f"in{s}_keys" in d else np.zeros(n, np.uint64)
-        keys = torch.from_numpy(kin.view(np.int64).copy()).cuda()
+        kin = d[f"in{s}_keys"] if f"in{s}_keys" in d else np.zeros(n, kdt)
+        keys = torch.from_numpy(kin.view(ksigned).copy()).cuda()
         scratch = torch.empty_like(x)
-        tag = torch.arange(n, dtype=torch.float64, device="cuda")  # a conserved property travelling along
+        # a conserved property travelling along (not wider than the coordinates: it shares their scratch buffer)
+        tag = torch.arange(n, dtype=torch.float64 if rb == 64 else torch.float32, device="cuda")
         late = [torch.stack([x, y, z], dim=1).to(torch.float32).contiguous(), (h * 1e3).to(torch.int16)]
         keys, x, y, z, h, scratch, props = dom.sync(keys, x, y, z, h, scratch, [tag])
         # reapplySync (domain.hpp:334-378): fields that were not part of the sync are brought into the new order later
@@ -44,15 +49,15 @@ def test_domain_sync_matches_reference(hip, path):
             info.tolist(), s
         assert np.array_equal(np.array(list(v.box.lim)), d[f"out{s}_box"]), s
         m = int(info[2])
-        assert np.array_equal(keys.cpu().numpy().view(np.uint64), d[f"out{s}_keys"])
+        assert np.array_equal(keys.cpu().numpy().view(kdt), d[f"out{s}_keys"])
         for t, c in ((x, "x"), (y, "y"), (z, "z"), (h, "h")):
             assert np.array_equal(t.cpu().numpy(), d[f"out{s}_{c}"]), (s, c)
         # the property followed its particle: tag[i] is the input index of output particle i
         src = props[0].cpu().numpy().astype(np.int64)
         assert np.array_equal(d[f"in{s}_x"][src], d[f"out{s}_x"])
         ngl, nfl = int(info[3]), int(info[4])
-        assert np.array_equal(dom.fetch(v.global_leaves, ngl + 1, np.uint64), d[f"out{s}_global_leaves"])
-        assert np.array_equal(dom.fetch(v.focus_leaves, nfl + 1, np.uint64), d[f"out{s}_focus_leaves"])
+        assert np.array_equal(dom.fetch(v.global_leaves, ngl + 1, kdt), d[f"out{s}_global_leaves"])
+        assert np.array_equal(dom.fetch(v.focus_leaves, nfl + 1, kdt), d[f"out{s}_focus_leaves"])
         assert np.array_equal(dom.fetch(v.focus_leaf_counts, nfl, np.uint32), d[f"out{s}_focus_counts"])
         assert np.array_equal(dom.fetch(v.layout, nfl + 1, np.uint32), d[f"out{s}_layout"])
         assert dom.fetch(v.halo_flags, nfl, np.int32).sum() == 0  # one rank: no halos
