@@ -68,10 +68,10 @@ def check_reapply(dom, late, r):
     return ok
 
 
-def make_native(backend, bucket, bucket_focus, lim, bc, curve=1, key_bits=64):
+def make_native(backend, bucket, bucket_focus, lim, bc, curve=1, key_bits=64, real_bits=64):
     from cstone_amd.distributed import NativeDistributedDomain
 
-    return NativeDistributedDomain(backend.ctx, curve, key_bits, 64, bucket, bucket_focus, lim, bc)
+    return NativeDistributedDomain(backend.ctx, curve, key_bits, real_bits, bucket, bucket_focus, lim, bc)
 
 
 def golden(a, backend, dev, rank, P):
@@ -84,28 +84,33 @@ def golden(a, backend, dev, rank, P):
     assert int(g["P"]) == P, "launch with the fixture's number of ranks"
     mine = np.nonzero(g["owner"] == rank)[0]
     x, y, z, h = [torch.from_numpy(g[k][mine].copy()).to(dev) for k in "xyzh"]
+    kb = int(g["key_bits"]) if "key_bits" in g else 64  # the instantiation Domain<KeyType, T> the fixture was made with
+    rb = int(g["real_bits"]) if "real_bits" in g else 64
+    kdt = np.uint64 if kb == 64 else np.uint32
+    assert x.element_size() * 8 == rb
     if a.impl == "native":
         dom = make_native(backend, int(g["bucket"]), int(g["bucket_focus"]), g["lim"].tolist(),
-                          tuple(int(v) for v in g["bc"]))
+                          tuple(int(v) for v in g["bc"]), key_bits=kb, real_bits=rb)
     else:
-        dom = DistributedDomain(backend, Comm(), orc.HILBERT, 64, 64, bucket=int(g["bucket"]),
+        dom = DistributedDomain(backend, Comm(), orc.HILBERT, kb, rb, bucket=int(g["bucket"]),
                                 bucket_focus=int(g["bucket_focus"]), box_lim=g["lim"].tolist(),
                                 box_bc=tuple(int(v) for v in g["bc"]))
     bad, halo_stats = [], []
-    c, top = 0.01, 1.0 - 2.0**-30
+    # the motion of oracle/ref_domain_mpi.cpp, in the fixture's real type (separately rounded operations)
+    c, top = 0.01, (1.0 - 2.0**-30 if rb == 64 else float(np.float32(1.0 - 2.0**-20)))
     for s in range(int(g["syncs"])):
         r = dom.sync(x, y, z, h)
         st, en = r["start"], r["end"]
-        keys = r["keys"].cpu().numpy().view(np.uint64)[st:en]
+        keys = r["keys"].cpu().numpy().view(kdt)[st:en]
         if a.impl == "native":
             v = dom.view()
             rng_ = [v.range_start, v.range_end]
-            gl = dom.fetch(v.global_leaves, v.num_global_leaves + 1, np.uint64)
+            gl = dom.fetch(v.global_leaves, v.num_global_leaves + 1, kdt)
             gc = dom.fetch(v.global_counts, v.num_global_leaves, np.uint32)
         else:
             L = dom.g_leaves
             rng_ = [dom.assignment[rank], dom.assignment[rank + 1]]
-            gl = backend.keys_to_numpy(dom.gtree[:L + 1], 64)
+            gl = backend.keys_to_numpy(dom.gtree[:L + 1], kb)
             gc = backend.to_numpy(dom.gcounts[:L]).view(np.uint32)
         checks = {
             "lim": np.array_equal(r["lim"], g[f"s{s}_r{rank}_lim"]),

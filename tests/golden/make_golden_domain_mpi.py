@@ -31,8 +31,14 @@ def cloud(n, seed, kind):
     return pos, h, owner
 
 
-def run(P, n, syncs, bucket, bucket_focus, bc, kind, seed):
+def run(P, n, syncs, bucket, bucket_focus, bc, kind, seed, key_bits=64, real_bits=64):
+    kdt = np.uint64 if key_bits == 64 else np.uint32
+    rdt = np.float64 if real_bits == 64 else np.float32
+    ks, rs = key_bits // 8, real_bits // 8
     pos, h, owner = cloud(n, seed, kind)
+    if real_bits == 32:  # the driver narrows on reading: keep the fixture's inputs exactly what the domain sees
+        pos = np.minimum(pos.astype(rdt), rdt(1.0 - 2.0**-20)).astype(np.float64)
+        h = h.astype(rdt).astype(np.float64)
     owner = (owner % P).astype(np.int32)
     lim = np.array([0, 1, 0, 1, 0, 1], dtype=np.float64)
     with tempfile.TemporaryDirectory() as tmp:
@@ -44,9 +50,11 @@ def run(P, n, syncs, bucket, bucket_focus, bc, kind, seed):
                 f.write(np.ascontiguousarray(pos[:, d]).tobytes())
             f.write(h.tobytes())
             f.write(owner.tobytes())
-        subprocess.run([MPIEXEC, "-n", str(P), EXE, inp, os.path.join(tmp, "out")], check=True, timeout=600)
+        subprocess.run([MPIEXEC, "-n", str(P), EXE, inp, os.path.join(tmp, "out"), f"k{key_bits}f{real_bits}"],
+                       check=True, timeout=600)
         out = dict(n=n, P=P, syncs=syncs, bucket=bucket, bucket_focus=bucket_focus, bc=np.array(bc), lim=lim,
-                   x=pos[:, 0].copy(), y=pos[:, 1].copy(), z=pos[:, 2].copy(), h=h, owner=owner)
+                   x=pos[:, 0].astype(rdt), y=pos[:, 1].astype(rdt), z=pos[:, 2].astype(rdt), h=h.astype(rdt),
+                   owner=owner, key_bits=key_bits, real_bits=real_bits)
         for r in range(P):
             raw = open(os.path.join(tmp, f"out.rank{r}.bin"), "rb").read()
             off = 0
@@ -55,15 +63,15 @@ def run(P, n, syncs, bucket, bucket_focus, bc, kind, seed):
                 st, en, wh, L, _ = [int(v) for v in info]
                 out[f"s{s}_r{r}_info"] = info.copy()
                 out[f"s{s}_r{r}_lim"] = np.frombuffer(raw, np.float64, 6, off).copy(); off += 48
-                out[f"s{s}_r{r}_range"] = np.frombuffer(raw, np.uint64, 2, off).copy(); off += 16
-                leaves = np.frombuffer(raw, np.uint64, L + 1, off).copy(); off += 8 * (L + 1)
+                out[f"s{s}_r{r}_range"] = np.frombuffer(raw, kdt, 2, off).copy(); off += 2 * ks
+                leaves = np.frombuffer(raw, kdt, L + 1, off).copy(); off += ks * (L + 1)
                 off += 4 * (L + (L & 1))
                 m = en - st
-                out[f"s{s}_r{r}_keys"] = np.frombuffer(raw, np.uint64, m, off).copy(); off += 8 * m
-                out[f"s{s}_r{r}_x"] = np.frombuffer(raw, np.float64, m, off).copy(); off += 8 * m
-                out[f"s{s}_r{r}_h"] = np.frombuffer(raw, np.float64, m, off).copy(); off += 8 * m
+                out[f"s{s}_r{r}_keys"] = np.frombuffer(raw, kdt, m, off).copy(); off += ks * m
+                out[f"s{s}_r{r}_x"] = np.frombuffer(raw, rdt, m, off).copy(); off += rs * m
+                out[f"s{s}_r{r}_h"] = np.frombuffer(raw, rdt, m, off).copy(); off += rs * m
                 nh = wh - m
-                out[f"s{s}_r{r}_halos"] = np.frombuffer(raw, np.float64, 3 * nh, off).reshape(3, nh).copy(); off += 24 * nh
+                out[f"s{s}_r{r}_halos"] = np.frombuffer(raw, rdt, 3 * nh, off).reshape(3, nh).copy(); off += 3 * rs * nh
                 if r == 0:
                     out[f"s{s}_leaves"] = leaves
             assert off == len(raw)
@@ -90,6 +98,11 @@ if __name__ == "__main__":
                                               kind="uniform", seed=104),
         "ref_domain_mpi_P8_blobs_open": dict(P=8, n=9600, syncs=3, bucket=32, bucket_focus=8, bc=(0, 0, 0),
                                              kind="blobs", seed=105),
+        # the other instantiations of Domain<KeyType, T>
+        "ref_domain_mpi_P3_k32_f32_blobs_open": dict(P=3, n=12000, syncs=3, bucket=64, bucket_focus=8, bc=(0, 0, 0),
+                                                     kind="blobs", seed=106, key_bits=32, real_bits=32),
+        "ref_domain_mpi_P2_k64_f32_uniform_pbc": dict(P=2, n=10000, syncs=3, bucket=64, bucket_focus=16, bc=(1, 1, 1),
+                                                      kind="uniform", seed=107, key_bits=64, real_bits=32),
     }
     only = sys.argv[1:]
     cases = {k: v for k, v in cases.items() if not only or k in only}
