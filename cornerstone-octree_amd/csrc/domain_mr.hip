@@ -317,7 +317,7 @@ public:
         if (firstCall_) return fail(ctx_, CSTONE_E_ARG, "reapply_sync: no sync yet");
         if (n != rsN_) // checkSizesEqual(prevBufDesc_.size, arrays...), R/domain/domain.hpp:341
             return fail(ctx_, CSTONE_E_ARG, "reapply_sync: array of %zu elements, the last sync took %zu", n, size_t(rsN_));
-        if (!in || !out) return fail(ctx_, CSTONE_E_ARG, "reapply_sync: null array");
+        if ((n && !in) || !out) return fail(ctx_, CSTONE_E_ARG, "reapply_sync: null array");
         const size_t e        = size_t(elemBytes);
         const uint32_t* keptO = order_.as<uint32_t>() + rsKeptOffset_;
         char* dst             = static_cast<char*>(out) + size_t(view_.start_index) * e;
@@ -399,7 +399,7 @@ public:
     {
         if (numProps < 0 || numProps > MAX_PROPS) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: at most %d properties", MAX_PROPS);
         for (int q = 0; q < numProps; ++q)
-            if (!props[q] || (propBytes[q] != 4 && propBytes[q] != 8))
+            if ((n && !props[q]) || (propBytes[q] != 4 && propBytes[q] != 8)) // an empty rank may pass null arrays
                 return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: property %d must be a 4- or 8-byte array", q);
         const T* x = static_cast<const T*>(xIn);
         const T* y = static_cast<const T*>(yIn);
@@ -610,8 +610,11 @@ public:
 
         // ---- this rank's finest tree over its assigned particles; its SFC range must end on leaf boundaries
         CS_TRY(updateFocusTree(keysM, nm));
+        tick("5a focus update");
         CS_TRY(enforceBoundaries(keysM, nm));
+        tick("5b boundaries");
         CS_TRY(buildFocusOctree());
+        tick("5c linked octree");
         {
             NodeIdx lr[32];
             CS_TRY(toHost(lr, fLevelRange_.p, (maxLevel<K>() + 2) * sizeof(NodeIdx)));

@@ -771,7 +771,7 @@ class NativeDistributedDomain:
     def exchange_halos(self, field):
         """Domain::exchangeHalos: field (tensor of num_particles_with_halos 4- or 8-byte elements, laid out like the
         result arrays) gets its halo ranges overwritten with the owners' values"""
-        elem = field.element_size() * (field[0].numel() if field.dim() > 1 and field.shape[0] else 1)
+        elem = field.element_size() * (int(np.prod(field.shape[1:])) if field.dim() > 1 else 1)
         rc = self.ctx.lib.cstone_hip_domain_mr_exchange_halos(self.h, C.c_void_p(field.data_ptr()), C.c_int(elem))
         if rc != 0 and self.coll.error is not None:
             err, self.coll.error = self.coll.error, None
@@ -806,7 +806,7 @@ class NativeDistributedDomain:
         """Domain::reapplySync: field (laid out like the INPUT arrays of the last sync, rows of 1..32 bytes) follows its
         particles; returns a tensor laid out like the result arrays whose assigned range is filled"""
         torch = _torch()
-        row = field[0].numel() if field.dim() > 1 and field.shape[0] else 1
+        row = int(np.prod(field.shape[1:])) if field.dim() > 1 else 1
         elem = field.element_size() * row
         v = self.view()
         out = torch.zeros((v.num_particles_with_halos,) + tuple(field.shape[1:]), dtype=field.dtype, device=field.device)

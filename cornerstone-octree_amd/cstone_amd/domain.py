@@ -65,7 +65,7 @@ class Domain:
         """Domain::reapplySync: field (n rows of the last sync's input, 1..32 bytes each) in the order of the result"""
         import torch
 
-        row = field[0].numel() if field.dim() > 1 and field.shape[0] else 1
+        row = int(np.prod(field.shape[1:])) if field.dim() > 1 else 1
         v = self.view()
         out = torch.zeros((v.num_particles_with_halos,) + tuple(field.shape[1:]), dtype=field.dtype, device=field.device)
         rc = self.ctx.lib.cstone_hip_domain_reapply_sync(self.h, C.c_void_p(field.data_ptr()), C.c_size_t(field.shape[0]),

@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--golden", default="", help="fixture of tests/golden/make_golden_domain_mpi.py to reproduce")
     ap.add_argument("--key-bits", type=int, default=64)
     ap.add_argument("--curve", default="hilbert", choices=["hilbert", "morton"])
+    ap.add_argument("--lopsided", type=int, default=0, help="1: the last rank starts without particles")
     ap.add_argument("--impl", default="python", choices=["python", "native"],
                     help="python: cstone_amd.distributed.DistributedDomain; native: cstone_hip_domain_mr_* (hip only)")
     a = ap.parse_args()
@@ -193,6 +194,8 @@ def main():
     pos = np.clip(pos, 0.0, 1.0 - 1e-9)
     hglob = 0.035 * rng.uniform(0.6, 1.2, N)
     owner = rng.integers(0, P, N)  # random initial ownership: worst-case first exchange
+    if a.lopsided and P > 1:
+        owner = owner % (P - 1)  # the last rank brings nothing to the first sync
     vel = rng.normal(0, 0.004, (N, 3))
 
     mine = np.nonzero(owner == rank)[0]

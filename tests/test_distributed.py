@@ -77,6 +77,18 @@ def test_gloo_ranks_hip_backend(nproc, pbc):
         assert step["neighbors"] == step["found"] and step["neighbors"] > 0
 
 
+def test_rank_that_starts_empty_cpu_backend():
+    """a rank may bring no particles to the first sync (the reference's domain_nranks tests extract per-rank slices that
+    can be empty): it receives its share through the exchange like everybody else"""
+    _launch(3, "cpu", 6000, 2, 0, 29640, extra=["--lopsided", "1"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("impl", ["python", "native"])
+def test_rank_that_starts_empty_hip(impl):
+    _launch(3, "hip", 30000, 2, 1, 29645, impl=impl, extra=["--lopsided", "1"])
+
+
 GOLDEN_MPI = [("ref_domain_mpi_P2_uniform_open.npz", 2), ("ref_domain_mpi_P3_blobs_pbc.npz", 3),
               ("ref_domain_mpi_P4_blobs_open.npz", 4),
               # Domain<unsigned, float> and Domain<uint64_t, float>
