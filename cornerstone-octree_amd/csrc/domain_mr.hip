@@ -669,7 +669,7 @@ public:
                                 "all_gather (halo boxes)"));
             }
             CS_TRY(oflags_.ensure(ctx_, size_t(L) * sizeof(int32_t)));
-            if (maxBoxes && P_ <= 32)
+            if (maxBoxes && P_ <= 32 && !peerLoop_)
             {
                 // all peers in one go: the records carry their exporter, find_overlaps sets one bit per exporter
                 // (two calls: the records before and behind my own); then counts, one scan and one fill for all peers
@@ -1214,6 +1214,7 @@ private:
     float haloExt_  = 1.0f;
     bool firstCall_ = true;
     bool timing_    = std::getenv("CSTONE_MR_TIMING") != nullptr;
+    bool peerLoop_  = std::getenv("CSTONE_MR_PEER_LOOP") != nullptr; // tests: take the > 32 ranks path (one traversal per peer)
     int syncs_      = 0;
     std::map<std::string, double> phase_;
     std::chrono::steady_clock::time_point t0_;

@@ -84,6 +84,14 @@ def test_rank_that_starts_empty_cpu_backend():
 
 
 @pytest.mark.gpu
+def test_native_domain_one_traversal_per_peer(monkeypatch):
+    """beyond 32 ranks the exporter bit mask does not fit and the halo discovery serves one peer at a time; the path is
+    forced here on 3 ranks"""
+    monkeypatch.setenv("CSTONE_MR_PEER_LOOP", "1")
+    _launch(3, "hip", 40000, 2, 1, 29648, impl="native")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("impl", ["python", "native"])
 def test_rank_that_starts_empty_hip(impl):
     _launch(3, "hip", 30000, 2, 1, 29645, impl=impl, extra=["--lopsided", "1"])
