@@ -557,8 +557,9 @@ public:
         //      previous sync).  The arrays handed out start at M - (halos of lower ranks).
         cur_ ^= 1; // the inputs may live in the other buffer set
         Out& o           = out_[cur_];
-        const uint64_t M = P_ > 1 ? std::max<uint64_t>(2 * prevLo_ + 4096, firstCall_ ? nm / 4 : 0) : 0;
-        uint64_t cap     = M + nm + (P_ > 1 ? std::max<uint64_t>(2 * prevHi_ + 4096, firstCall_ ? nm / 4 : 0) : 0);
+        const bool margins = P_ > 1 && !noMargin_;
+        const uint64_t M   = margins ? std::max<uint64_t>(2 * prevLo_ + 4096, firstCall_ ? nm / 4 : 0) : 0;
+        uint64_t cap       = M + nm + (margins ? std::max<uint64_t>(2 * prevHi_ + 4096, firstCall_ ? nm / 4 : 0) : 0);
         CS_TRY(o.keys.ensure(ctx_, cap * sizeof(K)));
         for (DevBuf* b : {&o.x, &o.y, &o.z, &o.h})
             CS_TRY(b->ensure(ctx_, cap * sizeof(T)));
@@ -1214,6 +1215,7 @@ private:
     float haloExt_  = 1.0f;
     bool firstCall_ = true;
     bool timing_    = std::getenv("CSTONE_MR_TIMING") != nullptr;
+    bool noMargin_  = std::getenv("CSTONE_MR_NO_MARGIN") != nullptr; // tests: no room left for halos, the block is moved
     bool peerLoop_  = std::getenv("CSTONE_MR_PEER_LOOP") != nullptr; // tests: take the > 32 ranks path (one traversal per peer)
     int syncs_      = 0;
     std::map<std::string, double> phase_;

@@ -84,6 +84,14 @@ def test_rank_that_starts_empty_cpu_backend():
 
 
 @pytest.mark.gpu
+def test_native_domain_without_halo_margins(monkeypatch):
+    """the assigned block is written before the halo counts are known, at an offset that normally leaves room for the
+    halos of the lower ranks; with no room at all the block has to be moved once (the fallback of abrupt changes)"""
+    monkeypatch.setenv("CSTONE_MR_NO_MARGIN", "1")
+    _launch(3, "hip", 40000, 3, 0, 29649, impl="native")
+
+
+@pytest.mark.gpu
 def test_native_domain_one_traversal_per_peer(monkeypatch):
     """beyond 32 ranks the exporter bit mask does not fit and the halo discovery serves one peer at a time; the path is
     forced here on 3 ranks"""
