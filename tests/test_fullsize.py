@@ -131,3 +131,73 @@ def test_neighbors_plummer_sample_against_oracle(hip, oracle):
         assert np.array_equal(c_got, c_ref)
         mask = np.arange(ngmax)[None, :] < np.minimum(c_ref, ngmax)[:, None]
         assert np.array_equal(n_got[mask], n_ref[mask])
+
+
+def test_domain_sync_1e8_plummer_with_neighbors(hip):
+    """BASELINE configs[2]: 10^8 Plummer-sphere particles through Domain::sync (bucketSize 64: a deep, very uneven
+    tree), then findNeighbors on the domain's own octree; the neighbour counts of scattered targets are checked against a
+    brute-force pass over all 10^8 particles that evaluates the same IEEE operations in the same order"""
+    import math
+
+    import torch
+
+    import cstone_amd
+    from cstone_amd.domain import Domain
+
+    n, bucket_focus = 100_000_000, 64
+    g = torch.Generator(device="cuda").manual_seed(11)
+    u = torch.rand(n, dtype=torch.float64, device="cuda", generator=g).clamp_(1e-12, 1.0)
+    r = (u.pow(-2.0 / 3.0) - 1.0).clamp_min_(1e-12).rsqrt().clamp_(max=10.0)
+    ct = 2 * torch.rand(n, dtype=torch.float64, device="cuda", generator=g) - 1
+    ph = 2 * math.pi * torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    st = (1 - ct * ct).sqrt()
+    x, y, z = r * st * ph.cos(), r * st * ph.sin(), r * ct
+    rho = 3.0 * n / (4 * math.pi) * (1 + r * r).pow(-2.5)
+    h = (0.5 * (3.0 * 100.0 / (4 * math.pi * rho)).pow(1 / 3)).clamp_(max=1.0)
+    del u, r, ct, ph, st, rho
+    ident = x * 3.0 + y * 5.0 + z * 7.0 + h
+    keys = torch.zeros(n, dtype=torch.int64, device="cuda")
+    scratch = torch.empty(n, dtype=torch.float64, device="cuda")
+    box = cstone_amd.make_cbox([-10.001, 10.001] * 3)
+    dom = Domain(hip, cstone_amd.HILBERT, 64, 64, n // 100, bucket_focus, 0.5, box)
+    for sync in range(2):  # the second call takes the steady-state path (partial radix passes + run fix-up)
+        keys, x, y, z, h, scratch, (ident,) = dom.sync(keys, x, y, z, h, scratch, [ident])
+        hip.sync()
+        v = dom.view()
+        assert (v.start_index, v.end_index, v.num_particles_with_halos) == (0, n, n)
+        assert bool((keys[1:] >= keys[:-1]).all())
+        assert bool((hip.compute_sfc_keys(cstone_amd.HILBERT, 64, x, y, z, v.box) == keys).all())
+        assert bool((ident == x * 3.0 + y * 5.0 + z * 7.0 + h).all())
+    L = v.num_focus_leaves
+    counts = dom.fetch(v.focus_leaf_counts, L, np.uint32)
+    leaves = dom.fetch(v.focus_leaves, L + 1, np.uint64)
+    layout = dom.fetch(v.layout, L + 1, np.uint32)
+    assert int(counts.sum(dtype=np.uint64)) == n and counts.max() <= bucket_focus
+    assert leaves[0] == 0 and leaves[-1] == 1 << 63 and np.all(leaves[1:] > leaves[:-1])
+    assert np.array_equal(layout, np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)]).astype(np.uint32))
+    level = 21 - (np.log2(np.diff(leaves).astype(np.float64)) / 3).round().astype(int)
+    assert level.max() >= 10 and level.min() <= 4  # the core of the sphere needs a deep tree, the outskirts do not
+
+    # neighbor search on the domain's octree view (device pointers wrapped as tensors)
+    from cstone_amd.distributed import _DevMem
+
+    def wrap(ptr, dt, count):
+        return torch.as_tensor(_DevMem(ptr, count * torch.empty(0, dtype=dt).element_size()), device="cuda").view(dt)
+
+    M = v.num_focus_nodes
+    oc = dict(child_offsets=wrap(v.child_offsets, torch.int32, M + 1),
+              internal_to_leaf=wrap(v.internal_to_leaf, torch.int32, M))
+    lay = wrap(v.layout, torch.int32, L + 1)
+    cen, siz = wrap(v.centers, torch.float64, 3 * M), wrap(v.sizes, torch.float64, 3 * M)
+    rng = np.random.default_rng(3)
+    for first in (0, n // 2, int(rng.integers(0, n - 70000)), n - 65536):
+        last = first + 65536
+        _, nc = hip.find_neighbors(x, y, z, h, first, last, v.box, oc, lay, cen, siz, 0)
+        hip.sync()
+        assert 20 < float(nc.double().mean()) < 2000  # about 100 by construction; more on the r = 10 cut-off shell
+        for i in rng.integers(first, last, 6):
+            i = int(i)
+            dx, dy, dz = x - x[i], y - y[i], z - z[i]
+            d2 = dx * dx + dy * dy + dz * dz
+            brute = int((d2 < 4.0 * h[i] * h[i]).sum()) - 1
+            assert int(nc[i - first]) == brute, (i, int(nc[i - first]), brute)
