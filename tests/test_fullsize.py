@@ -201,3 +201,43 @@ def test_domain_sync_1e8_plummer_with_neighbors(hip):
             d2 = dx * dx + dy * dy + dz * dz
             brute = int((d2 < 4.0 * h[i] * h[i]).sum()) - 1
             assert int(nc[i - first]) == brute, (i, int(nc[i - first]), brute)
+
+
+def test_domain_sync_clustered_2p5e8(hip):
+    """twice the per-GPU share of BASELINE configs[4] (10^9 clustered particles on 8 GPUs) on one GPU: half the
+    particles in a uniform background, half in a few tight blobs; sizes beyond 2^27 exercise the 32-bit index arithmetic
+    of the sort tiles and the leaf layout"""
+    import torch
+
+    import cstone_amd
+    from cstone_amd.domain import Domain
+
+    n, bucket_focus = 250_000_000, 64
+    g = torch.Generator(device="cuda").manual_seed(23)
+    centers = torch.rand((6, 3), dtype=torch.float64, device="cuda", generator=g) * 0.6 + 0.2
+    which = torch.randint(0, 12, (n,), device="cuda", generator=g)  # 0..5: a blob, 6..11: background
+    cols = []
+    for d in range(3):
+        v = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+        blob = centers[which.clamp(max=5), d] + 0.01 * torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+        cols.append(torch.where(which < 6, blob, v).clamp_(0.0, 1.0))
+        del v, blob
+    x, y, z = cols
+    del cols, which
+    h = torch.full((n,), 1e-3, dtype=torch.float64, device="cuda")
+    sx = float(x.sum())
+    keys = torch.zeros(n, dtype=torch.int64, device="cuda")
+    scratch = torch.empty(n, dtype=torch.float64, device="cuda")
+    dom = Domain(hip, cstone_amd.HILBERT, 64, 64, n // 100, bucket_focus, 0.5, cstone_amd.make_cbox([0, 1] * 3))
+    for sync in range(2):
+        keys, x, y, z, h, scratch, _ = dom.sync(keys, x, y, z, h, scratch)
+        hip.sync()
+        v = dom.view()
+        assert (v.start_index, v.end_index, v.num_particles_with_halos) == (0, n, n)
+        assert bool((keys[1:] >= keys[:-1]).all())
+        assert bool((hip.compute_sfc_keys(cstone_amd.HILBERT, 64, x, y, z, v.box) == keys).all())
+        assert abs(float(x.sum()) - sx) <= 1e-9 * sx
+    L = v.num_focus_leaves
+    counts = dom.fetch(v.focus_leaf_counts, L, np.uint32)
+    layout = dom.fetch(v.layout, L + 1, np.uint32)
+    assert int(counts.sum(dtype=np.uint64)) == n and counts.max() <= bucket_focus and int(layout[-1]) == n
