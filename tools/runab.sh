@@ -6,7 +6,7 @@ for round in 1 2; do
     if [ $v = default ]; then lib=$PWD/cornerstone-octree_amd/lib/libcstone_hip.so; else lib=$PWD/cornerstone-octree_amd/lib/variants/$v.so; fi
     for args in "" "--sorted"; do
       echo "== $v $args" >> gpurun_out/ab.log
-      CSTONE_HIP_LIB=$lib timeout -k 10 100 python3 tools/sort_bench.py --reps 3 $args 2>&1 | tail -1 >> gpurun_out/ab.log
+      CSTONE_HIP_LIB=$lib timeout -k 10 100 python3 tools/sort_bench.py --reps 3 $args 2>&1 | grep "^pass:" >> gpurun_out/ab.log
     done
   done
 done
