@@ -36,6 +36,7 @@ def parse():
     p.add_argument("--curve", default="hilbert", choices=["hilbert", "morton"])
     p.add_argument("--bucket-focus", type=int, default=64)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-plummer", action="store_true", help="skip extras.plummer (BASELINE configs[2])")
     p.add_argument("--neighbor-targets", type=float, default=1e7,
                    help="after the timed region: findNeighbors for this many particles of the synced domain (0: skip)")
     p.add_argument("--cpu-sample", type=float, default=4e6, help="particles in the CPU baseline sample")
@@ -45,7 +46,9 @@ def parse():
 class SyncPipeline:
     """Steady-state domain.sync through the C ABI: cstone_hip_domain_sync on device-resident arrays."""
 
-    def __init__(self, ctx, n, key_bits, real_bits, curve, bucket, bucket_focus, seed):
+    def __init__(self, ctx, n, key_bits, real_bits, curve, bucket, bucket_focus, seed, dist="uniform"):
+        import math
+
         import torch
 
         import cstone_amd
@@ -56,15 +59,30 @@ class SyncPipeline:
         dev = ctx.device
         rdt = torch.float64 if real_bits == 64 else torch.float32
         g = torch.Generator(device=dev).manual_seed(seed)
-        self.x = torch.rand(n, dtype=rdt, device=dev, generator=g)
-        self.y = torch.rand(n, dtype=rdt, device=dev, generator=g)
-        self.z = torch.rand(n, dtype=rdt, device=dev, generator=g)
-        # h ~ 1.2 * (3*100/(4 pi N))^(1/3) / 2  (about 100 neighbours inside 2h), SURVEY 8(d)
-        h0 = 0.6 * (3.0 * 100 / (4 * 3.141592653589793 * n)) ** (1.0 / 3.0)
-        self.h = torch.full((n,), h0, dtype=rdt, device=dev)
+        if dist == "plummer":
+            # Plummer sphere of scale radius 1 cut at r = 10 (BASELINE configs[2]); h from the local density so that a
+            # sphere of radius 2h holds about 100 particles
+            u = torch.rand(n, dtype=torch.float64, device=dev, generator=g).clamp_(1e-12, 1.0)
+            r = (u.pow(-2.0 / 3.0) - 1.0).clamp_min_(1e-12).rsqrt().clamp_(max=10.0)
+            ct = 2 * torch.rand(n, dtype=torch.float64, device=dev, generator=g) - 1
+            ph = 2 * math.pi * torch.rand(n, dtype=torch.float64, device=dev, generator=g)
+            st = (1 - ct * ct).sqrt()
+            self.x, self.y, self.z = (r * st * ph.cos()).to(rdt), (r * st * ph.sin()).to(rdt), (r * ct).to(rdt)
+            rho = 3.0 * n / (4 * math.pi) * (1 + r * r).pow(-2.5)
+            self.h = (0.5 * (3.0 * 100.0 / (4 * math.pi * rho)).pow(1 / 3)).clamp_(max=1.0).to(rdt)
+            del u, r, ct, ph, st, rho
+            lim = [-10.001, 10.001] * 3
+        else:
+            self.x = torch.rand(n, dtype=rdt, device=dev, generator=g)
+            self.y = torch.rand(n, dtype=rdt, device=dev, generator=g)
+            self.z = torch.rand(n, dtype=rdt, device=dev, generator=g)
+            # h ~ 1.2 * (3*100/(4 pi N))^(1/3) / 2  (about 100 neighbours inside 2h), SURVEY 8(d)
+            h0 = 0.6 * (3.0 * 100 / (4 * 3.141592653589793 * n)) ** (1.0 / 3.0)
+            self.h = torch.full((n,), h0, dtype=rdt, device=dev)
+            lim = [0, 1] * 3
         self.keys = torch.zeros(n, dtype=cstone_amd.key_torch_dtype(key_bits), device=dev)
         self.scratch = torch.empty(n, dtype=rdt, device=dev)
-        self.dom = Domain(ctx, cv, key_bits, real_bits, bucket, bucket_focus, 0.5, cstone_amd.make_cbox([0, 1] * 3))
+        self.dom = Domain(ctx, cv, key_bits, real_bits, bucket, bucket_focus, 0.5, cstone_amd.make_cbox(lim))
         self.f_leaves = self.g_leaves = 0
 
     def step(self):
@@ -356,6 +374,33 @@ def main():
     if not distributed and args.neighbor_targets > 0:
         extras["find_neighbors"] = [pipe.find_neighbors(args.neighbor_targets, 0),
                                     pipe.find_neighbors(args.neighbor_targets, 128)]
+    if not distributed and not args.no_plummer:
+        # BASELINE configs[2]: the same number of Plummer-sphere particles (deep, very uneven tree), full Domain::sync and
+        # findNeighbors on the domain's octree; reported next to the headline number, not part of it
+        f_leaves_uniform, g_leaves_uniform = pipe.f_leaves, pipe.g_leaves
+        del pipe
+        torch.cuda.empty_cache()
+        pl = SyncPipeline(ctx, n_local, args.key_bits, args.real_bits, args.curve, bucket_global, args.bucket_focus,
+                          seed=7, dist="plummer")
+        barrier()
+        t3 = time.perf_counter()
+        pl.first_sync()
+        barrier()
+        first_pl = time.perf_counter() - t3
+        pl.step()
+        barrier()
+        t4 = time.perf_counter()
+        for _ in range(args.steps):
+            pl.step()
+        barrier()
+        per = (time.perf_counter() - t4) / args.steps
+        extras["plummer"] = {"workload": f"{n_local:.0e} Plummer-sphere particles (r <= 10), bucketFocus {args.bucket_focus}",
+                             "first_sync_ms": first_pl * 1e3, "ms_per_step": per * 1e3, "value": n_local / per,
+                             "unit": "particles/s", "focus_leaves": pl.f_leaves,
+                             "find_neighbors": pl.find_neighbors(args.neighbor_targets, 0)
+                             if args.neighbor_targets > 0 else None}
+        pipe = pl
+        pipe.f_leaves, pipe.g_leaves = f_leaves_uniform, g_leaves_uniform  # config reports the headline workload
     ctx.profile_enable(False)
     ctx.sync()  # raises if a device-side check tripped
 

@@ -34,6 +34,8 @@ def test_bench_single_rank_contract():
     assert "workload" in j["config"] and "model" not in j["config"]
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    pl = j["extras"]["plummer"]  # BASELINE configs[2] next to the headline number
+    assert pl["value"] > 0 and pl["focus_leaves"] > 0 and pl["find_neighbors"]["mean_neighbors"] > 10
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
 
