@@ -375,6 +375,37 @@ def main():
         extras["find_neighbors"] = [pipe.find_neighbors(args.neighbor_targets, 0),
                                     pipe.find_neighbors(args.neighbor_targets, 128)]
     if not distributed and not args.no_plummer:
+        # BASELINE configs[1]: 10^7 uniform particles, encode + radix sort (all digits) + cornerstone tree from the root +
+        # linked octree, no halos, every stage through its own C-ABI entry (the kernel-level seam of the reference)
+        n1 = min(10_000_000, n_local)
+        g1 = torch.Generator(device=ctx.device).manual_seed(3)
+        rdt = torch.float64 if args.real_bits == 64 else torch.float32
+        cv = cstone_amd.HILBERT if args.curve == "hilbert" else cstone_amd.MORTON
+        xs = [torch.rand(n1, dtype=rdt, device=ctx.device, generator=g1) for _ in range(3)]
+        order = torch.empty(n1, dtype=torch.int32, device=ctx.device)
+        unit = cstone_amd.make_cbox([0, 1] * 3)
+
+        def config1():
+            k = ctx.compute_sfc_keys(cv, args.key_bits, xs[0], xs[1], xs[2], unit)
+            ctx.sequence(order)
+            ctx.sort_pairs(k, order)
+            tree, counts, _ = ctx.compute_octree(k, args.bucket_focus)
+            ctx.build_octree(tree, num_leaves=counts.numel())
+            return counts.numel()
+
+        config1()
+        barrier()
+        t5 = time.perf_counter()
+        for _ in range(args.steps):
+            leaves1 = config1()
+        barrier()
+        per1 = (time.perf_counter() - t5) / args.steps
+        extras["encode_sort_tree_1e7"] = {"workload": f"{n1:.0e} uniform particles: compute_sfc_keys + sort_pairs over all "
+                                                      f"digits + compute_octree from the root (bucket {args.bucket_focus}) + "
+                                                      "build_octree, no halos (BASELINE configs[1])",
+                                          "ms_per_step": per1 * 1e3, "value": n1 / per1, "unit": "particles/s",
+                                          "leaves": leaves1}
+        del xs, order
         # BASELINE configs[2]: the same number of Plummer-sphere particles (deep, very uneven tree), full Domain::sync and
         # findNeighbors on the domain's octree; reported next to the headline number, not part of it
         f_leaves_uniform, g_leaves_uniform = pipe.f_leaves, pipe.g_leaves

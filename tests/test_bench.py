@@ -36,6 +36,7 @@ def test_bench_single_rank_contract():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     pl = j["extras"]["plummer"]  # BASELINE configs[2] next to the headline number
     assert pl["value"] > 0 and pl["focus_leaves"] > 0 and pl["find_neighbors"]["mean_neighbors"] > 10
+    assert j["extras"]["encode_sort_tree_1e7"]["leaves"] > 0  # BASELINE configs[1]
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
 
