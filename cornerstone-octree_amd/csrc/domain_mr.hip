@@ -399,8 +399,12 @@ public:
     {
         if (numProps < 0 || numProps > MAX_PROPS) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: at most %d properties", MAX_PROPS);
         for (int q = 0; q < numProps; ++q)
-            if ((n && !props[q]) || (propBytes[q] != 4 && propBytes[q] != 8)) // an empty rank may pass null arrays
-                return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: property %d must be a 4- or 8-byte array", q);
+        {
+            const int e = propBytes[q]; // the element sizes gatherGpu is instantiated for (R/primitives/primitives_gpu.cu:126-148)
+            const bool sizeOk = e == 1 || e == 2 || e == 4 || e == 8 || e == 12 || e == 16 || e == 24 || e == 32;
+            if ((n && !props[q]) || !sizeOk) // an empty rank may pass null arrays
+                return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: property %d must have elements of 1, 2, 4, 8, 12, 16, 24 or 32 bytes", q);
+        }
         const T* x = static_cast<const T*>(xIn);
         const T* y = static_cast<const T*>(yIn);
         const T* z = static_cast<const T*>(zIn);
@@ -759,9 +763,9 @@ public:
         {
             // the margins were too small (first syncs, abrupt changes): move the block once, through a scratch copy
             const uint64_t M2 = nlo, cap2 = nlo + nm + nhi;
-            CS_TRY(moveTmp_.ensure(ctx_, nm * 8));
             auto shift = [&](DevBuf& buf, size_t elem) -> int
             {
+                CS_TRY(moveTmp_.ensure(ctx_, nm * elem));
                 CS_HIP(ctx_, hipMemcpyAsync(moveTmp_.p, buf.as<char>() + M * elem, nm * elem, hipMemcpyDeviceToDevice,
                                             ctx_->stream));
                 CS_TRY(buf.ensure(ctx_, cap2 * elem));

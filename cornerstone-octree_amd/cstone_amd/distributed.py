@@ -733,7 +733,7 @@ class NativeDistributedDomain:
 
     def sync(self, x, y, z, h, props=(), keys=None):
         """returns dict(keys, x, y, z, h, start, end[, props]) of tensors that alias the domain-owned result arrays (valid
-        until the next but one sync); props: further 4- or 8-byte fields that follow their particles; keys: optional
+        until the next but one sync); props: further fields (rows of 1..32 bytes) that follow their particles; keys: optional
         key array whose remove markers flag particles that leave the domain"""
         torch = _torch()
         import cstone_amd
@@ -741,7 +741,8 @@ class NativeDistributedDomain:
         self._keep = (x, y, z, h, props)  # inputs must outlive the call
         k = len(props)
         parr = (C.c_void_p * max(1, k))(*[t.data_ptr() for t in props])
-        pbytes = (C.c_int * max(1, k))(*[t.element_size() for t in props])
+        rows = [int(np.prod(t.shape[1:])) if t.dim() > 1 else 1 for t in props]
+        pbytes = (C.c_int * max(1, k))(*[t.element_size() * r for t, r in zip(props, rows)])
         self._keep = (x, y, z, h, props, keys)
         rc = self.ctx.lib.cstone_hip_domain_mr_sync_keys(self.h, C.c_void_p(keys.data_ptr() if keys is not None else 0),
                                                          C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
@@ -765,11 +766,12 @@ class NativeDistributedDomain:
                    z=wrap(v.z, rdt, n * es), h=wrap(v.h, rdt, n * es), start=v.start_index, end=v.end_index)
         lim = C.cast(C.byref(v.box), C.POINTER(C.c_double))
         out["lim"] = np.array([lim[i] for i in range(6)])
-        out["props"] = [wrap(v.props[q], props[q].dtype, n * props[q].element_size()) for q in range(len(props))]
+        out["props"] = [wrap(v.props[q], props[q].dtype, n * props[q].element_size() * rows[q])
+                        .view((n,) + tuple(props[q].shape[1:])) for q in range(len(props))]
         return out
 
     def exchange_halos(self, field):
-        """Domain::exchangeHalos: field (tensor of num_particles_with_halos 4- or 8-byte elements, laid out like the
+        """Domain::exchangeHalos: field (tensor of num_particles_with_halos rows of 1..32 bytes, laid out like the
         result arrays) gets its halo ranges overwritten with the owners' values"""
         elem = field.element_size() * (int(np.prod(field.shape[1:])) if field.dim() > 1 else 1)
         rc = self.ctx.lib.cstone_hip_domain_mr_exchange_halos(self.h, C.c_void_p(field.data_ptr()), C.c_int(elem))

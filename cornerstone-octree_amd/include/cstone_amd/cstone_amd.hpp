@@ -549,12 +549,14 @@ public:
         if (dom_) cstone_hip_domain_mr_destroy(dom_);
     }
 
-    //! x, y, z, h: device pointers to this rank's n particles in any order; properties: further conserved 4- or
-    //! 8-byte fields that follow their particles (results in view().props[i], halo ranges via exchangeHalos)
+    //! x, y, z, h: device pointers to this rank's n particles in any order; properties: further conserved fields with
+    //! elements of 1..32 bytes that follow their particles (results in view().props[i], halo ranges via exchangeHalos)
     template<class... Props>
     void sync(const T* x, const T* y, const T* z, const T* h, std::size_t n, const Props*... properties)
     {
-        static_assert(((sizeof(Props) == 4 || sizeof(Props) == 8) && ...));
+        static_assert(((sizeof(Props) == 1 || sizeof(Props) == 2 || sizeof(Props) == 4 || sizeof(Props) == 8 ||
+                        sizeof(Props) == 12 || sizeof(Props) == 16 || sizeof(Props) == 24 || sizeof(Props) == 32) &&
+                       ...));
         constexpr int np = sizeof...(Props);
         const void* pp[np + 1] = {static_cast<const void*>(properties)..., nullptr};
         const int pb[np + 1]   = {int(sizeof(Props))..., 0};

@@ -396,7 +396,7 @@ extern "C"
     int cstone_hip_domain_mr_sync(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z,
                                   const void* h, size_t n);
     /* the same with further conserved per-particle fields (the `properties` of Domain::sync, R/domain/domain.hpp:196-203:
-     * masses, velocities, ...; up to 16 arrays of 4- or 8-byte elements) that follow their particles to the new owner
+     * masses, velocities, ...; up to 16 arrays with elements of 1, 2, 4, 8, 12, 16, 24 or 32 bytes) that follow their particles to the new owner
      * and into SFC order */
     int cstone_hip_domain_mr_sync_props(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z,
                                         const void* h, size_t n, const void* const* props, const int* prop_bytes,

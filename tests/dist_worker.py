@@ -217,13 +217,15 @@ def main():
     for s in range(a.syncs):
         if a.impl == "native":
             late = late_fields(x, y, z, h)
-            r = dom.sync(x, y, z, h, props=[tag64, tag32])
+            vec3 = torch.stack([x, y, z], dim=1).to(torch.float32).contiguous()  # a Vec3<float> property (12 bytes)
+            r = dom.sync(x, y, z, h, props=[tag64, tag32, vec3])
         else:
             r = dom.sync(x, y, z, h)
         st, en = r["start"], r["end"]
         if a.impl == "native":
             ok &= check_reapply(dom, late, r)
-            p64, p32 = r["props"]
+            p64, p32, p3 = r["props"]
+            ok &= bool(torch.equal(p3[st:en], torch.stack([r[k][st:en] for k in "xyz"], dim=1).to(torch.float32)))
             ok &= bool(torch.equal(p64[st:en], tag64_of(r, st, en)))
             ok &= bool(torch.equal(p32[st:en], (r["x"][st:en] + 2.0 * r["y"][st:en]).to(torch.float32)))
         keys = r["keys"].cpu().numpy().view(kdt)
