@@ -554,3 +554,27 @@ def test_sort_adversarial_digit_patterns_large_tiles(hip, kb):
         hip.sync()
         assert torch.equal(keys, ref_k), name
         assert torch.equal(vals.long(), ref_v), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kb", [32, 64])
+def test_sort_pairs_fuzz_sizes(hip, kb):
+    """150 seeded random sizes between 1 and 3.3e6 (both tile shapes, partial tiles, tails of a few elements), keys with
+    a random number of significant bits: stable-sorted keys and permutation equal torch's stable sort"""
+    import torch
+
+    rng = np.random.default_rng(100 + kb)
+    dt = torch.int64 if kb == 64 else torch.int32
+    maxbits = 62 if kb == 64 else 30
+    g = torch.Generator(device="cuda").manual_seed(kb)
+    sizes = [int(v) for v in rng.integers(1, 3_300_000, 120)] + [16384 * k + d for k in (1, 64, 65) for d in (-1, 0, 1)] + \
+            [4096 * k + d for k in (1, 255, 256) for d in (-1, 0, 1)] + [1, 2, 63, 64, 65, 1 << 20, (1 << 20) - 1, (1 << 20) + 1]
+    for n in sizes:
+        bits = int(rng.integers(1, maxbits + 1))
+        keys = torch.randint(0, 1 << bits, (n,), dtype=torch.int64, device="cuda", generator=g).to(dt)
+        ref_k, ref_v = torch.sort(keys, stable=True)
+        vals = torch.arange(n, dtype=torch.int32, device="cuda")
+        hip.sort_pairs(keys, vals)
+        hip.sync()
+        assert torch.equal(keys, ref_k), (n, bits)
+        assert torch.equal(vals.long(), ref_v), (n, bits)
