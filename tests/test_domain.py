@@ -111,3 +111,85 @@ def test_partial_sort_fallback_when_particles_collapse(hip, oracle):
         assert np.array_equal(keys.cpu().numpy().view(np.uint64), ks), step
         assert np.array_equal(ident.cpu().numpy(), idin[order]), step   # the same stable permutation
         assert np.array_equal(xd.cpu().numpy(), xin[order]), step
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_domain_sync_random_configurations_against_oracle(hip, oracle, seed):
+    """Domain::sync over seeded random configurations the reference fixtures do not reach (Morton keys, tiny and huge
+    buckets, anisotropic boxes, all boundary combinations, 32/64-bit keys, float/double): after every sync the keys are
+    the sorted oracle keys under the domain's box, every field follows its particle, and both trees advance exactly like
+    the oracle's update rule (converged from the root on the first call, one rebalance step per later call)"""
+    import torch
+
+    import cstone_amd
+    from cstone_amd.domain import Domain
+    from oracle.oracle import HILBERT, MORTON, Box
+
+    rng = np.random.default_rng(500 + seed)
+    kb, rb = int(rng.choice([32, 64])), int(rng.choice([32, 64]))
+    curve = int(rng.choice([HILBERT, MORTON]))
+    n = int(rng.choice([300, 5000, 60000, 200000]))
+    bucket_focus = int(rng.choice([1, 8, 64, 1000]))
+    bucket = int(bucket_focus * rng.choice([1, 4, 50]))
+    bc = tuple(int(v) for v in rng.integers(0, 3, 3))  # open, periodic, fixed
+    lo = rng.uniform(-3, 0, 3)
+    hi = lo + rng.uniform(0.5, 4, 3)
+    lim = [lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]]
+    rdt, kdt, ksigned = (np.float64 if rb == 64 else np.float32), (np.uint64 if kb == 64 else np.uint32), \
+        (np.int64 if kb == 64 else np.int32)
+    if rng.uniform() < 0.5:
+        pos = rng.uniform(lo, hi, (n, 3))
+    else:
+        centers = rng.uniform(lo, hi, (4, 3))
+        pos = np.clip(centers[rng.integers(0, 4, n)] + rng.normal(0, (hi - lo) / 40, (n, 3)), lo, hi)
+    x, y, z = [np.ascontiguousarray(pos[:, d]).astype(rdt) for d in range(3)]
+    h = rng.uniform(0.001, 0.01, n).astype(rdt)
+    dom = Domain(hip, curve, kb, rb, bucket, bucket_focus, 0.5, cstone_amd.make_cbox(lim, bc))
+    ftree = gtree = None
+    for s in range(3):
+        xd, yd, zd, hd = [torch.from_numpy(a.copy()).cuda() for a in (x, y, z, h)]
+        m = x.size
+        keys = torch.zeros(m, dtype=torch.int64 if kb == 64 else torch.int32, device="cuda")
+        scratch = torch.empty_like(xd)
+        ident = torch.arange(m, dtype=torch.float64 if rb == 64 else torch.float32, device="cuda")
+        keys, xd, yd, zd, hd, scratch, (ident,) = dom.sync(keys, xd, yd, zd, hd, scratch, [ident])
+        hip.sync()
+        v = dom.view()
+        assert (v.start_index, v.end_index, v.num_particles_with_halos) == (0, m, m)
+        box = Box(list(v.box.lim), bc)
+        want = oracle.compute_sfc_keys(curve, kb, x, y, z, box)
+        order = np.argsort(want, kind="stable")
+        got_keys = keys.cpu().numpy().view(kdt)
+        assert np.array_equal(got_keys, want[order]), s
+        src = ident.cpu().numpy().astype(np.int64)
+        assert np.array_equal(src, order), s  # the stable permutation itself
+        for a, ad in ((x, xd), (y, yd), (z, zd), (h, hd)):
+            assert np.array_equal(ad.cpu().numpy(), a[order]), s
+        # global tree: converged from the root on the first call, one rebalance step (csarray.hpp:430-448) per later call
+        ks = want[order]
+        if s == 0:
+            gtree, gcounts = oracle.compute_octree(ks, bucket)
+        else:
+            gtree, gcounts, _ = oracle.update_octree(ks, bucket, gtree, gcounts)
+        assert np.array_equal(dom.fetch(v.global_leaves, v.num_global_leaves + 1, kdt), gtree), s
+        # focus tree: converged on the first call; later calls follow the focus rule (one level per step, merges decided
+        # on the parents, focus/rebalance.hpp:50-184), which the reference fixtures pin -- here: a valid cornerstone leaf
+        # array whose counts are those of the keys
+        got_f = dom.fetch(v.focus_leaves, v.num_focus_leaves + 1, kdt)
+        got_c = dom.fetch(v.focus_leaf_counts, v.num_focus_leaves, np.uint32)
+        if s == 0:
+            ftree, fcounts = oracle.compute_octree(ks, bucket_focus)
+            assert np.array_equal(got_f, ftree) and np.array_equal(got_c, fcounts)
+        assert got_f[0] == 0 and int(got_f[-1]) == 1 << (3 * (21 if kb == 64 else 10)) and np.all(got_f[1:] > got_f[:-1])
+        span = np.diff(got_f.astype(np.uint64) if kb == 64 else got_f.astype(np.uint64))
+        lvl = np.log2(span.astype(np.float64)) / 3
+        assert np.all(lvl == np.round(lvl)) and np.all(got_f[:-1].astype(np.uint64) % span == 0)  # octree nodes
+        assert np.array_equal(got_c, oracle.node_counts(got_f, ks)), s
+        assert np.array_equal(dom.fetch(v.layout, v.num_focus_leaves + 1, np.uint32),
+                              np.concatenate([[0], np.cumsum(got_c)]).astype(np.uint32))
+        # move a little (inside the box for fixed / periodic axes)
+        x, y, z, h = [a[order] for a in (x, y, z, h)]
+        for a, d in ((x, 0), (y, 1), (z, 2)):
+            a += (rng.normal(0, 0.003, m) * (hi[d] - lo[d])).astype(rdt)
+            np.clip(a, rdt(lo[d]), np.nextafter(rdt(hi[d]), rdt(lo[d])), out=a)
