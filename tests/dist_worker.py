@@ -38,7 +38,7 @@ def neighbor_sum(o, x, y, z, h, first, last, lim, bc):
     tree, counts = o.compute_octree(ks, 32)
     oc = o.build_octree(tree)
     layout = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
-    cen, siz = o.node_centers(HILBERT, oc["prefixes"], box, 64)
+    cen, siz = o.node_centers(HILBERT, oc["prefixes"], box, x.dtype.itemsize * 8)
     _, nc = o.find_neighbors(xs, ys, zs, hs, 0, x.size, box, oc, layout, cen, siz, 1)
     sel = inv[first:last]
     return int(nc[sel].astype(np.int64).sum())
@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--pbc", type=int, default=0)
     ap.add_argument("--golden", default="", help="fixture of tests/golden/make_golden_domain_mpi.py to reproduce")
     ap.add_argument("--key-bits", type=int, default=64)
+    ap.add_argument("--real-bits", type=int, default=64)
     ap.add_argument("--curve", default="hilbert", choices=["hilbert", "morton"])
     ap.add_argument("--lopsided", type=int, default=0, help="1: the last rank starts without particles")
     ap.add_argument("--impl", default="python", choices=["python", "native"],
@@ -200,15 +201,17 @@ def main():
 
     mine = np.nonzero(owner == rank)[0]
     ids = mine.copy()
-    x, y, z = [torch.from_numpy(pos[mine, d].copy()).to(dev) for d in range(3)]
-    h = torch.from_numpy(hglob[mine].copy()).to(dev)
+    rdt = torch.float64 if a.real_bits == 64 else torch.float32
+    top = 1.0 - 1e-9 if a.real_bits == 64 else 1.0 - 2.0**-20
+    x, y, z = [torch.from_numpy(pos[mine, d].copy()).to(dev).to(rdt).clamp_(0.0, top) for d in range(3)]
+    h = torch.from_numpy(hglob[mine].copy()).to(dev).to(rdt)
 
     curve = orc.HILBERT if a.curve == "hilbert" else orc.MORTON
     kdt = np.uint64 if a.key_bits == 64 else np.uint32
     if a.impl == "native":
-        dom = make_native(backend, max(64, N // (100 * P)), 16, lim, bc, curve, a.key_bits)
+        dom = make_native(backend, max(64, N // (100 * P)), 16, lim, bc, curve, a.key_bits, a.real_bits)
     else:
-        dom = DistributedDomain(backend, Comm(), curve, a.key_bits, 64, bucket=max(64, N // (100 * P)),
+        dom = DistributedDomain(backend, Comm(), curve, a.key_bits, a.real_bits, bucket=max(64, N // (100 * P)),
                                 bucket_focus=16, box_lim=lim, box_bc=bc)
     ok = True
     report = []
@@ -240,7 +243,7 @@ def main():
                                                                       served=v.halos_sent, halo_boxes=v.halo_boxes_exported)
             # exchangeHalos: a field that equals 2x + 1 on the assigned range gets the owners' values in the halo ranges
             for dt in (torch.float64, torch.float32):
-                f = torch.full_like(r["x"], -7.0, dtype=dt)
+                f = torch.full_like(r["x"], -7.0, dtype=dt)  # 8- and 4-byte fields whatever the coordinate type
                 f[st:en] = (2.0 * r["x"][st:en] + 1.0).to(dt)
                 dom.exchange_halos(f)
                 ok &= bool(torch.equal(f, (2.0 * r["x"] + 1.0).to(dt)))
@@ -280,13 +283,13 @@ def main():
             report.append(dict(step=s, neighbors=ref, found=int(tsum.item()), stats=stats))
         # move: assigned particles only (halos are discarded by the client before the next sync)
         m = en - st
-        drift = torch.from_numpy(rng.normal(0, 0.004, (m, 3))).to(dev)
+        drift = torch.from_numpy(rng.normal(0, 0.004, (m, 3))).to(dev).to(rdt)
         x, y, z, h = [r[k][st:en].clone() for k in "xyzh"]
         x, y, z = x + drift[:, 0], y + drift[:, 1], z + drift[:, 2]
         if a.pbc:
-            x, y, z = torch.remainder(x, 1.0), torch.remainder(y, 1.0), torch.remainder(z, 1.0)
+            x, y, z = [torch.remainder(v, 1.0).clamp_(0.0, top) for v in (x, y, z)]
         else:
-            x, y, z = x.clamp(0.0, 1.0 - 1e-9), y.clamp(0.0, 1.0 - 1e-9), z.clamp(0.0, 1.0 - 1e-9)
+            x, y, z = x.clamp(0.0, top), y.clamp(0.0, top), z.clamp(0.0, top)
         tag64 = x * 3.0 + y * 5.0 + z * 7.0 + h
         tag32 = (x + 2.0 * y).to(torch.float32)
     if a.impl == "native" and a.key_bits == 64:

@@ -84,6 +84,15 @@ def test_rank_that_starts_empty_cpu_backend():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kb,curve", [(32, "hilbert"), (64, "morton")])
+def test_native_domain_float_coordinates(kb, curve):
+    """Domain<KeyType, float> on 3 ranks: the invariants, exchangeHalos, reapplySync and the octree view with 4-byte
+    coordinates (the reference fixture k32_f32 pins the decomposition itself)"""
+    _launch(3, "hip", 40000, 3, 1, 29652 + kb // 32, impl="native",
+            extra=["--key-bits", str(kb), "--real-bits", "32", "--curve", curve])
+
+
+@pytest.mark.gpu
 def test_native_domain_without_halo_margins(monkeypatch):
     """the assigned block is written before the halo counts are known, at an offset that normally leaves room for the
     halos of the lower ranks; with no room at all the block has to be moved once (the fallback of abrupt changes)"""
