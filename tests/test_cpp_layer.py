@@ -32,3 +32,37 @@ def test_cpp_domain_example_runs():
     assert out.count("focus leaves") == 3
     assert "field followed its particles: yes" in out
     assert "target groups:" in out and "BAD" not in out
+
+
+MPI_EXE = os.path.join(ROOT, "cornerstone-octree_amd", "build", "domain_mpi_example")
+MPI_INC, MPI_LIB, MPIEXEC = "/opt/conda/include", "/opt/conda/lib/libmpi.so.12", "/opt/conda/bin/mpiexec"
+have_mpi = os.path.exists(os.path.join(MPI_INC, "mpi.h")) and os.path.exists(MPI_LIB) and os.path.exists(MPIEXEC)
+
+
+def _compile_mpi():
+    lib = os.path.join(ROOT, "cornerstone-octree_amd", "lib")
+    os.makedirs(os.path.dirname(MPI_EXE), exist_ok=True)
+    cmd = ["g++", "-std=c++20", "-O1", "-Wall", "-Wno-comment", "-I", os.path.join(ROOT, "include"), "-I",
+           os.path.join(ROOT, "cornerstone-octree_amd", "include"), "-I", MPI_INC,
+           os.path.join(ROOT, "examples", "domain_mpi_example.cpp"), "-L", lib, "-lcstone_hip", f"-Wl,-rpath,{lib}",
+           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", MPI_LIB, "-Wl,-rpath,/usr/lib/x86_64-linux-gnu",
+           "-Wl,-rpath,/opt/conda/lib", "-o", MPI_EXE]
+    subprocess.run(cmd, check=True, capture_output=True)
+
+
+@pytest.mark.skipif(not have_mpi, reason="no MPI in this image")
+def test_cpp_mpi_example_compiles():
+    """the multi-rank Domain with MPI as the transport behind cstone_hip_comm_ops (examples/domain_mpi_example.cpp)"""
+    _compile_mpi()
+    assert os.path.exists(MPI_EXE)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_mpi, reason="no MPI in this image")
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_cpp_mpi_example_runs(ranks):
+    if not os.path.exists(MPI_EXE):
+        _compile_mpi()
+    r = subprocess.run([MPIEXEC, "-n", str(ranks), MPI_EXE, "100000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all checks passed" in r.stdout and r.stdout.count(": ok") == 3
