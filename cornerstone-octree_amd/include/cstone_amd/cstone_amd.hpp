@@ -25,6 +25,7 @@
 #include <limits>
 #include <stdexcept>
 #include <string>
+#include <memory>
 #include <span>
 #include <tuple>
 #include <type_traits>
@@ -563,6 +564,17 @@ public:
         Context::check(cstone_hip_domain_mr_sync_props(dom_, x, y, z, h, n, pp, pb, np), "MultiRankDomain::sync");
         Context::check(cstone_hip_domain_mr_view_get(dom_, &view_), "MultiRankDomain::view");
     }
+    //! the same with the caller's key array, whose remove markers flag particles that leave the domain
+    template<class... Props>
+    void syncKeys(const KeyType* keys, const T* x, const T* y, const T* z, const T* h, std::size_t n,
+                  const Props*... properties)
+    {
+        constexpr int np = sizeof...(Props);
+        const void* pp[np + 1] = {static_cast<const void*>(properties)..., nullptr};
+        const int pb[np + 1]   = {int(sizeof(Props))..., 0};
+        Context::check(cstone_hip_domain_mr_sync_keys(dom_, keys, x, y, z, h, n, pp, pb, np), "MultiRankDomain::sync");
+        Context::check(cstone_hip_domain_mr_view_get(dom_, &view_), "MultiRankDomain::view");
+    }
     template<class V>
     V* property(int i) const
     {
@@ -633,9 +645,10 @@ private:
     cstone_hip_domain_mr_view view_{};
 };
 
-/*! cstone::Domain<KeyType, T, GpuTag> (R/domain/domain.hpp:66-699) on one rank.
- *  sync() keeps the reference's contract: caller-owned device vectors that are resized and SWAPPED with the scratch
- *  vector; properties need element sizes <= sizeof(T). */
+/*! cstone::Domain<KeyType, T, GpuTag> (R/domain/domain.hpp:66-699).
+ *  sync() keeps the reference's contract: caller-owned device vectors that are resized and, on one rank, SWAPPED with
+ *  the scratch vector (properties then need element sizes <= sizeof(T)).  On several ranks (constructor with a
+ *  cstone_hip_comm_ops) the work is done by a MultiRankDomain and the results are copied into the caller's vectors. */
 template<class KeyType, class T>
 class Domain
 {
@@ -650,6 +663,19 @@ public:
                                           &box.pod());
         Context::check(rc, "Domain");
     }
+    /*! several ranks: the same class, with the collectives of the application (cstone_hip_comm_ops).  sync() then keeps
+     *  the reference's contract on the caller's vectors -- pass the arrays of the previous layout, get them back resized
+     *  to nParticlesWithHalos() with the assigned range [startIndex(), endIndex()) and the halos of x, y, z, h filled --
+     *  at the price of one device copy per array out of the domain-owned result buffers; MultiRankDomain is the
+     *  zero-copy interface underneath. */
+    Domain(int rank, int nRanks, unsigned bucketSize, unsigned bucketSizeFocus, float /*theta*/, const Box<T>& box,
+           const cstone_hip_comm_ops& comm, Curve curve = Curve::hilbert)
+        : mr_(std::make_unique<MultiRankDomain<KeyType, T>>(rank, nRanks, bucketSize, bucketSizeFocus, box, comm, curve))
+    {
+        if (bucketSize < bucketSizeFocus)
+            throw std::runtime_error("The bucket size of the global tree must not be smaller than the bucket size"
+                                     " of the focused tree\n");
+    }
     Domain(const Domain&)            = delete;
     Domain& operator=(const Domain&) = delete;
     ~Domain()
@@ -661,10 +687,15 @@ public:
     void sync(DeviceVector<KeyType>& keys, DeviceVector<T>& x, DeviceVector<T>& y, DeviceVector<T>& z,
               DeviceVector<T>& h, std::tuple<DeviceVector<Props>&...> properties, DeviceVector<T>& scratch)
     {
-        static_assert(((sizeof(Props) <= sizeof(T)) && ...), "properties must not be wider than the scratch element");
         std::size_t n = x.size();
         if (keys.size() != n || y.size() != n || z.size() != n || h.size() != n)
             throw std::runtime_error("Domain sync: input array sizes are inconsistent\n");
+        if (mr_)
+        {
+            syncMultiRank(keys, x, y, z, h, properties);
+            return;
+        }
+        static_assert(((sizeof(Props) <= sizeof(T)) && ...), "properties must not be wider than the scratch element");
         scratch.resize(n);
         bool tooSmall = false;
         std::apply([&](auto&... v) { ((tooSmall = tooSmall || v.capacityBytes() < n * sizeof(T)), ...); }, properties);
@@ -711,35 +742,51 @@ public:
         std::apply([&](auto&... vec) { (vec.rebind(pp[i], m, capOf(pp[i])), ..., void(++i)); }, properties);
     }
 
+    //! single-rank mode only: the raw view of the C ABI (multi-rank: multiRank().view())
     cstone_hip_domain_view view() const
     {
         cstone_hip_domain_view v;
         Context::check(cstone_hip_domain_view_get(dom_, &v), "Domain::view");
         return v;
     }
-    LocalIndex startIndex() const { return view().start_index; }
-    LocalIndex endIndex() const { return view().end_index; }
+    const MultiRankDomain<KeyType, T>& multiRank() const { return *mr_; }
+    LocalIndex startIndex() const { return mr_ ? mr_->startIndex() : view().start_index; }
+    LocalIndex endIndex() const { return mr_ ? mr_->endIndex() : view().end_index; }
     LocalIndex nParticles() const { return endIndex() - startIndex(); }
-    LocalIndex nParticlesWithHalos() const { return view().num_particles_with_halos; }
-    Box<T> box() const { return Box<T>(view().box); }
+    LocalIndex nParticlesWithHalos() const { return mr_ ? mr_->nParticlesWithHalos() : view().num_particles_with_halos; }
+    Box<T> box() const { return mr_ ? mr_->box() : Box<T>(view().box); }
     TreeNodeIndex startCell() const { return 0; }
     TreeNodeIndex endCell() const { return view().num_focus_leaves; }
     //! particle offsets of each focus tree leaf cell, device pointer (Domain::layout)
     std::span<const LocalIndex> layout() const
     {
+        if (mr_) return mr_->layout();
         auto v = view();
         return {v.layout, std::size_t(v.num_focus_leaves) + 1};
     }
     void setHaloFactor(float factor)
     {
-        Context::check(cstone_hip_domain_set_halo_factor(dom_, factor), "Domain::setHaloFactor");
+        if (mr_) { mr_->setHaloFactor(factor); }
+        else { Context::check(cstone_hip_domain_set_halo_factor(dom_, factor), "Domain::setHaloFactor"); }
     }
     //! kept for source compatibility: the flag has no reader in the reference either (domain.hpp:411,661)
     void setTreeConv(bool) {}
-    /*! one rank: no halos to exchange.  Several ranks: cstone_amd/distributed.py */
+    /*! R/domain/domain.hpp:381-386: the halo ranges of every array (nParticlesWithHalos() elements) are overwritten with
+     *  the owners' values; the send/receive buffers of the reference's signature are not needed.  One rank: no halos. */
     template<class... Vectors, class SendBuffer, class ReceiveBuffer>
-    void exchangeHalos(std::tuple<Vectors&...>, SendBuffer&, ReceiveBuffer&) const
+    void exchangeHalos(std::tuple<Vectors&...> arrays, SendBuffer&, ReceiveBuffer&) const
     {
+        if (!mr_) return;
+        std::apply(
+            [this](auto&... a)
+            {
+                ((a.size() == nParticlesWithHalos()
+                      ? void()
+                      : throw std::runtime_error("Domain exchangeHalos: input array sizes are inconsistent\n")),
+                 ...);
+                (mr_->exchangeHalos(a.data()), ...);
+            },
+            arrays);
     }
 
     /*! R/domain/domain.hpp:334-378 with device vectors (the reference restricts its version to host vectors, :340):
@@ -755,8 +802,18 @@ public:
                           "the scratch vector must have the arrays' element type");
             const std::size_t m = nParticlesWithHalos();
             scratch.resize(std::max(m, a.size()));
-            Context::check(cstone_hip_domain_reapply_sync(dom_, a.data(), a.size(), int(sizeof(V)), scratch.data()),
-                           "Domain::reapplySync");
+            if (mr_)
+            {
+                // the arrays have the layout BEFORE the last sync: their assigned range then is what travelled
+                if (a.size() != prevSize_)
+                    throw std::runtime_error("Domain reapplySync: input array sizes are inconsistent\n");
+                mr_->reapplySync(a.data() + prevStart_, std::size_t(prevEnd_ - prevStart_), scratch.data());
+            }
+            else
+            {
+                Context::check(cstone_hip_domain_reapply_sync(dom_, a.data(), a.size(), int(sizeof(V)), scratch.data()),
+                               "Domain::reapplySync");
+            }
             scratch.resize(m);
             a.swap(scratch);
         };
@@ -765,6 +822,7 @@ public:
 
     OctreeNsView<T, KeyType> octreeProperties() const
     {
+        if (mr_) return mr_->octreeProperties();
         auto v = view();
         return {v.num_focus_leaves,
                 static_cast<const KeyType*>(v.prefixes),
@@ -778,7 +836,47 @@ public:
     }
 
 private:
+    //! sync() on several ranks: the assigned range of the caller's arrays goes in, the domain-owned results are copied back
+    template<class... Props>
+    void syncMultiRank(DeviceVector<KeyType>& keys, DeviceVector<T>& x, DeviceVector<T>& y, DeviceVector<T>& z,
+                       DeviceVector<T>& h, std::tuple<DeviceVector<Props>&...> properties)
+    {
+        const std::size_t n = x.size();
+        // first call: everything passed is assigned; later: the previous layout with its assigned range
+        const LocalIndex first = synced_ ? mr_->startIndex() : 0, last = synced_ ? mr_->endIndex() : LocalIndex(n);
+        if (synced_ && n != mr_->nParticlesWithHalos())
+            throw std::runtime_error("Domain sync: input array sizes are inconsistent\n");
+        bool sizesOk = true;
+        std::apply([&](auto&... p) { ((sizesOk = sizesOk && p.size() == n), ...); }, properties);
+        if (!sizesOk) throw std::runtime_error("Domain sync: input array sizes are inconsistent\n");
+        prevSize_ = n, prevStart_ = first, prevEnd_ = last;
+        std::apply([&](auto&... p)
+                   { mr_->syncKeys(keys.data() + first, x.data() + first, y.data() + first, z.data() + first,
+                                   h.data() + first, std::size_t(last - first), (p.data() + first)...); },
+                   properties);
+        synced_               = true;
+        const std::size_t m   = mr_->nParticlesWithHalos();
+        auto back = [m](auto& vec, const auto* src)
+        {
+            vec.resize(m);
+            memcpyD2D(src, m, vec.data());
+        };
+        back(keys, mr_->keys());
+        back(x, static_cast<const T*>(mr_->x()));
+        back(y, static_cast<const T*>(mr_->y()));
+        back(z, static_cast<const T*>(mr_->z()));
+        back(h, static_cast<const T*>(mr_->h()));
+        int i = 0;
+        std::apply([&](auto&... p)
+                   { (back(p, mr_->template property<std::decay_t<decltype(*p.data())>>(i++)), ...); },
+                   properties);
+    }
+
     cstone_hip_domain* dom_{nullptr};
+    std::unique_ptr<MultiRankDomain<KeyType, T>> mr_;
+    bool synced_{false};
+    std::size_t prevSize_{0};
+    LocalIndex prevStart_{0}, prevEnd_{0};
 };
 
 } // namespace cstone_amd

@@ -120,6 +120,51 @@ int main(int argc, char** argv)
         pid   = domain.template property<float>(0) + first;
         count = last - first;
     }
+    // The same through the reference's own class interface: Domain<KeyType, T> with caller-owned device vectors that
+    // come back resized to [halos | assigned | halos] (domain.hpp:196-243), exchangeHalos and reapplySync on top.
+    {
+        Domain<KeyType, T> dom(rank, P, unsigned(std::max<std::size_t>(64, n / 100)), 64, 0.5f, Box<T>{0, 1}, comm);
+        DeviceVector<KeyType> keys(n);
+        DeviceVector<T> dx(hx.data(), hx.data() + n), dy(hy.data(), hy.data() + n), dz(hz.data(), hz.data() + n),
+            dh(hh.data(), hh.data() + n), scratch;
+        DeviceVector<float> tag(hid.data(), hid.data() + n), tagScratch;
+        Context::check(cstone_hip_memset(Context::get(), keys.data(), 0, n * sizeof(KeyType)), "memset");
+        for (int step = 0; step < 2; ++step)
+        {
+            // a field that is NOT part of the sync: its values follow later through reapplySync
+            auto xin = toHost(dx);
+            std::vector<T> hlate(xin.size());
+            for (std::size_t i = 0; i < xin.size(); ++i)
+                hlate[i] = 3 * xin[i] - 1;
+            DeviceVector<T> late(hlate.data(), hlate.data() + hlate.size()), lateScratch;
+
+            dom.sync(keys, dx, dy, dz, dh, std::tie(tag), scratch);
+            dom.reapplySync(std::tie(late), lateScratch);
+            syncGpu();
+            const LocalIndex first = dom.startIndex(), last = dom.endIndex(), all = dom.nParticlesWithHalos();
+            bool sizes = dx.size() == all && keys.size() == all && tag.size() == all && late.size() == all;
+            auto xs = toHost(dx);
+            auto ls = toHost(late);
+            bool lateOk = true;
+            for (LocalIndex i = first; i < last; ++i)
+                lateOk = lateOk && ls[i] == 3 * xs[i] - 1;
+            // exchangeHalos: a field known on the assigned range only gets the owners' values in the halo ranges
+            std::vector<T> hf(all, T(-7));
+            for (LocalIndex i = first; i < last; ++i)
+                hf[i] = 2 * xs[i] + 1;
+            DeviceVector<T> f(hf.data(), hf.data() + all);
+            dom.exchangeHalos(std::tie(f), scratch, scratch);
+            auto fs = toHost(f);
+            bool halosOk = true;
+            for (LocalIndex i = 0; i < all; ++i)
+                halosOk = halosOk && fs[i] == 2 * xs[i] + 1;
+            auto ns = dom.octreeProperties();
+            ok = ok && sizes && lateOk && halosOk && ns.numLeafNodes > 0;
+            if (rank == 0)
+                std::printf("Domain class, step %d: [%u, %u) of %u, reapplySync %s, exchangeHalos %s, %d tree leaves\n", step,
+                            first, last, all, lateOk ? "ok" : "BAD", halosOk ? "ok" : "BAD", ns.numLeafNodes);
+        }
+    }
     int all = ok ? 1 : 0, every = 0;
     MPI_Allreduce(&all, &every, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
     if (rank == 0) std::printf("multi-rank domain over MPI: %s\n", every ? "all checks passed" : "FAILED");

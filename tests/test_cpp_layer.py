@@ -66,3 +66,4 @@ def test_cpp_mpi_example_runs(ranks):
     r = subprocess.run([MPIEXEC, "-n", str(ranks), MPI_EXE, "100000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all checks passed" in r.stdout and r.stdout.count(": ok") == 3
+    assert r.stdout.count("reapplySync ok, exchangeHalos ok") == 2  # the Domain<KeyType, T> class interface on top
