@@ -394,6 +394,17 @@ public:
         return CSTONE_OK;
     }
 
+    /*! Domain::sync on several ranks (R/domain/domain.hpp:196-243).  Phases, in the order of the tick() marks:
+     *    1  global box (min/max + all-reduce)                      R/sfc/box_mpi.hpp:85-121
+     *    2  keys + SFC ordering of the present particles            R/domain/assignment.hpp:81-86
+     *    3  global tree update + counts all-reduce, SFC assignment  R/domain/assignment.hpp:88-103
+     *    4  send ranges, particle all-to-all, merge of the newcomers, every field written once to its final slot
+     *                                                               R/domain/assignment.hpp:105-158, domaindecomp_mpi.hpp:86-174
+     *    5  this rank's finest tree over its assigned particles, range boundaries enforced, linked octree
+     *    6  owner-side halo discovery (boxes all-gathered, one traversal for all peers), halo count matrix
+     *    7  room for the halos left and right of the assigned block
+     *    8  halo all-to-all, keys of the halo particles             R/halos/halos.hpp:224-257
+     *  then the bookkeeping reapplySync / exchangeHalos / octree() work from. */
     int sync(const void* xIn, const void* yIn, const void* zIn, const void* hIn, size_t n, const void* const* props,
              const int* propBytes, int numProps, const void* keysIn) override
     {
