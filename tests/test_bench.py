@@ -14,6 +14,9 @@ KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "vs_baseline", "dtype", "data", "config", "roofline"]
 
 
+args_key_passes = 8  # one standalone sort of 64-bit keys
+
+
 def _json_line(out):
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out[-2000:]
@@ -53,6 +56,7 @@ def test_bench_two_ranks_rehearsal():
     for k in KEYS:
         assert k in j, k
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and "cpu_baseline" not in j
+    assert 0.0 < j["roofline"]["frac"] < 1.0 and j["roofline"]["launches"] == args_key_passes
     assert j["config"]["particles_per_gpu"] == 1000000
     assert j["config"]["orchestration"].startswith("libcstone_hip")
     # both exchanges moved data: particles changed owner and halos were served
