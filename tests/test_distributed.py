@@ -93,6 +93,13 @@ def test_native_domain_float_coordinates(kb, curve):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,particles,pbc", [(3, 600, 0), (4, 1500, 1), (2, 200, 0)])
+def test_native_domain_tiny_clouds(nproc, particles, pbc):
+    """a few hundred particles per rank: trees of a handful of leaves, ranges of a few cells, sort tails only"""
+    _launch(nproc, "hip", particles, 3, pbc, 29660 + nproc, impl="native")
+
+
+@pytest.mark.gpu
 def test_native_domain_without_halo_margins(monkeypatch):
     """the assigned block is written before the halo counts are known, at an offset that normally leaves room for the
     halos of the lower ranks; with no room at all the block has to be moved once (the fallback of abrupt changes)"""
