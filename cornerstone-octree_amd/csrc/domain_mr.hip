@@ -105,6 +105,29 @@ inline std::vector<int> uniformBinsHost(const std::vector<uint32_t>& counts, int
 
 // ---- device helpers ------------------------------------------------------------------------------------------------
 
+//! for each of two keys: the index of the leaf that contains it and that leaf's start and end key (one thread per key);
+//! out[3 q] = index, out[3 q + 1] = start, out[3 q + 2] = end.  A key at or behind the end of the curve gives index L.
+template<class K>
+__global__ void containingLeavesKernel(const K* __restrict__ tree, int numLeaves, K key0, K key1,
+                                       uint64_t* __restrict__ out)
+{
+    const int q = threadIdx.x;
+    if (q > 1) return;
+    const K key = q == 0 ? key0 : key1;
+    int lo = 0, hi = numLeaves + 1; // first entry of tree[0 .. L] greater than key
+    while (lo < hi)
+    {
+        int mid = (lo + hi) >> 1;
+        if (tree[mid] <= key) lo = mid + 1;
+        else hi = mid;
+    }
+    const int idx  = lo - 1; // tree[0] = 0 <= key: idx >= 0; key >= tree[L]: idx = L
+    out[3 * q]     = uint64_t(idx);
+    out[3 * q + 1] = uint64_t(tree[idx]);
+    out[3 * q + 2] = idx < numLeaves ? uint64_t(tree[idx + 1]) : uint64_t(tree[idx]);
+}
+
+
 //! rows[i] = {x, y, z, h}[idx[i]]: the fields of a particle travel as one record
 template<class T>
 __global__ __launch_bounds__(256) void packRowsKernel(const uint32_t* __restrict__ idx, size_t m,
@@ -627,7 +650,8 @@ public:
         // ---- this rank's finest tree over its assigned particles; its SFC range must end on leaf boundaries
         CS_TRY(updateFocusTree(keysM, nm));
         tick("5a focus update");
-        CS_TRY(enforceBoundaries(keysM, nm));
+        int first = 0, last = 0;
+        CS_TRY(enforceBoundaries(keysM, nm, &first, &last));
         tick("5b boundaries");
         CS_TRY(buildFocusOctree());
         tick("5c linked octree");
@@ -639,8 +663,6 @@ public:
                 if (lr[l + 1] > lr[l]) prevMaxLeafLevel_ = l;
         }
         const int L = fLeaves_;
-        int first = 0, last = L;
-        CS_TRY(findLeaves(&first, &last));
         CS_TRY(layout_.ensure(ctx_, size_t(L + 1) * sizeof(uint32_t)));
         CS_HIP(ctx_, hipMemsetAsync(layout_.p, 0, sizeof(uint32_t), ctx_->stream));
         CS_TRY(cstone_hip_inclusive_scan_u32(ctx_, fCounts_.as<uint32_t>(), layout_.as<uint32_t>() + 1, size_t(L)));
@@ -1079,63 +1101,103 @@ private:
         }
     }
 
-    //! index of the leaf that contains key (below = true) or of the first leaf starting at or behind key
-    int leafIndex(K key, bool below, int* out)
-    {
-        if (uint64_t(key) >= uint64_t(endKey<K>()))
-        {
-            *out = below ? fLeaves_ - 1 : fLeaves_;
-            return CSTONE_OK;
-        }
-        K* dq        = reinterpret_cast<K*>(scal_.as<char>() + 1024);
-        uint64_t* dr = reinterpret_cast<uint64_t*>(scal_.as<char>() + 1024 + 64);
-        K q          = below ? K(key + 1) : key; // leaf STARTS <= key  <=>  starts < key + 1
-        CS_HIP(ctx_, hipMemcpyAsync(dq, &q, sizeof(K), hipMemcpyHostToDevice, ctx_->stream));
-        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
-        CS_TRY(cstone_hip_lower_bound(ctx_, kb, fTree_.p, size_t(fLeaves_), dq, 1, dr));
-        uint64_t pos = 0;
-        CS_TRY(toHost(&pos, dr, 8));
-        *out = below ? int(pos) - 1 : int(pos);
-        return CSTONE_OK;
-    }
-
     /*! The rank's SFC range must start and end on leaf boundaries of its own tree (the job of enforceKeys in the
-     *  reference's focus tree, R/focus/rebalance.hpp:199-266): a leaf that straddles the range is replaced by the
+     *  reference's focus tree, R/focus/rebalance.hpp:199-266): a leaf that straddles a range boundary is replaced by the
      *  coarsest set of octree nodes that resolves the boundary key.  Such leaves are mostly empty, so the count-driven
-     *  update merges them again and the split is redone at every sync: a copy of the leaf array and a recount. */
-    int enforceBoundaries(const K* keysM, size_t nm)
+     *  update merges them again and the split is redone at every sync: a copy of the leaf array and a recount.
+     *  One device query and ONE read-back serve both boundaries; the leaf range [*first, *last) of the rank in the
+     *  resulting tree follows on the host. */
+    int enforceBoundaries(const K* keysM, size_t nm, int* first, int* last)
     {
-        bool changed = false;
-        for (K key : {assignment_[rank_], assignment_[rank_ + 1]})
+        const uint64_t end = uint64_t(endKey<K>());
+        const uint64_t b[2] = {uint64_t(assignment_[rank_]), uint64_t(assignment_[rank_ + 1])};
+        uint64_t* dq = reinterpret_cast<uint64_t*>(scal_.as<char>() + 1024);
+        hipLaunchKernelGGL(containingLeavesKernel<K>, 1, 64, 0, ctx_->stream, fTree_.as<K>(), fLeaves_,
+                           K(std::min(b[0], end)), K(std::min(b[1], end)), dq);
+        uint64_t q[6];
+        CS_TRY(toHost(q, dq, sizeof q));
+        const int L = fLeaves_;
+        // leaves to replace, in ascending order: (index, start, end, boundary keys strictly inside)
+        struct Cut
         {
-            if (key == 0 || uint64_t(key) >= uint64_t(endKey<K>())) continue;
-            int idx = 0;
-            CS_TRY(leafIndex(key, true, &idx));
-            K se[2];
-            CS_TRY(toHost(se, fTree_.as<K>() + idx, 2 * sizeof(K)));
-            if (se[0] == key) continue;
-            std::vector<K> cover;
-            appendCover(cover, uint64_t(se[0]), uint64_t(key));
-            appendCover(cover, uint64_t(key), uint64_t(se[1]));
-            const int extra = int(cover.size()) - 1; // the straddling leaf becomes cover.size() leaves
-            const int L     = fLeaves_;
-            CS_TRY(ensureTree(fTree_, fCounts_, fCap_, L + extra));
-            CS_TRY(fTmp_.ensure(ctx_, size_t(L + 1 + extra) * sizeof(K)));
-            K* t = fTmp_.as<K>();
-            CS_HIP(ctx_, hipMemcpyAsync(t, fTree_.p, size_t(idx) * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
-            CS_HIP(ctx_, hipMemcpyAsync(t + idx, cover.data(), cover.size() * sizeof(K), hipMemcpyHostToDevice,
-                                        ctx_->stream));
-            CS_HIP(ctx_, hipMemcpyAsync(t + idx + cover.size(), fTree_.as<K>() + idx + 1,
-                                        size_t(L + 1 - (idx + 1)) * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
-            CS_HIP(ctx_, hipMemcpyAsync(fTree_.p, t, size_t(L + 1 + extra) * sizeof(K), hipMemcpyDeviceToDevice,
-                                        ctx_->stream));
-            CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream)); // `cover` is a local
-            fLeaves_ = L + extra;
-            changed  = true;
+            int idx;
+            uint64_t s, e;
+            std::vector<uint64_t> keys;
+        };
+        std::vector<Cut> cuts;
+        for (int k = 0; k < 2; ++k)
+        {
+            const int idx = int(q[3 * k]);
+            if (b[k] == 0 || b[k] >= end || idx >= L || q[3 * k + 1] == b[k]) continue; // already a leaf boundary
+            if (!cuts.empty() && cuts.back().idx == idx) { cuts.back().keys.push_back(b[k]); }
+            else { cuts.push_back({idx, q[3 * k + 1], q[3 * k + 2], {b[k]}}); }
         }
-        if (changed)
+        // position of a boundary key in the new leaf array: leaves before it in the old array + what the covers add
+        coverHost_.clear();
+        std::vector<int> coverBegin, coverSize;
+        for (const Cut& c : cuts)
+        {
+            coverBegin.push_back(int(coverHost_.size()));
+            uint64_t a = c.s;
+            for (uint64_t key : c.keys)
+            {
+                appendCover(coverHost_, a, key);
+                a = key;
+            }
+            appendCover(coverHost_, a, c.e);
+            coverSize.push_back(int(coverHost_.size()) - coverBegin.back());
+        }
+        auto newIndexOf = [&](uint64_t key, int containing, bool aligned) -> int
+        {
+            if (key == 0) return 0;
+            int shift = 0;
+            for (size_t c = 0; c < cuts.size(); ++c)
+            {
+                if (cuts[c].idx < containing) { shift += coverSize[c] - 1; }
+                else if (cuts[c].idx == containing && !aligned)
+                {
+                    const K* cb = coverHost_.data() + coverBegin[c];
+                    return containing + shift + int(std::find(cb, cb + coverSize[c], K(key)) - cb);
+                }
+            }
+            return containing + shift;
+        };
+        int extra = 0;
+        for (int sz : coverSize)
+            extra += sz - 1;
+        const int newL = L + extra;
+        *first = newIndexOf(b[0], int(q[0]), b[0] == 0 || q[1] == b[0]);
+        *last  = b[1] >= end ? newL : newIndexOf(b[1], int(q[3]), q[4] == b[1]);
+        if (!cuts.empty())
+        {
+            CS_TRY(ensureTree(fTree_, fCounts_, fCap_, newL));
+            CS_TRY(fTmp_.ensure(ctx_, size_t(newL + 1) * sizeof(K)));
+            K* t        = fTmp_.as<K>();
+            const K* ft = fTree_.as<K>();
+            int src = 0, dst = 0; // old leaves [src, ...) still to copy, new position dst
+            for (size_t c = 0; c < cuts.size(); ++c)
+            {
+                const int keep = cuts[c].idx - src;
+                if (keep)
+                    CS_HIP(ctx_, hipMemcpyAsync(t + dst, ft + src, size_t(keep) * sizeof(K), hipMemcpyDeviceToDevice,
+                                                ctx_->stream));
+                dst += keep;
+                // coverHost_ is a member: it outlives the copy (the next sync refills it behind a stream sync)
+                CS_HIP(ctx_, hipMemcpyAsync(t + dst, coverHost_.data() + coverBegin[c], size_t(coverSize[c]) * sizeof(K),
+                                            hipMemcpyHostToDevice, ctx_->stream));
+                dst += coverSize[c];
+                src = cuts[c].idx + 1;
+            }
+            CS_HIP(ctx_, hipMemcpyAsync(t + dst, ft + src, size_t(L + 1 - src) * sizeof(K), hipMemcpyDeviceToDevice,
+                                        ctx_->stream));
+            CS_HIP(ctx_, hipMemcpyAsync(fTree_.p, t, size_t(newL + 1) * sizeof(K), hipMemcpyDeviceToDevice,
+                                        ctx_->stream));
+            fLeaves_ = newL;
             CS_TRY(cstone_hip_compute_node_counts(ctx_, kb, fTree_.p, fCounts_.as<uint32_t>(), fLeaves_, keysM, nm,
                                                   0xFFFFFFFFu));
+        }
+        if (*first < 0 || *last > fLeaves_ || *last <= *first)
+            return fail(ctx_, CSTONE_E_INTERNAL, "domain_mr_sync: bad leaf range [%d, %d) of %d", *first, *last, fLeaves_);
         return CSTONE_OK;
     }
 
@@ -1213,15 +1275,6 @@ private:
         return cstone_hip_node_centers(ctx_, curve_, kb, rb, nsPrefixes_.p, M, &box_, nsCenters_.p, nsSizes_.p);
     }
 
-    int findLeaves(int* first, int* last)
-    {
-        CS_TRY(leafIndex(assignment_[rank_], true, first));
-        CS_TRY(leafIndex(assignment_[rank_ + 1], false, last));
-        if (*first < 0 || *last > fLeaves_ || *last <= *first)
-            return fail(ctx_, CSTONE_E_INTERNAL, "domain_mr_sync: bad leaf range [%d, %d) of %d", *first, *last, fLeaves_);
-        return CSTONE_OK;
-    }
-
     cstone_hip_ctx* ctx_;
     int curve_, rank_, P_;
     uint32_t bucket_, bucketFocus_;
@@ -1248,6 +1301,7 @@ private:
     DevBuf leaving_, sendRows_, recvRows_, rcol_[4], rcolS_[4], rk_, ro_, posA_, posB_, moveTmp_;
     DevBuf propRecv_[MAX_PROPS], propRecvS_[MAX_PROPS];
     uint64_t prevLo_ = 0, prevHi_ = 0;
+    std::vector<K> coverHost_; // leaf keys inserted at the range boundaries, staged for the copy to the device
     // tree over all local particles incl. halos (octree()), built on request
     DevBuf nsTree_, nsCounts_, nsLayout_, nsPrefixes_, nsChild_, nsParents_, nsLevelRange_, nsItl_, nsLti_, nsCenters_,
         nsSizes_;
