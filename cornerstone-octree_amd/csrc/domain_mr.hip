@@ -596,7 +596,9 @@ public:
         cur_ ^= 1; // the inputs may live in the other buffer set
         Out& o           = out_[cur_];
         const bool margins = P_ > 1 && !noMargin_;
-        const uint64_t M   = margins ? std::max<uint64_t>(2 * prevLo_ + 4096, firstCall_ ? nm / 4 : 0) : 0;
+        // (a multiple of 4 elements: the assigned range the client passes back as the next input then starts on a
+        //  16-byte boundary, which the fused encode + digit counting kernel needs for its vector loads)
+        const uint64_t M   = margins ? (std::max<uint64_t>(2 * prevLo_ + 4096, firstCall_ ? nm / 4 : 0) + 3) & ~uint64_t(3) : 0;
         uint64_t cap       = M + nm + (margins ? std::max<uint64_t>(2 * prevHi_ + 4096, firstCall_ ? nm / 4 : 0) : 0);
         CS_TRY(o.keys.ensure(ctx_, cap * sizeof(K)));
         for (DevBuf* b : {&o.x, &o.y, &o.z, &o.h})
@@ -795,7 +797,7 @@ public:
         if (nlo > M || M + nm + nhi > cap)
         {
             // the margins were too small (first syncs, abrupt changes): move the block once, through a scratch copy
-            const uint64_t M2 = nlo, cap2 = nlo + nm + nhi;
+            const uint64_t M2 = (nlo + 3) & ~uint64_t(3), cap2 = M2 + nm + nhi;
             auto shift = [&](DevBuf& buf, size_t elem) -> int
             {
                 CS_TRY(moveTmp_.ensure(ctx_, nm * elem));
@@ -811,7 +813,7 @@ public:
                 CS_TRY(shift(*b, sizeof(T)));
             for (int q = 0; q < numProps; ++q)
                 CS_TRY(shift(o.props[q], size_t(propBytes[q])));
-            off = 0;
+            off = M2 - nlo;
         }
         const uint64_t A = off + nlo; // first assigned slot
         prevLo_ = nlo, prevHi_ = nhi;
