@@ -156,6 +156,24 @@ __global__ __launch_bounds__(256) void unpackRowsKernel(const T* __restrict__ ro
     h[i] = rows[4 * i + 3];
 }
 
+//! x, y, z, h of the kept particles from their input slots (order[i]) to their final slots (pos[i], or i when pos is
+//! null): the two index maps are read once for the four columns
+template<class T>
+__global__ __launch_bounds__(256) void placeColumnsKernel(const uint32_t* __restrict__ order,
+                                                          const uint32_t* __restrict__ pos, size_t m,
+                                                          const T* __restrict__ x, const T* __restrict__ y,
+                                                          const T* __restrict__ z, const T* __restrict__ h,
+                                                          T* __restrict__ dx, T* __restrict__ dy, T* __restrict__ dz,
+                                                          T* __restrict__ dh)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t s = order[i];
+    const size_t d   = pos ? size_t(pos[i]) : i;
+    const T vx = x[s], vy = y[s], vz = z[s], vh = h[s];
+    dx[d] = vx, dy[d] = vy, dz[d] = vz, dh[d] = vh;
+}
+
 __global__ __launch_bounds__(256) void boxFlagsKernel(const int32_t* __restrict__ boxes, int n,
                                                       uint32_t* __restrict__ flags)
 {
@@ -622,20 +640,15 @@ public:
         {
             CS_HIP(ctx_, hipMemcpyAsync(keysM, keptKeys, na * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
         }
-        auto place = [&](const T* src, const T* srcRecv, T* dst) -> int
         {
-            if (nb)
-            {
-                CS_TRY(cstone_hip_gather_scatter(ctx_, sizeof(T), keptO, posA_.as<uint32_t>(), na, src, dst));
-                CS_TRY(cstone_hip_scatter(ctx_, sizeof(T), posB_.as<uint32_t>(), nb, srcRecv, dst));
-            }
-            else { CS_TRY(cstone_hip_gather(ctx_, sizeof(T), keptO, na, src, dst)); }
-            return CSTONE_OK;
-        };
-        CS_TRY(place(x, recvSorted[0], o.x.as<T>() + M));
-        CS_TRY(place(y, recvSorted[1], o.y.as<T>() + M));
-        CS_TRY(place(z, recvSorted[2], o.z.as<T>() + M));
-        CS_TRY(place(h, recvSorted[3], o.h.as<T>() + M));
+            T* dst[4] = {o.x.as<T>() + M, o.y.as<T>() + M, o.z.as<T>() + M, o.h.as<T>() + M};
+            if (na)
+                hipLaunchKernelGGL(placeColumnsKernel<T>, gridFor(na, 256), 256, 0, ctx_->stream, keptO,
+                                   nb ? posA_.as<uint32_t>() : nullptr, size_t(na), x, y, z, h, dst[0], dst[1], dst[2],
+                                   dst[3]);
+            for (int c = 0; c < 4 && nb; ++c)
+                CS_TRY(cstone_hip_scatter(ctx_, sizeof(T), posB_.as<uint32_t>(), nb, recvSorted[c], dst[c]));
+        }
         for (int q = 0; q < numProps; ++q)
         {
             const int e = propBytes[q];
