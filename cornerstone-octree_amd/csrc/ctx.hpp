@@ -99,7 +99,7 @@ int minMaxCoordinates(cstone_hip_ctx* ctx, int real_bits, const void* const* xs,
 //! encode + the sort's digit histograms in one kernel (sfc.hip); *fused = false: hist untouched (unaligned input)
 int computeKeysAndHistogram(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
                             const void* z, void* keys, size_t n, const cstone_box& box, uint32_t* hist, bool* fused,
-                            int firstDigit = 0);
+                            int firstDigit = 0, bool honourMarkers = true);
 
 inline unsigned gridFor(size_t n, unsigned block, unsigned perThread = 1)
 {
@@ -107,11 +107,12 @@ inline unsigned gridFor(size_t n, unsigned block, unsigned perThread = 1)
     return unsigned((n + per - 1) / per);
 }
 
-//! encode + SFC ordering with only the digits at or above bit 8 * startPass radix-sorted (sort.hip)
+//! encode + SFC ordering with only the digits at or above bit 8 * startPass radix-sorted (sort.hip); honourMarkers =
+//! false: keys is pure output (nothing of the caller's in it), it is neither cleared nor read
 int sfcKeysAndOrderingHint(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
                            const void* z, void* keys, uint32_t* ordering, size_t n, const cstone_box& box,
                            void* keys_alt, uint32_t* values_alt, void* temp, size_t temp_bytes, int startPass,
-                           int* tooLongDev);
+                           int* tooLongDev, bool honourMarkers = true);
 
 //! bottom-up saturating sum over the linked octree, launching only the levels that exist (tree.hip)
 int upsweepSumLevels(cstone_hip_ctx* ctx, int numLevelsPlus2, const int32_t* levelRangeHost, const int32_t* levelRange,

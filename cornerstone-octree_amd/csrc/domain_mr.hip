@@ -476,10 +476,9 @@ public:
         CS_TRY(ensureSortScratch(nAlloc));
         // encode leaves entries that hold the remove marker 2^(3 maxLevel) alone (R/sfc/sfc.hpp:284-291): such particles
         // sort behind the end of the curve and leave the domain
+        // (without a key array from the caller there are no markers: the key buffer is then pure output)
         if (keysIn && n)
             CS_HIP(ctx_, hipMemcpyAsync(keys_.p, keysIn, n * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
-        else
-            CS_HIP(ctx_, hipMemsetAsync(keys_.p, 0, n * sizeof(K), ctx_->stream));
         if (n)
         {
             // radix passes only over the digits above the leaf level (+1) of the previous tree, runs of equal high digits
@@ -491,7 +490,7 @@ public:
             int* tooLong = reinterpret_cast<int*>(scal_.as<char>() + 128);
             CS_TRY(sfcKeysAndOrderingHint(ctx_, curve_, kb, rb, x, y, z, keys_.p, order_.as<uint32_t>(), n, box_,
                                           keysAlt_.p, orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes, startPass,
-                                          tooLong));
+                                          tooLong, keysIn != nullptr));
             if (startPass > 0)
             {
                 int flag = 0;

@@ -106,7 +106,8 @@ template<class K, class T, int VEC, bool HILBERT>
 __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict__ x, const T* __restrict__ y,
                                                              const T* __restrict__ z, K* __restrict__ keys, size_t n,
                                                              DBox<T> box, const uint16_t* __restrict__ encTable,
-                                                             uint32_t* __restrict__ hist, int firstDigit)
+                                                             uint32_t* __restrict__ hist, int firstDigit,
+                                                             bool honourMarkers)
 {
     constexpr int P = int(sizeof(K));
     __shared__ uint16_t enc[24 * 8];
@@ -166,7 +167,14 @@ __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict
             __builtin_memcpy(vx, __builtin_assume_aligned(x + base, sizeof(T) * VEC), sizeof vx);
             __builtin_memcpy(vy, __builtin_assume_aligned(y + base, sizeof(T) * VEC), sizeof vy);
             __builtin_memcpy(vz, __builtin_assume_aligned(z + base, sizeof(T) * VEC), sizeof vz);
-            __builtin_memcpy(vk, __builtin_assume_aligned(keys + base, sizeof(K) * VEC), sizeof vk);
+            // honourMarkers == false: the key array holds nothing of the caller's (no remove markers): it is not read
+            if (honourMarkers) { __builtin_memcpy(vk, __builtin_assume_aligned(keys + base, sizeof(K) * VEC), sizeof vk); }
+            else
+            {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    vk[v] = 0;
+            }
 #pragma unroll
             for (int v = 0; v < VEC; ++v)
                 out[v] = gridMorton<K, T>(vx[v], vy[v], vz[v], mx, my, mz, sx, sy, sz);
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict
         K key      = 0;
         if (valid)
         {
-            key     = encodeOne(x[i], y[i], z[i], keys[i]);
+            key     = encodeOne(x[i], y[i], z[i], honourMarkers ? keys[i] : K(0));
             keys[i] = key;
         }
         count(key, valid);
@@ -269,13 +277,18 @@ inline size_t encodeBlocksPerCu()
 
 template<class K, class T>
 int computeKeysHist(cstone_hip_ctx* ctx, int curve, const T* x, const T* y, const T* z, K* keys, size_t n,
-                    const cstone_box& hostBox, uint32_t* hist, bool* fused, int firstDigit)
+                    const cstone_box& hostBox, uint32_t* hist, bool* fused, int firstDigit, bool honourMarkers)
 {
     constexpr int VEC = 16 / sizeof(T);
     bool aligned = (uintptr_t(x) % 16 == 0) && (uintptr_t(y) % 16 == 0) && (uintptr_t(z) % 16 == 0) &&
                    (uintptr_t(keys) % (sizeof(K) * VEC) == 0);
     *fused = aligned && n > 0;
-    if (!*fused) return computeKeys<K, T>(ctx, curve, x, y, z, keys, n, hostBox); // the sort counts on its own
+    if (!*fused)
+    {
+        // the plain encode kernel always looks for remove markers: without any, give it a cleared array
+        if (!honourMarkers && n) CS_HIP(ctx, hipMemsetAsync(keys, 0, n * sizeof(K), ctx->stream));
+        return computeKeys<K, T>(ctx, curve, x, y, z, keys, n, hostBox); // the sort counts on its own
+    }
     StageTimer timer(ctx, CSTONE_STAGE_ENCODE);
     DBox<T> box   = makeDBox<T>(hostBox);
     auto* enc     = (const uint16_t*)ctx->hilbertTables;
@@ -283,30 +296,30 @@ int computeKeysHist(cstone_hip_ctx* ctx, int curve, const T* x, const T* y, cons
     unsigned grid = unsigned(std::max<size_t>(1, std::min<size_t>(size_t(ctx->numCu) * encodeBlocksPerCu(), (nVec + 255) / 256)));
     if (curve == CSTONE_HILBERT)
         hipLaunchKernelGGL((encodeHistogramKernel<K, T, VEC, true>), grid, 256, 0, ctx->stream, x, y, z, keys, n, box,
-                           enc, hist, firstDigit);
+                           enc, hist, firstDigit, honourMarkers);
     else
         hipLaunchKernelGGL((encodeHistogramKernel<K, T, VEC, false>), grid, 256, 0, ctx->stream, x, y, z, keys, n, box,
-                           enc, hist, firstDigit);
+                           enc, hist, firstDigit, honourMarkers);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }
 
 int computeKeysAndHistogram(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
                             const void* z, void* keys, size_t n, const cstone_box& box, uint32_t* hist, bool* fused,
-                            int firstDigit)
+                            int firstDigit, bool honourMarkers)
 {
     if (key_bits == 32 && real_bits == 32)
         return computeKeysHist<uint32_t, float>(ctx, curve, (const float*)x, (const float*)y, (const float*)z,
-                                                (uint32_t*)keys, n, box, hist, fused, firstDigit);
+                                                (uint32_t*)keys, n, box, hist, fused, firstDigit, honourMarkers);
     if (key_bits == 32 && real_bits == 64)
         return computeKeysHist<uint32_t, double>(ctx, curve, (const double*)x, (const double*)y, (const double*)z,
-                                                 (uint32_t*)keys, n, box, hist, fused, firstDigit);
+                                                 (uint32_t*)keys, n, box, hist, fused, firstDigit, honourMarkers);
     if (key_bits == 64 && real_bits == 32)
         return computeKeysHist<uint64_t, float>(ctx, curve, (const float*)x, (const float*)y, (const float*)z,
-                                                (uint64_t*)keys, n, box, hist, fused, firstDigit);
+                                                (uint64_t*)keys, n, box, hist, fused, firstDigit, honourMarkers);
     if (key_bits == 64 && real_bits == 64)
         return computeKeysHist<uint64_t, double>(ctx, curve, (const double*)x, (const double*)y, (const double*)z,
-                                                 (uint64_t*)keys, n, box, hist, fused, firstDigit);
+                                                 (uint64_t*)keys, n, box, hist, fused, firstDigit, honourMarkers);
     return fail(ctx, CSTONE_E_ARG, "sfc_keys_and_ordering: unsupported type combination");
 }
 

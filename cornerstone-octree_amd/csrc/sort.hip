@@ -966,7 +966,7 @@ namespace cship
 int sfcKeysAndOrderingHint(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
                            const void* z, void* keys, uint32_t* ordering, size_t n, const cstone_box& box,
                            void* keys_alt, uint32_t* values_alt, void* temp, size_t temp_bytes, int startPass,
-                           int* tooLongDev)
+                           int* tooLongDev, bool honourMarkers)
 {
     if (n == 0) return CSTONE_OK;
     startPass &= ~1; // an even number of passes leaves the result in the caller's buffers
@@ -980,7 +980,7 @@ int sfcKeysAndOrderingHint(cstone_hip_ctx* ctx, int curve, int key_bits, int rea
     CS_TRY(run(1));
     bool fused = false;
     CS_TRY(computeKeysAndHistogram(ctx, curve, key_bits, real_bits, x, y, z, keys, n, box, (uint32_t*)temp, &fused,
-                                   startPass));
+                                   startPass, honourMarkers));
     CS_TRY(run(fused ? 2 : 0));
     if (startPass > 0)
     {
