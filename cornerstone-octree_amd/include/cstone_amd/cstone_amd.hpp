@@ -463,6 +463,40 @@ struct OctreeNsView
     float searchExtFactor{1.0};
 };
 
+//! computeGeoCentersGpu (R/focus/source_center_gpu.h): geometric centers and half sizes of all nodes, Vec3<T>[numNodes] each
+template<class KeyType, class T>
+void computeGeoCentersGpu(const KeyType* prefixes, TreeNodeIndex numNodes, T* centers, T* sizes, const Box<T>& box,
+                          Curve curve = Curve::hilbert)
+{
+    Context::check(cstone_hip_node_centers(Context::get(), int(curve), detail::keyBits<KeyType>(), detail::realBits<T>(),
+                                           prefixes, numNodes, &box.pod(), centers, sizes),
+                   "computeGeoCentersGpu");
+}
+
+//! segmentMax + scaleGpu as Halos::discover uses them (R/halos/halos.hpp:150-160): radii[i] = 2 ext max(h) over leaf i
+template<class T>
+void haloRadiiGpu(const T* h, const LocalIndex* layout, TreeNodeIndex firstLeaf, TreeNodeIndex lastLeaf,
+                  TreeNodeIndex numLeaves, float searchExtFactor, float* radii)
+{
+    Context::check(cstone_hip_halo_radii(Context::get(), detail::realBits<T>(), h, layout, firstLeaf, lastLeaf, numLeaves,
+                                         searchExtFactor, radii),
+                   "haloRadiiGpu");
+}
+
+/*! findNeighbors (R/findneighbors.hpp:160-188) for the particles [first, last) on an OctreeNsView:
+ *  neighborsCount[i - first] = number of j != i with |r_i - r_j|^2 < (2 h_i)^2 (minimum image on periodic axes), the
+ *  first ngmax of them in neighbors[(i - first) * ngmax + k] (device arrays; CPU order of the reference) */
+template<class T, class KeyType>
+void findNeighborsGpu(const T* x, const T* y, const T* z, const T* h, LocalIndex first, LocalIndex last,
+                      const Box<T>& box, const OctreeNsView<T, KeyType>& tree, unsigned ngmax, LocalIndex* neighbors,
+                      unsigned* neighborsCount)
+{
+    Context::check(cstone_hip_find_neighbors(Context::get(), detail::realBits<T>(), x, y, z, h, first, last, &box.pod(),
+                                             tree.childOffsets, tree.internalToLeaf, tree.layout, tree.centers,
+                                             tree.sizes, tree.searchExtFactor, ngmax, neighbors, neighborsCount),
+                   "findNeighborsGpu");
+}
+
 //! R/traversal/groups.hpp:20-26: groups of target particles, device pointers
 struct GroupView
 {
@@ -524,6 +558,20 @@ void computeGroupSplits(LocalIndex first, LocalIndex last, const Tc* x, const Tc
     }
     Context::check(rc, "computeGroupSplits");
     groups.resize(std::size_t(numGroups) + 1);
+}
+
+//! findNeighbors with the targets of every wavefront taken from one group of a GroupView
+template<class T, class KeyType>
+void findNeighborsGpu(const T* x, const T* y, const T* z, const T* h, const GroupView& groups, const Box<T>& box,
+                      const OctreeNsView<T, KeyType>& tree, unsigned ngmax, LocalIndex* neighbors,
+                      unsigned* neighborsCount)
+{
+    Context::check(cstone_hip_find_neighbors_groups(Context::get(), detail::realBits<T>(), x, y, z, h, groups.firstBody,
+                                                    groups.lastBody, groups.groupStart, groups.groupEnd, groups.numGroups,
+                                                    &box.pod(), tree.childOffsets, tree.internalToLeaf, tree.layout,
+                                                    tree.centers, tree.sizes, tree.searchExtFactor, ngmax, neighbors,
+                                                    neighborsCount),
+                   "findNeighborsGpu");
 }
 
 /*! cstone::Domain<KeyType, T, GpuTag> on SEVERAL ranks, one process per GPU (cstone_hip_domain_mr_*).

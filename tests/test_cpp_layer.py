@@ -9,13 +9,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "cornerstone-octree_amd", "build", "domain_example")
 
 
-def _compile():
+SEAM_EXE = os.path.join(ROOT, "cornerstone-octree_amd", "build", "seam_check")
+
+
+def _compile(source="domain_example.cpp", exe=EXE):
     lib = os.path.join(ROOT, "cornerstone-octree_amd", "lib")
-    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
     cmd = ["g++", "-std=c++20", "-O1", "-Wall", "-Wno-comment", "-I", os.path.join(ROOT, "include"), "-I",
-           os.path.join(ROOT, "cornerstone-octree_amd", "include"), os.path.join(ROOT, "examples", "domain_example.cpp"),
-           "-L", lib, "-lcstone_hip", f"-Wl,-rpath,{lib}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", EXE]
+           os.path.join(ROOT, "cornerstone-octree_amd", "include"), os.path.join(ROOT, "examples", source),
+           "-L", lib, "-lcstone_hip", f"-Wl,-rpath,{lib}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
     subprocess.run(cmd, check=True, capture_output=True)
+
+
+def test_cpp_seam_check_compiles():
+    """every template of the host layer instantiated for both key widths and both real types (examples/seam_check.cpp)"""
+    _compile("seam_check.cpp", SEAM_EXE)
+    assert os.path.exists(SEAM_EXE)
+
+
+@pytest.mark.gpu
+def test_cpp_seam_check_runs():
+    if not os.path.exists(SEAM_EXE):
+        _compile("seam_check.cpp", SEAM_EXE)
+    r = subprocess.run([SEAM_EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "seam check: all passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
 
 
 def test_cpp_layer_compiles_with_host_compiler():
