@@ -72,6 +72,9 @@ __device__ __forceinline__ int toGridCeil(T x)
  *         the own key range [leaves[first], leaves[last]) are skipped, every other overlapped leaf is flagged
  *  MODE 1 (export): only compute the dilated boxes of leaves [first,last): boxes[k][0..5] = lo/hi per axis,
  *         boxes[k][6] = 1 if the box is NOT contained in the own key range (it needs halos from other ranks), [7] = 0
+ *  MODE 3 (export, proven): like MODE 1, but boxes[k][6] = 1 only if the box really overlaps a leaf OUTSIDE the own key
+ *         range of this tree (the walk of MODE 0, stopped at the first such leaf): the enclosing-node test of MODE 1
+ *         also exports every box that straddles a coarse octree boundary deep inside the own domain
  *  MODE 2 (serve): targets are numTargets foreign boxes (same 8-int records, record[6] == 0 are ignored); only nodes
  *         that intersect the own key range are visited and own leaves overlapped by a target are flagged: the owner
  *         of the particles answers "which of my leaves does your halo region touch" on its own, finest tree */
@@ -147,13 +150,13 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
             inside          = nodeStart >= lowest && nodeStart + nodeSpan<K>(common) <= highest;
         }
         active = !inside;
-        if (MODE == 1)
+        if (MODE == 1 || MODE == 3)
         {
             int* rec = boxesOut + size_t(slot0) * 8;
 #pragma unroll
             for (int d = 0; d < 3; ++d)
                 rec[2 * d] = lo[d], rec[2 * d + 1] = hi[d];
-            rec[6] = active ? 1 : 0;
+            rec[6] = (MODE == 1 && active) ? 1 : 0; // MODE 3: set by the walk below
             rec[7] = 0;
         }
     }
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
             unsigned level = prefixBits(prefix) / 3;
             isLeaf         = childOffsets[n] == 0;
             K end          = start + nodeSpan<K>(level);
-            if (MODE == 0 && !(start < lowest || end > highest)) return false; // inside my own range: nothing to find
+            if ((MODE == 0 || MODE == 3) && !(start < lowest || end > highest)) return false; // inside my own range: nothing to find
             if (MODE == 2 && (end <= lowest || start >= highest)) return false; // not mine: the owner serves it
             int c[3];
             nodeCorner<K, HILBERT>(start, level, dec, c[0], c[1], c[2]);
@@ -204,6 +207,7 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
                 if (lane == 0)
                 {
                     if (MODE == 2) atomicOr(&flags[internalToLeaf[0]], tmark);
+                    else if (MODE == 3) boxesOut[size_t(blockIdx.x * (HALO_WAVES * 64) + wave * 64 + src) * 8 + 6] = 1;
                     else flags[internalToLeaf[0]] = 1;
                 }
                 continue;
@@ -225,7 +229,17 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
                 child = childOffsets[par] + NodeIdx(lane & 7u);
                 go    = descend(child, isLeaf);
             }
-            if (go && isLeaf)
+            if (MODE == 3)
+            {
+                // one foreign leaf is proof enough: mark the record and leave this target
+                if (__any(go && isLeaf))
+                {
+                    if (lane == 0) boxesOut[size_t(blockIdx.x * (HALO_WAVES * 64) + wave * 64 + src) * 8 + 6] = 1;
+                    top = 0;
+                    break;
+                }
+            }
+            else if (go && isLeaf)
             {
                 if (MODE == 2) atomicOr(&flags[internalToLeaf[child]], tmark);
                 else flags[internalToLeaf[child]] = 1;
@@ -343,6 +357,41 @@ int cstone_hip_find_halos(cstone_hip_ctx* ctx, int curve, int key_bits, int real
 }
 
 /* ---- building blocks of the multi-rank halo exchange (owner-side discovery) ---- */
+
+int cstone_hip_halo_boxes_foreign(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* prefixes,
+                                  const int32_t* child_offsets, const int32_t* internal_to_leaf, const void* leaves,
+                                  const float* radii, const cstone_box* box_host, int first, int last, int32_t* boxes)
+{
+    if (!ctx || !prefixes || !child_offsets || !internal_to_leaf || !leaves || !radii || !box_host || !boxes ||
+        first < 0 || last < first)
+        return fail(ctx, CSTONE_E_ARG, "halo_boxes_foreign: bad argument");
+    if (last == first) return CSTONE_OK;
+    if (curve != CSTONE_MORTON && curve != CSTONE_HILBERT) return fail(ctx, CSTONE_E_ARG, "halo_boxes_foreign: bad curve");
+    StageTimer timer(ctx, CSTONE_STAGE_HALOS);
+    unsigned grid = gridFor(size_t(last - first), HALO_WAVES * 64);
+    auto* tables  = (const uint16_t*)ctx->hilbertTables;
+    int* errors   = ctx->devScalars + 63;
+#define CS_LAUNCH_BOXES3(K, T)                                                                                         \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (curve == CSTONE_HILBERT)                                                                                   \
+            hipLaunchKernelGGL((findHalosKernel<K, T, true, 3>), grid, HALO_WAVES * 64, 0, ctx->stream,                \
+                               (const K*)prefixes, child_offsets, internal_to_leaf, (const K*)leaves, radii,           \
+                               makeDBox<T>(*box_host), first, last, nullptr, tables, errors, nullptr, 0, boxes);       \
+        else                                                                                                           \
+            hipLaunchKernelGGL((findHalosKernel<K, T, false, 3>), grid, HALO_WAVES * 64, 0, ctx->stream,               \
+                               (const K*)prefixes, child_offsets, internal_to_leaf, (const K*)leaves, radii,           \
+                               makeDBox<T>(*box_host), first, last, nullptr, tables, errors, nullptr, 0, boxes);       \
+    } while (0)
+    if (key_bits == 32 && real_bits == 32) CS_LAUNCH_BOXES3(uint32_t, float);
+    else if (key_bits == 32 && real_bits == 64) CS_LAUNCH_BOXES3(uint32_t, double);
+    else if (key_bits == 64 && real_bits == 32) CS_LAUNCH_BOXES3(uint64_t, float);
+    else if (key_bits == 64 && real_bits == 64) CS_LAUNCH_BOXES3(uint64_t, double);
+    else return fail(ctx, CSTONE_E_ARG, "halo_boxes_foreign: unsupported type combination");
+#undef CS_LAUNCH_BOXES3
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
 
 int cstone_hip_halo_boxes(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* leaves,
                           const float* radii, const cstone_box* box_host, int first, int last, int32_t* boxes)

@@ -31,7 +31,7 @@ EXPORTS = [
     "cstone_hip_compute_node_counts", "cstone_hip_compute_node_counts_guided", "cstone_hip_compute_node_ops", "cstone_hip_rebalance_tree",
     "cstone_hip_update_octree", "cstone_hip_compute_octree", "cstone_hip_build_octree", "cstone_hip_upsweep_sum",
     "cstone_hip_node_centers", "cstone_hip_halo_radii", "cstone_hip_find_halos", "cstone_hip_find_neighbors",
-    "cstone_hip_halo_boxes", "cstone_hip_find_overlaps", "cstone_hip_compute_fixed_groups",
+    "cstone_hip_halo_boxes", "cstone_hip_halo_boxes_foreign", "cstone_hip_find_overlaps", "cstone_hip_compute_fixed_groups",
     "cstone_hip_compute_group_splits", "cstone_hip_find_neighbors_groups",
     "cstone_hip_domain_create", "cstone_hip_domain_destroy", "cstone_hip_domain_sync", "cstone_hip_domain_view_get",
     "cstone_hip_domain_set_halo_factor", "cstone_hip_domain_mr_create", "cstone_hip_domain_mr_destroy",
@@ -411,6 +411,17 @@ class Context:
         self._chk(self.lib.cstone_hip_halo_boxes(self.h, C.c_int(curve), C.c_int(kb), C.c_int(real_bits), _ptr(leaves),
                                                  _ptr(radii), C.byref(box), C.c_int(first), C.c_int(last),
                                                  _ptr(boxes)), "halo_boxes")
+        return boxes
+
+    def halo_boxes_foreign(self, curve, octree, leaves, radii, box, first, last, real_bits=64):
+        """halo_boxes whose record[6] is set only for boxes that really overlap a leaf outside [first, last)"""
+        torch = _torch()
+        kb = leaves.element_size() * 8
+        boxes = torch.zeros((last - first, 8), dtype=torch.int32, device=leaves.device)
+        self._chk(self.lib.cstone_hip_halo_boxes_foreign(
+            self.h, C.c_int(curve), C.c_int(kb), C.c_int(real_bits), _ptr(octree["prefixes"]),
+            _ptr(octree["child_offsets"]), _ptr(octree["internal_to_leaf"]), _ptr(leaves), _ptr(radii), C.byref(box),
+            C.c_int(first), C.c_int(last), _ptr(boxes)), "halo_boxes_foreign")
         return boxes
 
     def find_overlaps(self, curve, octree, leaves, boxes, first, last, flags=None):

@@ -238,6 +238,14 @@ extern "C"
      *                the boxes of up to 32 ranks in one traversal stores the exporting rank there */
     int cstone_hip_halo_boxes(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* leaves,
                               const float* radii, const cstone_box* box_host, int first, int last, int32_t* boxes);
+    /* halo_boxes with proof: record[6] = 1 only for boxes that overlap a leaf of this linked tree OUTSIDE the key range
+     * [leaves[first], leaves[last]) -- the walk of findHalos (R/traversal/collisions.hpp:79-105) stopped at the first
+     * such leaf.  The enclosing-node test of halo_boxes (containedIn, :91-98) also lets through every box that
+     * straddles a coarse octree boundary deep inside the own range; an exporter wants none of those. */
+    int cstone_hip_halo_boxes_foreign(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* prefixes,
+                                      const int32_t* child_offsets, const int32_t* internal_to_leaf,
+                                      const void* leaves, const float* radii, const cstone_box* box_host, int first,
+                                      int last, int32_t* boxes);
     int cstone_hip_find_overlaps(cstone_hip_ctx* ctx, int curve, int key_bits, const void* prefixes,
                                  const int32_t* child_offsets, const int32_t* internal_to_leaf, const void* leaves,
                                  const int32_t* boxes, int num_boxes, int first, int last, int32_t* flags);

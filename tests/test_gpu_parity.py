@@ -578,3 +578,34 @@ def test_sort_pairs_fuzz_sizes(hip, kb):
         hip.sync()
         assert torch.equal(keys, ref_k), (n, bits)
         assert torch.equal(vals.long(), ref_v), (n, bits)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kb", [32, 64])
+@pytest.mark.parametrize("curve", [MORTON, HILBERT])
+@pytest.mark.parametrize("bc", [(0, 0, 0), (1, 1, 1)])
+def test_halo_boxes_foreign_flags_only_boxes_that_leave_the_range(hip, oracle, kb, curve, bc):
+    """the exporter's filter: same boxes as halo_boxes, record[6] set exactly for those that overlap a leaf outside the
+    own leaf range (brute-force overlap checker of the oracle, one box at a time), never for a box halo_boxes lets go"""
+    box = Box([-1.3, 2.1, 0.2, 0.9, -5, 7], bc)
+    x, y, z, keys = _sorted_keys(oracle, curve, kb, 20000, box, 64, seed=61, kind="clustered")
+    tree, counts = oracle.compute_octree(keys, 16)
+    o = oracle.build_octree(tree)
+    od = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in o.items()}
+    nl = tree.size - 1
+    radii = np.random.default_rng(4).uniform(0.0, 0.05, nl).astype(np.float32)
+    for first, last in ((0, nl // 3), (nl // 3, 2 * nl // 3), (2 * nl // 3, nl)):
+        plain = host(hip.halo_boxes(curve, dev(tree), dev(radii), cbox(box), first, last), False)
+        got = host(hip.halo_boxes_foreign(curve, od, dev(tree), dev(radii), cbox(box), first, last), False)
+        assert np.array_equal(got[:, :6], plain[:, :6]) and np.all(got[:, 7] == 0)
+        assert np.all(got[:, 6] <= plain[:, 6]) and 0 < got[:, 6].sum() < plain[:, 6].sum()
+        rng = np.random.default_rng(first)
+        for k in rng.choice(last - first, 150, replace=False):
+            rec = plain[k:k + 1].copy()
+            rec[0, 6] = 1
+            outside = 0
+            if first > 0:
+                outside += int(oracle.find_overlaps(curve, tree, rec, 0, first).sum())
+            if last < nl:
+                outside += int(oracle.find_overlaps(curve, tree, rec, last, nl).sum())
+            assert int(got[k, 6]) == (1 if outside else 0), (first, int(k), outside)
