@@ -479,6 +479,7 @@ public:
         // (without a key array from the caller there are no markers: the key buffer is then pure output)
         if (keysIn && n)
             CS_HIP(ctx_, hipMemcpyAsync(keys_.p, keysIn, n * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
+        bool partialSort = false;
         if (n)
         {
             // radix passes only over the digits above the leaf level (+1) of the previous tree, runs of equal high digits
@@ -491,18 +492,20 @@ public:
             CS_TRY(sfcKeysAndOrderingHint(ctx_, curve_, kb, rb, x, y, z, keys_.p, order_.as<uint32_t>(), n, box_,
                                           keysAlt_.p, orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes, startPass,
                                           tooLong, keysIn != nullptr));
-            if (startPass > 0)
-            {
-                int flag = 0;
-                CS_TRY(toHost(&flag, tooLong, sizeof(int)));
-                if (flag)
-                    CS_TRY(cstone_hip_sort_pairs(ctx_, kb, keys_.p, order_.as<uint32_t>(), n, keysAlt_.p,
-                                                 orderAlt_.as<uint32_t>(), sortTmp_.p, sortTmp_.bytes));
-            }
+            // the flag travels to the (pinned) host block behind the sort; the read-back of the global tree update below
+            // completes the stream, so no synchronisation of its own is needed (the global leaf boundaries cannot fall
+            // inside a run: the update is not affected by an unfinished order)
+            partialSort = startPass > 0;
+            if (partialSort)
+                CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars + 3, tooLong, sizeof(int), hipMemcpyDeviceToHost,
+                                            ctx_->stream));
         }
 
         tick("2 encode+sort");
         CS_TRY(updateGlobalTree(n));
+        if (partialSort && ctx_->hostScalars[3] != 0)
+            CS_TRY(cstone_hip_sort_pairs(ctx_, kb, keys_.p, order_.as<uint32_t>(), n, keysAlt_.p, orderAlt_.as<uint32_t>(),
+                                         sortTmp_.p, sortTmp_.bytes));
         CS_TRY(assign());
         tick("3 global tree+assign");
 
