@@ -89,3 +89,10 @@ if perk:
                          "per kernel; FETCH_SIZE doubled (gfx950); durations are those of the counter runs",
                "kernels": table}, open(f"profiles/{tag}_kernel_hbm_traffic.json", "w"), indent=1)
 print("wrote", sorted(os.listdir("profiles")))
+
+# the JSON line bench.py printed under the profiler (its live roofline number belongs next to the kernel stats)
+blog = os.path.join(src, "bench_stdout.log") if "src" in dir() else "gpurun_out/prof_r1/bench_stdout.log"
+if os.path.exists(blog):
+    lines = [ln for ln in open(blog) if ln.startswith("{")]
+    if lines:
+        json.dump(json.loads(lines[0]), open(f"profiles/{tag}_bench_line_under_rocprof.json", "w"), indent=1)
