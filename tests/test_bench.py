@@ -62,3 +62,27 @@ def test_bench_two_ranks_rehearsal():
     # both exchanges moved data: particles changed owner and halos were served
     ex = j["config"]["rank0_exchange"]
     assert ex["halos"] > 0 and j["config"]["rank0_assigned"] > 0
+
+
+def _num_gpus():
+    try:
+        import torch
+
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_num_gpus() < 2, reason="needs two GPUs: the RCCL path with more than one rank")
+def test_bench_two_ranks_rccl():
+    """the same run over RCCL, one rank per GPU (skipped on the one-GPU test boxes)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CSTONE_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29791", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--particles", "4e6",
+           "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["rank0_exchange"]["halos"] > 0 and 0.0 < j["roofline"]["frac"] < 1.0
