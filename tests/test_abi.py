@@ -50,3 +50,25 @@ def test_product_does_not_reference_the_oracle():
                 for needle in ("oracle/", "cstone_oracle", "libcstone_ref", "import oracle", "from oracle",
                                "cstone_ref_"):
                     assert needle not in text, (dirpath, f, needle)
+
+
+def test_header_is_plain_c_and_struct_layouts_match_the_bindings(tmp_path):
+    """include/cstone_hip.h compiles as C99 (the boundary is a C ABI, not a C++ one) and the structs the ctypes bindings
+    mirror have the sizes the C compiler gives them"""
+    import subprocess
+
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "cstone_hip.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(cstone_box), sizeof(cstone_hip_domain_view),\n'
+                   '  sizeof(cstone_hip_domain_mr_view), sizeof(cstone_hip_domain_mr_octree), sizeof(cstone_hip_comm_ops));\n'
+                   '  return 0; }\n')
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe)], check=True, capture_output=True)
+    sizes = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    import cstone_amd
+    from cstone_amd.distributed import CommOps, MrOctree, MrView
+    from cstone_amd.domain import DomainView
+
+    assert sizes == [ctypes.sizeof(cstone_amd.CBox), ctypes.sizeof(DomainView), ctypes.sizeof(MrView),
+                     ctypes.sizeof(MrOctree), ctypes.sizeof(CommOps)]
