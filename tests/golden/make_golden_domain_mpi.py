@@ -19,6 +19,12 @@ MPIEXEC = "/opt/conda/bin/mpiexec"
 
 def cloud(n, seed, kind):
     rng = np.random.default_rng(seed)
+    if kind == "dups":  # three very tight blobs: with 30-bit keys a fifth of the particles share their key with another
+        centers = rng.uniform(0.3, 0.7, (3, 3))
+        pos = np.where(rng.uniform(size=(n, 1)) < 0.3, rng.uniform(0, 1, (n, 3)),
+                       centers[rng.integers(0, 3, n)] + rng.normal(0, 0.004, (n, 3)))
+        pos = np.clip(pos, 0.0, 1.0 - 2.0**-20)
+        return pos, 0.01 * rng.uniform(0.5, 1.0, n), rng.integers(0, 1 << 30, n)
     if kind == "uniform":
         pos = rng.uniform(0, 1, (n, 3))
     else:  # half uniform background, half in four blobs: an imbalanced decomposition
@@ -103,6 +109,10 @@ if __name__ == "__main__":
                                                      kind="blobs", seed=106, key_bits=32, real_bits=32),
         "ref_domain_mpi_P2_k64_f32_uniform_pbc": dict(P=2, n=10000, syncs=3, bucket=64, bucket_focus=16, bc=(1, 1, 1),
                                                       kind="uniform", seed=107, key_bits=64, real_bits=32),
+        # many equal keys: the order among them after an exchange is not defined by the reference (MPI_ANY_SOURCE),
+        # the test compares such particles as multisets per key
+        "ref_domain_mpi_P3_k32_f32_dups": dict(P=3, n=12000, syncs=3, bucket=64, bucket_focus=8, bc=(0, 0, 0),
+                                               kind="dups", seed=108, key_bits=32, real_bits=32),
     }
     only = sys.argv[1:]
     cases = {k: v for k, v in cases.items() if not only or k in only}

@@ -124,7 +124,9 @@ def test_rank_that_starts_empty_hip(impl):
 GOLDEN_MPI = [("ref_domain_mpi_P2_uniform_open.npz", 2), ("ref_domain_mpi_P3_blobs_pbc.npz", 3),
               ("ref_domain_mpi_P4_blobs_open.npz", 4),
               # Domain<unsigned, float> and Domain<uint64_t, float>
-              ("ref_domain_mpi_P3_k32_f32_blobs_open.npz", 3), ("ref_domain_mpi_P2_k64_f32_uniform_pbc.npz", 2)]
+              ("ref_domain_mpi_P3_k32_f32_blobs_open.npz", 3), ("ref_domain_mpi_P2_k64_f32_uniform_pbc.npz", 2),
+              # a fifth of the particles share their 30-bit key with another one (compared as multisets per key)
+              ("ref_domain_mpi_P3_k32_f32_dups.npz", 3)]
 # 6 and 8 ranks: CPU suite only (a GPU box admits 6 processes on its card, the test runner included)
 GOLDEN_MPI_CPU = GOLDEN_MPI + [("ref_domain_mpi_P6_uniform_pbc.npz", 6), ("ref_domain_mpi_P8_blobs_open.npz", 8)]
 
