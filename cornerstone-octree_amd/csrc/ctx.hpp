@@ -95,6 +95,9 @@ struct StageTimer
 
 //! min/max of up to three equally long coordinate arrays, out = {min0, max0, min1, max1, ...} (primitives.hip)
 int minMaxCoordinates(cstone_hip_ctx* ctx, int real_bits, const void* const* xs, int numArrays, size_t n, double* out);
+//! the same without the read-back: devOut[2 d] = min, devOut[2 d + 1] = -max as doubles on the device (primitives.hip)
+int minMaxCoordinatesDev(cstone_hip_ctx* ctx, int real_bits, const void* const* xs, int numArrays, size_t n,
+                         double* devOut);
 
 //! encode + the sort's digit histograms in one kernel (sfc.hip); *fused = false: hist untouched (unaligned input)
 int computeKeysAndHistogram(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,

@@ -979,20 +979,22 @@ private:
     // ---- C1
     int updateBox(const T* x, const T* y, const T* z, size_t n)
     {
-        const double inf = std::numeric_limits<double>::infinity();
-        double ext[6]    = {inf, inf, inf, inf, inf, inf}; // (lo, -hi) per axis
+        // periodic axes keep their limits (R/sfc/box_mpi.hpp:81-121): with three of them there is nothing to measure
+        if (box_.bc[0] == 1 && box_.bc[1] == 1 && box_.bc[2] == 1) return CSTONE_OK;
+        // (lo, -hi) per axis stay on the device from the reduction over the particles through the MIN all-reduce over
+        // the ranks; one read-back at the end
+        static const double nothing[6] = {std::numeric_limits<double>::infinity(), std::numeric_limits<double>::infinity(),
+                                          std::numeric_limits<double>::infinity(), std::numeric_limits<double>::infinity(),
+                                          std::numeric_limits<double>::infinity(), std::numeric_limits<double>::infinity()};
+        double* dev = scal_.as<double>();
         if (n)
         {
             const void* arrays[3] = {x, y, z};
-            double mm[6];
-            CS_TRY(minMaxCoordinates(ctx_, rb, arrays, 3, n, mm));
-            for (int d = 0; d < 3; ++d)
-                ext[2 * d] = mm[2 * d], ext[2 * d + 1] = -mm[2 * d + 1];
+            CS_TRY(minMaxCoordinatesDev(ctx_, rb, arrays, 3, n, dev));
         }
-        double* dev = scal_.as<double>();
-        CS_HIP(ctx_, hipMemcpyAsync(dev, ext, sizeof ext, hipMemcpyHostToDevice, ctx_->stream));
-        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream)); // `ext` is a stack variable
+        else { CS_HIP(ctx_, hipMemcpyAsync(dev, nothing, sizeof nothing, hipMemcpyHostToDevice, ctx_->stream)); }
         if (P_ > 1) CS_TRY(callComm(comm_.all_reduce(comm_.user, dev, 6, 0, 1), "all_reduce (box)"));
+        double ext[6];
         CS_TRY(toHost(ext, dev, sizeof ext));
         double fit[6];
         for (int d = 0; d < 3; ++d)

@@ -339,7 +339,42 @@ int minMax(cstone_hip_ctx* ctx, const T* x, size_t n, double* out2)
     return minMaxArrays<T>(ctx, &x, 1, n, out2);
 }
 
+//! (min, -max) of each array as doubles: the operand of a MIN all-reduce over the ranks
+template<class T>
+__global__ void minNegMaxKernel(const T* __restrict__ res, int numArrays, double* __restrict__ out)
+{
+    int i = threadIdx.x;
+    if (i < numArrays) out[2 * i] = double(res[2 * i]), out[2 * i + 1] = -double(res[2 * i + 1]);
+}
+
+//! the extents stay on the device (no read-back): devOut[2 d] = min, devOut[2 d + 1] = -max of array d
+template<class T>
+int minMaxArraysDev(cstone_hip_ctx* ctx, const T* const* xs, int numArrays, size_t n, double* devOut)
+{
+    if (n == 0) return fail(ctx, CSTONE_E_ARG, "minmax: empty range");
+    unsigned grid = unsigned(std::min<size_t>(size_t(ctx->numCu) * 8, (n + 255) / 256));
+    CS_TRY(arenaReserve(ctx, alignUp(size_t(grid) * 6 * sizeof(T)) + 1024));
+    T* partial = (T*)arenaTake(ctx, size_t(grid) * 6 * sizeof(T));
+    T* res     = (T*)arenaTake(ctx, 6 * sizeof(T));
+    MinMaxArrays<T> arrays{{xs[0], xs[numArrays > 1 ? 1 : 0], xs[numArrays > 2 ? 2 : 0]}};
+    {
+        StageTimer timer(ctx, CSTONE_STAGE_MINMAX);
+        hipLaunchKernelGGL(minMaxPartialKernel<T>, dim3(grid, numArrays), 256, 0, ctx->stream, arrays, n, partial);
+        hipLaunchKernelGGL(minMaxFinalKernel<T>, numArrays, 256, 0, ctx->stream, partial, grid, res);
+        hipLaunchKernelGGL(minNegMaxKernel<T>, 1, 64, 0, ctx->stream, res, numArrays, devOut);
+    }
+    arenaReset(ctx); // later calls reuse the slices behind these launches in stream order
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
 } // namespace
+
+int minMaxCoordinatesDev(cstone_hip_ctx* ctx, int real_bits, const void* const* xs, int numArrays, size_t n, double* devOut)
+{
+    if (real_bits == 32) return minMaxArraysDev<float>(ctx, (const float* const*)xs, numArrays, n, devOut);
+    return minMaxArraysDev<double>(ctx, (const double* const*)xs, numArrays, n, devOut);
+}
 
 int minMaxCoordinates(cstone_hip_ctx* ctx, int real_bits, const void* const* xs, int numArrays, size_t n, double* out)
 {
