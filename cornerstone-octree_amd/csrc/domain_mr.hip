@@ -156,6 +156,13 @@ __global__ __launch_bounds__(256) void unpackRowsKernel(const T* __restrict__ ro
     h[i] = rows[4 * i + 3];
 }
 
+//! out[p] = in[p + 1] - in[p] for p < n: the send counts from the cut points
+__global__ void differencesKernel(const uint64_t* __restrict__ in, int n, uint64_t* __restrict__ out)
+{
+    int p = blockIdx.x * 64 + threadIdx.x;
+    if (p < n) out[p] = in[p + 1] - in[p];
+}
+
 //! x, y, z, h of the kept particles from their input slots (order[i]) to their final slots (pos[i], or i when pos is
 //! null): the two index maps are read once for the four columns
 template<class T>
@@ -517,12 +524,24 @@ public:
             CS_HIP(ctx_, hipMemcpyAsync(dq, assignment_.data(), size_t(P_ + 1) * sizeof(K), hipMemcpyHostToDevice,
                                         ctx_->stream));
             CS_TRY(cstone_hip_lower_bound(ctx_, kb, keys_.p, n, dq, P_ + 1, dr));
-            CS_TRY(toHost(cut.data(), dr, size_t(P_ + 1) * 8));
         }
-        std::vector<uint64_t> sendCounts(P_), matrix;
-        for (int p = 0; p < P_; ++p)
-            sendCounts[p] = cut[p + 1] - cut[p];
-        CS_TRY(countMatrix(sendCounts, matrix));
+        // the send counts go from the device into the all-gather; cut points and count matrix come back in one read-back
+        std::vector<uint64_t> sendCounts(P_), matrix(size_t(P_) * P_, 0);
+        {
+            uint64_t* dr   = reinterpret_cast<uint64_t*>(scal_.as<char>() + 2048 + size_t(P_ + 1) * 8);
+            uint64_t* send = scal_.as<uint64_t>() + 32;
+            uint64_t* recv = reinterpret_cast<uint64_t*>(scal_.as<char>() + 4096);
+            hipLaunchKernelGGL(differencesKernel, gridFor(P_, 64), 64, 0, ctx_->stream, dr, P_, send);
+            if (P_ > 1)
+            {
+                CS_TRY(callComm(comm_.all_gather(comm_.user, send, recv, size_t(P_) * 8), "all_gather (counts)"));
+                CS_HIP(ctx_, hipMemcpyAsync(matrix.data(), recv, size_t(P_) * P_ * 8, hipMemcpyDeviceToHost, ctx_->stream));
+            }
+            CS_TRY(toHost(cut.data(), dr, size_t(P_ + 1) * 8));
+            for (int p = 0; p < P_; ++p)
+                sendCounts[p] = cut[p + 1] - cut[p];
+            if (P_ == 1) matrix[0] = sendCounts[0];
+        }
         std::vector<size_t> sendBytes(P_, 0), recvBytes(P_, 0);
         uint64_t movedAny = 0, mSend = 0, nb = 0;
         for (int p = 0; p < P_; ++p)
@@ -705,16 +724,22 @@ public:
                                boxFlags_.as<uint32_t>());
             uint32_t* total = scal_.as<uint32_t>() + 16;
             CS_TRY(exclusiveScanWithTotal(boxFlags_.as<uint32_t>(), nLocal, total));
-            uint32_t nbx = 0;
-            CS_TRY(toHost(&nbx, total, 4));
-            numMyBoxes = nbx;
+            // box counts of everybody straight from the device scalar (one read-back for mine and theirs), then the
+            // boxes themselves padded to the longest list
+            std::vector<uint64_t> boxCounts(P_);
+            {
+                uint32_t* recv = reinterpret_cast<uint32_t*>(scal_.as<char>() + 4096);
+                CS_TRY(callComm(comm_.all_gather(comm_.user, total, recv, 4), "all_gather (box counts)"));
+                std::vector<uint32_t> c32(P_);
+                CS_TRY(toHost(c32.data(), recv, size_t(P_) * 4));
+                for (int p = 0; p < P_; ++p)
+                    boxCounts[p] = c32[p];
+            }
+            const uint32_t nbx = uint32_t(boxCounts[rank_]);
+            numMyBoxes         = nbx;
             CS_TRY(myBoxes_.ensure(ctx_, size_t(std::max<uint32_t>(nbx, 1)) * 32));
             hipLaunchKernelGGL(compactBoxesKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream, boxes_.as<int32_t>(),
                                boxFlags_.as<uint32_t>(), nLocal, rank_, myBoxes_.as<int32_t>());
-
-            // box counts of everybody, then the boxes themselves padded to the longest list
-            std::vector<uint64_t> boxCounts(P_);
-            CS_TRY(allGatherU64(numMyBoxes, boxCounts));
             uint64_t maxBoxes = *std::max_element(boxCounts.begin(), boxCounts.end());
             if (maxBoxes)
             {
@@ -964,16 +989,6 @@ private:
         CS_HIP(ctx_, hipMemcpyAsync(send, mine.data(), size_t(P_) * 8, hipMemcpyHostToDevice, ctx_->stream));
         CS_TRY(callComm(comm_.all_gather(comm_.user, send, recv, size_t(P_) * 8), "all_gather (counts)"));
         return toHost(matrix.data(), recv, size_t(P_) * P_ * 8);
-    }
-
-    int allGatherU64(uint64_t mine, std::vector<uint64_t>& all)
-    {
-        uint64_t* send = scal_.as<uint64_t>() + 32;
-        uint64_t* recv = reinterpret_cast<uint64_t*>(scal_.as<char>() + 4096);
-        CS_HIP(ctx_, hipMemcpyAsync(send, &mine, 8, hipMemcpyHostToDevice, ctx_->stream));
-        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream)); // `mine` is a stack variable
-        CS_TRY(callComm(comm_.all_gather(comm_.user, send, recv, 8), "all_gather (box counts)"));
-        return toHost(all.data(), recv, size_t(P_) * 8);
     }
 
     // ---- C1
@@ -1361,6 +1376,8 @@ int cstone_hip_domain_mr_create(cstone_hip_ctx* ctx, cstone_hip_domain_mr** out,
 {
     if (!ctx || !out || !box_host || !comm) return fail(ctx, CSTONE_E_ARG, "domain_mr_create: null argument");
     if (num_ranks < 1 || rank < 0 || rank >= num_ranks) return fail(ctx, CSTONE_E_ARG, "domain_mr_create: bad rank");
+    // the small per-rank tables of a sync (cut points, send counts) live in fixed slots of one scalar block
+    if (num_ranks > 96) return fail(ctx, CSTONE_E_ARG, "domain_mr_create: at most 96 ranks in this version");
     if (num_ranks > 1 && (!comm->all_reduce || !comm->all_gather || !comm->all_to_all_v))
         return fail(ctx, CSTONE_E_ARG, "domain_mr_create: missing collective");
     if (curve != CSTONE_MORTON && curve != CSTONE_HILBERT) return fail(ctx, CSTONE_E_ARG, "domain_mr_create: bad curve");
