@@ -223,14 +223,16 @@ __global__ __launch_bounds__(256) void peerCountsKernel(const int32_t* __restric
 }
 
 //! totals[q] = particles served to peer q, from the exclusive scan of cnt (grand total in *total)
+//! my row of the halo count matrix, one u64 per rank (0 for myself): what the all-gather of the rows takes
 __global__ void peerTotalsKernel(const uint32_t* __restrict__ scan, const uint32_t* __restrict__ total, int n,
-                                 int numPeers, uint32_t* __restrict__ totals)
+                                 int numPeers, int rank, uint64_t* __restrict__ row)
 {
     int q = threadIdx.x;
+    if (q == numPeers) row[rank] = 0;
     if (q >= numPeers) return;
     uint32_t a = scan[size_t(q) * n];
     uint32_t b = (q + 1 < numPeers) ? scan[size_t(q + 1) * n] : *total;
-    totals[q]  = b - a;
+    row[q < rank ? q : q + 1] = b - a;
 }
 
 //! particle indices of the leaves each peer needs, grouped by peer in rank order, 16 lanes per (peer, leaf)
@@ -752,6 +754,7 @@ public:
                                 "all_gather (halo boxes)"));
             }
             CS_TRY(oflags_.ensure(ctx_, size_t(L) * sizeof(int32_t)));
+            bool haveMatrix = false;
             if (maxBoxes && P_ <= 32 && !peerLoop_)
             {
                 // all peers in one go: the records carry their exporter, find_overlaps sets one bit per exporter
@@ -773,15 +776,18 @@ public:
                 hipLaunchKernelGGL(peerCountsKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream, oflags_.as<int32_t>(),
                                    layout_.as<uint32_t>(), first, last, P_, rank_, cnt_.as<uint32_t>());
                 CS_TRY(exclusiveScanWithTotal(cnt_.as<uint32_t>(), int(items), total));
-                uint32_t* totalsDev = scal_.as<uint32_t>() + 128;
+                // my row of the count matrix goes from the device into the all-gather of the rows; one read-back
+                uint64_t* row  = scal_.as<uint64_t>() + 32;
+                uint64_t* rows = reinterpret_cast<uint64_t*>(scal_.as<char>() + 4096);
                 hipLaunchKernelGGL(peerTotalsKernel, 1, 64, 0, ctx_->stream, cnt_.as<uint32_t>(), total, nLocal, np,
-                                   totalsDev);
-                std::vector<uint32_t> totals(np);
-                CS_TRY(toHost(totals.data(), totalsDev, size_t(np) * 4));
-                for (int p = 0, q = 0; p < P_; ++p)
+                                   rank_, row);
+                CS_TRY(callComm(comm_.all_gather(comm_.user, row, rows, size_t(P_) * 8), "all_gather (halo counts)"));
+                hmatrix.assign(size_t(P_) * P_, 0);
+                CS_TRY(toHost(hmatrix.data(), rows, size_t(P_) * P_ * 8));
+                haveMatrix = true;
+                for (int p = 0; p < P_; ++p)
                 {
-                    if (p == rank_) continue;
-                    hsCounts[p] = totals[q++];
+                    hsCounts[p] = hmatrix[size_t(rank_) * P_ + p];
                     selTotal += hsCounts[p];
                 }
                 if (selTotal)
@@ -819,7 +825,7 @@ public:
                 selTotal += tp;
             }
             }
-            CS_TRY(countMatrix(hsCounts, hmatrix));
+            if (!haveMatrix) CS_TRY(countMatrix(hsCounts, hmatrix));
         }
         uint64_t nlo = 0, nhi = 0, haloAny = 0; // haloAny: the same on every rank, it decides about the collective
         for (uint64_t v : hmatrix)
