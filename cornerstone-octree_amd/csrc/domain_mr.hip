@@ -429,6 +429,11 @@ public:
 
     ~MultiRankDomain() override
     {
+        if (hostLevelRange_)
+        {
+            (void)hipStreamSynchronize(ctx_->stream); // a copy into the block may still be queued
+            (void)hipHostFree(hostLevelRange_);
+        }
         if (timing_ && rank_ == 0)
         {
             std::fprintf(stderr, "[cstone_hip_domain_mr] phase times per sync over %d syncs (ms, synchronising):", syncs_);
@@ -494,6 +499,13 @@ public:
             // radix passes only over the digits above the leaf level (+1) of the previous tree, runs of equal high digits
             // are finished by a fix-up pass; a run that is too long raises a flag and the regular sort completes the job
             int startPass = 0;
+            if (levelRangePending_)
+            {
+                prevMaxLeafLevel_ = 0;
+                for (int l = 0; l <= int(maxLevel<K>()); ++l)
+                    if (hostLevelRange_[l + 1] > hostLevelRange_[l]) prevMaxLeafLevel_ = l;
+                levelRangePending_ = false;
+            }
             if (!firstCall_ && prevMaxLeafLevel_ >= 0 && std::getenv("CSTONE_FULL_SORT") == nullptr)
                 startPass = std::max(0, (3 * int(maxLevel<K>()) -
                                          3 * (prevMaxLeafLevel_ + 1 + (bucketFocus_ > 128) + (bucketFocus_ > 1024))) / 8) & ~1;
@@ -693,13 +705,13 @@ public:
         tick("5b boundaries");
         CS_TRY(buildFocusOctree());
         tick("5c linked octree");
-        {
-            NodeIdx lr[32];
-            CS_TRY(toHost(lr, fLevelRange_.p, (maxLevel<K>() + 2) * sizeof(NodeIdx)));
-            prevMaxLeafLevel_ = 0;
-            for (int l = 0; l <= int(maxLevel<K>()); ++l)
-                if (lr[l + 1] > lr[l]) prevMaxLeafLevel_ = l;
-        }
+        // the level ranges are only needed by the NEXT sync (how many digits to sort): they travel to a pinned block of
+        // this domain now and are looked at then, behind many later synchronisations of the stream
+        if (!hostLevelRange_)
+            CS_HIP(ctx_, hipHostMalloc(reinterpret_cast<void**>(&hostLevelRange_), 32 * sizeof(NodeIdx), hipHostMallocDefault));
+        CS_HIP(ctx_, hipMemcpyAsync(hostLevelRange_, fLevelRange_.p, (maxLevel<K>() + 2) * sizeof(NodeIdx),
+                                    hipMemcpyDeviceToHost, ctx_->stream));
+        levelRangePending_ = true;
         const int L = fLeaves_;
         CS_TRY(layout_.ensure(ctx_, size_t(L + 1) * sizeof(uint32_t)));
         CS_HIP(ctx_, hipMemsetAsync(layout_.p, 0, sizeof(uint32_t), ctx_->stream));
@@ -1353,6 +1365,8 @@ private:
     uint64_t rsN_ = 0, rsNa_ = 0, rsNb_ = 0, rsSend_ = 0, rsMoved_ = 0, rsKeptOffset_ = 0;
     std::vector<uint64_t> rsSendCounts_, rsRecvCounts_;
     int prevMaxLeafLevel_ = -1; // deepest level of this rank's tree at the previous sync
+    NodeIdx* hostLevelRange_ = nullptr; // pinned: the level ranges of the last tree, read at the start of the next sync
+    bool levelRangePending_  = false;
     // halo exchange pattern of the last sync (exchangeHalos)
     std::vector<uint64_t> haloSend_, haloRecv_;
     uint64_t haloRecvLo_ = 0, haloRecvHi_ = 0, haloAssigned_ = 0, haloSel_ = 0, haloAnyLast_ = 0;
