@@ -185,6 +185,7 @@ class DistributedPipeline:
         # the client owns the assigned particles (updated in place); halos are re-discovered by the next sync
         self.x, self.y, self.z, self.h = r["x"][s:e], r["y"][s:e], r["z"][s:e], r["h"][s:e]
         self.assigned, self.halos = e - s, r["x"].numel() - (e - s)
+        self.last = r
         if self.native:
             v = self.dom.view()
             self.f_leaves, self.g_leaves = v.num_focus_leaves, v.num_global_leaves
@@ -195,6 +196,25 @@ class DistributedPipeline:
             self.stats = dict(self.dom.stats)
 
     first_sync = step
+
+    def invariants(self, n_global):
+        """after the timed region: what the reference's multi-rank tests check first (T/integration_mpi/domain_nranks.cpp:
+        117-131) -- no particle lost over the ranks, keys sorted, assigned keys inside the rank's own SFC range"""
+        import torch.distributed as dist
+
+        torch, r = self.torch, self.last
+        s, e = r["start"], r["end"]
+        keys = r["keys"]
+        ok = bool((keys[1:] >= keys[:-1]).all()) if keys.numel() > 1 else True
+        if self.native and e > s:
+            v = self.dom.view()
+            lo = int(keys[s].item())
+            hi = int(keys[e - 1].item())
+            ok = ok and lo >= v.range_start and hi < v.range_end
+        t = torch.tensor([e - s, 1 if ok else 0], dtype=torch.int64,
+                         device=self.x.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t[0].item()) == n_global and int(t[1].item()) == dist.get_world_size()
 
 
 def cpu_baseline_domain(n_sample, bucket, bucket_focus, min_seconds=10.0):
@@ -361,6 +381,7 @@ def main():
         pass_ms, pass_launches = ctx.profile_get("sort_pass")
         roofline_source = f"cstone_hip_sort_pairs of {n_sorted} random pairs (this rank's share), outside the timed region"
         del rk, rv, work
+        invariants_ok = pipe.invariants(n_local * world)
     extras = {}
     if not distributed:
         # the same syncs with the radix sort forced over ALL key digits (what the reference's GPU path does every time;
@@ -487,7 +508,7 @@ def main():
                                       f"; {world} rank(s): SFC domain decomposition, particle + halo exchange with "
                                       f"all_to_all over RCCL, 1% of the particles displaced by <=2h before every sync"),
                        "particles_per_gpu": n_local, "focus_leaves": pipe.f_leaves, "global_leaves": pipe.g_leaves,
-                       **({"rank0_assigned": pipe.assigned, "rank0_halos": pipe.halos,
+                       **({"invariants_ok": invariants_ok, "rank0_assigned": pipe.assigned, "rank0_halos": pipe.halos,
                            "rank0_exchange": dict(pipe.stats),
                            "orchestration": "libcstone_hip (cstone_hip_domain_mr_sync)" if pipe.native
                            else "python (cstone_amd.distributed)"} if distributed else {}),

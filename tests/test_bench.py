@@ -57,7 +57,7 @@ def test_bench_two_ranks_rehearsal():
         assert k in j, k
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and "cpu_baseline" not in j
     assert 0.0 < j["roofline"]["frac"] < 1.0 and j["roofline"]["launches"] == args_key_passes
-    assert j["config"]["particles_per_gpu"] == 1000000
+    assert j["config"]["particles_per_gpu"] == 1000000 and j["config"]["invariants_ok"] is True
     assert j["config"]["orchestration"].startswith("libcstone_hip")
     # both exchanges moved data: particles changed owner and halos were served
     ex = j["config"]["rank0_exchange"]
