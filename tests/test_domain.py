@@ -13,9 +13,13 @@ GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "gold
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("full_sort", [False, True], ids=["partial-digit-sort", "all-digits-sorted"])
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
-def test_domain_sync_matches_reference(hip, path):
+def test_domain_sync_matches_reference(hip, path, full_sort, monkeypatch):
     import torch
+
+    if full_sort:  # the radix passes over ALL key digits instead of the digits above the previous tree's leaf level
+        monkeypatch.setenv("CSTONE_FULL_SORT", "1")
 
     import cstone_amd
     from cstone_amd.domain import Domain
