@@ -662,7 +662,28 @@ __global__ __launch_bounds__(BLOCK) void onesweepKernel(const K* __restrict__ ke
         sm.waveHist[i] = 0;
     __syncthreads();
     const uint32_t tile = sm.tileShared[0];
-    if (tile >= numFullTiles) return;
+    if (tile > numFullTiles) return;
+#ifndef CSTONE_SORT_TRACE
+    if (tile == numFullTiles)
+    {
+        // the partial last tile (launched only when there is one): no look-back, see sortTile<TAIL = true>.  Handling it
+        // here lets it run next to the full tiles instead of in a one-workgroup launch of its own behind them.
+        const uint32_t tileBase  = numFullTiles * uint32_t(TILE);
+        const unsigned tileCount = n - tileBase;
+        K tkey[ITEMS];
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r)
+        {
+            unsigned idx = segBase + r * 64 + lane;
+            tkey[r]      = idx < tileCount ? keysIn[tileBase + idx] : K(~K(0));
+        }
+        sortTile<K, BLOCK, true>(sm, tkey, numFullTiles, tileCount, valsIn, keysOut, valsOut, pass * RADIX_BITS, bases,
+                                 nullptr, errors, n);
+        return;
+    }
+#else
+    if (tile == numFullTiles) return;
+#endif
 #ifdef CSTONE_SORT_TRACE
     const size_t traceRow = size_t(pass) * (n / TILE + 1) + tile;
     SORT_TRACE_VAL(0, tEntry)
@@ -844,6 +865,12 @@ void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* val
     {
         StageTimer timer(ctx, CSTONE_STAGE_SORT_PASS);
         const uint32_t* bases = t.hist + size_t(p) * RADIX;
+#ifndef CSTONE_SORT_TRACE
+        // one launch: the workgroup that draws ticket numFullTiles takes the partial last tile
+        hipLaunchKernelGGL((onesweepKernel<K, BLOCK>), numFullTiles + (haveTail ? 1u : 0u), BLOCK, 0, ctx->stream, kIn, vIn,
+                           kOut, vOut, uint32_t(n), p, numFullTiles, bases, t.tickets + p,
+                           t.status + size_t(p) * numFullTiles * RADIX, t.errors);
+#else
         if (numFullTiles)
             hipLaunchKernelGGL((onesweepKernel<K, BLOCK>), numFullTiles, BLOCK, 0, ctx->stream, kIn, vIn, kOut, vOut,
                                uint32_t(n), p, numFullTiles, bases, t.tickets + p,
@@ -851,6 +878,7 @@ void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* val
         if (haveTail)
             hipLaunchKernelGGL((onesweepTailKernel<K, BLOCK>), 1, BLOCK, 0, ctx->stream, kIn, vIn, kOut, vOut,
                                uint32_t(n), p, numFullTiles, bases, t.errors);
+#endif
         std::swap(kIn, kOut);
         if (p == startPass && iotaValues) { vIn = vOut, vOut = vals; }
         else { std::swap(vIn, vOut); }
