@@ -163,13 +163,14 @@ __global__ void differencesKernel(const uint64_t* __restrict__ in, int n, uint64
     if (p < n) out[p] = in[p + 1] - in[p];
 }
 
-//! x, y, z, h of the kept particles from their input slots (order[i]) to their final slots (pos[i], or i when pos is
-//! null): the two index maps are read once for the four columns
-template<class T>
+//! keys (already sorted) and x, y, z, h (from their input slots order[i]) of the kept particles to their final slots
+//! (pos[i], or i when pos is null): the two index maps are read once for the five columns
+template<class K, class T>
 __global__ __launch_bounds__(256) void placeColumnsKernel(const uint32_t* __restrict__ order,
                                                           const uint32_t* __restrict__ pos, size_t m,
-                                                          const T* __restrict__ x, const T* __restrict__ y,
-                                                          const T* __restrict__ z, const T* __restrict__ h,
+                                                          const K* __restrict__ keys, const T* __restrict__ x,
+                                                          const T* __restrict__ y, const T* __restrict__ z,
+                                                          const T* __restrict__ h, K* __restrict__ dk,
                                                           T* __restrict__ dx, T* __restrict__ dy, T* __restrict__ dz,
                                                           T* __restrict__ dh)
 {
@@ -177,8 +178,9 @@ __global__ __launch_bounds__(256) void placeColumnsKernel(const uint32_t* __rest
     if (i >= m) return;
     const uint32_t s = order[i];
     const size_t d   = pos ? size_t(pos[i]) : i;
+    const K vk = keys[i]; // the kept keys are already in sorted order
     const T vx = x[s], vy = y[s], vz = z[s], vh = h[s];
-    dx[d] = vx, dy[d] = vy, dz[d] = vz, dh[d] = vh;
+    dk[d] = vk, dx[d] = vx, dy[d] = vy, dz[d] = vz, dh[d] = vh;
 }
 
 __global__ __launch_bounds__(256) void boxFlagsKernel(const int32_t* __restrict__ boxes, int n,
@@ -668,19 +670,14 @@ public:
             CS_TRY(posB_.ensure(ctx_, nb * sizeof(uint32_t)));
             CS_TRY(cstone_hip_merge_positions(ctx_, kb, keptKeys, na, rk_.p, nb, 0, posA_.as<uint32_t>(),
                                               posB_.as<uint32_t>()));
-            CS_TRY(cstone_hip_scatter(ctx_, sizeof(K), posA_.as<uint32_t>(), na, keptKeys, keysM));
             CS_TRY(cstone_hip_scatter(ctx_, sizeof(K), posB_.as<uint32_t>(), nb, rk_.p, keysM));
-        }
-        else
-        {
-            CS_HIP(ctx_, hipMemcpyAsync(keysM, keptKeys, na * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
         }
         {
             T* dst[4] = {o.x.as<T>() + M, o.y.as<T>() + M, o.z.as<T>() + M, o.h.as<T>() + M};
             if (na)
-                hipLaunchKernelGGL(placeColumnsKernel<T>, gridFor(na, 256), 256, 0, ctx_->stream, keptO,
-                                   nb ? posA_.as<uint32_t>() : nullptr, size_t(na), x, y, z, h, dst[0], dst[1], dst[2],
-                                   dst[3]);
+                hipLaunchKernelGGL((placeColumnsKernel<K, T>), gridFor(na, 256), 256, 0, ctx_->stream, keptO,
+                                   nb ? posA_.as<uint32_t>() : nullptr, size_t(na), keptKeys, x, y, z, h, keysM, dst[0],
+                                   dst[1], dst[2], dst[3]);
             for (int c = 0; c < 4 && nb; ++c)
                 CS_TRY(cstone_hip_scatter(ctx_, sizeof(T), posB_.as<uint32_t>(), nb, recvSorted[c], dst[c]));
         }
