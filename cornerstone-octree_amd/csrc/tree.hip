@@ -365,12 +365,13 @@ int updateOctree(cstone_hip_ctx* ctx, const K* keys, size_t n, uint32_t bucket, 
                 rc = fail(ctx, CSTONE_E_CAPACITY, "update_octree: %d leaves needed, capacity %d", newNumNodes, capLeaves);
             }
         }
-        if (rc == CSTONE_OK)
+        if (rc == CSTONE_OK && !*convergedHost)
         {
             hipLaunchKernelGGL(rebalanceKernel<K>, gridFor(newNumNodes + 1, 256), 256, 0, ctx->stream, tree, numNodes,
                                ops, newNumNodes, newTree);
             (void)hipMemcpyAsync(tree, newTree, size_t(newNumNodes + 1) * sizeof(K), hipMemcpyDeviceToDevice, ctx->stream);
         }
+        // converged: every node op is "keep", the leaf array is what it was (only the counts are refreshed below)
     }
     arenaReset(ctx);
     CS_TRY(rc);
