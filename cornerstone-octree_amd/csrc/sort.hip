@@ -20,7 +20,8 @@
 //      quarterLookBack), then the INCLUSIVE row is published
 //   7. keys, then values, are streamed from LDS to their global slots: consecutive lanes write
 //      consecutive addresses within each digit run
-// The last, partial tile is handled by a separate one-workgroup kernel without look-back.
+// The last, partial tile needs no look-back; the workgroup that draws the ticket behind the last full tile takes it
+// (phase-trace builds keep it in a one-workgroup kernel of its own).
 // Measured phase budget of a 16 Ki tile (CSTONE_SORT_TRACE build, tools/sort_trace.py, 1e8 random 64-bit pairs):
 // ticket 0.7 us, key load 4.6-5.2, rank 3.6-4.1, digit scans 1.2, permute 1.1, look-back 4.5, key store 2.1,
 // value stage + store 2.9: about 23 us per tile and CU, i.e. the kernel is bound by the tile's serial phases with
@@ -702,7 +703,8 @@ __global__ __launch_bounds__(BLOCK) void onesweepKernel(const K* __restrict__ ke
                               bases, status, errors, n);
 }
 
-//! the last, partial tile (n % TILE pairs): one workgroup, no look-back (see sortTile<TAIL = true>)
+//! the last, partial tile (n % TILE pairs) as a kernel of its own: only used by -DCSTONE_SORT_TRACE builds, the regular
+//! build handles it inside onesweepKernel (see sortTile<TAIL = true>)
 template<class K, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void onesweepTailKernel(const K* __restrict__ keysIn,
                                                             const uint32_t* __restrict__ valsIn,
