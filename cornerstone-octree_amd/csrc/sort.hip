@@ -664,6 +664,17 @@ __global__ __launch_bounds__(BLOCK) void onesweepKernel(const K* __restrict__ ke
     __syncthreads();
     const uint32_t tile = sm.tileShared[0];
     if (tile > numFullTiles) return;
+    // Long passes (many generations of tiles per CU): the first generation starts spread over about 16 us instead of
+    // all at once, so that the load / rank / store phases of the CUs are out of step from the beginning (measured
+    // 1.5-3 % per pass at 1e8 pairs; 24 or 48 us spreads gain nothing, short passes would only lose the delay).
+    if (numFullTiles >= 2048u && tile < 256u)
+    {
+        unsigned units = (tile * 600u) >> 8; // units of 64 clocks
+        for (; units >= 100; units -= 100)
+            __builtin_amdgcn_s_sleep(100);
+        for (; units > 0; --units)
+            __builtin_amdgcn_s_sleep(1);
+    }
 #ifndef CSTONE_SORT_TRACE
     if (tile == numFullTiles)
     {
