@@ -1,0 +1,422 @@
+// The remaining small primitives of the reference's GPU seam (R/primitives/primitives_gpu.h:36-124,
+// R/halos/gather_halos_gpu.h): fill, scale, increment, count, reduce, segment maxima, range gathers, scalar
+// lower bound, keys-only sort.  In the reference these are Thrust one-liners (R/primitives/primitives_gpu.cu:51-107,
+// 217-283, 296-324, 440-448) and two small kernels (:241-259, R/halos/gather_halos_gpu.cu:26-40).
+#include <algorithm>
+
+#include "ctx.hpp"
+#include "device_keys.hpp"
+
+namespace cship
+{
+template<class K>
+int sortPairsArena(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n);
+
+namespace
+{
+
+template<class T>
+__global__ __launch_bounds__(256) void fillKernel(T* __restrict__ dst, size_t n, T value)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+
+template<class T>
+__global__ __launch_bounds__(256) void scaleKernel(T* __restrict__ data, size_t n, T factor)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) data[i] *= factor;
+}
+
+template<class T>
+__global__ __launch_bounds__(256) void incrementKernel(const T* __restrict__ in, T* __restrict__ out, size_t n, T value)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i] + value;
+}
+
+//! acc[0] += number of elements equal to value (MODE 0) or the sum of the elements (MODE 1), 64-bit
+template<class T, int MODE>
+__global__ __launch_bounds__(256) void countOrSumKernel(const T* __restrict__ data, size_t n, T value,
+                                                        unsigned long long* __restrict__ acc)
+{
+    unsigned long long local = 0;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256)
+        local += MODE == 0 ? (unsigned long long)(data[i] == value) : (unsigned long long)(data[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63u) == 0 && local) atomicAdd(acc, local);
+}
+
+//! max(|r|^2) in T, R/primitives/primitives_gpu.cu:194-215 (squares are exact to compare: a max is order-free)
+template<class T>
+__global__ __launch_bounds__(256) void maxNormSquareKernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                           const T* __restrict__ z, size_t n, T* __restrict__ partial)
+{
+    __shared__ T smax[4];
+    T m = T(0);
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256)
+    {
+        T v = x[i] * x[i] + y[i] * y[i] + z[i] * z[i];
+        m   = v > m ? v : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        T t = __shfl_xor(m, o);
+        m   = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63u) == 0) smax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        for (int w = 1; w < 4; ++w)
+            m = smax[w] > m ? smax[w] : m;
+        partial[blockIdx.x] = m;
+    }
+}
+
+//! segmentMax, R/primitives/primitives_gpu.cu:241-268: out[s] = max(in[seg[s]..seg[s+1])) starting from the first
+//! element (an empty segment reads in[seg[s]] like the reference does); 16 lanes per segment
+template<class Tin, class Tout, class I>
+__global__ __launch_bounds__(256) void segmentMaxKernel(const Tin* __restrict__ in, const I* __restrict__ seg,
+                                                        size_t numSegments, Tout* __restrict__ out)
+{
+    const unsigned sub = threadIdx.x & 15u;
+    size_t s           = size_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
+    if (s >= numSegments) return;
+    I a = seg[s], b = seg[s + 1];
+    Tin m = in[a];
+    for (I i = a + sub; i < b; i += 16)
+    {
+        Tin v = in[i];
+        m     = v > m ? v : m;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1)
+    {
+        Tin t = __shfl_xor(m, o);
+        m     = t > m ? t : m;
+    }
+    if (sub == 0) out[s] = Tout(m);
+}
+
+template<int B>
+struct alignas(B >= 16 ? 16 : (B >= 8 ? 8 : B)) Blob
+{
+    unsigned char b[B];
+};
+template<>
+struct alignas(4) Blob<12>
+{
+    unsigned char b[12];
+};
+template<>
+struct alignas(8) Blob<24>
+{
+    unsigned char b[24];
+};
+
+//! gatherRanges, R/halos/gather_halos_gpu.cu:26-40: buffer[i] = src[offsets[r] + i - scan[r]], r = the range that
+//! holds output slot i (scan[r] <= i < scan[r+1])
+template<class E, class I>
+__global__ __launch_bounds__(256) void gatherRangesKernel(const I* __restrict__ scan, const I* __restrict__ offsets,
+                                                          int numRanges, const E* __restrict__ src,
+                                                          E* __restrict__ buffer, size_t bufferSize)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= bufferSize) return;
+    int lo = 0, len = numRanges; // upper_bound(scan, scan + numRanges, i) - 1
+    while (len > 0)
+    {
+        int half = len >> 1;
+        if (!(I(i) < scan[lo + half])) { lo += half + 1, len -= half + 1; }
+        else { len = half; }
+    }
+    const int r = lo - 1;
+    buffer[i]   = src[offsets[r] + I(i) - scan[r]];
+}
+
+//! index of the first element >= value in a sorted device array, one thread (the arrays are small or the call is rare)
+template<class T>
+__global__ void lowerBoundOneKernel(const T* __restrict__ data, size_t n, T value, unsigned long long* out)
+{
+    size_t lo = 0, len = n;
+    while (len > 0)
+    {
+        size_t half = len >> 1;
+        if (data[lo + half] < value) { lo += half + 1, len -= half + 1; }
+        else { len = half; }
+    }
+    *out = lo;
+}
+
+int readU64(cstone_hip_ctx* ctx, unsigned long long* dev, uint64_t* out)
+{
+    auto* host = reinterpret_cast<unsigned long long*>(ctx->hostScalars + 12);
+    CS_HIP(ctx, hipMemcpyAsync(host, dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = *host;
+    return CSTONE_OK;
+}
+
+} // namespace
+
+} // namespace cship
+
+using namespace cship;
+
+extern "C"
+{
+
+int cstone_hip_fill(cstone_hip_ctx* ctx, int elem_bytes, void* dst, size_t n, const void* value_host)
+{
+    if (!ctx || !value_host || (n && !dst)) return fail(ctx, CSTONE_E_ARG, "fill: bad argument");
+    if (n == 0) return CSTONE_OK;
+    unsigned grid = gridFor(n, 256);
+    switch (elem_bytes)
+    {
+        case 1:
+            hipLaunchKernelGGL(fillKernel<uint8_t>, grid, 256, 0, ctx->stream, (uint8_t*)dst, n, *(const uint8_t*)value_host);
+            break;
+        case 4:
+            hipLaunchKernelGGL(fillKernel<uint32_t>, grid, 256, 0, ctx->stream, (uint32_t*)dst, n,
+                               *(const uint32_t*)value_host);
+            break;
+        case 8:
+            hipLaunchKernelGGL(fillKernel<uint64_t>, grid, 256, 0, ctx->stream, (uint64_t*)dst, n,
+                               *(const uint64_t*)value_host);
+            break;
+        default: return fail(ctx, CSTONE_E_ARG, "fill: element size %d unsupported", elem_bytes);
+    }
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int cstone_hip_scale(cstone_hip_ctx* ctx, int real_bits, void* data, size_t n, double factor)
+{
+    if (!ctx || (real_bits != 32 && real_bits != 64) || (n && !data)) return fail(ctx, CSTONE_E_ARG, "scale: bad argument");
+    if (n == 0) return CSTONE_OK;
+    unsigned grid = gridFor(n, 256);
+    if (real_bits == 32) hipLaunchKernelGGL(scaleKernel<float>, grid, 256, 0, ctx->stream, (float*)data, n, float(factor));
+    else hipLaunchKernelGGL(scaleKernel<double>, grid, 256, 0, ctx->stream, (double*)data, n, factor);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int cstone_hip_increment(cstone_hip_ctx* ctx, int elem_bits, const void* in, void* out, size_t n, uint64_t value)
+{
+    if (!ctx || (elem_bits != 32 && elem_bits != 64) || (n && (!in || !out)))
+        return fail(ctx, CSTONE_E_ARG, "increment: bad argument");
+    if (n == 0) return CSTONE_OK;
+    unsigned grid = gridFor(n, 256);
+    if (elem_bits == 32)
+        hipLaunchKernelGGL(incrementKernel<uint32_t>, grid, 256, 0, ctx->stream, (const uint32_t*)in, (uint32_t*)out, n,
+                           uint32_t(value));
+    else
+        hipLaunchKernelGGL(incrementKernel<uint64_t>, grid, 256, 0, ctx->stream, (const uint64_t*)in, (uint64_t*)out, n,
+                           value);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+static int countOrSum(cstone_hip_ctx* ctx, int mode, int elem_bits, const void* data, size_t n, uint64_t value,
+                      uint64_t* out_host)
+{
+    auto* acc = reinterpret_cast<unsigned long long*>(ctx->devScalars + 12);
+    CS_HIP(ctx, hipMemsetAsync(acc, 0, sizeof(unsigned long long), ctx->stream));
+    unsigned grid = unsigned(std::min<size_t>(size_t(ctx->numCu) * 8, (n + 255) / 256));
+    if (elem_bits == 32)
+    {
+        if (mode == 0)
+            hipLaunchKernelGGL((countOrSumKernel<uint32_t, 0>), grid, 256, 0, ctx->stream, (const uint32_t*)data, n,
+                               uint32_t(value), acc);
+        else
+            hipLaunchKernelGGL((countOrSumKernel<uint32_t, 1>), grid, 256, 0, ctx->stream, (const uint32_t*)data, n,
+                               uint32_t(value), acc);
+    }
+    else
+    {
+        if (mode == 0)
+            hipLaunchKernelGGL((countOrSumKernel<uint64_t, 0>), grid, 256, 0, ctx->stream, (const uint64_t*)data, n,
+                               value, acc);
+        else
+            hipLaunchKernelGGL((countOrSumKernel<uint64_t, 1>), grid, 256, 0, ctx->stream, (const uint64_t*)data, n,
+                               value, acc);
+    }
+    CS_HIP(ctx, hipGetLastError());
+    return readU64(ctx, acc, out_host);
+}
+
+int cstone_hip_count_equal(cstone_hip_ctx* ctx, int elem_bits, const void* data, size_t n, uint64_t value,
+                           uint64_t* count_host)
+{
+    if (!ctx || (elem_bits != 32 && elem_bits != 64) || !count_host || (n && !data))
+        return fail(ctx, CSTONE_E_ARG, "count_equal: bad argument");
+    *count_host = 0;
+    if (n == 0) return CSTONE_OK;
+    return countOrSum(ctx, 0, elem_bits, data, n, value, count_host);
+}
+
+int cstone_hip_reduce_sum(cstone_hip_ctx* ctx, int elem_bits, const void* data, size_t n, uint64_t init,
+                          uint64_t* sum_host)
+{
+    if (!ctx || (elem_bits != 32 && elem_bits != 64) || !sum_host || (n && !data))
+        return fail(ctx, CSTONE_E_ARG, "reduce_sum: bad argument");
+    *sum_host = init;
+    if (n == 0) return CSTONE_OK;
+    uint64_t s = 0;
+    CS_TRY(countOrSum(ctx, 1, elem_bits, data, n, 0, &s));
+    *sum_host = init + s;
+    return CSTONE_OK;
+}
+
+int cstone_hip_max_norm_square(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y, const void* z, size_t n,
+                               double* out_host)
+{
+    if (!ctx || (real_bits != 32 && real_bits != 64) || !out_host || (n && (!x || !y || !z)))
+        return fail(ctx, CSTONE_E_ARG, "max_norm_square: bad argument");
+    *out_host = 0;
+    if (n == 0) return CSTONE_OK;
+    unsigned grid = unsigned(std::min<size_t>(size_t(ctx->numCu) * 4, (n + 255) / 256));
+    CS_TRY(arenaReserve(ctx, alignUp(size_t(grid) * 8) + 256));
+    void* partial = arenaTake(ctx, size_t(grid) * 8);
+    std::vector<double> host64(grid);
+    std::vector<float> host32(grid);
+    hipError_t e;
+    if (real_bits == 32)
+    {
+        hipLaunchKernelGGL(maxNormSquareKernel<float>, grid, 256, 0, ctx->stream, (const float*)x, (const float*)y,
+                           (const float*)z, n, (float*)partial);
+        e = hipMemcpyAsync(host32.data(), partial, size_t(grid) * 4, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    else
+    {
+        hipLaunchKernelGGL(maxNormSquareKernel<double>, grid, 256, 0, ctx->stream, (const double*)x, (const double*)y,
+                           (const double*)z, n, (double*)partial);
+        e = hipMemcpyAsync(host64.data(), partial, size_t(grid) * 8, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    arenaReset(ctx);
+    if (e != hipSuccess) return fail(ctx, CSTONE_E_HIP, "max_norm_square: %s", hipGetErrorString(e));
+    double m = 0;
+    for (unsigned i = 0; i < grid; ++i)
+        m = std::max(m, real_bits == 32 ? double(host32[i]) : host64[i]);
+    *out_host = m;
+    return CSTONE_OK;
+}
+
+int cstone_hip_segment_max(cstone_hip_ctx* ctx, int in_bits, int out_bits, int index_bits, const void* in,
+                           const void* segments, size_t num_segments, void* out)
+{
+    if (!ctx || (num_segments && (!in || !segments || !out)))
+        return fail(ctx, CSTONE_E_ARG, "segment_max: bad argument");
+    if (num_segments == 0) return CSTONE_OK;
+    unsigned grid = gridFor(num_segments, 16);
+#define CSTONE_SEGMAX(Tin, Tout, I)                                                                                    \
+    hipLaunchKernelGGL((segmentMaxKernel<Tin, Tout, I>), grid, 256, 0, ctx->stream, (const Tin*)in, (const I*)segments, \
+                       num_segments, (Tout*)out)
+    // the reference's instantiations, R/primitives/primitives_gpu.cu:270-275
+    if (in_bits == 32 && out_bits == 32 && index_bits == 32) CSTONE_SEGMAX(float, float, uint32_t);
+    else if (in_bits == 64 && out_bits == 32 && index_bits == 32) CSTONE_SEGMAX(double, float, uint32_t);
+    else if (in_bits == 64 && out_bits == 64 && index_bits == 32) CSTONE_SEGMAX(double, double, uint32_t);
+    else if (in_bits == 32 && out_bits == 32 && index_bits == 64) CSTONE_SEGMAX(float, float, uint64_t);
+    else if (in_bits == 64 && out_bits == 32 && index_bits == 64) CSTONE_SEGMAX(double, float, uint64_t);
+    else if (in_bits == 64 && out_bits == 64 && index_bits == 64) CSTONE_SEGMAX(double, double, uint64_t);
+    else return fail(ctx, CSTONE_E_ARG, "segment_max: unsupported type combination %d/%d/%d", in_bits, out_bits, index_bits);
+#undef CSTONE_SEGMAX
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int cstone_hip_gather_ranges(cstone_hip_ctx* ctx, int elem_bytes, int index_bits, const void* range_scan,
+                             const void* range_offsets, int num_ranges, const void* src, void* buffer,
+                             size_t buffer_size)
+{
+    if (!ctx || (index_bits != 32 && index_bits != 64) || num_ranges < 0 ||
+        (buffer_size && (!range_scan || !range_offsets || !src || !buffer || num_ranges == 0)))
+        return fail(ctx, CSTONE_E_ARG, "gather_ranges: bad argument");
+    if (buffer_size == 0) return CSTONE_OK;
+    StageTimer timer(ctx, CSTONE_STAGE_GATHER);
+    unsigned grid = gridFor(buffer_size, 256);
+#define CSTONE_GR_CASE(B)                                                                                              \
+    case B:                                                                                                            \
+        if (index_bits == 32)                                                                                          \
+            hipLaunchKernelGGL((gatherRangesKernel<Blob<B>, uint32_t>), grid, 256, 0, ctx->stream,                     \
+                               (const uint32_t*)range_scan, (const uint32_t*)range_offsets, num_ranges,                \
+                               (const Blob<B>*)src, (Blob<B>*)buffer, buffer_size);                                    \
+        else                                                                                                           \
+            hipLaunchKernelGGL((gatherRangesKernel<Blob<B>, uint64_t>), grid, 256, 0, ctx->stream,                     \
+                               (const uint64_t*)range_scan, (const uint64_t*)range_offsets, num_ranges,                \
+                               (const Blob<B>*)src, (Blob<B>*)buffer, buffer_size);                                    \
+        break
+    switch (elem_bytes)
+    {
+        CSTONE_GR_CASE(1);
+        CSTONE_GR_CASE(2);
+        CSTONE_GR_CASE(4);
+        CSTONE_GR_CASE(8);
+        CSTONE_GR_CASE(12);
+        CSTONE_GR_CASE(16);
+        CSTONE_GR_CASE(24);
+        CSTONE_GR_CASE(32);
+        default: return fail(ctx, CSTONE_E_ARG, "gather_ranges: element size %d unsupported", elem_bytes);
+    }
+#undef CSTONE_GR_CASE
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int cstone_hip_lower_bound_value(cstone_hip_ctx* ctx, int kind, const void* data, size_t n, const void* value_host,
+                                 uint64_t* index_host)
+{
+    if (!ctx || !value_host || !index_host || (n && !data)) return fail(ctx, CSTONE_E_ARG, "lower_bound_value: bad argument");
+    *index_host = 0;
+    if (n == 0) return CSTONE_OK;
+    auto* out = reinterpret_cast<unsigned long long*>(ctx->devScalars + 12);
+    switch (kind)
+    {
+        case 0:
+            hipLaunchKernelGGL(lowerBoundOneKernel<uint32_t>, 1, 1, 0, ctx->stream, (const uint32_t*)data, n,
+                               *(const uint32_t*)value_host, out);
+            break;
+        case 1:
+            hipLaunchKernelGGL(lowerBoundOneKernel<uint64_t>, 1, 1, 0, ctx->stream, (const uint64_t*)data, n,
+                               *(const uint64_t*)value_host, out);
+            break;
+        case 2:
+            hipLaunchKernelGGL(lowerBoundOneKernel<int32_t>, 1, 1, 0, ctx->stream, (const int32_t*)data, n,
+                               *(const int32_t*)value_host, out);
+            break;
+        case 3:
+            hipLaunchKernelGGL(lowerBoundOneKernel<int64_t>, 1, 1, 0, ctx->stream, (const int64_t*)data, n,
+                               *(const int64_t*)value_host, out);
+            break;
+        case 4:
+            hipLaunchKernelGGL(lowerBoundOneKernel<float>, 1, 1, 0, ctx->stream, (const float*)data, n,
+                               *(const float*)value_host, out);
+            break;
+        default: return fail(ctx, CSTONE_E_ARG, "lower_bound_value: kind %d unsupported", kind);
+    }
+    CS_HIP(ctx, hipGetLastError());
+    return readU64(ctx, out, index_host);
+}
+
+int cstone_hip_sort_keys(cstone_hip_ctx* ctx, int key_bits, void* keys, size_t n)
+{
+    if (!ctx || (key_bits != 32 && key_bits != 64) || (n && !keys)) return fail(ctx, CSTONE_E_ARG, "sort_keys: bad argument");
+    if (n < 2) return CSTONE_OK;
+    // rare and small (injectKeys, R/focus/inject.hpp:97): the pair sort with a throw-away payload
+    uint32_t* payload = nullptr;
+    CS_HIP(ctx, hipMalloc((void**)&payload, n * sizeof(uint32_t)));
+    int rc = key_bits == 32 ? sortPairsArena<uint32_t>(ctx, (uint32_t*)keys, payload, n)
+                            : sortPairsArena<uint64_t>(ctx, (uint64_t*)keys, payload, n);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(payload);
+    if (rc == CSTONE_OK && e != hipSuccess) return fail(ctx, CSTONE_E_HIP, "sort_keys: %s", hipGetErrorString(e));
+    return rc;
+}
+
+} // extern "C"

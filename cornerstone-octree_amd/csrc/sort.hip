@@ -53,6 +53,9 @@ constexpr int SMALL_BLOCK  = 256;  // 4 Ki pairs per tile
 #ifndef CSTONE_LARGE_BLOCK
 #define CSTONE_LARGE_BLOCK 1024
 #endif
+#ifndef CSTONE_SORT_EARLY_LB
+#define CSTONE_SORT_EARLY_LB 1
+#endif
 constexpr int LARGE_BLOCK  = CSTONE_LARGE_BLOCK; // 16 Ki pairs per tile
 
 // CSTONE_SORT_TRACE (tuning builds only, tools/sort_trace.py): wave 0 of every tile records wall-clock stamps
@@ -238,6 +241,26 @@ __global__ __launch_bounds__(1024) void ldsOrderProbeKernel(uint32_t* __restrict
 __device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// streaming hints of the pass: every pair is read once and written once per pass (tuning switches)
+template<class V>
+__device__ __forceinline__ V streamLoad(const V* p)
+{
+#ifdef CSTONE_SORT_NT_LOAD
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template<class V>
+__device__ __forceinline__ void streamStore(V* p, V v)
+{
+#ifdef CSTONE_SORT_NT_STORE
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 
 //! 16-byte agent-scope (sc1) row accesses for the look-back: one wave moves a whole 256-digit status row with a
 //! single instruction (dword-sized sc1 accesses cost one fabric transaction each)
@@ -446,15 +469,24 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
 #endif
 
     // values are fetched now so that their latency hides behind the ranking
+#if CSTONE_SORT_EARLY_LB
+    constexpr bool EARLY = FULL && WAVES > LB_WAVES;
+#else
+    constexpr bool EARLY = false;
+#endif
+    // EARLY: the look-back waves fetch their values behind the look-back (their registers hold keys and ranks until then)
+    const bool lateValues = EARLY && wave < unsigned(LB_WAVES);
     uint32_t val[ITEMS];
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r)
-    {
-        unsigned idx = segBase + r * 64 + lane;
-        // valsIn == nullptr: the values are the positions 0..n-1 (first pass of a sort that starts from the identity
-        // ordering, sequenceGpu + sortByKeyGpu in one): nothing to read
-        val[r] = valsIn == nullptr ? tileBase + idx : ((FULL || idx < tileCount) ? valsIn[tileBase + idx] : 0u);
+    // valsIn == nullptr: the values are the positions 0..n-1 (first pass of a sort that starts from the identity
+    // ordering, sequenceGpu + sortByKeyGpu in one): nothing to read
+#define CSTONE_LOAD_VALUES()                                                                                           \
+    _Pragma("unroll") for (int r = 0; r < ITEMS; ++r)                                                                  \
+    {                                                                                                                  \
+        unsigned idx = segBase + r * 64 + lane;                                                                        \
+        val[r]       = valsIn == nullptr ? tileBase + idx                                                              \
+                                         : ((FULL || idx < tileCount) ? streamLoad(valsIn + tileBase + idx) : 0u);     \
     }
+    if (!lateValues) { CSTONE_LOAD_VALUES() }
 #ifdef CSTONE_SORT_TRACE
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); // the keys have arrived, the 16 value loads may still fly
     SORT_TRACE(2)
@@ -492,113 +524,211 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
     ldsBarrier();
     SORT_TRACE(4)
 
-    // ---- 2. digit threads (the first RADIX threads): tile totals and their scan over the digits
-    uint32_t total = 0, inc = 0;
-    if (tid < RADIX)
-    {
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w)
-            total += sm.waveHist[w * RADIX + tid];
-        sm.total[tid] = total;
-        inc           = total;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1)
-        {
-            uint32_t t = __shfl_up(inc, o);
-            if (lane >= unsigned(o)) inc += t;
-        }
-        if (lane == 63) sm.scanTmp[wave] = inc;
-    }
-    ldsBarrier();
-    SORT_TRACE(5)
-
-    u32x4 base4 = {0, 0, 0, 0};
-    if (!TAIL && wave < unsigned(LB_WAVES))
-    {
-        // global digit bases of this wave's digit quarter: fetched now, so that no load has to be waited for behind
-        // the INCLUSIVE store below (vmcnt counts stores too: a wait for a younger load would also sit out the
-        // store's round trip)
-        base4 = *reinterpret_cast<const u32x4*>(bases + 64 * wave + 4 * (lane & 15u));
-        if (wave == 0)
-        {
-            // publish the tile aggregate (tile 0: already the inclusive prefix) as one 1 KiB row
-            u32x4 t4 = *reinterpret_cast<const u32x4*>(&sm.total[4 * lane]);
-            storeRowSc1(status + size_t(tile) * RADIX + 4 * lane, t4 | (tile == 0 ? STATE_INC : STATE_AGG));
-        }
-    }
-
-    // ---- 3. tile-local slot of the first element of every (wave, digit)
-    if (tid < RADIX)
-    {
-        uint32_t off = 0;
-        for (unsigned w = 0; w < wave; ++w)
-            off += sm.scanTmp[w];
-        uint32_t run       = off + inc - total;
-        sm.digitStart[tid] = run;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w)
-        {
-            uint32_t c                   = sm.waveHist[w * RADIX + tid];
-            sm.waveHist[w * RADIX + tid] = run;
-            run += c;
-        }
-    }
-    ldsBarrier();
-    SORT_TRACE(6)
-
-    // ---- 4. permute keys into tile-sorted order through LDS
     unsigned pos[ITEMS];
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r)
+    if constexpr (EARLY)
     {
-        unsigned d = unsigned(key[r] >> shift) & (RADIX - 1);
-        pos[r]     = myHist[d] + rank[r];
-        if (FULL || segBase + r * 64 + lane < tileCount) sm.stage[pos[r]] = key[r];
+        // ---- 2-5 (16-wave tiles inside the chain). The look-back of the predecessors needs nothing of THIS tile, so
+        //      the four look-back waves start it right behind the ranking barrier, while ONE other wave (4 digits per
+        //      lane) adds up the tile totals, publishes the AGGREGATE row and turns the per-wave counts into slots; the
+        //      remaining waves pick the slots up through an LDS flag (a wave's LDS instructions execute in order) and
+        //      permute their keys meanwhile.  No workgroup barrier between the ranking and the stores.
+        constexpr unsigned SCAN_WAVE = LB_WAVES;
+        volatile uint32_t* slotsReady = &sm.tileShared[1];
+        u32x4 excl = {0, 0, 0, 0}, base4 = {0, 0, 0, 0};
+        SORT_TRACE(5)
+        SORT_TRACE(6)
+        SORT_TRACE(7)
+        if (wave == SCAN_WAVE)
+        {
+            u32x4 tot = {0, 0, 0, 0};
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w)
+                tot += *reinterpret_cast<const u32x4*>(&sm.waveHist[w * RADIX + 4 * lane]);
+            // this wave's value loads are retired before its AGGREGATE store goes out (one vmcnt queue, see below)
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r)
+                asm volatile("" : "+v"(val[r]));
+            storeRowSc1(status + size_t(tile) * RADIX + 4 * lane, tot | (tile == 0 ? STATE_INC : STATE_AGG));
+            *reinterpret_cast<u32x4*>(&sm.total[4 * lane]) = tot;
+            uint32_t s4 = tot[0] + tot[1] + tot[2] + tot[3], inc4 = s4;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                uint32_t t = __shfl_up(inc4, o);
+                if (lane >= unsigned(o)) inc4 += t;
+            }
+            u32x4 run;
+            run[0] = inc4 - s4;
+            run[1] = run[0] + tot[0];
+            run[2] = run[1] + tot[1];
+            run[3] = run[2] + tot[2];
+            *reinterpret_cast<u32x4*>(&sm.digitStart[4 * lane]) = run;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w)
+            {
+                u32x4* slot = reinterpret_cast<u32x4*>(&sm.waveHist[w * RADIX + 4 * lane]);
+                const u32x4 c = *slot;
+                *slot         = run;
+                run += c;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *slotsReady = 1u;
+        }
+        else if (wave < unsigned(LB_WAVES))
+        {
+            base4 = *reinterpret_cast<const u32x4*>(bases + 64 * wave + 4 * (lane & 15u));
+#ifdef CSTONE_SORT_TRACE
+            unsigned rounds = 0, rowsUsed = 0;
+            excl = quarterLookBack(status, tile, wave, lane, errors, rounds, rowsUsed);
+            if (wave == 0)
+            {
+                SORT_TRACE_VAL(13, rounds)
+                SORT_TRACE_VAL(14, rowsUsed)
+                SORT_TRACE(8)
+            }
+#else
+            excl = quarterLookBack(status, tile, wave, lane, errors);
+#endif
+            CSTONE_LOAD_VALUES()
+        }
+        while (*slotsReady == 0u)
+            __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        if (wave < unsigned(LB_WAVES))
+        {
+            asm volatile("" : "+v"(base4)); // pins the wait for base4 here, ahead of the store
+            if (lane < 16)
+            {
+                const unsigned d0 = 64 * wave + 4 * lane;
+                const u32x4 tot   = *reinterpret_cast<const u32x4*>(&sm.total[d0]);
+                if (tile > 0) storeRowSc1(status + size_t(tile) * RADIX + d0, ((excl + tot) & COUNT_MASK) | STATE_INC);
+                const u32x4 start4 = *reinterpret_cast<const u32x4*>(&sm.digitStart[d0]);
+                *reinterpret_cast<u32x4*>(&sm.binOffset[d0]) = base4 + excl - start4;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r)
+        {
+            unsigned d        = unsigned(key[r] >> shift) & (RADIX - 1);
+            pos[r]            = myHist[d] + rank[r];
+            sm.stage[pos[r]]  = key[r];
+        }
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r)
+            asm volatile("" : "+v"(val[r]));
+        ldsBarrier();
+        SORT_TRACE(9)
     }
-    SORT_TRACE(7)
-    // The value loads are retired HERE, before any store of this tile is issued (the INCLUSIVE row, the keys): vmcnt
-    // counts loads and stores in one queue, a wait for val[] behind a store would sit out its round trip as well.
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r)
-        asm volatile("" : "+v"(val[r]));
-
-    // ---- 5. global slot of every digit run of this tile
-    if (TAIL)
+    else
     {
+        // ---- 2. digit threads (the first RADIX threads): tile totals and their scan over the digits
+        uint32_t total = 0, inc = 0;
         if (tid < RADIX)
         {
-            uint32_t end      = (tid == RADIX - 1) ? n : bases[tid + 1];
-            sm.binOffset[tid] = end - total - sm.digitStart[tid];
+    #pragma unroll
+            for (int w = 0; w < WAVES; ++w)
+                total += sm.waveHist[w * RADIX + tid];
+            sm.total[tid] = total;
+            inc           = total;
+    #pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                uint32_t t = __shfl_up(inc, o);
+                if (lane >= unsigned(o)) inc += t;
+            }
+            if (lane == 63) sm.scanTmp[wave] = inc;
         }
-    }
-    else if (wave < unsigned(LB_WAVES))
-    {
-#ifdef CSTONE_SORT_TRACE
-        unsigned rounds = 0, rowsUsed = 0;
-        u32x4 excl = quarterLookBack(status, tile, wave, lane, errors, rounds, rowsUsed);
-#else
-        u32x4 excl = quarterLookBack(status, tile, wave, lane, errors);
-#endif
-        asm volatile("" : "+v"(base4)); // pins the wait for base4 here, ahead of the store
-        if (lane < 16)
+        ldsBarrier();
+        SORT_TRACE(5)
+
+        u32x4 base4 = {0, 0, 0, 0};
+        if (!TAIL && wave < unsigned(LB_WAVES))
         {
-            const unsigned d0 = 64 * wave + 4 * lane;
-            const u32x4 tot   = *reinterpret_cast<const u32x4*>(&sm.total[d0]);
-            if (tile > 0) storeRowSc1(status + size_t(tile) * RADIX + d0, ((excl + tot) & COUNT_MASK) | STATE_INC);
-            const u32x4 start4 = *reinterpret_cast<const u32x4*>(&sm.digitStart[d0]);
-            *reinterpret_cast<u32x4*>(&sm.binOffset[d0]) = base4 + excl - start4;
+            // global digit bases of this wave's digit quarter: fetched now, so that no load has to be waited for behind
+            // the INCLUSIVE store below (vmcnt counts stores too: a wait for a younger load would also sit out the
+            // store's round trip)
+            base4 = *reinterpret_cast<const u32x4*>(bases + 64 * wave + 4 * (lane & 15u));
+            if (wave == 0)
+            {
+                // publish the tile aggregate (tile 0: already the inclusive prefix) as one 1 KiB row
+                u32x4 t4 = *reinterpret_cast<const u32x4*>(&sm.total[4 * lane]);
+                storeRowSc1(status + size_t(tile) * RADIX + 4 * lane, t4 | (tile == 0 ? STATE_INC : STATE_AGG));
+            }
         }
-#ifdef CSTONE_SORT_TRACE
-        if (wave == 0)
+
+        // ---- 3. tile-local slot of the first element of every (wave, digit)
+        if (tid < RADIX)
         {
-            SORT_TRACE_VAL(13, rounds)
-            SORT_TRACE_VAL(14, rowsUsed)
-            SORT_TRACE(8)
+            uint32_t off = 0;
+            for (unsigned w = 0; w < wave; ++w)
+                off += sm.scanTmp[w];
+            uint32_t run       = off + inc - total;
+            sm.digitStart[tid] = run;
+    #pragma unroll
+            for (int w = 0; w < WAVES; ++w)
+            {
+                uint32_t c                   = sm.waveHist[w * RADIX + tid];
+                sm.waveHist[w * RADIX + tid] = run;
+                run += c;
+            }
         }
-#endif
+        ldsBarrier();
+        SORT_TRACE(6)
+
+        // ---- 4. permute keys into tile-sorted order through LDS
+    #pragma unroll
+        for (int r = 0; r < ITEMS; ++r)
+        {
+            unsigned d = unsigned(key[r] >> shift) & (RADIX - 1);
+            pos[r]     = myHist[d] + rank[r];
+            if (FULL || segBase + r * 64 + lane < tileCount) sm.stage[pos[r]] = key[r];
+        }
+        SORT_TRACE(7)
+        // The value loads are retired HERE, before any store of this tile is issued (the INCLUSIVE row, the keys): vmcnt
+        // counts loads and stores in one queue, a wait for val[] behind a store would sit out its round trip as well.
+    #pragma unroll
+        for (int r = 0; r < ITEMS; ++r)
+            asm volatile("" : "+v"(val[r]));
+
+        // ---- 5. global slot of every digit run of this tile
+        if (TAIL)
+        {
+            if (tid < RADIX)
+            {
+                uint32_t end      = (tid == RADIX - 1) ? n : bases[tid + 1];
+                sm.binOffset[tid] = end - total - sm.digitStart[tid];
+            }
+        }
+        else if (wave < unsigned(LB_WAVES))
+        {
+    #ifdef CSTONE_SORT_TRACE
+            unsigned rounds = 0, rowsUsed = 0;
+            u32x4 excl = quarterLookBack(status, tile, wave, lane, errors, rounds, rowsUsed);
+    #else
+            u32x4 excl = quarterLookBack(status, tile, wave, lane, errors);
+    #endif
+            asm volatile("" : "+v"(base4)); // pins the wait for base4 here, ahead of the store
+            if (lane < 16)
+            {
+                const unsigned d0 = 64 * wave + 4 * lane;
+                const u32x4 tot   = *reinterpret_cast<const u32x4*>(&sm.total[d0]);
+                if (tile > 0) storeRowSc1(status + size_t(tile) * RADIX + d0, ((excl + tot) & COUNT_MASK) | STATE_INC);
+                const u32x4 start4 = *reinterpret_cast<const u32x4*>(&sm.digitStart[d0]);
+                *reinterpret_cast<u32x4*>(&sm.binOffset[d0]) = base4 + excl - start4;
+            }
+    #ifdef CSTONE_SORT_TRACE
+            if (wave == 0)
+            {
+                SORT_TRACE_VAL(13, rounds)
+                SORT_TRACE_VAL(14, rowsUsed)
+                SORT_TRACE(8)
+            }
+    #endif
+        }
+        ldsBarrier();
+        SORT_TRACE(9)
+
     }
-    ldsBarrier();
-    SORT_TRACE(9)
 
     // ---- 6. stream out keys (remember each slot for the values), then values through the same LDS block
     uint32_t dst[ITEMS];
@@ -612,7 +742,7 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
             K kk       = sm.stage[i];
             unsigned d = unsigned(kk >> shift) & (RADIX - 1);
             dst[k]     = sm.binOffset[d] + i;
-            if (dst[k] < n) { keysOut[dst[k]] = kk; }
+            if (dst[k] < n) { streamStore(keysOut + dst[k], kk); }
             else { atomicOr(errors, 8u); } // cannot happen; turns a would-be wild store into a reported error
         }
     }
@@ -630,7 +760,7 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
     for (int k = 0; k < ITEMS; ++k)
     {
         unsigned i = k * BLOCK + tid;
-        if (dst[k] < n) valsOut[dst[k]] = vstage[i];
+        if (dst[k] < n) streamStore(valsOut + dst[k], vstage[i]);
     }
     SORT_TRACE(12)
 }
@@ -659,6 +789,7 @@ __global__ __launch_bounds__(BLOCK) void onesweepKernel(const K* __restrict__ ke
 #endif
 
     if (tid == 0) sm.tileShared[0] = atomicAdd(ticket, 1u);
+    if (tid == 64) sm.tileShared[1] = 0; // "slots ready" flag of sortTile
     for (int i = tid; i < WAVES * RADIX; i += BLOCK)
         sm.waveHist[i] = 0;
     __syncthreads();
@@ -709,7 +840,7 @@ __global__ __launch_bounds__(BLOCK) void onesweepKernel(const K* __restrict__ ke
     K key[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r)
-        key[r] = keysIn[tile * uint32_t(TILE) + segBase + r * 64 + lane];
+        key[r] = streamLoad(keysIn + tile * uint32_t(TILE) + segBase + r * 64 + lane);
     sortTile<K, BLOCK, false>(sm, key, tile, unsigned(TILE), valsIn, keysOut, valsOut, pass * RADIX_BITS,
                               bases, status, errors, n);
 }

@@ -37,6 +37,12 @@ EXPORTS = [
     "cstone_hip_domain_set_halo_factor", "cstone_hip_domain_mr_create", "cstone_hip_domain_mr_destroy",
     "cstone_hip_domain_mr_sync", "cstone_hip_domain_mr_sync_props", "cstone_hip_domain_mr_sync_keys", "cstone_hip_domain_mr_view_get", "cstone_hip_domain_mr_set_halo_factor", "cstone_hip_domain_mr_exchange_halos", "cstone_hip_domain_mr_reapply_sync",
     "cstone_hip_domain_reapply_sync", "cstone_hip_domain_mr_octree_get",
+    "cstone_hip_fill", "cstone_hip_scale", "cstone_hip_increment", "cstone_hip_count_equal", "cstone_hip_reduce_sum",
+    "cstone_hip_max_norm_square", "cstone_hip_segment_max", "cstone_hip_gather_ranges", "cstone_hip_lower_bound_value",
+    "cstone_hip_sort_keys", "cstone_hip_rebalance_decision_essential", "cstone_hip_mac_refine_decision",
+    "cstone_hip_protect_ancestors", "cstone_hip_enforce_keys", "cstone_hip_range_count", "cstone_hip_mark_macs",
+    "cstone_hip_count_sfc_gaps", "cstone_hip_fill_sfc_gaps", "cstone_hip_geo_mac_spheres", "cstone_hip_set_mac",
+    "cstone_hip_move_centers", "cstone_hip_leaf_source_centers", "cstone_hip_upsweep_centers",
 ]
 
 

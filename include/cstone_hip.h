@@ -162,6 +162,41 @@ extern "C"
                                int num_values, uint64_t* result);
 
     /* ---------------------------------------------------------------------------------------------
+     * the small primitives of the seam (R/primitives/primitives_gpu.h:36-124, Thrust one-liners in the reference)
+     * fill          : fillGpu (:39-40), dst[i] = *value_host for elements of 1, 4 or 8 bytes
+     * scale         : scaleGpu (:42-43), data[i] *= factor (float | double)
+     * increment     : incrementGpu (:45-46), out[i] = in[i] + value for uint32 | uint64 (elem_bits)
+     * count_equal   : countGpu (:123-124), number of elements equal to value (elements of 32 | 64 bits)
+     * reduce_sum    : reduceGpu (:82-83), init + sum of uint32 | uint64 elements in 64-bit arithmetic
+     * max_norm_square : maxNormSquareGpu (:64-65), max of x^2 + y^2 + z^2 evaluated in real_bits precision
+     * segment_max   : segmentMax (:79-80), out[s] = max(in[segments[s] .. segments[s+1])), seeded with the segment's
+     *                 first element like the reference (:241-259); in/out float|double, segments uint32|uint64
+     * gather_ranges : gatherRanges (R/halos/gather_halos_gpu.h): buffer[i] = src[range_offsets[r] + i - range_scan[r]]
+     *                 for the range r with range_scan[r] <= i < range_scan[r+1]; indices uint32 | uint64 (index_bits),
+     *                 elements of 1..32 bytes as gather
+     * lower_bound_value : lowerBoundGpu, scalar form (:67-68); kind 0 u32, 1 u64, 2 i32, 3 i64, 4 f32
+     * sort_keys     : sortGpu (:91-92), ascending keys-only sort (the key buffer of the reference's signature is not
+     *                 needed: scratch comes from the context)
+     * ------------------------------------------------------------------------------------------- */
+    int cstone_hip_fill(cstone_hip_ctx* ctx, int elem_bytes, void* dst, size_t n, const void* value_host);
+    int cstone_hip_scale(cstone_hip_ctx* ctx, int real_bits, void* data, size_t n, double factor);
+    int cstone_hip_increment(cstone_hip_ctx* ctx, int elem_bits, const void* in, void* out, size_t n, uint64_t value);
+    int cstone_hip_count_equal(cstone_hip_ctx* ctx, int elem_bits, const void* data, size_t n, uint64_t value,
+                               uint64_t* count_host);
+    int cstone_hip_reduce_sum(cstone_hip_ctx* ctx, int elem_bits, const void* data, size_t n, uint64_t init,
+                              uint64_t* sum_host);
+    int cstone_hip_max_norm_square(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y, const void* z,
+                                   size_t n, double* out_host);
+    int cstone_hip_segment_max(cstone_hip_ctx* ctx, int in_bits, int out_bits, int index_bits, const void* in,
+                               const void* segments, size_t num_segments, void* out);
+    int cstone_hip_gather_ranges(cstone_hip_ctx* ctx, int elem_bytes, int index_bits, const void* range_scan,
+                                 const void* range_offsets, int num_ranges, const void* src, void* buffer,
+                                 size_t buffer_size);
+    int cstone_hip_lower_bound_value(cstone_hip_ctx* ctx, int kind, const void* data, size_t n, const void* value_host,
+                                     uint64_t* index_host);
+    int cstone_hip_sort_keys(cstone_hip_ctx* ctx, int key_bits, void* keys, size_t n);
+
+    /* ---------------------------------------------------------------------------------------------
      * cornerstone leaf array (R/tree/csarray_gpu.h:56-88, R/tree/update_gpu.cuh:59-82)
      * ------------------------------------------------------------------------------------------- */
     /* computeNodeCountsGpu: counts[i] = min(#keys in [tree[i],tree[i+1]), max_count); keys sorted */
@@ -249,6 +284,77 @@ extern "C"
     int cstone_hip_find_overlaps(cstone_hip_ctx* ctx, int curve, int key_bits, const void* prefixes,
                                  const int32_t* child_offsets, const int32_t* internal_to_leaf, const void* leaves,
                                  const int32_t* boxes, int num_boxes, int first, int last, int32_t* flags);
+
+    /* ---------------------------------------------------------------------------------------------
+     * focus tree (locally essential tree): the GPU seam of R/focus/rebalance_gpu.h:40-81, markMacsGpu
+     * (R/traversal/collisions_gpu.h:68-77), countSfcGapsGpu / fillSfcGapsGpu (R/tree/csarray_gpu.h:78-88) and the node
+     * spheres of R/focus/source_center_gpu.h:50-89.  Arrays indexed by node follow the linked octree (prefixes,
+     * child_offsets, parents of cstone_hip_build_octree); macs / markings are char[num_nodes].
+     * rebalance_decision_essential : node_ops[i] in {0 merge, 1 keep, 8 split} from counts and MAC flags
+     *                 (mergeCountAndMacOp, R/focus/rebalance.hpp:50-79), focus = keys [focus_start, focus_end)
+     * mac_refine_decision : node_ops[leaf] = 8 for leaves outside [focus_first, focus_last) whose MAC flag is set
+     *                 (and that can still be split), 1 otherwise (macRefineOp, :81-88)
+     * protect_ancestors : a 0 (merge) becomes the op of the closest ancestor with a non-zero op if the node is that
+     *                 ancestor's left-most descendant (nzAncestorOp, :113-131); *converged_host = 1 iff every op is 1
+     * enforce_keys  : makes sure the tree keeps / gets a node boundary at each of the num_forced_keys keys (device
+     *                 array): cancels merges of the supporting ancestors and requests a split by ONE level
+     *                 (enforceKeySingle, :199-250); *status_host = max over the keys of ResolutionStatus (:186-196:
+     *                 0 converged, 1 cancelMerge, 2 rebalance, 3 failed).  Concurrent keys give the result of the
+     *                 reference's sequential CPU loop (atomic updates)
+     * range_count   : counts_focus[j] = min(2^32-1, sum of the global counts of the global leaves under focus leaf j)
+     *                 for the num_idx leaf indices j listed in leaves_focus_idx (rangeCount, :279-301); leaves has
+     *                 num_leaves + 1 keys
+     * mark_macs     : markings[n] = 1 for every node outside the focus key range [focus_nodes[0],
+     *                 focus_nodes[num_focus_nodes]) that fails the MAC (|min. distance|^2 < centers[n][3], centers =
+     *                 Vec4<T>[num_nodes]) against one of the focus cells and, with limit_source, is not deeper than that
+     *                 cell's level - 1 (markMacs, R/traversal/macs.hpp:199-270); markings is NOT cleared
+     * count_sfc_gaps / fill_sfc_gaps : spanSfcRange (R/sfc/common.hpp:370-438) per pair of consecutive keys: the
+     *                 number of nodes resp. the keys of the coarsest cornerstone sub-tree covering [tree[i], tree[i+1]);
+     *                 fill writes them at new_tree + node_ops[i] (node_ops = exclusive scan of the counts, num_nodes + 1
+     *                 entries) and the terminal key at new_tree[node_ops[num_nodes]]
+     * geo_mac_spheres : spheres[n] = (geometric centre, (2 max(size) inv_theta)^2)   (computeMinMacR2)
+     * set_mac       : spheres[n][3] <- (2 max(size) inv_theta + |spheres[n].xyz - geometric centre|)^2, 0 if it was 0
+     *                 (computeVecMacR2 / setMac)
+     * move_centers  : dst[n] = (src[n], 1) from Vec3<T> to Vec4<T>
+     * leaf_source_centers : centre of |mass| of the particles of every leaf, stored at its node index
+     *                 (computeLeafSourceCenterGpu; coord/mass/center bits = 64/64/64, 64/32/64 or 32/32/32)
+     * upsweep_centers : centres of |mass| of the internal nodes, bottom-up (upsweepCentersGpu); level_range is a HOST
+     *                 array of num_levels + 1 entries like in the reference
+     * ------------------------------------------------------------------------------------------- */
+    int cstone_hip_rebalance_decision_essential(cstone_hip_ctx* ctx, int key_bits, const void* prefixes,
+                                                const int32_t* child_offsets, const int32_t* parents,
+                                                const uint32_t* counts, const char* macs, uint64_t focus_start,
+                                                uint64_t focus_end, uint32_t bucket_size, int32_t* node_ops,
+                                                int num_nodes);
+    int cstone_hip_mac_refine_decision(cstone_hip_ctx* ctx, int key_bits, const void* prefixes, const char* macs,
+                                       const int32_t* leaf_to_internal, int num_leaves, int focus_first,
+                                       int focus_last, int32_t* node_ops);
+    int cstone_hip_protect_ancestors(cstone_hip_ctx* ctx, int key_bits, const void* prefixes, const int32_t* parents,
+                                     int32_t* node_ops, int num_nodes, int* converged_host);
+    int cstone_hip_enforce_keys(cstone_hip_ctx* ctx, int key_bits, const void* forced_keys, int num_forced_keys,
+                                const void* prefixes, const int32_t* child_offsets, const int32_t* parents,
+                                int32_t* node_ops, int* status_host);
+    int cstone_hip_range_count(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int num_leaves,
+                               const uint32_t* counts, const void* leaves_focus, const int32_t* leaves_focus_idx,
+                               int num_idx, uint32_t* counts_focus);
+    int cstone_hip_mark_macs(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* prefixes,
+                             const int32_t* child_offsets, const void* centers, const cstone_box* box_host,
+                             const void* focus_nodes, int num_focus_nodes, int limit_source, char* markings);
+    int cstone_hip_count_sfc_gaps(cstone_hip_ctx* ctx, int key_bits, const void* tree, int num_nodes,
+                                  int32_t* node_ops);
+    int cstone_hip_fill_sfc_gaps(cstone_hip_ctx* ctx, int key_bits, const void* tree, int num_nodes,
+                                 const int32_t* node_ops, void* new_tree);
+    int cstone_hip_geo_mac_spheres(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* prefixes,
+                                   int num_nodes, void* spheres, float inv_theta, const cstone_box* box_host);
+    int cstone_hip_set_mac(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* prefixes,
+                           int num_nodes, void* spheres, float inv_theta, const cstone_box* box_host);
+    int cstone_hip_move_centers(cstone_hip_ctx* ctx, int real_bits, const void* src, int num_nodes, void* dst);
+    int cstone_hip_leaf_source_centers(cstone_hip_ctx* ctx, int coord_bits, int mass_bits, int center_bits,
+                                       const void* x, const void* y, const void* z, const void* m,
+                                       const int32_t* leaf_to_internal, int num_leaves, const uint32_t* layout,
+                                       void* centers);
+    int cstone_hip_upsweep_centers(cstone_hip_ctx* ctx, int real_bits, int num_levels, const int32_t* level_range_host,
+                                   const int32_t* child_offsets, void* centers);
 
     /* ---------------------------------------------------------------------------------------------
      * neighbor search: replaces findNeighbors (R/findneighbors.hpp:160-188) / the traverseNeighbors

@@ -1013,4 +1013,292 @@ std::vector<LocalIdx> groupSplits(LocalIdx first, LocalIdx last, const T* x, con
     return groups;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// focus tree (locally essential tree), R/focus/rebalance.hpp, R/traversal/macs.hpp, R/focus/source_center.hpp
+// ---------------------------------------------------------------------------------------------------------------------
+
+//! mergeCountAndMacOp for every node, R/focus/rebalance.hpp:50-79,152-171: 0 merge, 1 keep, 8 split
+template<class K>
+void essentialOps(const K* prefixes, const NodeIdx* childOffsets, const NodeIdx* parents, const unsigned* counts,
+                  const char* macs, K focusStart, K focusEnd, unsigned bucket, NodeIdx* ops, NodeIdx numNodes)
+{
+    for (NodeIdx i = 0; i < numNodes; ++i)
+    {
+        unsigned level = prefixBits(prefixes[i]) / 3;
+        ops[i]         = 1;
+        if (i > 0)
+        {
+            NodeIdx parent = parents[(i - 1) / 8];
+            K groupStart   = fromPrefix(prefixes[parent]);
+            K groupEnd     = groupStart + 8 * nodeSpan<K>(level);
+            bool fringe    = groupEnd > focusStart && focusEnd > groupStart; // overlapTwoRanges, boxoverlap.hpp:42-47
+            if (counts[parent] <= bucket || (macs[parent] == 0 && !fringe))
+            {
+                ops[i] = 0;
+                continue;
+            }
+        }
+        K start      = fromPrefix(prefixes[i]);
+        bool inFocus = start >= focusStart && start < focusEnd;
+        if (childOffsets[i] == 0 && level < maxLevel<K>() && counts[i] > bucket && (macs[i] || inFocus)) ops[i] = 8;
+    }
+}
+
+//! macRefineOp per leaf outside the focus, R/focus/rebalance.hpp:81-88, R/focus/rebalance_gpu.cu:88-101
+template<class K>
+void macRefineOps(const K* prefixes, const char* macs, const NodeIdx* leafToInternal, NodeIdx numLeaves,
+                  NodeIdx focusFirst, NodeIdx focusLast, NodeIdx* ops)
+{
+    for (NodeIdx i = 0; i < numLeaves; ++i)
+    {
+        ops[i] = 1;
+        if (i < focusFirst || i >= focusLast)
+        {
+            NodeIdx n = leafToInternal[i];
+            if (prefixBits(prefixes[n]) / 3 < maxLevel<K>() && macs[n]) ops[i] = 8;
+        }
+    }
+}
+
+//! protectAncestors, R/focus/rebalance.hpp:113-184 (sequential here: the result does not depend on the order);
+//! returns true when every op is 1
+template<class K>
+bool protectAncestors(const K* prefixes, const NodeIdx* parents, NodeIdx* ops, NodeIdx numNodes)
+{
+    int changes = 0;
+    for (NodeIdx i = 0; i < numNodes; ++i)
+    {
+        NodeIdx a = i;
+        while (ops[a] == 0 && a != 0)
+            a = parents[(a - 1) / 8];
+        int op = (a == i || fromPrefix(prefixes[i]) == fromPrefix(prefixes[a])) ? ops[a] : 0;
+        if (op != 1) ++changes;
+        ops[i] = op;
+    }
+    return changes == 0;
+}
+
+//! smallest node that contains the node with placeholder prefix @p want, R/tree/octree.hpp:245-262
+template<class K>
+inline NodeIdx containingNode(K want, const K* prefixes, const NodeIdx* childOffsets)
+{
+    int level = prefixBits(want) / 3;
+    K key     = fromPrefix(want);
+    NodeIdx n = 0;
+    for (int l = 1; l <= level; ++l)
+    {
+        if (childOffsets[n] == 0 || prefixes[n] == want) break;
+        n = childOffsets[n] + NodeIdx(octDigit(key, unsigned(l)));
+    }
+    return n;
+}
+
+//! enforceKeys, R/focus/rebalance.hpp:199-267; status 0 converged, 1 cancelMerge, 2 rebalance, 3 failed (:186-196)
+template<class K>
+int enforceKeys(const K* forcedKeys, NodeIdx numKeys, const K* prefixes, const NodeIdx* childOffsets,
+                const NodeIdx* parents, NodeIdx* ops)
+{
+    int status = 0;
+    for (NodeIdx q = 0; q < numKeys; ++q)
+    {
+        K key = forcedKeys[q];
+        if (key == 0 || key == endKey<K>()) continue;
+        K want        = makePrefix(key);
+        NodeIdx node  = containingNode(want, prefixes, childOffsets);
+        int haveLevel = prefixBits(prefixes[node]) / 3;
+        bool trySplit = prefixes[node] != want && haveLevel < int(maxLevel<K>());
+        int st        = 0;
+        if ((ops[node] == 0 || trySplit) && node > 0)
+        {
+            st        = 1;
+            NodeIdx p = node;
+            do
+            {
+                p = parents[(p - 1) / 8];
+                for (NodeIdx c = childOffsets[p]; c < childOffsets[p] + 8; ++c)
+                    if (ops[c] == 0) ops[c] = 1;
+            } while (p != 0);
+        }
+        if (trySplit)
+        {
+            int levelDiff = lastNonZeroDigit(key) - haveLevel;
+            st            = levelDiff > 1 ? 3 : 2;
+            levelDiff     = std::min(levelDiff, 1);
+            ops[node]     = std::max(ops[node], 1 << (3 * levelDiff));
+        }
+        status = std::max(status, st);
+    }
+    return status;
+}
+
+//! rangeCount, R/focus/rebalance.hpp:279-301 (findNodeBelow / findNodeAbove over ALL numLeaves + 1 keys, csarray.hpp:78-90)
+template<class K>
+void rangeCount(const K* leaves, NodeIdx numLeaves, const unsigned* counts, const K* leavesFocus, const NodeIdx* focusIdx,
+                NodeIdx numIdx, unsigned* countsFocus)
+{
+    for (NodeIdx q = 0; q < numIdx; ++q)
+    {
+        NodeIdx leaf  = focusIdx[q];
+        NodeIdx first = NodeIdx(std::upper_bound(leaves, leaves + numLeaves + 1, leavesFocus[leaf]) - leaves) - 1;
+        NodeIdx last  = NodeIdx(std::lower_bound(leaves, leaves + numLeaves + 1, leavesFocus[leaf + 1]) - leaves);
+        uint64_t sum  = 0;
+        for (NodeIdx i = first; i < last; ++i)
+            sum += counts[i];
+        countsFocus[leaf] = unsigned(std::min<uint64_t>(0xFFFFFFFFull, sum));
+    }
+}
+
+//! centre and half-size of an integer box, R/sfc/box.hpp:335-352
+template<class K, class T>
+inline void centerAndSize(const IBox& b, const Box<T>& box, T (&center)[3], T (&size)[3])
+{
+    constexpr int g = 1u << maxLevel<K>();
+    constexpr T uL  = T(1.) / g;
+    for (int d = 0; d < 3; ++d)
+    {
+        T half    = T(0.5) * uL * box.len[d];
+        center[d] = box.lo[d] + (b.hi[d] + b.lo[d]) * half;
+        size[d]   = (b.hi[d] - b.lo[d]) * half;
+    }
+}
+
+//! computeMinMacR2 (mode 0), R/traversal/macs.hpp:44-58, and setMac / computeVecMacR2 (mode 1), :69-85 with
+//! R/focus/source_center.hpp:118-131; spheres = Vec4<T>[numNodes]
+template<class K, class T>
+void macSpheres(Curve c, int mode, const K* prefixes, NodeIdx numNodes, T* spheres, float invTheta, const Box<T>& box)
+{
+    for (NodeIdx i = 0; i < numNodes; ++i)
+    {
+        unsigned level = prefixBits(prefixes[i]) / 3;
+        IBox b         = nodeIBox<K>(c, fromPrefix(prefixes[i]), level);
+        T ctr[3], sz[3];
+        centerAndSize<K, T>(b, box, ctr, sz);
+        T l = T(2) * std::max(sz[0], std::max(sz[1], sz[2]));
+        if (mode == 0)
+        {
+            T mac              = l * invTheta;
+            spheres[4 * i]     = ctr[0], spheres[4 * i + 1] = ctr[1], spheres[4 * i + 2] = ctr[2];
+            spheres[4 * i + 3] = mac * mac;
+        }
+        else
+        {
+            T m  = spheres[4 * i + 3];
+            T dx = spheres[4 * i] - ctr[0], dy = spheres[4 * i + 1] - ctr[1], dz = spheres[4 * i + 2] - ctr[2];
+            T s  = std::sqrt(dx * dx + (dy * dy + dz * dz)); // right fold of util::dot, R/util/array.hpp:252-256
+            T mac = l * invTheta + s;
+            spheres[4 * i + 3] = (m != T(0)) ? mac * mac : T(0);
+        }
+    }
+}
+
+//! markMacs, R/traversal/macs.hpp:199-270 with markMacPerBox :138-170 and evaluateMacPbc :121-134
+template<class K, class T>
+void markMacs(Curve c, const K* prefixes, const NodeIdx* childOffsets, const T* centers /*Vec4*/, const Box<T>& box,
+              const K* focusNodes, NodeIdx numFocusNodes, bool limitSource, char* markings)
+{
+    K focusStart = focusNodes[0], focusEnd = focusNodes[numFocusNodes];
+    for (NodeIdx i = 0; i < numFocusNodes; ++i)
+    {
+        unsigned level = levelOfSpan<K>(focusNodes[i + 1] - focusNodes[i]);
+        IBox target    = nodeIBox<K>(c, focusNodes[i], level);
+        IBox ext       = target;
+        for (int d = 0; d < 3; ++d)
+            ext.lo[d] -= 1, ext.hi[d] += 1;
+        if (boxInsideKeyRange<K>(c, focusStart, focusEnd, ext)) continue;
+        T tc[3], ts[3];
+        centerAndSize<K, T>(target, box, tc, ts);
+        unsigned maxSource = limitSource ? unsigned(std::max(int(level) - 1, 0)) : maxLevel<K>();
+
+        auto violates = [&](NodeIdx n)
+        {
+            unsigned l = prefixBits(prefixes[n]) / 3;
+            K start    = fromPrefix(prefixes[n]);
+            K end      = start + nodeSpan<K>(l);
+            if (!(start < focusStart || end > focusEnd)) return false;
+            const T* sc = centers + 4 * size_t(n);
+            T dX[3];
+            for (int d = 0; d < 3; ++d)
+            {
+                T dx = tc[d] - sc[d];
+                dx -= T(box.bc[d] == 1) * box.len[d] * std::rint(dx * box.inv[d]); // applyPbc, R/sfc/box.hpp:195-206
+                dx = std::abs(dx);
+                dx -= ts[d];
+                dx += std::abs(dx);
+                dx *= T(0.5);
+                dX[d] = dx;
+            }
+            T r2   = dX[0] * dX[0] + (dX[1] * dX[1] + dX[2] * dX[2]);
+            bool v = r2 < std::abs(sc[3]) && l <= maxSource;
+            if (v && !markings[n]) markings[n] = 1;
+            return v;
+        };
+        walkTree(childOffsets, violates, [](NodeIdx) {});
+    }
+}
+
+//! massCenter per leaf, R/focus/source_center.hpp:44-77,96-118
+template<class Tc, class Tm, class Tf>
+void leafSourceCenters(const Tc* x, const Tc* y, const Tc* z, const Tm* m, const NodeIdx* leafToInternal,
+                       NodeIdx numLeaves, const LocalIdx* layout, Tf* centers /*Vec4*/)
+{
+    for (NodeIdx leaf = 0; leaf < numLeaves; ++leaf)
+    {
+        Tf c[4] = {0, 0, 0, 0};
+        for (LocalIdx i = layout[leaf]; i < layout[leaf + 1]; ++i)
+        {
+            Tf w = std::abs(Tf(m[i]));
+            c[0] += w * Tf(x[i]), c[1] += w * Tf(y[i]), c[2] += w * Tf(z[i]), c[3] += w;
+        }
+        Tf inv    = (c[3] != Tf(0.0)) ? Tf(1.0) / c[3] : Tf(1.0);
+        NodeIdx n = leafToInternal[leaf];
+        centers[4 * n] = c[0] * inv, centers[4 * n + 1] = c[1] * inv, centers[4 * n + 2] = c[2] * inv, centers[4 * n + 3] = c[3];
+    }
+}
+
+//! CombineSourceCenter bottom-up, R/focus/source_center.hpp:79-95 with the level loop of source_center_gpu.cu:95-113
+template<class T>
+void upsweepCenters(int numLevels, const NodeIdx* levelRange, const NodeIdx* childOffsets, T* centers /*Vec4*/)
+{
+    for (int level = numLevels - 1; level >= 0; --level)
+        for (NodeIdx cell = levelRange[level]; cell < levelRange[level + 1]; ++cell)
+        {
+            NodeIdx child = childOffsets[cell];
+            if (!child) continue;
+            T c[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 8; ++k)
+            {
+                const T* s = centers + 4 * size_t(child + k);
+                T w        = std::abs(s[3]);
+                c[0] += w * s[0], c[1] += w * s[1], c[2] += w * s[2], c[3] += w;
+            }
+            T inv = (c[3] != T(0.0)) ? T(1.0) / c[3] : T(1.0);
+            centers[4 * size_t(cell)] = c[0] * inv, centers[4 * size_t(cell) + 1] = c[1] * inv;
+            centers[4 * size_t(cell) + 2] = c[2] * inv, centers[4 * size_t(cell) + 3] = c[3];
+        }
+}
+
+//! segmentMax, R/primitives/primitives_gpu.cu:241-259 (seeded with the segment's first element)
+template<class Tin, class Tout, class I>
+void segmentMax(const Tin* in, const I* seg, size_t numSegments, Tout* out)
+{
+    for (size_t s = 0; s < numSegments; ++s)
+    {
+        Tin m = in[seg[s]];
+        for (I i = seg[s]; i < seg[s + 1]; ++i)
+            m = std::max(m, in[i]);
+        out[s] = Tout(m);
+    }
+}
+
+//! gatherRanges, R/halos/gather_halos_gpu.cu:26-40
+template<class E, class I>
+void gatherRanges(const I* scan, const I* offsets, int numRanges, const E* src, E* buffer, size_t bufferSize)
+{
+    for (size_t i = 0; i < bufferSize; ++i)
+    {
+        int r     = int(std::upper_bound(scan, scan + numRanges, I(i)) - scan) - 1;
+        buffer[i] = src[offsets[r] + I(i) - scan[r]];
+    }
+}
+
 } // namespace orc

@@ -299,6 +299,114 @@ class _CpuImpl:
         assert rc == 0, rc
         return flags
 
+    # ---- focus tree (locally essential tree)
+    def essential_ops(self, octree, counts, macs, focus_start, focus_end, bucket):
+        pre = octree["prefixes"]
+        nn = pre.size
+        ops = np.zeros(nn, dtype=np.int32)
+        rc = self._f("essential_ops")(C.c_int(pre.dtype.itemsize * 8), _p(pre), _p(octree["child_offsets"]),
+                                      _p(octree["parents"]), _p(np.ascontiguousarray(counts, dtype=np.uint32)),
+                                      _p(np.ascontiguousarray(macs, dtype=np.int8)), C.c_uint64(int(focus_start)),
+                                      C.c_uint64(int(focus_end)), C.c_uint(bucket), _p(ops), C.c_int(nn))
+        assert rc == 0, rc
+        return ops
+
+    def mac_refine_ops(self, octree, macs, num_leaves, focus_first, focus_last):
+        pre = octree["prefixes"]
+        ops = np.zeros(num_leaves, dtype=np.int32)
+        rc = self._f("mac_refine_ops")(C.c_int(pre.dtype.itemsize * 8), _p(pre),
+                                       _p(np.ascontiguousarray(macs, dtype=np.int8)), _p(octree["leaf_to_internal"]),
+                                       C.c_int(num_leaves), C.c_int(focus_first), C.c_int(focus_last), _p(ops))
+        assert rc == 0, rc
+        return ops
+
+    def protect_ancestors(self, octree, ops):
+        pre = octree["prefixes"]
+        ops = np.ascontiguousarray(ops, dtype=np.int32).copy()
+        rc = self._f("protect_ancestors")(C.c_int(pre.dtype.itemsize * 8), _p(pre), _p(octree["parents"]), _p(ops),
+                                          C.c_int(pre.size))
+        assert rc >= 0, rc
+        return ops, bool(rc)
+
+    def enforce_keys(self, forced_keys, octree, ops):
+        pre = octree["prefixes"]
+        ops = np.ascontiguousarray(ops, dtype=np.int32).copy()
+        fk = np.ascontiguousarray(forced_keys, dtype=pre.dtype)
+        rc = self._f("enforce_keys")(C.c_int(pre.dtype.itemsize * 8), _p(fk), C.c_int(fk.size), _p(pre),
+                                     _p(octree["child_offsets"]), _p(octree["parents"]), _p(ops))
+        assert rc >= 0, rc
+        return ops, int(rc)
+
+    def range_count(self, leaves, counts, leaves_focus, focus_idx, counts_focus=None):
+        nf = leaves_focus.size - 1
+        out = np.zeros(nf, dtype=np.uint32) if counts_focus is None else np.ascontiguousarray(counts_focus, dtype=np.uint32).copy()
+        idx = np.ascontiguousarray(focus_idx, dtype=np.int32)
+        rc = self._f("range_count")(C.c_int(leaves.dtype.itemsize * 8), _p(leaves), C.c_int(leaves.size - 1),
+                                    _p(np.ascontiguousarray(counts, dtype=np.uint32)), _p(leaves_focus), C.c_int(nf),
+                                    _p(idx), C.c_int(idx.size), _p(out))
+        assert rc == 0, rc
+        return out
+
+    def mac_spheres(self, curve, mode, prefixes, box, inv_theta, real_bits=64, spheres=None):
+        nn = prefixes.size
+        sph = (np.zeros((nn, 4), dtype=real_dtype(real_bits)) if spheres is None
+               else np.ascontiguousarray(spheres, dtype=real_dtype(real_bits)).copy())
+        rc = self._f("mac_spheres")(C.c_int(curve), C.c_int(mode), C.c_int(prefixes.dtype.itemsize * 8),
+                                    C.c_int(real_bits), _p(prefixes), C.c_int(nn), _p(sph), C.c_float(inv_theta),
+                                    _p(box.lim), _p(box.bc))
+        if rc == -3:
+            return None
+        assert rc == 0, rc
+        return sph
+
+    def mark_macs(self, curve, octree, centers, box, focus_nodes, limit_source, markings=None):
+        pre = octree["prefixes"]
+        real_bits = centers.dtype.itemsize * 8
+        marks = np.zeros(pre.size, dtype=np.int8) if markings is None else np.ascontiguousarray(markings, dtype=np.int8).copy()
+        fn = np.ascontiguousarray(focus_nodes, dtype=pre.dtype)
+        rc = self._f("mark_macs")(C.c_int(curve), C.c_int(pre.dtype.itemsize * 8), C.c_int(real_bits), _p(pre),
+                                  _p(octree["child_offsets"]), _p(np.ascontiguousarray(centers)), _p(box.lim),
+                                  _p(box.bc), _p(fn), C.c_int(fn.size - 1), C.c_int(int(limit_source)), _p(marks))
+        if rc == -3:
+            return None
+        assert rc == 0, rc
+        return marks
+
+    def span_sfc_range(self, key_bits, a, b):
+        f = self._f("span_sfc_range")
+        n = f(C.c_int(key_bits), C.c_uint64(int(a)), C.c_uint64(int(b)), None)
+        assert n >= 0, n
+        out = np.zeros(n, dtype=key_dtype(key_bits))
+        if n:
+            n2 = f(C.c_int(key_bits), C.c_uint64(int(a)), C.c_uint64(int(b)), _p(out))
+            assert n2 == n
+        return out
+
+    def leaf_source_centers(self, x, y, z, m, leaf_to_internal, layout, num_nodes, center_bits=64):
+        ctr = np.zeros((num_nodes, 4), dtype=real_dtype(center_bits))
+        l2i = np.ascontiguousarray(leaf_to_internal, dtype=np.int32)
+        lay = np.ascontiguousarray(layout, dtype=np.uint32)
+        rc = self._f("leaf_source_centers")(C.c_int(x.dtype.itemsize * 8), C.c_int(m.dtype.itemsize * 8),
+                                            C.c_int(center_bits), _p(x), _p(y), _p(z), _p(m), _p(l2i),
+                                            C.c_int(lay.size - 1), _p(lay), _p(ctr))
+        assert rc == 0, rc
+        return ctr
+
+    def upsweep_centers(self, octree, centers, num_levels):
+        ctr = np.ascontiguousarray(centers).copy()
+        rc = self._f("upsweep_centers")(C.c_int(ctr.dtype.itemsize * 8), C.c_int(num_levels), _p(octree["level_range"]),
+                                        _p(octree["child_offsets"]), _p(ctr))
+        assert rc == 0, rc
+        return ctr
+
+    def segment_max(self, values, segments, out_bits):
+        seg = np.ascontiguousarray(segments, dtype=np.uint32)
+        out = np.zeros(seg.size - 1, dtype=real_dtype(out_bits))
+        rc = self._f("segment_max")(C.c_int(values.dtype.itemsize * 8), C.c_int(out_bits), _p(values), _p(seg),
+                                    C.c_size_t(seg.size - 1), _p(out))
+        assert rc == 0, rc
+        return out
+
     def num_threads(self):
         return int(self._f("num_threads")())
 

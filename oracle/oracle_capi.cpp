@@ -395,6 +395,163 @@ int cstone_oracle_make_splits(const uint64_t* masks, int words, int width, unsig
     return int(l.size());
 }
 
+// ---- focus tree (locally essential tree)
+int cstone_oracle_essential_ops(int key_bits, const void* prefixes, const int* child_offsets, const int* parents,
+                                const unsigned* counts, const char* macs, uint64_t focus_start, uint64_t focus_end,
+                                unsigned bucket, int* ops, int num_nodes)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       essentialOps<K>((const K*)prefixes, child_offsets, parents, counts, macs, K(focus_start),
+                                       K(focus_end), bucket, ops, num_nodes);
+                   });
+}
+
+int cstone_oracle_mac_refine_ops(int key_bits, const void* prefixes, const char* macs, const int* leaf_to_internal,
+                                 int num_leaves, int focus_first, int focus_last, int* ops)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       macRefineOps<K>((const K*)prefixes, macs, leaf_to_internal, num_leaves, focus_first, focus_last, ops);
+                   });
+}
+
+//! returns 1 if converged, 0 if not, < 0 on a bad argument
+int cstone_oracle_protect_ancestors(int key_bits, const void* prefixes, const int* parents, int* ops, int num_nodes)
+{
+    int converged = 0;
+    int rc        = withKey(key_bits,
+                            [&](auto k)
+                            {
+                         using K   = decltype(k);
+                         converged = protectAncestors<K>((const K*)prefixes, parents, ops, num_nodes);
+                     });
+    return rc ? rc : converged;
+}
+
+//! returns the ResolutionStatus (0..3), < 0 on a bad argument
+int cstone_oracle_enforce_keys(int key_bits, const void* forced_keys, int num_keys, const void* prefixes,
+                               const int* child_offsets, const int* parents, int* ops)
+{
+    int status = 0;
+    int rc     = withKey(key_bits,
+                         [&](auto k)
+                         {
+                         using K = decltype(k);
+                         status  = enforceKeys<K>((const K*)forced_keys, num_keys, (const K*)prefixes, child_offsets,
+                                                  parents, ops);
+                     });
+    return rc ? rc : status;
+}
+
+int cstone_oracle_range_count(int key_bits, const void* leaves, int num_leaves, const unsigned* counts,
+                              const void* leaves_focus, int num_focus_leaves, const int* focus_idx, int num_idx,
+                              unsigned* counts_focus)
+{
+    (void)num_focus_leaves;
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       rangeCount<K>((const K*)leaves, num_leaves, counts, (const K*)leaves_focus, focus_idx, num_idx,
+                                     counts_focus);
+                   });
+}
+
+//! mode 0: geoMacSpheres, mode 1: setMac; spheres = Vec4<T>[num_nodes]
+int cstone_oracle_mac_spheres(int curve, int mode, int key_bits, int real_bits, const void* prefixes, int num_nodes,
+                              void* spheres, float inv_theta, const double* lim, const int* bc)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    macSpheres<K, T>(Curve(curve), mode, (const K*)prefixes, num_nodes, (T*)spheres,
+                                                     inv_theta, mkBox<T>(lim, bc));
+                                });
+                   });
+}
+
+int cstone_oracle_mark_macs(int curve, int key_bits, int real_bits, const void* prefixes, const int* child_offsets,
+                            const void* centers, const double* lim, const int* bc, const void* focus_nodes,
+                            int num_focus_nodes, int limit_source, char* markings)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    markMacs<K, T>(Curve(curve), (const K*)prefixes, child_offsets, (const T*)centers,
+                                                   mkBox<T>(lim, bc), (const K*)focus_nodes, num_focus_nodes,
+                                                   limit_source != 0, markings);
+                                });
+                   });
+}
+
+//! out == NULL: only count; returns the number of keys of the coarsest cornerstone tiling of [a, b)
+int cstone_oracle_span_sfc_range(int key_bits, uint64_t a, uint64_t b, void* out)
+{
+    int num = 0;
+    int rc  = withKey(key_bits,
+                      [&](auto k)
+                      {
+                         using K = decltype(k);
+                         num     = spanRange<K>(K(a), K(b), (K*)out);
+                     });
+    return rc ? rc : num;
+}
+
+//! bits = coordinate / mass / centre precision: 64/64/64, 64/32/64 or 32/32/32
+int cstone_oracle_leaf_source_centers(int coord_bits, int mass_bits, int center_bits, const void* x, const void* y,
+                                      const void* z, const void* m, const int* leaf_to_internal, int num_leaves,
+                                      const unsigned* layout, void* centers)
+{
+    if (coord_bits == 64 && mass_bits == 64 && center_bits == 64)
+        leafSourceCenters((const double*)x, (const double*)y, (const double*)z, (const double*)m, leaf_to_internal,
+                          num_leaves, layout, (double*)centers);
+    else if (coord_bits == 64 && mass_bits == 32 && center_bits == 64)
+        leafSourceCenters((const double*)x, (const double*)y, (const double*)z, (const float*)m, leaf_to_internal,
+                          num_leaves, layout, (double*)centers);
+    else if (coord_bits == 32 && mass_bits == 32 && center_bits == 32)
+        leafSourceCenters((const float*)x, (const float*)y, (const float*)z, (const float*)m, leaf_to_internal,
+                          num_leaves, layout, (float*)centers);
+    else
+        return -1;
+    return 0;
+}
+
+int cstone_oracle_upsweep_centers(int real_bits, int num_levels, const int* level_range, const int* child_offsets,
+                                  void* centers)
+{
+    return withReal(real_bits,
+                    [&](auto t)
+                    {
+                        using T = decltype(t);
+                        upsweepCenters<T>(num_levels, level_range, child_offsets, (T*)centers);
+                    });
+}
+
+int cstone_oracle_segment_max(int in_bits, int out_bits, const void* in, const unsigned* segments, size_t num_segments,
+                              void* out)
+{
+    if (in_bits == 32 && out_bits == 32) segmentMax((const float*)in, segments, num_segments, (float*)out);
+    else if (in_bits == 64 && out_bits == 32) segmentMax((const double*)in, segments, num_segments, (float*)out);
+    else if (in_bits == 64 && out_bits == 64) segmentMax((const double*)in, segments, num_segments, (double*)out);
+    else return -1;
+    return 0;
+}
+
 int cstone_oracle_num_threads()
 {
 #ifdef _OPENMP

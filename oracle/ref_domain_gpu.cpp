@@ -1,0 +1,201 @@
+// TEST INFRASTRUCTURE (oracle/_ref): the REFERENCE's own cstone::Domain<KeyType, T, GpuTag>, compiled where it lies under
+// /root/reference/include, linked against libcstone_hip.so through cornerstone-octree_amd/shim/cstone_gpu_hip.cpp (no
+// cstone_gpu, no CUDA, no Thrust), compared with the reference's Domain<KeyType, T, CpuTag> on the same particles.
+// This is the comparison of the reference's test/integration_mpi/domain_gpu.cpp:117-136 (nParticles, startIndex,
+// endIndex, nParticlesWithHalos, global tree, keys, x, conserved property) as a plain main(), extended to the focus tree,
+// its counts, the layout, y/z/h with their halos and several syncs with moving particles.
+//   mpiexec -n P oracle/_ref/ref_domain_gpu [particlesPerRank] [numSyncs]      exit code 0 = every comparison equal
+#define USE_CUDA
+#include <mpi.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "cstone/domain/domain.hpp"
+#include "cstone/util/reallocate.hpp"
+
+using namespace cstone;
+
+static int g_rank = 0, g_failures = 0;
+
+template<class V1, class V2>
+static void expectEqual(const char* what, const V1& a, const V2& b, int sync)
+{
+    bool same = a.size() == b.size() && std::equal(a.begin(), a.end(), b.begin());
+    if (!same)
+    {
+        ++g_failures;
+        size_t first = 0;
+        while (first < a.size() && first < b.size() && a[first] == b[first])
+            ++first;
+        std::printf("[rank %d] sync %d: %s DIFFERS (sizes %zu / %zu, first difference at %zu)\n", g_rank, sync, what,
+                    size_t(a.size()), size_t(b.size()), first);
+    }
+}
+
+template<class A, class B>
+static void expectSame(const char* what, A a, B b, int sync)
+{
+    if (!(a == b))
+    {
+        ++g_failures;
+        std::printf("[rank %d] sync %d: %s DIFFERS (%lld / %lld)\n", g_rank, sync, what, (long long)a, (long long)b);
+    }
+}
+
+template<class T>
+static std::vector<T> download(const DeviceVector<T>& v)
+{
+    std::vector<T> ret(v.size());
+    if (!ret.empty()) memcpyD2H(v.data(), v.size(), ret.data());
+    return ret;
+}
+
+template<class KeyType, class T>
+static void run(int rank, int numRanks, LocalIndex numParticles, int numSyncs, const Box<T>& box, unsigned bucketSize,
+                unsigned bucketSizeFocus, T hValue, bool clustered, const char* name)
+{
+    std::mt19937 gen(1234 + rank);
+    std::vector<T> x(numParticles), y(numParticles), z(numParticles), h(numParticles, hValue), m(numParticles);
+    auto draw = [&](T lo, T hi)
+    {
+        if (clustered)
+        {
+            std::normal_distribution<T> d((lo + hi) / 2, (hi - lo) / 6);
+            return std::max(std::min(d(gen), hi), lo);
+        }
+        return std::uniform_real_distribution<T>(lo, hi)(gen);
+    };
+    for (auto& v : x) v = draw(box.xmin(), box.xmax());
+    for (auto& v : y) v = draw(box.ymin(), box.ymax());
+    for (auto& v : z) v = draw(box.zmin(), box.zmax());
+    for (LocalIndex i = 0; i < numParticles; ++i)
+        m[i] = T(rank * 100000 + i);
+    std::vector<uint8_t> tag(numParticles, uint8_t(rank));
+    std::vector<KeyType> keys(numParticles);
+
+    DeviceVector<KeyType> d_keys;
+    reallocate(d_keys, numParticles, 1.0);
+    DeviceVector<T> d_x = x, d_y = y, d_z = z, d_h = h, d_m = m;
+    DeviceVector<uint8_t> d_tag = tag;
+
+    Domain<KeyType, T, CpuTag> cpu(rank, numRanks, bucketSize, bucketSizeFocus, 1.0, box);
+    Domain<KeyType, T, GpuTag> gpu(rank, numRanks, bucketSize, bucketSizeFocus, 1.0, box);
+    std::vector<T> hs1, hs2, hs3;
+    DeviceVector<T> s1, s2, s3;
+
+    for (int sync = 0; sync < numSyncs; ++sync)
+    {
+        cpu.sync(keys, x, y, z, h, std::tie(m, tag), std::tie(hs1, hs2, hs3));
+        gpu.sync(d_keys, d_x, d_y, d_z, d_h, std::tie(d_m, d_tag), std::tie(s1, s2, s3));
+
+        expectSame("nParticles", cpu.nParticles(), gpu.nParticles(), sync);
+        expectSame("startIndex", cpu.startIndex(), gpu.startIndex(), sync);
+        expectSame("endIndex", cpu.endIndex(), gpu.endIndex(), sync);
+        expectSame("nParticlesWithHalos", cpu.nParticlesWithHalos(), gpu.nParticlesWithHalos(), sync);
+        expectSame("startCell", cpu.startCell(), gpu.startCell(), sync);
+        expectSame("endCell", cpu.endCell(), gpu.endCell(), sync);
+        expectEqual("global tree leaves", cpu.globalTree().treeLeaves(), gpu.globalTree().treeLeaves(), sync);
+        expectEqual("focus tree leaves", cpu.focusTree().treeLeaves(), gpu.focusTree().treeLeaves(), sync);
+        expectEqual("focus leaf counts", cpu.focusTree().leafCounts(), gpu.focusTree().leafCounts(), sync);
+        for (int d = 0; d < 6; ++d)
+        {
+            T a[6] = {cpu.box().xmin(), cpu.box().xmax(), cpu.box().ymin(), cpu.box().ymax(), cpu.box().zmin(), cpu.box().zmax()};
+            T b[6] = {gpu.box().xmin(), gpu.box().xmax(), gpu.box().ymin(), gpu.box().ymax(), gpu.box().zmin(), gpu.box().zmax()};
+            if (a[d] != b[d])
+            {
+                ++g_failures;
+                std::printf("[rank %d] sync %d: box limit %d DIFFERS\n", rank, sync, d);
+            }
+        }
+        {
+            auto lc = cpu.layout();
+            auto lg = gpu.layout();
+            std::vector<LocalIndex> layoutGpu(lg.size());
+            if (!layoutGpu.empty()) memcpyD2H(lg.data(), lg.size(), layoutGpu.data());
+            expectEqual("layout", std::vector<LocalIndex>(lc.begin(), lc.end()), layoutGpu, sync);
+        }
+        expectEqual("keys", keys, download(d_keys), sync);
+        expectEqual("x", x, download(d_x), sync);
+        expectEqual("y", y, download(d_y), sync);
+        expectEqual("z", z, download(d_z), sync);
+        expectEqual("h", h, download(d_h), sync);
+        {
+            auto gm   = download(d_m);
+            auto gtag = download(d_tag);
+            LocalIndex s = cpu.startIndex(), e = cpu.endIndex();
+            if (gm.size() == m.size() && gpu.startIndex() == s && gpu.endIndex() == e)
+            {
+                expectEqual("m (assigned)", std::vector<T>(m.begin() + s, m.begin() + e),
+                            std::vector<T>(gm.begin() + s, gm.begin() + e), sync);
+                expectEqual("tag (assigned)", std::vector<uint8_t>(tag.begin() + s, tag.begin() + e),
+                            std::vector<uint8_t>(gtag.begin() + s, gtag.begin() + e), sync);
+            }
+            else { expectSame("property sizes", m.size(), gm.size(), sync); }
+        }
+        // one more field through the halo exchange of both domains
+        {
+            std::vector<T> f(x.size());
+            for (size_t i = 0; i < f.size(); ++i)
+                f[i] = (i >= cpu.startIndex() && i < cpu.endIndex()) ? x[i] + 2 * y[i] : T(-1);
+            DeviceVector<T> d_f = f;
+            std::vector<T> sb, rb;
+            DeviceVector<T> dsb, drb;
+            cpu.exchangeHalos(std::tie(f), sb, rb);
+            gpu.exchangeHalos(std::tie(d_f), dsb, drb);
+            expectEqual("exchangeHalos field", f, download(d_f), sync);
+        }
+
+        if (g_failures) break;
+        // move the assigned particles (identically on both sides) for the next sync
+        std::mt19937 mv(77 * sync + rank);
+        std::uniform_real_distribution<T> step(-1, 1);
+        for (LocalIndex i = cpu.startIndex(); i < cpu.endIndex(); ++i)
+        {
+            auto clampTo = [](T v, T lo, T hi) { return std::min(std::max(v, lo), std::nextafter(hi, lo)); };
+            x[i] = clampTo(x[i] + hValue * step(mv), box.xmin(), box.xmax());
+            y[i] = clampTo(y[i] + hValue * step(mv), box.ymin(), box.ymax());
+            z[i] = clampTo(z[i] + hValue * step(mv), box.zmin(), box.zmax());
+        }
+        d_x = x, d_y = y, d_z = z;
+    }
+    int local = g_failures, total = 0;
+    MPI_Allreduce(&local, &total, 1, MPI_INT, MPI_SUM, MPI_COMM_WORLD);
+    if (rank == 0)
+        std::printf("%s: %s (%d ranks, %u particles per rank, %d syncs, halos on rank 0: %u)\n", name,
+                    total ? "FAIL" : "PASS", numRanks, unsigned(numParticles), numSyncs,
+                    unsigned(gpu.nParticlesWithHalos() - gpu.nParticles()));
+}
+
+int main(int argc, char** argv)
+{
+    MPI_Init(&argc, &argv);
+    int rank = 0, numRanks = 1;
+    MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+    MPI_Comm_size(MPI_COMM_WORLD, &numRanks);
+    g_rank              = rank;
+    LocalIndex n        = argc > 1 ? LocalIndex(std::atol(argv[1])) : 5000;
+    int numSyncs        = argc > 2 ? std::atoi(argv[2]) : 3;
+    try
+    {
+        run<uint64_t, double>(rank, numRanks, n, numSyncs, Box<double>(0, 1), 64, 8, 0.02, true, "u64/f64 clustered open");
+        run<uint64_t, double>(rank, numRanks, n, numSyncs, Box<double>(0, 1, BoundaryType::periodic), 50, 10, 0.015, false,
+                              "u64/f64 uniform periodic");
+        run<unsigned, float>(rank, numRanks, n, numSyncs, Box<float>(-1, 1), 64, 16, 0.03f, false, "u32/f32 uniform open");
+        run<uint64_t, float>(rank, numRanks, n, numSyncs, Box<float>(0, 1, 0, 2, 0, 1, BoundaryType::open, BoundaryType::periodic,
+                                                                   BoundaryType::open),
+                             40, 10, 0.02f, true, "u64/f32 clustered mixed");
+    }
+    catch (const std::exception& e)
+    {
+        std::printf("[rank %d] exception: %s\n", rank, e.what());
+        ++g_failures;
+    }
+    int local = g_failures, total = 0;
+    MPI_Allreduce(&local, &total, 1, MPI_INT, MPI_SUM, MPI_COMM_WORLD);
+    MPI_Finalize();
+    return total ? 1 : 0;
+}

@@ -12,10 +12,12 @@
 #include <vector>
 
 #include "cstone/findneighbors.hpp"
+#include "cstone/focus/rebalance.hpp"
 #include "cstone/focus/source_center.hpp"
 #include "cstone/primitives/gather.hpp"
 #include "cstone/sfc/sfc.hpp"
 #include "cstone/traversal/collisions.hpp"
+#include "cstone/traversal/macs.hpp"
 #include "cstone/tree/csarray.hpp"
 #include "cstone/tree/octree.hpp"
 
@@ -283,6 +285,163 @@ int cstone_ref_find_neighbors(int real_bits, const void* x, const void* y, const
                                                        ext};
                         findNeighbors((const T*)x, (const T*)y, (const T*)z, (const T*)h, first, last,
                                       mkBox<T>(lim, bc), view, ngmax, neighbors, counts);
+                    });
+}
+
+// ---- focus tree: the reference's own CPU functions (R/focus/rebalance.hpp, R/traversal/macs.hpp, R/focus/source_center.hpp)
+int cstone_ref_essential_ops(int key_bits, const void* prefixes, const int* child_offsets, const int* parents,
+                             const unsigned* counts, const char* macs, uint64_t focus_start, uint64_t focus_end,
+                             unsigned bucket, int* ops, int num_nodes)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       rebalanceDecisionEssential<K>({(const K*)prefixes, size_t(num_nodes)}, child_offsets, parents,
+                                                     counts, macs, K(focus_start), K(focus_end), bucket, ops);
+                   });
+}
+
+int cstone_ref_mac_refine_ops(int key_bits, const void* prefixes, const char* macs, const int* leaf_to_internal,
+                              int num_leaves, int focus_first, int focus_last, int* ops)
+{
+    // the reference has this loop only as a GPU kernel (R/focus/rebalance_gpu.cu:88-101); its per-leaf rule is macRefineOp
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       for (int i = 0; i < num_leaves; ++i)
+                       {
+                           int n  = leaf_to_internal[i];
+                           ops[i] = (i < focus_first || i >= focus_last) ? macRefineOp(((const K*)prefixes)[n], macs[n]) : 1;
+                       }
+                   });
+}
+
+int cstone_ref_protect_ancestors(int key_bits, const void* prefixes, const int* parents, int* ops, int num_nodes)
+{
+    int converged = 0;
+    int rc        = withKey(key_bits,
+                            [&](auto k)
+                            {
+                         using K   = decltype(k);
+                         converged = protectAncestors<K>({(const K*)prefixes, size_t(num_nodes)}, parents, ops);
+                     });
+    return rc ? rc : converged;
+}
+
+int cstone_ref_enforce_keys(int key_bits, const void* forced_keys, int num_keys, const void* prefixes,
+                            const int* child_offsets, const int* parents, int* ops)
+{
+    int status = 0;
+    int rc     = withKey(key_bits,
+                         [&](auto k)
+                         {
+                         using K = decltype(k);
+                         status  = int(enforceKeys<K>({(const K*)forced_keys, size_t(num_keys)}, (const K*)prefixes,
+                                                      child_offsets, parents, ops));
+                     });
+    return rc ? rc : status;
+}
+
+int cstone_ref_range_count(int key_bits, const void* leaves, int num_leaves, const unsigned* counts,
+                           const void* leaves_focus, int num_focus_leaves, const int* focus_idx, int num_idx,
+                           unsigned* counts_focus)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       rangeCount<K>({(const K*)leaves, size_t(num_leaves) + 1}, {counts, size_t(num_leaves)},
+                                     {(const K*)leaves_focus, size_t(num_focus_leaves) + 1},
+                                     {focus_idx, size_t(num_idx)}, {counts_focus, size_t(num_focus_leaves)});
+                   });
+}
+
+int cstone_ref_mac_spheres(int curve, int mode, int key_bits, int real_bits, const void* prefixes, int num_nodes,
+                           void* spheres, float inv_theta, const double* lim, const int* bc)
+{
+    if (curve != 1) return -3;
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T  = decltype(t);
+                                    auto box = mkBox<T>(lim, bc);
+                                    gsl::span<const K> keys{(const K*)prefixes, size_t(num_nodes)};
+                                    auto* c = (SourceCenterType<T>*)spheres;
+                                    if (mode == 0) geoMacSpheres<K, T>(keys, c, inv_theta, box);
+                                    else setMac<T, K>(keys, {c, size_t(num_nodes)}, inv_theta, box);
+                                });
+                   });
+}
+
+int cstone_ref_mark_macs(int curve, int key_bits, int real_bits, const void* prefixes, const int* child_offsets,
+                         const void* centers, const double* lim, const int* bc, const void* focus_nodes,
+                         int num_focus_nodes, int limit_source, char* markings)
+{
+    if (curve != 1) return -3;
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    markMacs<T, K>((const K*)prefixes, child_offsets, (const Vec4<T>*)centers,
+                                                   mkBox<T>(lim, bc), (const K*)focus_nodes, num_focus_nodes,
+                                                   limit_source != 0, markings);
+                                });
+                   });
+}
+
+int cstone_ref_span_sfc_range(int key_bits, uint64_t a, uint64_t b, void* out)
+{
+    int num = 0;
+    int rc  = withKey(key_bits,
+                      [&](auto k)
+                      {
+                         using K = decltype(k);
+                         num     = out ? spanSfcRange<K>(K(a), K(b), (K*)out) : spanSfcRange<K>(K(a), K(b));
+                     });
+    return rc ? rc : num;
+}
+
+int cstone_ref_leaf_source_centers(int coord_bits, int mass_bits, int center_bits, const void* x, const void* y,
+                                   const void* z, const void* m, const int* leaf_to_internal, int num_leaves,
+                                   const unsigned* layout, void* centers)
+{
+    auto run = [&](auto tc, auto tm, auto tf)
+    {
+        using Tc = decltype(tc);
+        using Tm = decltype(tm);
+        using Tf = decltype(tf);
+        size_t n = layout[num_leaves];
+        computeLeafMassCenter<Tc, Tm, Tf>({(const Tc*)x, n}, {(const Tc*)y, n}, {(const Tc*)z, n}, {(const Tm*)m, n},
+                                          {leaf_to_internal, size_t(num_leaves)}, layout, (SourceCenterType<Tf>*)centers);
+    };
+    if (coord_bits == 64 && mass_bits == 64 && center_bits == 64) run(double{}, double{}, double{});
+    else if (coord_bits == 64 && mass_bits == 32 && center_bits == 64) run(double{}, float{}, double{});
+    else if (coord_bits == 32 && mass_bits == 32 && center_bits == 32) run(float{}, float{}, float{});
+    else return -1;
+    return 0;
+}
+
+int cstone_ref_upsweep_centers(int real_bits, int num_levels, const int* level_range, const int* child_offsets,
+                               void* centers)
+{
+    return withReal(real_bits,
+                    [&](auto t)
+                    {
+                        using T = decltype(t);
+                        // the generic bottom-up pass of R/tree/octree.hpp:584-628 with the combination rule of
+                        // R/focus/source_center.hpp:79-95, as the CPU branch of FocusedOctree::updateCenters uses it
+                        upsweep({level_range, size_t(num_levels) + 1}, {child_offsets, size_t(level_range[num_levels])},
+                                (SourceCenterType<T>*)centers, CombineSourceCenter<T>{});
                     });
 }
 
