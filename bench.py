@@ -159,8 +159,20 @@ class DistributedPipeline:
         self.h = torch.full((n_local,), self.h0, dtype=rdt, device=dev)
         cv = cstone_amd.HILBERT if curve == "hilbert" else cstone_amd.MORTON
         self.native = os.environ.get("CSTONE_BENCH_PYTHON_DIST") != "1"
+        self.transport = "torch.distributed callbacks"
         if self.native:
-            self.dom = NativeDistributedDomain(ctx, cv, key_bits, real_bits, bucket, bucket_focus, [0, 1] * 3, (0, 0, 0))
+            import torch.distributed as dist
+
+            from cstone_amd.distributed import RcclCollectives
+
+            coll = None
+            if dist.get_backend() == "nccl" and os.environ.get("CSTONE_BENCH_TORCH_COLL") != "1":
+                # the data path: RCCL from C++ on the library's stream (csrc/comm_rccl.hip); torch.distributed only
+                # carries the RCCL id at start-up and serves the bench's own barriers and the max over the ranks
+                coll = RcclCollectives(ctx)
+                self.transport = "RCCL inside libcstone_hip (cstone_hip_comm_rccl, collectives on the library's stream)"
+            self.dom = NativeDistributedDomain(ctx, cv, key_bits, real_bits, bucket, bucket_focus, [0, 1] * 3, (0, 0, 0),
+                                               coll=coll)
         else:
             self.dom = DistributedDomain(HipBackend(ctx), Comm(), cv, key_bits, real_bits, bucket, bucket_focus,
                                          [0, 1] * 3, (0, 0, 0))
@@ -362,6 +374,8 @@ def main():
         elapsed = float(tt.item())
         n_sorted = pipe.assigned
     pass_ms, pass_launches = ctx.profile_get("sort_pass")
+    iota_ms, iota_launches = ctx.profile_get("sort_pass_iota")
+    pass_spread, iota_spread = ctx.profile_spread("sort_pass"), ctx.profile_spread("sort_pass_iota")
     stage_ms = {s: ctx.profile_get(s)[0] / args.steps for s in cstone_amd.STAGES}
     roofline_source = "the digit passes of the timed syncs"
     if distributed:
@@ -379,6 +393,8 @@ def main():
             ctx.sort_pairs(work, rv)
         ctx.sync()
         pass_ms, pass_launches = ctx.profile_get("sort_pass")
+        iota_ms, iota_launches = ctx.profile_get("sort_pass_iota")
+        pass_spread, iota_spread = ctx.profile_spread("sort_pass"), ctx.profile_spread("sort_pass_iota")
         roofline_source = f"cstone_hip_sort_pairs of {n_sorted} random pairs (this rank's share), outside the timed region"
         del rk, rv, work
         invariants_ok = pipe.invariants(n_local * world)
@@ -478,14 +494,34 @@ def main():
         # HBM bytes of the dominant kernel from the PMC counters (FETCH_SIZE doubled per the gfx950 correction,
         # + WRITE_SIZE), collected in their own rocprofv3 --pmc passes (tools/profile_r1.sh) and scaled per pair
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_onesweep_traffic.json")
-        if os.path.exists(tpath) and args.key_bits == 64:
-            tj = json.load(open(tpath))
-            traffic = tj["traffic_bytes_per_launch"] / tj["n_pairs"] * n_sorted
+        traffic_per_launch, traffic_source = None, None
+        for tname in ("r02_onesweep_traffic.json", "r01_onesweep_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath) and args.key_bits == 64:
+                tj = json.load(open(tpath))
+                # NOT measured in this run: the committed rocprofv3 --pmc passes over tools/sort_bench.py (regular 24 B/pair
+                # launches), scaled to this run's pairs per launch
+                traffic_per_launch = tj["traffic_bytes_per_launch"] / tj["n_pairs"] * n_sorted
+                traffic_source = f"profiles/{tname} (separate --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)"
+                break
         kbytes = args.key_bits // 8
-        per_launch_bytes = 2.0 * (kbytes + 4) * n_sorted  # read + write of (key, u32 value), SURVEY 8(d)
-        avg_s = pass_ms * 1e-3 / max(1, pass_launches)
-        achieved = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        # algorithmic bytes of one digit pass, SURVEY 8(d): read + write of (key, u32 value) = 2 (K + 4) B/pair; the pass
+        # that starts from the identity ordering produces the positions instead of reading them: K + (K + 4) B/pair
+        per_launch_bytes = 2.0 * (kbytes + 4) * n_sorted
+        iota_launch_bytes = (2.0 * kbytes + 4) * n_sorted
+        total_bytes = per_launch_bytes * pass_launches + iota_launch_bytes * iota_launches
+        total_s = (pass_ms + iota_ms) * 1e-3
+        launches = pass_launches + iota_launches
+        avg_s = total_s / max(1, launches)
+        achieved = total_bytes / total_s / 1e9 if total_s > 0 else 0.0
+        per_pass = {"regular": {"launches": pass_launches, "bytes_per_launch": per_launch_bytes,
+                                "avg_ms": pass_ms / max(1, pass_launches), "min_ms": pass_spread[0],
+                                "median_ms": pass_spread[1], "max_ms": pass_spread[2]},
+                    "positions_generated": {"launches": iota_launches, "bytes_per_launch": iota_launch_bytes,
+                                            "avg_ms": iota_ms / max(1, iota_launches), "min_ms": iota_spread[0],
+                                            "median_ms": iota_spread[1], "max_ms": iota_spread[2]}}
+        if traffic is not None:
+            traffic = None  # the PMC passes profile cstone_hip_sort_pairs (24 B/pair launches only): reported separately
         out = {
             "metric": "particles/sec domain.sync (encode+sort+tree+halo), 10^8 uniform, 1/2/4/8 GPU",
             "value": n_local * world * args.steps / elapsed,
@@ -511,13 +547,15 @@ def main():
                        **({"invariants_ok": invariants_ok, "rank0_assigned": pipe.assigned, "rank0_halos": pipe.halos,
                            "rank0_exchange": dict(pipe.stats),
                            "orchestration": "libcstone_hip (cstone_hip_domain_mr_sync)" if pipe.native
-                           else "python (cstone_amd.distributed)"} if distributed else {}),
+                           else "python (cstone_amd.distributed)",
+                           "transport": pipe.transport} if distributed else {}),
                        **({"rank0_phase_ms": {k: v * 1e3 for k, v in pipe.dom.timing.items()}}
                           if distributed and not pipe.native and pipe.dom.timing else {})},
             "roofline": {"bound": "hbm", "kernel": "onesweepKernel (one 8-bit radix pass over key+index pairs)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3,
-                         "launches": pass_launches, "measured_on": roofline_source},
+                         "traffic": traffic_per_launch, "traffic_source": traffic_source,
+                         "bytes_per_launch": total_bytes / max(1, launches), "avg_launch_ms": avg_s * 1e3,
+                         "launches": launches, "per_pass": per_pass, "measured_on": roofline_source},
             "stage_ms_per_step": stage_ms,
             "first_sync_ms": first_sync_ms,
             "extras": extras,

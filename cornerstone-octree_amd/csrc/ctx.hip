@@ -1,5 +1,7 @@
 // runtime part of the C ABI: context, memory, copies, stage timers
 // replaces R/cuda/device_vector.{h,cu}, cuda_stubs.h:48-57, errorcheck.cuh (R = reference include/cstone)
+#include <algorithm>
+
 #include "ctx.hpp"
 #include "hilbert_tables.hpp"
 
@@ -69,6 +71,7 @@ static int drainBrackets(cstone_hip_ctx* ctx)
         CS_HIP(ctx, hipEventElapsedTime(&ms, b.a, b.b));
         ctx->stageMs[b.stage] += ms;
         ctx->stageLaunches[b.stage] += 1;
+        if (ctx->stageSamples[b.stage].size() < 8192) ctx->stageSamples[b.stage].push_back(ms);
         ctx->eventPool.push_back(b.a);
         ctx->eventPool.push_back(b.b);
     }
@@ -244,7 +247,7 @@ int cstone_hip_profile_reset(cstone_hip_ctx* ctx)
     if (!ctx) return CSTONE_E_ARG;
     CS_TRY(drainBrackets(ctx));
     for (int s = 0; s < CSTONE_NUM_STAGES; ++s)
-        ctx->stageMs[s] = 0, ctx->stageLaunches[s] = 0;
+        ctx->stageMs[s] = 0, ctx->stageLaunches[s] = 0, ctx->stageSamples[s].clear();
     return CSTONE_OK;
 }
 
@@ -254,6 +257,18 @@ int cstone_hip_profile_get(cstone_hip_ctx* ctx, int stage, double* total_ms, int
     CS_TRY(drainBrackets(ctx));
     if (total_ms) *total_ms = ctx->stageMs[stage];
     if (launches) *launches = ctx->stageLaunches[stage];
+    return CSTONE_OK;
+}
+
+int cstone_hip_profile_get_spread(cstone_hip_ctx* ctx, int stage, double* min_ms, double* median_ms, double* max_ms)
+{
+    if (!ctx || stage < 0 || stage >= CSTONE_NUM_STAGES) return CSTONE_E_ARG;
+    CS_TRY(drainBrackets(ctx));
+    std::vector<float> v = ctx->stageSamples[stage];
+    std::sort(v.begin(), v.end());
+    if (min_ms) *min_ms = v.empty() ? 0.0 : v.front();
+    if (median_ms) *median_ms = v.empty() ? 0.0 : v[v.size() / 2];
+    if (max_ms) *max_ms = v.empty() ? 0.0 : v.back();
     return CSTONE_OK;
 }
 

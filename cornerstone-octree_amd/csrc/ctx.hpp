@@ -46,6 +46,7 @@ struct cstone_hip_ctx
     std::vector<hipEvent_t> eventPool;
     double stageMs[CSTONE_NUM_STAGES]   = {0};
     int stageLaunches[CSTONE_NUM_STAGES] = {0};
+    std::vector<float> stageSamples[CSTONE_NUM_STAGES]; // individual brackets (bounded), for min / median / max
 };
 
 namespace cship

@@ -312,7 +312,10 @@ public:
         lastN_      = n;
         bufSize_    = numAssigned;
         firstCall_  = false;
-        return CSTONE_OK;
+        // the sticky device-side error word (look-back spin bail-out of the sort, traversal stack overflow ...): a sync
+        // that tripped one of those checks must not report success (tests: CSTONE_FORCE_DEVICE_ERROR raises it)
+        if (std::getenv("CSTONE_FORCE_DEVICE_ERROR")) CS_HIP(ctx_, hipMemsetAsync(ctx_->devScalars + 63, 1, 1, ctx_->stream));
+        return cstone_hip_ctx_sync(ctx_);
     }
 
     void setHaloFactor(float factor) override { haloSearchExt_ = factor; }

@@ -17,6 +17,7 @@
 // (tests/golden/ref_domain_mpi_*.npz); the halo set is compared there as well.
 #include <algorithm>
 #include <chrono>
+#include <cstdarg>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -127,6 +128,15 @@ __global__ void containingLeavesKernel(const K* __restrict__ tree, int numLeaves
     out[3 * q + 2] = idx < numLeaves ? uint64_t(tree[idx + 1]) : uint64_t(tree[idx]);
 }
 
+
+//! counts[i] = max(counts[i], local[i]): a wrapped 32-bit sum over the ranks cannot make a full node look empty
+//! (R/tree/update_mpi.hpp:60-64)
+__global__ __launch_bounds__(256) void maxWithLocalKernel(uint32_t* __restrict__ counts,
+                                                          const uint32_t* __restrict__ local, int n)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) counts[i] = max(counts[i], local[i]);
+}
 
 //! rows[i] = {x, y, z, h}[idx[i]]: the fields of a particle travel as one record
 template<class T>
@@ -465,20 +475,31 @@ public:
     int sync(const void* xIn, const void* yIn, const void* zIn, const void* hIn, size_t n, const void* const* props,
              const int* propBytes, int numProps, const void* keysIn) override
     {
-        if (numProps < 0 || numProps > MAX_PROPS) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: at most %d properties", MAX_PROPS);
-        for (int q = 0; q < numProps; ++q)
+        // A rank-local failure must reach the peers: they are about to enter the collectives of this sync and would wait
+        // there for ever.  Failures of the arguments (and the failures injected by the tests, CSTONE_MR_FAIL_AT) are
+        // therefore kept as a pending status; the rank goes on as an EMPTY rank, the status word rides on the next
+        // collective (box all-reduce, count all-gathers) and every rank returns an error behind it.
+        pending_ = 0, toggled_ = false;
+        if (numProps < 0 || numProps > MAX_PROPS) setPending(CSTONE_E_ARG, "domain_mr_sync: at most %d properties", MAX_PROPS);
+        for (int q = 0; q < numProps && !pending_; ++q)
         {
             const int e = propBytes[q]; // the element sizes gatherGpu is instantiated for (R/primitives/primitives_gpu.cu:126-148)
             const bool sizeOk = e == 1 || e == 2 || e == 4 || e == 8 || e == 12 || e == 16 || e == 24 || e == 32;
             if ((n && !props[q]) || !sizeOk) // an empty rank may pass null arrays
-                return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: property %d must have elements of 1, 2, 4, 8, 12, 16, 24 or 32 bytes", q);
+                setPending(CSTONE_E_ARG, "domain_mr_sync: property %d must have elements of 1, 2, 4, 8, 12, 16, 24 or 32 bytes", q);
         }
         const T* x = static_cast<const T*>(xIn);
         const T* y = static_cast<const T*>(yIn);
         const T* z = static_cast<const T*>(zIn);
         const T* h = static_cast<const T*>(hIn);
-        if (n >= (size_t(1) << 30)) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: too many particles per rank");
-        CS_TRY(scal_.ensure(ctx_, 4096 + size_t(P_) * P_ * 8 + size_t(P_ + 1) * 16));
+        if (n >= (size_t(1) << 30)) setPending(CSTONE_E_ARG, "domain_mr_sync: too many particles per rank");
+        injectFailure("start");
+        if (pending_)
+        {
+            if (P_ == 1) return agreed(rank_);
+            n = 0, numProps = 0; // limp on as an empty rank until the peers know
+        }
+        CS_TRY(scal_.ensure(ctx_, 4096 + size_t(P_) * (P_ + 1) * 8 + size_t(P_ + 1) * 16));
         ++syncs_;
         tick(nullptr);
 
@@ -548,15 +569,36 @@ public:
             uint64_t* send = scal_.as<uint64_t>() + 32;
             uint64_t* recv = reinterpret_cast<uint64_t*>(scal_.as<char>() + 4096);
             hipLaunchKernelGGL(differencesKernel, gridFor(P_, 64), 64, 0, ctx_->stream, dr, P_, send);
+            std::vector<uint64_t> rows(size_t(P_) * (P_ + 1), 0);
             if (P_ > 1)
             {
-                CS_TRY(callComm(comm_.all_gather(comm_.user, send, recv, size_t(P_) * 8), "all_gather (counts)"));
-                CS_HIP(ctx_, hipMemcpyAsync(matrix.data(), recv, size_t(P_) * P_ * 8, hipMemcpyDeviceToHost, ctx_->stream));
+                // word P of every row: the status of that rank (0 = fine), see the top of sync()
+                injectFailure("assign");
+                const uint64_t status = pending_ ? 1 : 0;
+                CS_HIP(ctx_, hipMemcpyAsync(send + P_, &status, 8, hipMemcpyHostToDevice, ctx_->stream));
+                CS_TRY(callComm(comm_.all_gather(comm_.user, send, recv, size_t(P_ + 1) * 8), "all_gather (counts)"));
+                CS_HIP(ctx_, hipMemcpyAsync(rows.data(), recv, rows.size() * 8, hipMemcpyDeviceToHost, ctx_->stream));
             }
             CS_TRY(toHost(cut.data(), dr, size_t(P_ + 1) * 8));
             for (int p = 0; p < P_; ++p)
                 sendCounts[p] = cut[p + 1] - cut[p];
             if (P_ == 1) matrix[0] = sendCounts[0];
+            for (int p = 0; p < P_ && P_ > 1; ++p)
+            {
+                if (rows[size_t(p) * (P_ + 1) + P_] != 0) return agreed(p);
+                for (int q = 0; q < P_; ++q)
+                    matrix[size_t(p) * P_ + q] = rows[size_t(p) * (P_ + 1) + q];
+            }
+        }
+        // conditions every rank derives from the same matrix: all of them return the same error, nobody is left waiting
+        for (int q = 0; q < P_; ++q)
+        {
+            uint64_t arriving = 0;
+            for (int p = 0; p < P_; ++p)
+                arriving += matrix[size_t(p) * P_ + q];
+            if (arriving == 0) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: rank %d is left without particles", q);
+            if (arriving >= (uint64_t(1) << 30))
+                return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: too many particles for rank %d", q);
         }
         std::vector<size_t> sendBytes(P_, 0), recvBytes(P_, 0);
         uint64_t movedAny = 0, mSend = 0, nb = 0;
@@ -574,8 +616,6 @@ public:
         const K* keptKeys     = keys_.as<K>() + cut[rank_];
         const uint32_t* keptO = order_.as<uint32_t>() + cut[rank_];
         const uint64_t nm     = na + nb;
-        if (nm == 0) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: rank %d is left without particles", rank_);
-        if (nm >= (uint64_t(1) << 30)) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync: too many particles per rank");
 
         if (movedAny)
         {
@@ -649,6 +689,7 @@ public:
         //      lower ranks (their number is only known after the discovery below; M is generous and follows the
         //      previous sync).  The arrays handed out start at M - (halos of lower ranks).
         cur_ ^= 1; // the inputs may live in the other buffer set
+        toggled_ = true;
         Out& o           = out_[cur_];
         const bool margins = P_ > 1 && !noMargin_;
         // (a multiple of 4 elements: the assigned range the client passes back as the next input then starts on a
@@ -740,11 +781,17 @@ public:
             std::vector<uint64_t> boxCounts(P_);
             {
                 uint32_t* recv = reinterpret_cast<uint32_t*>(scal_.as<char>() + 4096);
-                CS_TRY(callComm(comm_.all_gather(comm_.user, total, recv, 4), "all_gather (box counts)"));
-                std::vector<uint32_t> c32(P_);
-                CS_TRY(toHost(c32.data(), recv, size_t(P_) * 4));
+                injectFailure("exchange");
+                const uint32_t status = pending_ ? 1u : 0u; // second word: the status of this rank
+                CS_HIP(ctx_, hipMemcpyAsync(total + 1, &status, 4, hipMemcpyHostToDevice, ctx_->stream));
+                CS_TRY(callComm(comm_.all_gather(comm_.user, total, recv, 8), "all_gather (box counts)"));
+                std::vector<uint32_t> c32(size_t(P_) * 2);
+                CS_TRY(toHost(c32.data(), recv, c32.size() * 4));
                 for (int p = 0; p < P_; ++p)
-                    boxCounts[p] = c32[p];
+                {
+                    if (c32[2 * p + 1] != 0) return agreed(p);
+                    boxCounts[p] = c32[2 * p];
+                }
             }
             const uint32_t nbx = uint32_t(boxCounts[rank_]);
             numMyBoxes         = nbx;
@@ -941,7 +988,8 @@ public:
         view_.halos_received      = nlo + nhi;
         view_.halos_sent          = selTotal;
         view_.halo_boxes_exported = numMyBoxes;
-        return CSTONE_OK;
+        // the sticky device-side error word: a sync that tripped a device-side check must not report success
+        return cstone_hip_ctx_sync(ctx_);
     }
 
 private:
@@ -953,6 +1001,38 @@ private:
         auto now = std::chrono::steady_clock::now();
         if (name) phase_[name] += std::chrono::duration<double>(now - t0_).count();
         t0_ = now;
+    }
+
+    //! a failure of THIS rank that the peers must learn about before anybody returns (see the top of sync())
+    void setPending(int code, const char* fmt, ...)
+    {
+        if (pending_) return;
+        char buf[384];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        pending_    = code;
+        pendingMsg_ = buf;
+    }
+
+    //! tests: CSTONE_MR_FAIL_AT="<rank>:<point>" makes that rank fail at the named point of sync()
+    void injectFailure(const char* point)
+    {
+        const char* e = std::getenv("CSTONE_MR_FAIL_AT");
+        if (!e) return;
+        const std::string want = std::to_string(rank_) + ":" + point;
+        if (want == e) setPending(CSTONE_E_INTERNAL, "domain_mr_sync: failure injected at '%s'", point);
+    }
+
+    //! every rank has seen that rank `culprit` failed: all of them return an error from the same point of the sync
+    int agreed(int culprit)
+    {
+        const int code      = culprit == rank_ && pending_ ? pending_ : CSTONE_E_INTERNAL;
+        const std::string m = culprit == rank_ ? pendingMsg_ : "rank " + std::to_string(culprit) + " reported a failure";
+        pending_            = 0;
+        if (toggled_) cur_ ^= 1, toggled_ = false; // the client's arrays of the last good sync stay untouched by the next one
+        return fail(ctx_, code, "%s (the sync was abandoned on every rank)", m.c_str());
     }
 
     int callComm(int rc, const char* what)
@@ -1023,9 +1103,13 @@ private:
             CS_TRY(minMaxCoordinatesDev(ctx_, rb, arrays, 3, n, dev));
         }
         else { CS_HIP(ctx_, hipMemcpyAsync(dev, nothing, sizeof nothing, hipMemcpyHostToDevice, ctx_->stream)); }
-        if (P_ > 1) CS_TRY(callComm(comm_.all_reduce(comm_.user, dev, 6, 0, 1), "all_reduce (box)"));
-        double ext[6];
+        // seventh value: the status of this rank (0, or -(rank + 1) if it has a failure pending); MIN over the ranks
+        const double status = pending_ ? -double(rank_ + 1) : 0.0;
+        CS_HIP(ctx_, hipMemcpyAsync(dev + 6, &status, sizeof status, hipMemcpyHostToDevice, ctx_->stream));
+        if (P_ > 1) CS_TRY(callComm(comm_.all_reduce(comm_.user, dev, 7, 0, 1), "all_reduce (box)"));
+        double ext[7];
         CS_TRY(toHost(ext, dev, sizeof ext));
+        if (ext[6] < 0) return agreed(int(-ext[6]) - 1);
         double fit[6];
         for (int d = 0; d < 3; ++d)
         {
@@ -1085,7 +1169,14 @@ private:
             CS_TRY(rc);
             gLeaves_ = leaves;
             if (P_ > 1)
+            {
+                CS_TRY(gLocalCounts_.ensure(ctx_, size_t(leaves) * sizeof(uint32_t)));
+                CS_HIP(ctx_, hipMemcpyAsync(gLocalCounts_.p, gCounts_.p, size_t(leaves) * sizeof(uint32_t),
+                                            hipMemcpyDeviceToDevice, ctx_->stream));
                 CS_TRY(callComm(comm_.all_reduce(comm_.user, gCounts_.p, size_t(leaves), 1, 0), "all_reduce (counts)"));
+                hipLaunchKernelGGL(maxWithLocalKernel, gridFor(size_t(leaves), 256), 256, 0, ctx_->stream,
+                                   gCounts_.as<uint32_t>(), gLocalCounts_.as<uint32_t>(), leaves);
+            }
             ++steps;
             // later calls: exactly one step; first call: one step, then `while (!update)` (assignment.hpp:92-98)
             if (!firstCall_ || (steps >= 2 && conv)) break;
@@ -1334,6 +1425,9 @@ private:
     cstone_hip_comm_ops comm_;
     float haloExt_  = 1.0f;
     bool firstCall_ = true;
+    bool toggled_   = false; // this sync has switched to the other output buffer set already
+    int pending_    = 0; // status of this rank inside sync(): 0, or the error code the peers have to learn about
+    std::string pendingMsg_;
     bool timing_    = std::getenv("CSTONE_MR_TIMING") != nullptr;
     bool noMargin_  = std::getenv("CSTONE_MR_NO_MARGIN") != nullptr; // tests: no room left for halos, the block is moved
     bool peerLoop_  = std::getenv("CSTONE_MR_PEER_LOOP") != nullptr; // tests: take the > 32 ranks path (one traversal per peer)
@@ -1345,7 +1439,7 @@ private:
 
     DevBuf scal_;
     DevBuf keys_, order_, keysAlt_, orderAlt_, sortTmp_;
-    DevBuf gTree_, gCounts_;
+    DevBuf gTree_, gCounts_, gLocalCounts_;
     int gCap_ = 0, gLeaves_ = 0;
     DevBuf fTree_, fCounts_, fTmp_;
     int fCap_ = 0, fLeaves_ = 0;

@@ -70,7 +70,9 @@ int scanU32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, ui
 {
     if (n == 0)
     {
-        if (totalOut) CS_HIP(ctx, hipMemcpyAsync(totalOut, &init, 0, hipMemcpyHostToDevice, ctx->stream));
+        // nothing to scan: the grand total is the initial value (written by the sums kernel over zero blocks)
+        if (totalOut) hipLaunchKernelGGL(scanSumsKernel, 1, SCAN_BLOCK, 0, ctx->stream, (uint32_t*)nullptr, 0u, init, totalOut);
+        CS_HIP(ctx, hipGetLastError());
         return CSTONE_OK;
     }
     unsigned blocks = unsigned((n + SCAN_TILE - 1) / SCAN_TILE);

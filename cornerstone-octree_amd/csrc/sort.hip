@@ -432,8 +432,16 @@ __device__ __forceinline__ u32x4 quarterLookBack(const uint32_t* __restrict__ st
             if (t < 0) finished = true; // row 0 is always inclusive: cannot be reached with open digits
             if (stop == 0)
             {
+#ifdef CSTONE_SORT_DEBUG
+                if (++spins > (1u << 16))
+                {
+                    if (lane == 0 || lane == 16 || lane == 63)
+                        printf("look-back stuck: tile %u wave %u lane %u t %d words %08x %08x %08x %08x | %08x\n", tile, wave,
+                               lane, t, w[0][0], w[0][1], w[0][2], w[0][3], w[1][0]);
+#else
                 if (++spins > (1u << 22)) // seconds: something is badly wrong, do not hang the GPU
                 {
+#endif
                     if (lane == 0) atomicOr(errors, 1u);
                     finished = true;
                 }
@@ -533,7 +541,13 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
         //      remaining waves pick the slots up through an LDS flag (a wave's LDS instructions execute in order) and
         //      permute their keys meanwhile.  No workgroup barrier between the ranking and the stores.
         constexpr unsigned SCAN_WAVE = LB_WAVES;
+#ifdef CSTONE_SORT_FLAT_FLAG
         volatile uint32_t* slotsReady = &sm.tileShared[1];
+#else
+        // an LDS (address space 3) pointer: a generic volatile pointer would turn the polls into FLAT loads that wait
+        // for the wave's global memory operations as well (vmcnt)
+        auto* slotsReady = (__attribute__((address_space(3))) volatile uint32_t*)&sm.tileShared[1];
+#endif
         u32x4 excl = {0, 0, 0, 0}, base4 = {0, 0, 0, 0};
         SORT_TRACE(5)
         SORT_TRACE(6)
@@ -1007,7 +1021,7 @@ void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* val
     uint32_t* vOut = valsAlt;
     for (int p = startPass; p < P; ++p)
     {
-        StageTimer timer(ctx, CSTONE_STAGE_SORT_PASS);
+        StageTimer timer(ctx, vIn == nullptr ? CSTONE_STAGE_SORT_PASS_IOTA : CSTONE_STAGE_SORT_PASS);
         const uint32_t* bases = t.hist + size_t(p) * RADIX;
 #ifndef CSTONE_SORT_TRACE
         // one launch: the workgroup that draws ticket numFullTiles takes the partial last tile

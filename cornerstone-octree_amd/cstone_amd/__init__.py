@@ -18,14 +18,14 @@ MORTON, HILBERT = 0, 1
 
 STAGES = {
     "encode": 0, "sort_hist": 1, "sort_pass": 2, "gather": 3, "node_counts": 4, "rebalance": 5, "link_octree": 6,
-    "halos": 7, "neighbors": 8, "minmax": 9,
+    "halos": 7, "neighbors": 8, "minmax": 9, "sort_pass_iota": 10,
 }
 
 EXPORTS = [
     "cstone_hip_ctx_create", "cstone_hip_ctx_destroy", "cstone_hip_ctx_sync", "cstone_hip_last_error",
     "cstone_hip_device_info", "cstone_hip_malloc", "cstone_hip_free", "cstone_hip_memcpy_h2d",
     "cstone_hip_memcpy_d2h", "cstone_hip_memcpy_d2d", "cstone_hip_memset", "cstone_hip_profile_enable",
-    "cstone_hip_profile_reset", "cstone_hip_profile_get", "cstone_hip_compute_sfc_keys",
+    "cstone_hip_profile_reset", "cstone_hip_profile_get", "cstone_hip_profile_get_spread", "cstone_hip_compute_sfc_keys",
     "cstone_hip_sort_pairs_temp_bytes", "cstone_hip_sort_pairs", "cstone_hip_sort_keys_ordering", "cstone_hip_sfc_keys_and_ordering", "cstone_hip_sequence_u32", "cstone_hip_gather",
     "cstone_hip_scatter", "cstone_hip_gather_scatter", "cstone_hip_merge_positions", "cstone_hip_minmax", "cstone_hip_minmax_arrays", "cstone_hip_exclusive_scan_u32", "cstone_hip_inclusive_scan_u32", "cstone_hip_lower_bound",
     "cstone_hip_compute_node_counts", "cstone_hip_compute_node_counts_guided", "cstone_hip_compute_node_ops", "cstone_hip_rebalance_tree",
@@ -43,6 +43,8 @@ EXPORTS = [
     "cstone_hip_protect_ancestors", "cstone_hip_enforce_keys", "cstone_hip_range_count", "cstone_hip_mark_macs",
     "cstone_hip_count_sfc_gaps", "cstone_hip_fill_sfc_gaps", "cstone_hip_geo_mac_spheres", "cstone_hip_set_mac",
     "cstone_hip_move_centers", "cstone_hip_leaf_source_centers", "cstone_hip_upsweep_centers",
+    "cstone_hip_comm_rccl_unique_id", "cstone_hip_comm_rccl_create", "cstone_hip_comm_rccl_ops",
+    "cstone_hip_comm_rccl_destroy",
 ]
 
 
@@ -157,6 +159,13 @@ class Context:
         self._chk(self.lib.cstone_hip_profile_get(self.h, C.c_int(STAGES[stage]), C.byref(ms), C.byref(cnt)),
                   "profile_get")
         return ms.value, cnt.value
+
+    def profile_spread(self, stage):
+        """(min, median, max) ms of the individual brackets of a stage since the last reset"""
+        lo, med, hi = C.c_double(0), C.c_double(0), C.c_double(0)
+        self._chk(self.lib.cstone_hip_profile_get_spread(self.h, C.c_int(STAGES[stage]), C.byref(lo), C.byref(med),
+                                                         C.byref(hi)), "profile_get_spread")
+        return lo.value, med.value, hi.value
 
     # ---- keys
     def compute_sfc_keys(self, curve, key_bits, x, y, z, box, keys=None):

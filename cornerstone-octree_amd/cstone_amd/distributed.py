@@ -698,14 +698,59 @@ class TorchCollectives:
         return self._guard(run)
 
 
+class RcclCollectives:
+    """cstone_hip_comm_ops served by RCCL INSIDE libcstone_hip (csrc/comm_rccl.hip): collectives are enqueued on the
+    context's stream by C++ code, nothing of Python runs per collective.  torch.distributed (any backend) is only the
+    bootstrap channel that carries the 128-byte RCCL id from rank 0 to the other ranks."""
+
+    def __init__(self, ctx, group=None, rank=None, size=None, unique_id=None):
+        self.ctx, self.error = ctx, None
+        if rank is None:
+            import torch.distributed as dist
+
+            rank, size = dist.get_rank(group), dist.get_world_size(group)
+        self.rank, self.size = rank, size
+        if unique_id is None:
+            import torch.distributed as dist
+
+            box = [None]
+            if rank == 0:
+                buf = (C.c_char * 128)()
+                ctx._chk(ctx.lib.cstone_hip_comm_rccl_unique_id(ctx.h, buf), "comm_rccl_unique_id")
+                box[0] = bytes(buf.raw)
+            if size > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            unique_id = box[0]
+        self.unique_id = unique_id
+        self.h = C.c_void_p()
+        ctx._chk(ctx.lib.cstone_hip_comm_rccl_create(ctx.h, C.c_char_p(unique_id), C.c_int(rank), C.c_int(size),
+                                                     C.byref(self.h)), "comm_rccl_create")
+        self.ops = CommOps()
+        ctx._chk(ctx.lib.cstone_hip_comm_rccl_ops(self.h, C.byref(self.ops)), "comm_rccl_ops")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.cstone_hip_comm_rccl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class NativeDistributedDomain:
     """cstone_hip_domain_mr_* (multi-rank Domain::sync inside libcstone_hip) with torch.distributed collectives"""
 
-    def __init__(self, ctx, curve, key_bits, real_bits, bucket, bucket_focus, box_lim, box_bc=(0, 0, 0), group=None):
+    def __init__(self, ctx, curve, key_bits, real_bits, bucket, bucket_focus, box_lim, box_bc=(0, 0, 0), group=None,
+                 coll=None):
         import cstone_amd
 
         self.ctx, self.kb, self.rb = ctx, key_bits, real_bits
-        self.coll = TorchCollectives(ctx, group)
+        # coll: the transport (TorchCollectives: torch.distributed callbacks, any backend; RcclCollectives: RCCL from
+        # C++ inside the library)
+        self.coll = coll if coll is not None else TorchCollectives(ctx, group)
         self.h = C.c_void_p()
         box = cstone_amd.make_cbox(box_lim, box_bc)
         ctx._chk(ctx.lib.cstone_hip_domain_mr_create(ctx.h, C.byref(self.h), C.c_int(curve), C.c_int(key_bits),

@@ -87,11 +87,14 @@ extern "C"
 #define CSTONE_STAGE_HALOS 7
 #define CSTONE_STAGE_NEIGHBORS 8
 #define CSTONE_STAGE_MINMAX 9
+#define CSTONE_STAGE_SORT_PASS_IOTA 10 /* a digit pass that produces the positions instead of reading values: K + (K+4) B/pair */
 #define CSTONE_NUM_STAGES 16
     int cstone_hip_profile_enable(cstone_hip_ctx* ctx, int on);
     int cstone_hip_profile_reset(cstone_hip_ctx* ctx);
     /* synchronises the stream; total_ms and launches accumulated since the last reset */
     int cstone_hip_profile_get(cstone_hip_ctx* ctx, int stage, double* total_ms, int* launches);
+    /* min / median / max of the individual brackets of a stage since the last reset (the first 8192 are kept) */
+    int cstone_hip_profile_get_spread(cstone_hip_ctx* ctx, int stage, double* min_ms, double* median_ms, double* max_ms);
 
     /* ---------------------------------------------------------------------------------------------
      * SFC keys: replaces computeSfcKeysGpu (R/sfc/sfc_gpu.h:37-38, kernel R/sfc/sfc_gpu.cu:39-57).
@@ -479,6 +482,20 @@ extern "C"
         int (*all_to_all_v)(void* user, const void* send, const size_t* send_bytes, void* recv,
                             const size_t* recv_bytes);
     } cstone_hip_comm_ops;
+
+    /* cstone_hip_comm_ops served by RCCL inside the library (csrc/comm_rccl.hip): every collective is enqueued on the
+     * context's stream -- no host synchronisation, no host-language callback.  all_reduce = ncclAllReduce, all_gather =
+     * ncclAllGather, all_to_all_v = one group of ncclSend / ncclRecv per peer (xGMI links are point to point).
+     * Bootstrap like any RCCL program: ONE rank obtains the 128-byte id (unique_id) and hands it to the others through
+     * whatever channel the application has (a file, MPI_Bcast, a TCP store ...); then every rank calls create (collective,
+     * blocks until all num_ranks ranks have joined) with the context of ITS GPU.  ops fills a cstone_hip_comm_ops that
+     * stays valid until destroy.  librccl.so is opened on the first of these calls. */
+    typedef struct cstone_hip_comm_rccl cstone_hip_comm_rccl;
+    int cstone_hip_comm_rccl_unique_id(cstone_hip_ctx* ctx, void* id128_host);
+    int cstone_hip_comm_rccl_create(cstone_hip_ctx* ctx, const void* id128_host, int rank, int num_ranks,
+                                    cstone_hip_comm_rccl** out);
+    int cstone_hip_comm_rccl_ops(cstone_hip_comm_rccl* comm, cstone_hip_comm_ops* ops);
+    int cstone_hip_comm_rccl_destroy(cstone_hip_comm_rccl* comm);
 
     typedef struct cstone_hip_domain_mr cstone_hip_domain_mr;
 

@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--lopsided", type=int, default=0, help="1: the last rank starts without particles")
     ap.add_argument("--impl", default="python", choices=["python", "native"],
                     help="python: cstone_amd.distributed.DistributedDomain; native: cstone_hip_domain_mr_* (hip only)")
+    ap.add_argument("--fail-at", default="", help="native only: after one good sync, rank 1 is made to fail at this point "
+                                                  "of the next sync (CSTONE_MR_FAIL_AT); every rank must get an error")
     a = ap.parse_args()
     dist.init_process_group("gloo")
     rank, P = dist.get_rank(), dist.get_world_size()
@@ -227,6 +229,34 @@ def main():
                                 bucket_focus=16, box_lim=lim, box_bc=bc)
     ok = True
     report = []
+    if a.fail_at:
+        # collective-safe failure: one good sync, then rank 1 fails inside the next one; nobody may hang, everybody must
+        # see an error, and the domain must work again afterwards
+        import cstone_amd
+
+        r = dom.sync(x, y, z, h)
+        os.environ["CSTONE_MR_FAIL_AT"] = f"1:{a.fail_at}"
+        raised, msg = 0, ""
+        try:
+            dom.sync(r["x"][r["start"]:r["end"]].clone(), r["y"][r["start"]:r["end"]].clone(),
+                     r["z"][r["start"]:r["end"]].clone(), r["h"][r["start"]:r["end"]].clone())
+        except cstone_amd.CstoneError as e:
+            raised, msg = 1, str(e)
+        del os.environ["CSTONE_MR_FAIL_AT"]
+        flag = torch.tensor([raised])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        named = ("injected" in msg) if rank == 1 else ("rank 1 reported a failure" in msg)
+        good = torch.tensor([1 if named else 0])
+        dist.all_reduce(good, op=dist.ReduceOp.MIN)
+        r2 = dom.sync(r["x"][r["start"]:r["end"]].clone(), r["y"][r["start"]:r["end"]].clone(),
+                      r["z"][r["start"]:r["end"]].clone(), r["h"][r["start"]:r["end"]].clone())
+        tot = torch.tensor([r2["end"] - r2["start"]], dtype=torch.int64)
+        dist.all_reduce(tot)
+        ok = bool(flag.item()) and bool(good.item()) and int(tot.item()) == N
+        if rank == 0:
+            print("DIST_RESULT " + json.dumps(dict(ok=ok, ranks=P, report=[dict(message=msg)])))
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
     tag64 = x * 3.0 + y * 5.0 + z * 7.0 + h          # conserved fields that must stay attached to their particles
     tag32 = (x + 2.0 * y).to(torch.float32)
     for s in range(a.syncs):

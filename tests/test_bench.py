@@ -86,3 +86,20 @@ def test_bench_two_ranks_rccl():
     assert r.returncode == 0, r.stderr[-3000:]
     j = _json_line(r.stdout)
     assert j["n_gpus"] == 2 and j["config"]["rank0_exchange"]["halos"] > 0 and 0.0 < j["roofline"]["frac"] < 1.0
+    assert j["config"]["transport"].startswith("RCCL inside libcstone_hip") and j["config"]["invariants_ok"] is True
+
+
+@pytest.mark.gpu
+def test_bench_native_rccl_world_of_one():
+    """the multi-rank domain over RCCL served from C++ inside the library (csrc/comm_rccl.hip), rehearsed with a world of
+    ONE rank on the one-GPU box: the same entry points, callbacks and stream ordering as the N-GPU run (all-reduce,
+    all-gather and the grouped send/recv with no peer)"""
+    env = dict(os.environ, CSTONE_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29793")
+    env.pop("CSTONE_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--particles", "2e6", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["config"]["transport"].startswith("RCCL inside libcstone_hip"), j["config"]["transport"]
+    assert j["config"]["invariants_ok"] is True and j["config"]["rank0_assigned"] == 2000000
+    assert j["config"]["orchestration"].startswith("libcstone_hip")

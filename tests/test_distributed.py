@@ -181,3 +181,12 @@ def test_gloo_ranks_morton_32bit_keys(impl):
     r = _launch(2, "hip", 40000, 2, 1, 29740 + len(impl), impl=impl, extra=["--key-bits", "32", "--curve", "morton"])
     for step in r["report"]:
         assert step["neighbors"] == step["found"] and step["neighbors"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("point", ["start", "assign", "exchange"])
+def test_native_domain_failure_reaches_every_rank(point):
+    """a rank-local failure inside cstone_hip_domain_mr_sync (injected on rank 1: CSTONE_MR_FAIL_AT) travels as a status
+    word on the next collective: every rank returns an error from the same point, nobody is left waiting in a
+    collective, and the next sync works again"""
+    _launch(3, "hip", 30000, 1, 0, 29670 + len(point), impl="native", extra=["--fail-at", point], timeout=300)
