@@ -266,7 +266,11 @@ __device__ __forceinline__ void streamStore(V* p, V v)
 //! single instruction (dword-sized sc1 accesses cost one fabric transaction each)
 __device__ __forceinline__ void storeRowSc1(uint32_t* p, u32x4 v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    // The wait states are part of the statement: a store of more than 64 bits reads its data registers over several
+    // cycles, and an instruction that overwrites them must keep its distance (the compiler's hazard recogniser inserts
+    // the s_nop for stores it emits itself, but it does not look inside inline assembly).  Found the hard way: with a
+    // v_mbcnt writing the first data register right behind the store, dword 0 of every 16th lane went out as zero.
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 4" ::"v"(p), "v"(v) : "memory");
 }
 
 template<class K, int BLOCK>
@@ -458,7 +462,7 @@ __device__ __forceinline__ u32x4 quarterLookBack(const uint32_t* __restrict__ st
  *  TAIL = true : the last, partial tile. It sits at the END of every digit bin (it is the last tile in input
  *                order), so its slots follow from the global digit bases alone and it needs no look-back:
  *                first slot of digit d = end(d) - (tail count of d), end(d) = bases[d+1] (n for the last digit) */
-template<class K, int BLOCK, bool TAIL>
+template<class K, int BLOCK, bool TAIL, bool BALLOT>
 __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCfg<K, BLOCK>::ITEMS],
                                          uint32_t tile, unsigned tileCount,
                                          const uint32_t* __restrict__ valsIn,
@@ -511,7 +515,21 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
     for (int r = 0; r < ITEMS; ++r)
     {
         unsigned d = unsigned(key[r] >> shift) & (RADIX - 1);
-        if (FULL)
+        if (BALLOT)
+        {
+            // the ranking that does not rely on the service order of LDS atomics (selected when the one-time probe of
+            // that order fails, or by CSTONE_SORT_BALLOT_RANK): wave64 match-any of the digit by 8 ballots; the lowest
+            // lane of every digit class advances the class counter, all read it before (LDS executes a wave in order)
+            const bool valid = FULL || segBase + r * 64 + lane < tileCount;
+            const uint64_t vm = __ballot(valid);
+            uint32_t mlo = uint32_t(vm), mhi = uint32_t(vm >> 32);
+            matchDigit(d, mlo, mhi);
+            const unsigned below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+            const unsigned base  = myHist[d];
+            if (valid && below == 0) myHist[d] = base + unsigned(__popc(mlo) + __popc(mhi));
+            rank[r] = valid ? base + below : 0u;
+        }
+        else if (FULL)
         {
             unsigned d0 = __builtin_amdgcn_readfirstlane(d);
             if (__all(d == d0))
@@ -784,7 +802,7 @@ __device__ __forceinline__ void sortTile(SortSmem<K, BLOCK>& sm, K (&key)[SortCf
  *  continuously, which keeps their phases (load / rank / look-back / store) staggered across the chip; persistent
  *  variants (ticket per tile with key prefetch, or round-robin tiles) measured 8-40 % slower on MI355X because they
  *  synchronise the look-back rounds. */
-template<class K, int BLOCK>
+template<class K, int BLOCK, bool BALLOT>
 __global__ __launch_bounds__(BLOCK) void onesweepKernel(const K* __restrict__ keysIn,
                                                         const uint32_t* __restrict__ valsIn, K* __restrict__ keysOut,
                                                         uint32_t* __restrict__ valsOut, uint32_t n, int pass,
@@ -834,7 +852,7 @@ __global__ __launch_bounds__(BLOCK) void onesweepKernel(const K* __restrict__ ke
             unsigned idx = segBase + r * 64 + lane;
             tkey[r]      = idx < tileCount ? keysIn[tileBase + idx] : K(~K(0));
         }
-        sortTile<K, BLOCK, true>(sm, tkey, numFullTiles, tileCount, valsIn, keysOut, valsOut, pass * RADIX_BITS, bases,
+        sortTile<K, BLOCK, true, BALLOT>(sm, tkey, numFullTiles, tileCount, valsIn, keysOut, valsOut, pass * RADIX_BITS, bases,
                                  nullptr, errors, n);
         return;
     }
@@ -855,7 +873,7 @@ __global__ __launch_bounds__(BLOCK) void onesweepKernel(const K* __restrict__ ke
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r)
         key[r] = streamLoad(keysIn + tile * uint32_t(TILE) + segBase + r * 64 + lane);
-    sortTile<K, BLOCK, false>(sm, key, tile, unsigned(TILE), valsIn, keysOut, valsOut, pass * RADIX_BITS,
+    sortTile<K, BLOCK, false, BALLOT>(sm, key, tile, unsigned(TILE), valsIn, keysOut, valsOut, pass * RADIX_BITS,
                               bases, status, errors, n);
 }
 
@@ -886,8 +904,8 @@ __global__ __launch_bounds__(BLOCK) void onesweepTailKernel(const K* __restrict_
         key[r]       = idx < tileCount ? keysIn[tileBase + idx] : K(~K(0));
     }
     ldsBarrier();
-    sortTile<K, BLOCK, true>(sm, key, numFullTiles, tileCount, valsIn, keysOut, valsOut, pass * RADIX_BITS, bases,
-                             nullptr, errors, n);
+    sortTile<K, BLOCK, true, false>(sm, key, numFullTiles, tileCount, valsIn, keysOut, valsOut, pass * RADIX_BITS, bases,
+                                    nullptr, errors, n);
 }
 
 /*! @brief orders the low key bits inside runs of equal high bits (keys >> shift), stably
@@ -1007,7 +1025,7 @@ size_t sortTempBytes(size_t n)
     return alignUp((headerWords(P) + size_t(P) * numTiles * RADIX) * sizeof(uint32_t));
 }
 
-template<class K, int BLOCK>
+template<class K, int BLOCK, bool BALLOT>
 void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* vals, size_t n, K* keysAlt,
                   uint32_t* valsAlt, bool iotaValues, int startPass)
 {
@@ -1025,12 +1043,12 @@ void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* val
         const uint32_t* bases = t.hist + size_t(p) * RADIX;
 #ifndef CSTONE_SORT_TRACE
         // one launch: the workgroup that draws ticket numFullTiles takes the partial last tile
-        hipLaunchKernelGGL((onesweepKernel<K, BLOCK>), numFullTiles + (haveTail ? 1u : 0u), BLOCK, 0, ctx->stream, kIn, vIn,
+        hipLaunchKernelGGL((onesweepKernel<K, BLOCK, BALLOT>), numFullTiles + (haveTail ? 1u : 0u), BLOCK, 0, ctx->stream, kIn, vIn,
                            kOut, vOut, uint32_t(n), p, numFullTiles, bases, t.tickets + p,
                            t.status + size_t(p) * numFullTiles * RADIX, t.errors);
 #else
         if (numFullTiles)
-            hipLaunchKernelGGL((onesweepKernel<K, BLOCK>), numFullTiles, BLOCK, 0, ctx->stream, kIn, vIn, kOut, vOut,
+            hipLaunchKernelGGL((onesweepKernel<K, BLOCK, BALLOT>), numFullTiles, BLOCK, 0, ctx->stream, kIn, vIn, kOut, vOut,
                                uint32_t(n), p, numFullTiles, bases, t.tickets + p,
                                t.status + size_t(p) * numFullTiles * RADIX, t.errors);
         if (haveTail)
@@ -1065,9 +1083,8 @@ int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt
         CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->ldsOrderOk = ctx->hostScalars[62] == 0;
     }
-    if (!ctx->ldsOrderOk)
-        return fail(ctx, CSTONE_E_INTERNAL, "sort_pairs: LDS atomics of this device are not served in lane order; "
-                                            "the stable ranking of the radix sort cannot be used");
+    // a device that failed the probe (none has so far) sorts with the ballot-based ranking: slower, order-independent
+    const bool ballot = !ctx->ldsOrderOk || std::getenv("CSTONE_SORT_BALLOT_RANK") != nullptr;
 
     constexpr int P = sizeof(K);
     auto* words     = (uint32_t*)temp;
@@ -1102,8 +1119,13 @@ int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt
     CS_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sortTrace), &traceDev, sizeof(traceDev), 0, hipMemcpyHostToDevice,
                                        ctx->stream));
 #endif
-    if (large) launchPasses<K, LARGE_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass);
-    else launchPasses<K, SMALL_BLOCK>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass);
+    if (ballot)
+    {
+        if (large) launchPasses<K, LARGE_BLOCK, true>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass);
+        else launchPasses<K, SMALL_BLOCK, true>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass);
+    }
+    else if (large) launchPasses<K, LARGE_BLOCK, false>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass);
+    else launchPasses<K, SMALL_BLOCK, false>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass);
     CS_HIP(ctx, hipGetLastError());
 #ifdef CSTONE_SORT_TRACE
     if (traceFile)

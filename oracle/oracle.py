@@ -415,6 +415,13 @@ class Oracle(_CpuImpl):
     prefix = "cstone_oracle_"
     libpath = os.path.join(HERE, "libcstone_oracle.so")
 
+    def random_uniform(self, n, box, seed=42, real_bits=64):
+        """the reference's RandomCoordinates cloud (std::mt19937(seed); all x, then all y, then all z)"""
+        x, y, z = [np.empty(n, dtype=real_dtype(real_bits)) for _ in range(3)]
+        rc = self._f("random_uniform")(C.c_int(real_bits), C.c_uint(seed), C.c_size_t(n), _p(box.lim), _p(x), _p(y), _p(z))
+        assert rc == 0, rc
+        return x, y, z
+
 
 class Reference(_CpuImpl):
     prefix = "cstone_ref_"

@@ -1,6 +1,8 @@
 // TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  C entry points (ctypes) onto the CPU restatement in
 // cstone_oracle.hpp.  All pointers are HOST pointers.  key_bits in {32,64}, real_bits in {32,64},
 // curve 0 = Morton, 1 = Hilbert.  box = {xmin,xmax,ymin,ymax,zmin,zmax}, bc = boundary type per axis.
+#include <random>
+
 #include "cstone_oracle.hpp"
 
 #ifdef _OPENMP
@@ -550,6 +552,26 @@ int cstone_oracle_segment_max(int in_bits, int out_bits, const void* in, const u
     else if (in_bits == 64 && out_bits == 64) segmentMax((const double*)in, segments, num_segments, (double*)out);
     else return -1;
     return 0;
+}
+
+/*! the uniform cloud of the reference's tests and benchmarks (test/coord_samples/random.hpp:93-113): std::mt19937(seed),
+ *  x drawn completely, then y, then z from std::uniform_real_distribution<T>(lo, hi); restated here so that the GPU box
+ *  can regenerate the 1e7-particle input of BASELINE configs[1] instead of shipping 240 MB */
+int cstone_oracle_random_uniform(int real_bits, unsigned seed, size_t n, const double* lim, void* x, void* y, void* z)
+{
+    return withReal(real_bits,
+                    [&](auto t)
+                    {
+                        using T = decltype(t);
+                        std::mt19937 gen(seed);
+                        T* out[3] = {(T*)x, (T*)y, (T*)z};
+                        for (int d = 0; d < 3; ++d)
+                        {
+                            std::uniform_real_distribution<T> dis{T(lim[2 * d]), T(lim[2 * d + 1])};
+                            for (size_t i = 0; i < n; ++i)
+                                out[d][i] = dis(gen);
+                        }
+                    });
 }
 
 int cstone_oracle_num_threads()

@@ -135,4 +135,48 @@ void cstone_refdom_get(void* p, void* keys, void* x, void* y, void* z, void* h, 
     ((HolderBase*)p)->get(keys, x, y, z, h, globalLeaves, focusLeaves, focusCounts, layout);
 }
 
+/*! The reference's own Halos::discover + computeLayout (R/halos/halos.hpp:128-222, CPU branch: halo radii = max h per
+ *  leaf * 2 * ext, then findHalos) for a pretended assignment [first, last) on ONE rank.  layout_out[numLeaves + 1] is the
+ *  layout computeLayout produces: a leaf outside [first, last) has a non-empty range there iff it was flagged as a halo
+ *  (and holds particles) -- this pins the halo radius rule, which lives inline inside the member function.
+ *  h_bits in {32, 64}; h holds the particles of the leaves [first, last) back to back. */
+int cstone_refdom_halo_discover(int key_bits, int real_bits, int h_bits, const void* prefixes, const int* child_offsets,
+                                const int* internal_to_leaf, const void* leaves, const unsigned* counts, int num_leaves,
+                                int first, int last, const double* lim, const int* bc, const void* h, float ext,
+                                unsigned* layout_out)
+{
+    ensureMpi();
+    auto run = [&](auto k, auto t, auto th)
+    {
+        using K  = decltype(k);
+        using T  = decltype(t);
+        using Th = decltype(th);
+        Box<T> box(static_cast<T>(lim[0]), static_cast<T>(lim[1]), static_cast<T>(lim[2]), static_cast<T>(lim[3]),
+                   static_cast<T>(lim[4]), static_cast<T>(lim[5]), static_cast<BoundaryType>(bc[0]),
+                   static_cast<BoundaryType>(bc[1]), static_cast<BoundaryType>(bc[2]));
+        Halos<K, CpuTag> halos(0);
+        std::vector<TreeIndexPair> assignment{TreeIndexPair(first, last)};
+        std::vector<LocalIndex> layout(num_leaves + 1, 0);
+        std::vector<int> scratch;
+        halos.discover((const K*)prefixes, child_offsets, internal_to_leaf, (const K*)leaves,
+                       gsl::span<const unsigned>(counts, num_leaves), assignment, layout, box, (const Th*)h, ext, scratch);
+        std::vector<int> peers;
+        // returns 1 when a halo has no peer to come from (always the case on one rank): the layout is complete before
+        halos.computeLayout(gsl::span<const K>((const K*)leaves, num_leaves + 1), gsl::span<const unsigned>(counts, num_leaves),
+                            assignment, peers, layout);
+        std::copy(layout.begin(), layout.end(), layout_out);
+    };
+    auto withH = [&](auto k, auto t)
+    {
+        if (h_bits == 32) run(k, t, float{});
+        else run(k, t, double{});
+    };
+    if (key_bits == 64 && real_bits == 64) withH(uint64_t{}, double{});
+    else if (key_bits == 64 && real_bits == 32) withH(uint64_t{}, float{});
+    else if (key_bits == 32 && real_bits == 64) withH(unsigned{}, double{});
+    else if (key_bits == 32 && real_bits == 32) withH(unsigned{}, float{});
+    else return -1;
+    return 0;
+}
+
 } // extern "C"

@@ -241,3 +241,42 @@ def test_domain_sync_clustered_2p5e8(hip):
     counts = dom.fetch(v.focus_leaf_counts, L, np.uint32)
     layout = dom.fetch(v.layout, L + 1, np.uint32)
     assert int(counts.sum(dtype=np.uint64)) == n and counts.max() <= bucket_focus and int(layout[-1]) == n
+
+
+def test_encode_sort_tree_1e7_against_reference_digests(hip, oracle):
+    """BASELINE configs[1] (10^7 uniform particles: encode + radix sort + cornerstone tree, no halos) BIT FOR BIT against
+    the reference: tests/golden/ref_1e7_digests.json holds the SHA-256 of what the reference's own computeSfcKeys,
+    sort_by_key and computeOctree produce on its RandomCoordinates cloud (tests/golden/make_golden_1e7.py, run where
+    /root/reference exists); the input is regenerated here by the restated generator"""
+    import hashlib
+    import json
+
+    import torch
+
+    import cstone_amd
+    from oracle import oracle as orc
+
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_1e7_digests.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    n, box = want["n"], orc.Box(want["box"])
+    x, y, z = oracle.random_uniform(n, box, want["seed"])
+    assert sha(x) == want["x_sha256"]  # the same cloud as the one the reference saw
+    cb = cstone_amd.make_cbox(box.lim, box.bc)
+    xd, yd, zd = [torch.from_numpy(a).cuda() for a in (x, y, z)]
+    keys = hip.compute_sfc_keys(cstone_amd.HILBERT, 64, xd, yd, zd, cb)
+    assert sha(cstone_amd.keys_to_numpy(keys, 64)) == want["keys_sha256"]
+    order = torch.arange(n, dtype=torch.int32, device="cuda")
+    hip.sort_pairs(keys, order)
+    hip.sync()
+    assert sha(cstone_amd.keys_to_numpy(keys, 64)) == want["sorted_keys_sha256"]
+    assert sha(order.cpu().numpy().view(np.uint32)) == want["order_sha256"]
+    tree, counts, _ = hip.compute_octree(keys, want["bucket"])
+    hip.sync()
+    assert tree.numel() - 1 == want["num_leaves"] == 262256
+    assert sha(cstone_amd.keys_to_numpy(tree, 64)) == want["leaves_sha256"]
+    assert sha(counts.cpu().numpy().view(np.uint32)) == want["counts_sha256"]
+    # the fused entry (encode + digit counting + sort, what Domain::sync issues) gives the same keys and ordering
+    k2, o2 = hip.sfc_keys_and_ordering(cstone_amd.HILBERT, 64, xd, yd, zd, cb)
+    hip.sync()
+    assert sha(cstone_amd.keys_to_numpy(k2, 64)) == want["sorted_keys_sha256"]
+    assert sha(o2.cpu().numpy().view(np.uint32)) == want["order_sha256"]

@@ -609,3 +609,14 @@ def test_halo_boxes_foreign_flags_only_boxes_that_leave_the_range(hip, oracle, k
             if last < nl:
                 outside += int(oracle.find_overlaps(curve, tree, rec, last, nl).sum())
             assert int(got[k, 6]) == (1 if outside else 0), (first, int(k), outside)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kb", [32, 64])
+def test_sort_with_ballot_ranking(hip, kb, monkeypatch):
+    """the ranking variant that does not rely on the service order of returning LDS atomics (what a device that failed
+    the one-time probe would run; forced here with CSTONE_SORT_BALLOT_RANK): the fuzzed sizes and the adversarial digit
+    patterns give torch's stable sort"""
+    monkeypatch.setenv("CSTONE_SORT_BALLOT_RANK", "1")
+    test_sort_adversarial_digit_patterns_large_tiles(hip, kb)
+    test_sort_pairs_fuzz_sizes(hip, kb)

@@ -82,3 +82,51 @@ def test_stepwise_updates_and_spanning_tree(oracle, reference, kb):
         assert np.array_equal(counts, reference.node_counts(t1, keys))
     cs = np.array(sorted({0, 1, 0o30173, 0o3333333333, end_key(kb) - 1, end_key(kb)}), dtype=key_dtype(kb))
     assert np.array_equal(oracle.spanning_tree(cs), reference.spanning_tree(cs))
+
+
+@pytest.mark.parametrize("kb,rb,hb", [(64, 64, 64), (64, 64, 32), (32, 32, 32), (64, 32, 32)])
+@pytest.mark.parametrize("bc", [(0, 0, 0), (1, 1, 1)])
+def test_halo_radii_rule_against_reference_halos_discover(oracle, kb, rb, hb, bc):
+    """the halo search radius (max h of a leaf * 2 * ext, rounded to float) lives inline inside the reference's member
+    function Halos::discover (R/halos/halos.hpp:168-180).  The reference's own discover + computeLayout run here for a
+    pretended assignment [first, last) on one rank (oracle/_ref/libcstone_ref_domain.so): a leaf outside the assignment
+    gets a non-empty layout range iff it was flagged.  oracle.halo_radii + oracle.find_halos must flag the same leaves."""
+    import ctypes as C
+    import os
+
+    from oracle import oracle as orc
+
+    path = os.path.join(os.path.dirname(orc.__file__), "_ref", "libcstone_ref_domain.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libcstone_ref_domain.so not built")
+    lib = C.CDLL(path)
+    box = Box([0, 1, 0, 2, -1, 1], bc)
+    n = 30000
+    x, y, z = random_cloud(n, box, rb, seed=kb + hb, kind="clustered")
+    keys = oracle.compute_sfc_keys(HILBERT, kb, x, y, z, box)
+    ks, order = oracle.sort_pairs(keys, np.arange(n))
+    tree, counts = oracle.compute_octree(ks, 16)
+    o = oracle.build_octree(tree)
+    nl = tree.size - 1
+    rng = np.random.default_rng(5)
+    h_all = (0.02 * rng.uniform(0.2, 2.0, n)).astype(real_dtype(hb))
+    layout_all = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    for first, last in ((0, nl // 3), (nl // 3, 2 * nl // 3), (nl // 2, nl)):
+        for ext in (1.0, 1.3):
+            h_loc = np.ascontiguousarray(h_all[layout_all[first]:layout_all[last]])
+            lay = np.zeros(nl + 1, dtype=np.uint32)
+            rc = lib.cstone_refdom_halo_discover(C.c_int(kb), C.c_int(rb), C.c_int(hb), p(o["prefixes"]), p(o["child_offsets"]),
+                                                 p(o["internal_to_leaf"]), p(tree), p(counts), C.c_int(nl), C.c_int(first),
+                                                 C.c_int(last), p(box.lim), p(box.bc), p(h_loc), C.c_float(ext), p(lay))
+            assert rc == 0
+            present = np.diff(lay.astype(np.int64)) > 0
+            layout_loc = (layout_all[first:last + 1] - layout_all[first]).astype(np.uint32)
+            radii = oracle.halo_radii(h_loc, layout_loc, first, last, nl, ext)
+            flags = oracle.find_halos(HILBERT, o, tree, radii, box, first, last, rb)
+            outside = np.ones(nl, dtype=bool)
+            outside[first:last] = False
+            nonempty = counts > 0
+            assert np.array_equal(present[outside & nonempty], flags[outside & nonempty] != 0)
+            assert present[first:last][counts[first:last] > 0].all()
+            assert flags[outside].sum() > 0
