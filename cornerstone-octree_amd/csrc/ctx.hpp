@@ -101,9 +101,11 @@ int minMaxCoordinatesDev(cstone_hip_ctx* ctx, int real_bits, const void* const* 
                          double* devOut);
 
 //! encode + the sort's digit histograms in one kernel (sfc.hip); *fused = false: hist untouched (unaligned input)
+//! extentsOut (device, 6 reals {xmin, xmax, ymin, ...}, or nullptr): the extents of x, y, z measured by the same pass;
+//! written only when *fused comes back true
 int computeKeysAndHistogram(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
                             const void* z, void* keys, size_t n, const cstone_box& box, uint32_t* hist, bool* fused,
-                            int firstDigit = 0, bool honourMarkers = true);
+                            int firstDigit = 0, bool honourMarkers = true, void* extentsOut = nullptr);
 
 inline unsigned gridFor(size_t n, unsigned block, unsigned perThread = 1)
 {
@@ -116,7 +118,13 @@ inline unsigned gridFor(size_t n, unsigned block, unsigned perThread = 1)
 int sfcKeysAndOrderingHint(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
                            const void* z, void* keys, uint32_t* ordering, size_t n, const cstone_box& box,
                            void* keys_alt, uint32_t* values_alt, void* temp, size_t temp_bytes, int startPass,
-                           int* tooLongDev, bool honourMarkers = true);
+                           int* tooLongDev, bool honourMarkers = true, void* extentsOut = nullptr,
+                           bool* extentsMeasured = nullptr);
+
+//! hOut[i] = h[order[i]] for the particles of the leaves [0, numLeaves) (layout: their offsets) and, from the same pass,
+//! radii[leaf] = float(max h of the leaf * 2 * ext) (halos.hip): the gather of h and Halos::discover's radii in one
+int gatherWithHaloRadii(cstone_hip_ctx* ctx, int h_bits, const void* h, const uint32_t* order, void* hOut,
+                        const uint32_t* layout, int numLeaves, float ext, float* radii);
 
 //! bottom-up saturating sum over the linked octree, launching only the levels that exist (tree.hip)
 int upsweepSumLevels(cstone_hip_ctx* ctx, int numLevelsPlus2, const int32_t* levelRangeHost, const int32_t* levelRange,

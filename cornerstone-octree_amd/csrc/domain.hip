@@ -150,8 +150,32 @@ public:
         const int kb = 8 * sizeof(K), rb = 8 * sizeof(T);
 
         // ---- GlobalAssignment::assign (assignment.hpp:57-103): box, keys, sort, one global-tree step
-        double lim[6];
+        // The box of a sync follows from the extents of x, y, z (makeGlobalBox + limitBoxShrinking).  After the first call
+        // it rarely changes, so the keys are computed SPECULATIVELY with the box of the previous sync while the same
+        // pass over x, y, z measures the extents; the box rule is evaluated afterwards and only a box that really
+        // changed costs a second encode + sort.  Saves the separate 2.4 GB pass over the coordinates per sync at 1e8.
+        auto boxFromExtents = [&](const double* lim, cstone_box& box)
         {
+            if (firstCall_) { std::copy(lim, lim + 6, box.lim); }
+            else
+            {
+                // limitBoxShrinking (sfc/box.hpp:415-431), evaluated in T like the reference
+                const T shrink = T(0.05);
+                for (int d = 0; d < 3; ++d)
+                {
+                    T lo = T(box.lim[2 * d]), hi = T(box.lim[2 * d + 1]);
+                    T len = hi - lo;
+                    T a = lo + shrink * len, b = hi - shrink * len;
+                    box.lim[2 * d]     = std::min(T(lim[2 * d]), a);
+                    box.lim[2 * d + 1] = std::max(T(lim[2 * d + 1]), b);
+                }
+            }
+        };
+        const bool anyOpen = box_.bc[0] != 1 || box_.bc[1] != 1 || box_.bc[2] != 1;
+        bool speculate     = anyOpen && !firstCall_ && std::getenv("CSTONE_NO_SPECULATIVE_BOX") == nullptr;
+        if (anyOpen && !speculate)
+        {
+            double lim[6];
             // extents of the open dimensions in one launch and one read-back (MinMaxGpu x3 in the reference)
             const void* open[3];
             int dims[3], numOpen = 0;
@@ -161,27 +185,11 @@ public:
                 if (box_.bc[d] == 1) { lim[2 * d] = box_.lim[2 * d], lim[2 * d + 1] = box_.lim[2 * d + 1]; }
                 else { open[numOpen] = coords[d], dims[numOpen++] = d; }
             }
-            if (numOpen)
-            {
-                double ext[6];
-                CS_TRY(minMaxCoordinates(ctx_, rb, open, numOpen, n, ext));
-                for (int i = 0; i < numOpen; ++i)
-                    lim[2 * dims[i]] = ext[2 * i], lim[2 * dims[i] + 1] = ext[2 * i + 1];
-            }
-        }
-        if (firstCall_) { std::copy(lim, lim + 6, box_.lim); }
-        else
-        {
-            // limitBoxShrinking (sfc/box.hpp:415-431), evaluated in T like the reference
-            const T shrink = T(0.05);
-            for (int d = 0; d < 3; ++d)
-            {
-                T lo = T(box_.lim[2 * d]), hi = T(box_.lim[2 * d + 1]);
-                T len = hi - lo;
-                T a = lo + shrink * len, b = hi - shrink * len;
-                box_.lim[2 * d]     = std::min(T(lim[2 * d]), a);
-                box_.lim[2 * d + 1] = std::max(T(lim[2 * d + 1]), b);
-            }
+            double ext[6];
+            CS_TRY(minMaxCoordinates(ctx_, rb, open, numOpen, n, ext));
+            for (int i = 0; i < numOpen; ++i)
+                lim[2 * dims[i]] = ext[2 * i], lim[2 * dims[i] + 1] = ext[2 * i + 1];
+            boxFromExtents(lim, box_);
         }
         // computeSfcKeys + setMapFromCodes (assignment.hpp:81-86) in one call: the sort's digits are counted while the keys
         // are still in the encode kernel's registers, its first pass produces the positions instead of reading an iota
@@ -206,10 +214,53 @@ public:
             int lowBits = 3 * int(maxLevel<K>()) - 3 * (lmax + margin);
             startPass   = std::max(0, lowBits / 8) & ~1;
         }
-        CS_TRY(sfcKeysAndOrderingHint(ctx_, curve_, kb, rb, *xPP, *yPP, *zPP, keys, order_.as<uint32_t>(), n, box_,
-                                      keysAlt_.p, orderAlt_.as<uint32_t>(), sortTmp_.p, tb, startPass,
-                                      ctx_->devScalars + 3));
-        if (startPass == 0) CS_HIP(ctx_, hipMemsetAsync(ctx_->devScalars + 3, 0, sizeof(int), ctx_->stream));
+        T* extentsDev  = reinterpret_cast<T*>(ctx_->devScalars + 16);
+        T* extentsHost = reinterpret_cast<T*>(ctx_->hostScalars + 16);
+        auto encodeAndSort = [&](bool measure, bool* measured)
+        {
+            CS_TRY(sfcKeysAndOrderingHint(ctx_, curve_, kb, rb, *xPP, *yPP, *zPP, keys, order_.as<uint32_t>(), n, box_,
+                                          keysAlt_.p, orderAlt_.as<uint32_t>(), sortTmp_.p, tb, startPass,
+                                          ctx_->devScalars + 3, true, measure ? extentsDev : nullptr, measured));
+            if (startPass == 0) CS_HIP(ctx_, hipMemsetAsync(ctx_->devScalars + 3, 0, sizeof(int), ctx_->stream));
+            return CSTONE_OK;
+        };
+        bool measured = false;
+        CS_TRY(encodeAndSort(speculate, &measured));
+        if (speculate)
+        {
+            double lim[6];
+            if (measured)
+            {
+                CS_HIP(ctx_, hipMemcpyAsync(extentsHost, extentsDev, 6 * sizeof(T), hipMemcpyDeviceToHost, ctx_->stream));
+                CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
+                for (int k = 0; k < 6; ++k)
+                    lim[k] = double(extentsHost[k]);
+            }
+            else
+            {
+                // unaligned arrays: the plain encode ran, measure the extents the regular way
+                const void* all[3] = {*xPP, *yPP, *zPP};
+                CS_TRY(minMaxCoordinates(ctx_, rb, all, 3, n, lim));
+            }
+            for (int d = 0; d < 3; ++d)
+                if (box_.bc[d] == 1) lim[2 * d] = box_.lim[2 * d], lim[2 * d + 1] = box_.lim[2 * d + 1];
+            cstone_box next = box_;
+            boxFromExtents(lim, next);
+            bool changed = false;
+            for (int k = 0; k < 6; ++k)
+                changed = changed || next.lim[k] != box_.lim[k];
+            if (changed)
+            {
+                // the particles have left the box (or shrunk away from it by more than 5 %): keys and order again
+                box_ = next;
+                ++boxRedos_;
+                // the key array is sorted by now: put every entry back to its particle first (the remove markers of the
+                // caller must meet their own particles again), then encode with the new box
+                CS_TRY(cstone_hip_scatter(ctx_, sizeof(K), order_.as<uint32_t>(), n, keys, keysAlt_.p));
+                CS_HIP(ctx_, hipMemcpyAsync(keys, keysAlt_.p, n * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
+                CS_TRY(encodeAndSort(false, nullptr));
+            }
+        }
 
         if (firstCall_)
         {
@@ -250,9 +301,8 @@ public:
 
         // ---- GlobalAssignment::distribute on one rank: nothing to exchange; the second sort (assignment.hpp:156) of an
         //      already sorted range is the identity and is skipped.
-        // ---- h into SFC order first, it feeds the halo radii (domain.hpp:213-215)
-        CS_TRY(cstone_hip_gather(ctx_, sizeof(T), order_.as<uint32_t>(), numAssigned, *hPP, *scratchPP));
-        std::swap(*hPP, *scratchPP);
+        // ---- h goes into SFC order for the halo radii (domain.hpp:213-215): gathered further down, in the pass that
+        //      takes the maximum per leaf
 
         // ---- focus tree (octree_focus_mpi.hpp:535-553 on first call, then :225-227)
         if (firstCall_)
@@ -284,8 +334,22 @@ public:
         CS_HIP(ctx_, hipMemsetAsync(layout_.p, 0, sizeof(uint32_t), ctx_->stream));
         CS_TRY(cstone_hip_inclusive_scan_u32(ctx_, fLeafCounts_.as<uint32_t>(), layout_.as<uint32_t>() + 1, size_t(L)));
         layoutLeaves_ = L;
-        CS_TRY(cstone_hip_halo_radii(ctx_, rb, *hPP, layout_.as<uint32_t>(), 0, L, L, haloSearchExt_,
-                                     radii_.as<float>()));
+        // gatherArrays(h) + segmentMax + scale in one pass over h (every leaf is assigned on one rank: the leaves' particles
+        // are all the assigned particles)
+        static const bool splitGather = std::getenv("CSTONE_SPLIT_H_GATHER") != nullptr; // tuning: the two-pass form
+        if (splitGather)
+        {
+            CS_TRY(cstone_hip_gather(ctx_, sizeof(T), order_.as<uint32_t>(), numAssigned, *hPP, *scratchPP));
+            std::swap(*hPP, *scratchPP);
+            CS_TRY(cstone_hip_halo_radii(ctx_, rb, *hPP, layout_.as<uint32_t>(), 0, L, L, haloSearchExt_,
+                                         radii_.as<float>()));
+        }
+        else
+        {
+            CS_TRY(gatherWithHaloRadii(ctx_, rb, *hPP, order_.as<uint32_t>(), *scratchPP, layout_.as<uint32_t>(), L,
+                                       haloSearchExt_, radii_.as<float>()));
+            std::swap(*hPP, *scratchPP);
+        }
         CS_HIP(ctx_, hipMemsetAsync(flags_.p, 0, size_t(L) * sizeof(int), ctx_->stream));
         CS_TRY(cstone_hip_find_halos(ctx_, curve_, kb, rb, fPrefixes_.p, fChild_.as<int32_t>(), fItl_.as<int32_t>(),
                                      fTree_.p, radii_.as<float>(), &box_, 0, L, flags_.as<int32_t>()));
@@ -361,6 +425,7 @@ public:
 
 private:
     size_t lastN_ = 0; // input size of the last sync
+    int boxRedos_ = 0; // syncs whose speculative keys had to be recomputed because the box changed
     int ensureTree(DevBuf& tree, DevBuf& counts, int& cap, int need)
     {
         if (need <= cap) return CSTONE_OK;

@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void maxNormSquareKernel(const T* __restrict__
     }
 }
 
-//! segmentMax, R/primitives/primitives_gpu.cu:241-268: out[s] = max(in[seg[s]..seg[s+1])) starting from the first
-//! element (an empty segment reads in[seg[s]] like the reference does); 16 lanes per segment
+//! segmentMax, R/primitives/primitives_gpu.cu:241-268: out[s] = max(0, in[seg[s]..seg[s+1])) -- the reference starts
+//! every segment at 0, so an empty segment (an empty leaf) gives 0; 16 lanes per segment
 template<class Tin, class Tout, class I>
 __global__ __launch_bounds__(256) void segmentMaxKernel(const Tin* __restrict__ in, const I* __restrict__ seg,
                                                         size_t numSegments, Tout* __restrict__ out)
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void segmentMaxKernel(const Tin* __restrict__ 
     size_t s           = size_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
     if (s >= numSegments) return;
     I a = seg[s], b = seg[s + 1];
-    Tin m = in[a];
+    Tin m = 0;
     for (I i = a + sub; i < b; i += 16)
     {
         Tin v = in[i];

@@ -290,7 +290,56 @@ __global__ __launch_bounds__(256) void haloRadiiKernel(const Th* __restrict__ h,
     if (sub == 0) radii[first + k] = out;
 }
 
+//! the same with the gather of h into SFC order in the same pass: hOut[i] = h[order[i]] for the particles of the leaves
+//! [first, last) (layout = their offsets, hOut indexed like layout), radii from the values on their way through
+template<class Th>
+__global__ __launch_bounds__(256) void gatherHaloRadiiKernel(const Th* __restrict__ h, const uint32_t* __restrict__ order,
+                                                             Th* __restrict__ hOut, const uint32_t* __restrict__ layout,
+                                                             NodeIdx first, NodeIdx last, float ext,
+                                                             float* __restrict__ radii)
+{
+    const unsigned sub = threadIdx.x & 15u;
+    NodeIdx k = NodeIdx(blockIdx.x) * RADII_LEAVES_PER_BLOCK + NodeIdx(threadIdx.x >> 4);
+    if (first + k >= last) return;
+    uint32_t a = layout[k], b = layout[k + 1];
+    float out = 0.0f;
+    if (b > a)
+    {
+        Th m = h[order[a]];
+        for (uint32_t i = a + sub; i < b; i += 16)
+        {
+            Th v    = h[order[i]];
+            hOut[i] = v;
+            m       = v > m ? v : m;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1)
+        {
+            Th t = __shfl_xor(m, o);
+            m    = t > m ? t : m;
+        }
+        out = float(m * 2 * ext);
+    }
+    if (sub == 0) radii[first + k] = out;
+}
+
 } // namespace
+
+int gatherWithHaloRadii(cstone_hip_ctx* ctx, int h_bits, const void* h, const uint32_t* order, void* hOut,
+                        const uint32_t* layout, int numLeaves, float ext, float* radii)
+{
+    if (numLeaves == 0) return CSTONE_OK;
+    StageTimer timer(ctx, CSTONE_STAGE_HALOS);
+    unsigned grid = gridFor(size_t(numLeaves), RADII_LEAVES_PER_BLOCK);
+    if (h_bits == 32)
+        hipLaunchKernelGGL(gatherHaloRadiiKernel<float>, grid, 256, 0, ctx->stream, (const float*)h, order, (float*)hOut,
+                           layout, 0, numLeaves, ext, radii);
+    else
+        hipLaunchKernelGGL(gatherHaloRadiiKernel<double>, grid, 256, 0, ctx->stream, (const double*)h, order,
+                           (double*)hOut, layout, 0, numLeaves, ext, radii);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
 
 } // namespace cship
 

@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <limits>
+
 #include "ctx.hpp"
 #include "device_keys.hpp"
 
@@ -107,11 +109,22 @@ __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict
                                                              const T* __restrict__ z, K* __restrict__ keys, size_t n,
                                                              DBox<T> box, const uint16_t* __restrict__ encTable,
                                                              uint32_t* __restrict__ hist, int firstDigit,
-                                                             bool honourMarkers)
+                                                             bool honourMarkers, T* __restrict__ extentPartials)
 {
     constexpr int P = int(sizeof(K));
     __shared__ uint16_t enc[24 * 8];
     __shared__ uint32_t lh[P * 256];
+    // extentPartials != nullptr: the coordinates' extents are measured on the way (Domain::sync encodes with the box of
+    // the previous sync and checks afterwards that the box has not changed: no separate pass over x, y, z)
+    T ext[6] = {std::numeric_limits<T>::infinity(),  -std::numeric_limits<T>::infinity(),
+                std::numeric_limits<T>::infinity(),  -std::numeric_limits<T>::infinity(),
+                std::numeric_limits<T>::infinity(),  -std::numeric_limits<T>::infinity()};
+    auto widen = [&](T xv, T yv, T zv)
+    {
+        ext[0] = xv < ext[0] ? xv : ext[0], ext[1] = xv > ext[1] ? xv : ext[1];
+        ext[2] = yv < ext[2] ? yv : ext[2], ext[3] = yv > ext[3] ? yv : ext[3];
+        ext[4] = zv < ext[4] ? zv : ext[4], ext[5] = zv > ext[5] ? zv : ext[5];
+    };
     if (threadIdx.x < 24 * 8) enc[threadIdx.x] = encTable[threadIdx.x];
     for (int i = threadIdx.x; i < P * 256; i += 256)
         lh[i] = 0;
@@ -178,6 +191,12 @@ __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict
 #pragma unroll
             for (int v = 0; v < VEC; ++v)
                 out[v] = gridMorton<K, T>(vx[v], vy[v], vz[v], mx, my, mz, sx, sy, sz);
+            if (extentPartials)
+            {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    widen(vx[v], vy[v], vz[v]);
+            }
             if (HILBERT)
             {
                 K h[VEC];
@@ -219,6 +238,7 @@ __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict
         {
             key     = encodeOne(x[i], y[i], z[i], honourMarkers ? keys[i] : K(0));
             keys[i] = key;
+            if (extentPartials) widen(x[i], y[i], z[i]);
         }
         count(key, valid);
     }
@@ -227,6 +247,66 @@ __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict
     {
         uint32_t c = lh[i];
         if (c) atomicAdd(&hist[i], c);
+    }
+    if (extentPartials)
+    {
+        __shared__ T wext[4][6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+        {
+            T v = ext[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+            {
+                T t = __shfl_xor(v, o);
+                v   = (k & 1) ? (t > v ? t : v) : (t < v ? t : v);
+            }
+            if (lane == 0) wext[threadIdx.x >> 6][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 6)
+        {
+            const int k = threadIdx.x;
+            T v         = wext[0][k];
+            for (int w = 1; w < 4; ++w)
+                v = (k & 1) ? (wext[w][k] > v ? wext[w][k] : v) : (wext[w][k] < v ? wext[w][k] : v);
+            extentPartials[size_t(blockIdx.x) * 6 + k] = v;
+        }
+    }
+}
+
+//! folds the per-workgroup extents of encodeHistogramKernel: out = {xmin, xmax, ymin, ymax, zmin, zmax}
+template<class T>
+__global__ __launch_bounds__(256) void foldExtentsKernel(const T* __restrict__ partials, unsigned numBlocks,
+                                                         T* __restrict__ out)
+{
+    __shared__ T wext[4][6];
+    const unsigned lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+    {
+        T v = (k & 1) ? -std::numeric_limits<T>::infinity() : std::numeric_limits<T>::infinity();
+        for (unsigned b = threadIdx.x; b < numBlocks; b += 256)
+        {
+            T t = partials[size_t(b) * 6 + k];
+            v   = (k & 1) ? (t > v ? t : v) : (t < v ? t : v);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+        {
+            T t = __shfl_xor(v, o);
+            v   = (k & 1) ? (t > v ? t : v) : (t < v ? t : v);
+        }
+        if (lane == 0) wext[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6)
+    {
+        const int k = threadIdx.x;
+        T v         = wext[0][k];
+        for (int w = 1; w < 4; ++w)
+            v = (k & 1) ? (wext[w][k] > v ? wext[w][k] : v) : (wext[w][k] < v ? wext[w][k] : v);
+        out[k] = v;
     }
 }
 
@@ -277,7 +357,8 @@ inline size_t encodeBlocksPerCu()
 
 template<class K, class T>
 int computeKeysHist(cstone_hip_ctx* ctx, int curve, const T* x, const T* y, const T* z, K* keys, size_t n,
-                    const cstone_box& hostBox, uint32_t* hist, bool* fused, int firstDigit, bool honourMarkers)
+                    const cstone_box& hostBox, uint32_t* hist, bool* fused, int firstDigit, bool honourMarkers,
+                    void* extentsOut /* device T[6] or nullptr; only written when *fused */)
 {
     constexpr int VEC = 16 / sizeof(T);
     bool aligned = (uintptr_t(x) % 16 == 0) && (uintptr_t(y) % 16 == 0) && (uintptr_t(z) % 16 == 0) &&
@@ -294,32 +375,43 @@ int computeKeysHist(cstone_hip_ctx* ctx, int curve, const T* x, const T* y, cons
     auto* enc     = (const uint16_t*)ctx->hilbertTables;
     size_t nVec   = n / VEC;
     unsigned grid = unsigned(std::max<size_t>(1, std::min<size_t>(size_t(ctx->numCu) * encodeBlocksPerCu(), (nVec + 255) / 256)));
+    T* partials   = nullptr;
+    if (extentsOut)
+    {
+        CS_TRY(arenaReserve(ctx, alignUp(size_t(grid) * 6 * sizeof(T)) + 256));
+        partials = (T*)arenaTake(ctx, size_t(grid) * 6 * sizeof(T));
+    }
     if (curve == CSTONE_HILBERT)
         hipLaunchKernelGGL((encodeHistogramKernel<K, T, VEC, true>), grid, 256, 0, ctx->stream, x, y, z, keys, n, box,
-                           enc, hist, firstDigit, honourMarkers);
+                           enc, hist, firstDigit, honourMarkers, partials);
     else
         hipLaunchKernelGGL((encodeHistogramKernel<K, T, VEC, false>), grid, 256, 0, ctx->stream, x, y, z, keys, n, box,
-                           enc, hist, firstDigit, honourMarkers);
+                           enc, hist, firstDigit, honourMarkers, partials);
+    if (extentsOut)
+    {
+        hipLaunchKernelGGL(foldExtentsKernel<T>, 1, 256, 0, ctx->stream, partials, grid, (T*)extentsOut);
+        arenaReset(ctx); // later launches reuse the slice behind these in stream order
+    }
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }
 
 int computeKeysAndHistogram(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
                             const void* z, void* keys, size_t n, const cstone_box& box, uint32_t* hist, bool* fused,
-                            int firstDigit, bool honourMarkers)
+                            int firstDigit, bool honourMarkers, void* extentsOut)
 {
     if (key_bits == 32 && real_bits == 32)
         return computeKeysHist<uint32_t, float>(ctx, curve, (const float*)x, (const float*)y, (const float*)z,
-                                                (uint32_t*)keys, n, box, hist, fused, firstDigit, honourMarkers);
+                                                (uint32_t*)keys, n, box, hist, fused, firstDigit, honourMarkers, extentsOut);
     if (key_bits == 32 && real_bits == 64)
         return computeKeysHist<uint32_t, double>(ctx, curve, (const double*)x, (const double*)y, (const double*)z,
-                                                 (uint32_t*)keys, n, box, hist, fused, firstDigit, honourMarkers);
+                                                 (uint32_t*)keys, n, box, hist, fused, firstDigit, honourMarkers, extentsOut);
     if (key_bits == 64 && real_bits == 32)
         return computeKeysHist<uint64_t, float>(ctx, curve, (const float*)x, (const float*)y, (const float*)z,
-                                                (uint64_t*)keys, n, box, hist, fused, firstDigit, honourMarkers);
+                                                (uint64_t*)keys, n, box, hist, fused, firstDigit, honourMarkers, extentsOut);
     if (key_bits == 64 && real_bits == 64)
         return computeKeysHist<uint64_t, double>(ctx, curve, (const double*)x, (const double*)y, (const double*)z,
-                                                 (uint64_t*)keys, n, box, hist, fused, firstDigit, honourMarkers);
+                                                 (uint64_t*)keys, n, box, hist, fused, firstDigit, honourMarkers, extentsOut);
     return fail(ctx, CSTONE_E_ARG, "sfc_keys_and_ordering: unsupported type combination");
 }
 

@@ -53,8 +53,14 @@ constexpr int SMALL_BLOCK  = 256;  // 4 Ki pairs per tile
 #ifndef CSTONE_LARGE_BLOCK
 #define CSTONE_LARGE_BLOCK 1024
 #endif
+// tuning switches of the pass kernel (tools/build_variant.sh); the defaults are what measured best on MI355X:
+//   CSTONE_SORT_EARLY_LB  look-back started right behind the ranking barrier, next to the digit scan (r2: 3 % SLOWER)
+//   CSTONE_SORT_NO_TICKET tile = blockIdx.x instead of an atomic ticket (relies on in-order dispatch per XCD)
 #ifndef CSTONE_SORT_EARLY_LB
-#define CSTONE_SORT_EARLY_LB 1
+#define CSTONE_SORT_EARLY_LB 0
+#endif
+#ifndef CSTONE_SORT_NO_TICKET
+#define CSTONE_SORT_NO_TICKET 0
 #endif
 constexpr int LARGE_BLOCK  = CSTONE_LARGE_BLOCK; // 16 Ki pairs per tile
 
@@ -820,12 +826,23 @@ __global__ __launch_bounds__(BLOCK) void onesweepKernel(const K* __restrict__ ke
     uint64_t tEntry = wall_clock64();
 #endif
 
+#if CSTONE_SORT_NO_TICKET
+    // workgroups are dispatched in the order of their index on every XCD and lower tiles never wait for higher ones, so
+    // the lowest unfinished tile is always resident: the look-back cannot deadlock; every wave clears its own counters,
+    // nothing has to be agreed before the key loads go out
+    const uint32_t tile = blockIdx.x;
+    if (tid == 64) sm.tileShared[1] = 0; // "slots ready" flag of sortTile
+    for (int i = lane; i < RADIX; i += 64)
+        sm.waveHist[wave * RADIX + i] = 0;
+    (void)ticket;
+#else
     if (tid == 0) sm.tileShared[0] = atomicAdd(ticket, 1u);
     if (tid == 64) sm.tileShared[1] = 0; // "slots ready" flag of sortTile
     for (int i = tid; i < WAVES * RADIX; i += BLOCK)
         sm.waveHist[i] = 0;
     __syncthreads();
     const uint32_t tile = sm.tileShared[0];
+#endif
     if (tile > numFullTiles) return;
     // Long passes (many generations of tiles per CU): the first generation starts spread over about 16 us instead of
     // all at once, so that the load / rank / store phases of the CUs are out of step from the beginning (measured
@@ -1174,8 +1191,9 @@ namespace cship
 int sfcKeysAndOrderingHint(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
                            const void* z, void* keys, uint32_t* ordering, size_t n, const cstone_box& box,
                            void* keys_alt, uint32_t* values_alt, void* temp, size_t temp_bytes, int startPass,
-                           int* tooLongDev, bool honourMarkers)
+                           int* tooLongDev, bool honourMarkers, void* extentsOut, bool* extentsMeasured)
 {
+    if (extentsMeasured) *extentsMeasured = false;
     if (n == 0) return CSTONE_OK;
     startPass &= ~1; // an even number of passes leaves the result in the caller's buffers
     auto run = [&](int state)
@@ -1188,7 +1206,8 @@ int sfcKeysAndOrderingHint(cstone_hip_ctx* ctx, int curve, int key_bits, int rea
     CS_TRY(run(1));
     bool fused = false;
     CS_TRY(computeKeysAndHistogram(ctx, curve, key_bits, real_bits, x, y, z, keys, n, box, (uint32_t*)temp, &fused,
-                                   startPass, honourMarkers));
+                                   startPass, honourMarkers, extentsOut));
+    if (extentsMeasured) *extentsMeasured = fused && extentsOut != nullptr;
     CS_TRY(run(fused ? 2 : 0));
     if (startPass > 0)
     {

@@ -20,6 +20,7 @@
  */
 #pragma once
 
+#include <array>
 #include <cstddef>
 #include <cstdint>
 #include <limits>
@@ -573,6 +574,38 @@ void findNeighborsGpu(const T* x, const T* y, const T* z, const T* h, const Grou
                                                     neighborsCount),
                    "findNeighborsGpu");
 }
+
+/*! The transport of the multi-rank Domain on a node of MI355X: RCCL, served from C++ inside libcstone_hip on the context's
+ *  stream (csrc/comm_rccl.hip) -- replaces the MPI point-to-point exchanges of the reference
+ *  (R/domain/domaindecomp_mpi_gpu.cuh:86-185, R/halos/exchange_halos_gpu.cuh:35-119).  One rank obtains the id
+ *  (RcclComm::uniqueId) and passes its 128 bytes to the others by whatever means the application has; every rank then
+ *  constructs an RcclComm (collective) and hands ops() to Domain / MultiRankDomain. */
+class RcclComm
+{
+public:
+    static std::array<char, 128> uniqueId()
+    {
+        std::array<char, 128> id{};
+        Context::check(cstone_hip_comm_rccl_unique_id(Context::get(), id.data()), "RcclComm::uniqueId");
+        return id;
+    }
+    RcclComm(const std::array<char, 128>& id, int rank, int nRanks)
+    {
+        Context::check(cstone_hip_comm_rccl_create(Context::get(), id.data(), rank, nRanks, &comm_), "RcclComm");
+        Context::check(cstone_hip_comm_rccl_ops(comm_, &ops_), "RcclComm::ops");
+    }
+    RcclComm(const RcclComm&)            = delete;
+    RcclComm& operator=(const RcclComm&) = delete;
+    ~RcclComm()
+    {
+        if (comm_) cstone_hip_comm_rccl_destroy(comm_);
+    }
+    const cstone_hip_comm_ops& ops() const { return ops_; }
+
+private:
+    cstone_hip_comm_rccl* comm_ = nullptr;
+    cstone_hip_comm_ops ops_{};
+};
 
 /*! cstone::Domain<KeyType, T, GpuTag> on SEVERAL ranks, one process per GPU (cstone_hip_domain_mr_*).
  *  The three collectives of a sync (all-reduce, all-gather, all-to-all-v on device buffers) are supplied by the

@@ -172,8 +172,9 @@ extern "C"
      * count_equal   : countGpu (:123-124), number of elements equal to value (elements of 32 | 64 bits)
      * reduce_sum    : reduceGpu (:82-83), init + sum of uint32 | uint64 elements in 64-bit arithmetic
      * max_norm_square : maxNormSquareGpu (:64-65), max of x^2 + y^2 + z^2 evaluated in real_bits precision
-     * segment_max   : segmentMax (:79-80), out[s] = max(in[segments[s] .. segments[s+1])), seeded with the segment's
-     *                 first element like the reference (:241-259); in/out float|double, segments uint32|uint64
+     * segment_max   : segmentMax (:79-80), out[s] = max(0, in[segments[s] .. segments[s+1])): every segment starts at 0
+     *                 like the reference's kernel (:241-259), an empty segment gives 0; in/out float|double, segments
+     *                 uint32|uint64
      * gather_ranges : gatherRanges (R/halos/gather_halos_gpu.h): buffer[i] = src[range_offsets[r] + i - range_scan[r]]
      *                 for the range r with range_scan[r] <= i < range_scan[r+1]; indices uint32 | uint64 (index_bits),
      *                 elements of 1..32 bytes as gather

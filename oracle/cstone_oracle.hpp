@@ -1277,13 +1277,13 @@ void upsweepCenters(int numLevels, const NodeIdx* levelRange, const NodeIdx* chi
         }
 }
 
-//! segmentMax, R/primitives/primitives_gpu.cu:241-259 (seeded with the segment's first element)
+//! segmentMax, R/primitives/primitives_gpu.cu:241-259 (every segment starts at 0: an empty one gives 0)
 template<class Tin, class Tout, class I>
 void segmentMax(const Tin* in, const I* seg, size_t numSegments, Tout* out)
 {
     for (size_t s = 0; s < numSegments; ++s)
     {
-        Tin m = in[seg[s]];
+        Tin m = 0;
         for (I i = seg[s]; i < seg[s + 1]; ++i)
             m = std::max(m, in[i]);
         out[s] = Tout(m);

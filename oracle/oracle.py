@@ -314,8 +314,10 @@ class _CpuImpl:
     def mac_refine_ops(self, octree, macs, num_leaves, focus_first, focus_last):
         pre = octree["prefixes"]
         ops = np.zeros(num_leaves, dtype=np.int32)
+        # leaf index -> node index: the part of leafToInternal behind the internal nodes (R/tree/octree.hpp:367-370)
+        l2i = np.ascontiguousarray(octree["leaf_to_internal"][octree["num_internal"]:])
         rc = self._f("mac_refine_ops")(C.c_int(pre.dtype.itemsize * 8), _p(pre),
-                                       _p(np.ascontiguousarray(macs, dtype=np.int8)), _p(octree["leaf_to_internal"]),
+                                       _p(np.ascontiguousarray(macs, dtype=np.int8)), _p(l2i),
                                        C.c_int(num_leaves), C.c_int(focus_first), C.c_int(focus_last), _p(ops))
         assert rc == 0, rc
         return ops

@@ -21,6 +21,17 @@ using namespace cstone;
 
 static int g_rank = 0, g_failures = 0;
 
+//! REF_DOMAIN_GPU_VERBOSE: one line per step on stderr (where a run stops is then visible)
+static void progress(const char* name, const char* what, int sync)
+{
+    static const bool verbose = std::getenv("REF_DOMAIN_GPU_VERBOSE") != nullptr;
+    if (verbose)
+    {
+        std::fprintf(stderr, "[rank %d] %s: %s (sync %d)\n", g_rank, name, what, sync);
+        std::fflush(stderr);
+    }
+}
+
 template<class V1, class V2>
 static void expectEqual(const char* what, const V1& a, const V2& b, int sync)
 {
@@ -90,7 +101,9 @@ static void run(int rank, int numRanks, LocalIndex numParticles, int numSyncs, c
     for (int sync = 0; sync < numSyncs; ++sync)
     {
         cpu.sync(keys, x, y, z, h, std::tie(m, tag), std::tie(hs1, hs2, hs3));
+        progress(name, "cpu sync done", sync);
         gpu.sync(d_keys, d_x, d_y, d_z, d_h, std::tie(d_m, d_tag), std::tie(s1, s2, s3));
+        progress(name, "gpu sync done", sync);
 
         expectSame("nParticles", cpu.nParticles(), gpu.nParticles(), sync);
         expectSame("startIndex", cpu.startIndex(), gpu.startIndex(), sync);
@@ -149,7 +162,12 @@ static void run(int rank, int numRanks, LocalIndex numParticles, int numSyncs, c
             expectEqual("exchangeHalos field", f, download(d_f), sync);
         }
 
-        if (g_failures) break;
+        {
+            // every rank leaves the loop together (a rank that went on alone would wait for the others in the next sync)
+            int mine = g_failures, all = 0;
+            MPI_Allreduce(&mine, &all, 1, MPI_INT, MPI_SUM, MPI_COMM_WORLD);
+            if (all) break;
+        }
         // move the assigned particles (identically on both sides) for the next sync
         std::mt19937 mv(77 * sync + rank);
         std::uniform_real_distribution<T> step(-1, 1);
@@ -170,6 +188,91 @@ static void run(int rank, int numRanks, LocalIndex numParticles, int numSyncs, c
                     unsigned(gpu.nParticlesWithHalos() - gpu.nParticles()));
 }
 
+/*! Domain::syncGrav (R/domain/domain.hpp:245-325) on both flavours: the gravity-side focus tree -- vector MAC from the
+ *  expansion centres (computeLeafSourceCenterGpu, upsweepCentersGpu, setMacGpu on the GPU side), markMacs refinement,
+ *  treelet and centre exchange -- must give the same tree, layout, particles and expansion centres */
+template<class KeyType, class T>
+static void runGrav(int rank, int numRanks, LocalIndex numParticles, int numSyncs, unsigned bucketSize,
+                    unsigned bucketSizeFocus, float theta, const char* name)
+{
+    Box<T> box(-1, 1);
+    std::mt19937 gen(4321 + rank);
+    std::vector<T> x(numParticles), y(numParticles), z(numParticles), h(numParticles, T(0.01)), m(numParticles);
+    std::normal_distribution<T> blob(0, 0.3);
+    auto draw = [&]() { return std::max(std::min(blob(gen), T(0.999)), T(-0.999)); };
+    for (auto& v : x) v = draw();
+    for (auto& v : y) v = draw();
+    for (auto& v : z) v = draw();
+    for (LocalIndex i = 0; i < numParticles; ++i)
+        m[i] = T(1.0 + 0.001 * (i % 97)) / T(numParticles * numRanks);
+    std::vector<KeyType> keys(numParticles);
+
+    DeviceVector<KeyType> d_keys;
+    reallocate(d_keys, numParticles, 1.0);
+    DeviceVector<T> d_x = x, d_y = y, d_z = z, d_h = h, d_m = m;
+
+    Domain<KeyType, T, CpuTag> cpu(rank, numRanks, bucketSize, bucketSizeFocus, theta, box);
+    Domain<KeyType, T, GpuTag> gpu(rank, numRanks, bucketSize, bucketSizeFocus, theta, box);
+    std::vector<T> hs1, hs2, hs3;
+    DeviceVector<T> s1, s2, s3;
+    int before = g_failures;
+    for (int sync = 0; sync < numSyncs; ++sync)
+    {
+        {
+            int mine = g_failures - before, all = 0;
+            MPI_Allreduce(&mine, &all, 1, MPI_INT, MPI_SUM, MPI_COMM_WORLD);
+            if (all) break;
+        }
+        cpu.syncGrav(keys, x, y, z, h, m, std::tuple<>{}, std::tie(hs1, hs2, hs3));
+        progress(name, "cpu syncGrav done", sync);
+        gpu.syncGrav(d_keys, d_x, d_y, d_z, d_h, d_m, std::tuple<>{}, std::tie(s1, s2, s3));
+        progress(name, "gpu syncGrav done", sync);
+        expectSame("grav nParticles", cpu.nParticles(), gpu.nParticles(), sync);
+        expectSame("grav startIndex", cpu.startIndex(), gpu.startIndex(), sync);
+        expectSame("grav nParticlesWithHalos", cpu.nParticlesWithHalos(), gpu.nParticlesWithHalos(), sync);
+        expectEqual("grav global tree leaves", cpu.globalTree().treeLeaves(), gpu.globalTree().treeLeaves(), sync);
+        expectEqual("grav focus tree leaves", cpu.focusTree().treeLeaves(), gpu.focusTree().treeLeaves(), sync);
+        expectEqual("grav focus leaf counts", cpu.focusTree().leafCounts(), gpu.focusTree().leafCounts(), sync);
+        expectEqual("grav keys", keys, download(d_keys), sync);
+        expectEqual("grav x", x, download(d_x), sync);
+        expectEqual("grav m", m, download(d_m), sync);
+        {
+            // expansion (mass) centres and MAC radii of every focus-tree node
+            auto cc = cpu.focusTree().expansionCentersAcc();
+            auto cg = gpu.focusTree().expansionCentersAcc();
+            std::vector<SourceCenterType<T>> hostG(cg.size());
+            if (!hostG.empty()) memcpyD2H(cg.data(), cg.size(), hostG.data());
+            bool same = cc.size() == hostG.size();
+            size_t bad = 0;
+            for (size_t i = 0; same && i < hostG.size(); ++i)
+                for (int d = 0; d < 4; ++d)
+                    if (!(cc[i][d] == hostG[i][d])) { same = false, bad = i; }
+            if (!same)
+            {
+                ++g_failures;
+                std::printf("[rank %d] sync %d: grav expansion centres DIFFER (sizes %zu / %zu, node %zu)\n", rank, sync,
+                            size_t(cc.size()), hostG.size(), bad);
+            }
+        }
+        std::mt19937 mv(99 * sync + rank);
+        std::uniform_real_distribution<T> step(-1, 1);
+        for (LocalIndex i = cpu.startIndex(); i < cpu.endIndex(); ++i)
+        {
+            auto clampTo = [](T v) { return std::min(std::max(v, T(-0.999)), T(0.999)); };
+            x[i] = clampTo(x[i] + T(0.005) * step(mv));
+            y[i] = clampTo(y[i] + T(0.005) * step(mv));
+            z[i] = clampTo(z[i] + T(0.005) * step(mv));
+        }
+        d_x = x, d_y = y, d_z = z;
+    }
+    int local = g_failures - before, total = 0;
+    MPI_Allreduce(&local, &total, 1, MPI_INT, MPI_SUM, MPI_COMM_WORLD);
+    if (rank == 0)
+        std::printf("%s: %s (%d ranks, %u particles per rank, %d syncGrav calls, focus leaves on rank 0: %zu)\n", name,
+                    total ? "FAIL" : "PASS", numRanks, unsigned(numParticles), numSyncs,
+                    size_t(gpu.focusTree().treeLeaves().size() - 1));
+}
+
 int main(int argc, char** argv)
 {
     MPI_Init(&argc, &argv);
@@ -188,11 +291,14 @@ int main(int argc, char** argv)
         run<uint64_t, float>(rank, numRanks, n, numSyncs, Box<float>(0, 1, 0, 2, 0, 1, BoundaryType::open, BoundaryType::periodic,
                                                                    BoundaryType::open),
                              40, 10, 0.02f, true, "u64/f32 clustered mixed");
+        runGrav<uint64_t, double>(rank, numRanks, n, numSyncs, 64, 8, 0.5f, "u64/f64 syncGrav theta 0.5");
+        runGrav<unsigned, float>(rank, numRanks, n, numSyncs, 64, 16, 0.7f, "u32/f32 syncGrav theta 0.7");
     }
     catch (const std::exception& e)
     {
         std::printf("[rank %d] exception: %s\n", rank, e.what());
-        ++g_failures;
+        std::fflush(stdout);
+        MPI_Abort(MPI_COMM_WORLD, 2); // the peers are inside a sync: end the run instead of leaving them there
     }
     int local = g_failures, total = 0;
     MPI_Allreduce(&local, &total, 1, MPI_INT, MPI_SUM, MPI_COMM_WORLD);

@@ -166,15 +166,23 @@ def test_oracle_source_centers_against_reference(oracle, reference, tc, tm, tf):
 # ------------------------------------------------------------------------------------------------------------------
 # GPU: libcstone_hip == oracle
 # ------------------------------------------------------------------------------------------------------------------
+_KEEP = []  # uploaded arrays stay referenced: a temporary freed inside an argument list could be reused by the next upload
+
+
 def _dev(a):
     import torch
 
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:]
     a = np.ascontiguousarray(a)
     if a.dtype == np.uint32:
         a = a.view(np.int32)
     elif a.dtype == np.uint64:
         a = a.view(np.int64)
-    return torch.from_numpy(a.copy()).cuda()
+    t = torch.from_numpy(a.copy()).cuda()
+    _KEEP.append(t)
+    return t
 
 
 def _host(t, dtype):
@@ -353,7 +361,7 @@ def test_hip_small_primitives(hip, oracle):
     lens = rng.integers(0, 90, 5000)
     seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
     for ib, ob in ((32, 32), (64, 32), (64, 64)):
-        vals = rng.uniform(0, 1, int(seg[-1]) + 1).astype(orc.real_dtype(ib))
+        vals = rng.uniform(0, 1, int(seg[-1]) + 1).astype(orc.real_dtype(ib))  # empty segments must give 0
         out = torch.zeros(seg.size - 1, dtype=torch.float32 if ob == 32 else torch.float64, device="cuda")
         hip._chk(lib.cstone_hip_segment_max(h, ib, ob, 32, _p(_dev(vals)), _p(_dev(seg)), C.c_size_t(seg.size - 1), _p(out)),
                  "segment_max")
@@ -367,7 +375,7 @@ def test_hip_small_primitives(hip, oracle):
         src = rng.integers(0, 255, (101000, eb), dtype=np.uint8)
         buf = torch.zeros(int(scan[-1]) * eb, dtype=torch.uint8, device="cuda")
         hip._chk(lib.cstone_hip_gather_ranges(h, eb, 32, _p(_dev(scan[:-1])), _p(_dev(offs)), C.c_int(nr),
-                                              _p(torch.from_numpy(src).cuda()), _p(buf), C.c_size_t(int(scan[-1]))), "gather_ranges")
+                                              _p(_dev(src)), _p(buf), C.c_size_t(int(scan[-1]))), "gather_ranges")
         want = np.concatenate([src[offs[r]:offs[r] + rl[r]] for r in range(nr)])
         assert np.array_equal(buf.cpu().numpy().reshape(-1, eb), want)
     # fill / increment / scale / count / reduce / max norm / lower bound / keys-only sort

@@ -1,13 +1,9 @@
 cd $GRAFT_REPO_ROOT
-# debug / A-B of sort variants on one box: tools/rundbg.sh  (writes gpurun_out/dbg.log)
+# A-B of sort variants on one box: tools/rundbg.sh v1 v2 ...  (writes gpurun_out/dbg.log); "default" = the regular build
 : > gpurun_out/dbg.log
 V=$PWD/cornerstone-octree_amd/lib/variants
-for v in dbglds; do
-  echo "== $v 1e7" >> gpurun_out/dbg.log
-  CSTONE_HIP_LIB=$V/$v.so timeout -k 10 60 python3 tools/sort_bench.py --n 1e7 --reps 1 2>&1 | grep -v amdgpu.ids | head -40 >> gpurun_out/dbg.log
-done
 for round in 1 2 3; do
-  for v in early0 default; do
+  for v in "$@"; do
     if [ $v = default ]; then lib=$PWD/cornerstone-octree_amd/lib/libcstone_hip.so; else lib=$V/$v.so; fi
     for args in "" "--sorted"; do
       echo "== $v $args" >> gpurun_out/dbg.log
