@@ -141,14 +141,13 @@ class DistributedPipeline:
     global tree all-reduce, SFC assignment, particle all_to_all + merge, owner-side halo discovery + halo all_to_all;
     SURVEY.md section 8e) with the collectives served by torch.distributed (RCCL).  Every rank starts with a random 1/N
     of the cloud (the first sync moves (N-1)/N of it); before every step a random 1% of the assigned particles is
-    displaced by up to 2h so that the steady-state exchange really moves particles across the boundaries.
-    CSTONE_BENCH_PYTHON_DIST=1 selects the Python orchestration of the same algorithm (cstone_amd.distributed)."""
+    displaced by up to 2h so that the steady-state exchange really moves particles across the boundaries."""
 
     def __init__(self, ctx, n_local, n_global, key_bits, real_bits, curve, bucket, bucket_focus, seed):
         import torch
 
         import cstone_amd
-        from cstone_amd.distributed import Comm, DistributedDomain, HipBackend, NativeDistributedDomain
+        from cstone_amd.distributed import NativeDistributedDomain
 
         self.torch = torch
         dev = ctx.device
@@ -158,24 +157,20 @@ class DistributedPipeline:
         self.h0 = 0.6 * (3.0 * 100 / (4 * 3.141592653589793 * n_global)) ** (1.0 / 3.0)
         self.h = torch.full((n_local,), self.h0, dtype=rdt, device=dev)
         cv = cstone_amd.HILBERT if curve == "hilbert" else cstone_amd.MORTON
-        self.native = os.environ.get("CSTONE_BENCH_PYTHON_DIST") != "1"
+        self.native = True  # the multi-rank sync inside libcstone_hip (cstone_hip_domain_mr_sync)
         self.transport = "torch.distributed callbacks"
-        if self.native:
-            import torch.distributed as dist
+        import torch.distributed as dist
 
-            from cstone_amd.distributed import RcclCollectives
+        from cstone_amd.distributed import RcclCollectives
 
-            coll = None
-            if dist.get_backend() == "nccl" and os.environ.get("CSTONE_BENCH_TORCH_COLL") != "1":
-                # the data path: RCCL from C++ on the library's stream (csrc/comm_rccl.hip); torch.distributed only
-                # carries the RCCL id at start-up and serves the bench's own barriers and the max over the ranks
-                coll = RcclCollectives(ctx)
-                self.transport = "RCCL inside libcstone_hip (cstone_hip_comm_rccl, collectives on the library's stream)"
-            self.dom = NativeDistributedDomain(ctx, cv, key_bits, real_bits, bucket, bucket_focus, [0, 1] * 3, (0, 0, 0),
-                                               coll=coll)
-        else:
-            self.dom = DistributedDomain(HipBackend(ctx), Comm(), cv, key_bits, real_bits, bucket, bucket_focus,
-                                         [0, 1] * 3, (0, 0, 0))
+        coll = None
+        if dist.get_backend() == "nccl" and os.environ.get("CSTONE_BENCH_TORCH_COLL") != "1":
+            # the data path: RCCL from C++ on the library's stream (csrc/comm_rccl.hip); torch.distributed only carries the
+            # RCCL id at start-up and serves the bench's own barriers and the max over the ranks
+            coll = RcclCollectives(ctx)
+            self.transport = "RCCL inside libcstone_hip (cstone_hip_comm_rccl, collectives on the library's stream)"
+        self.dom = NativeDistributedDomain(ctx, cv, key_bits, real_bits, bucket, bucket_focus, [0, 1] * 3, (0, 0, 0),
+                                           coll=coll)
         self.f_leaves = self.g_leaves = 0
         self.assigned = n_local
         self.halos = 0
@@ -198,14 +193,10 @@ class DistributedPipeline:
         self.x, self.y, self.z, self.h = r["x"][s:e], r["y"][s:e], r["z"][s:e], r["h"][s:e]
         self.assigned, self.halos = e - s, r["x"].numel() - (e - s)
         self.last = r
-        if self.native:
-            v = self.dom.view()
-            self.f_leaves, self.g_leaves = v.num_focus_leaves, v.num_global_leaves
-            self.stats = dict(moved=v.particles_sent, halos=v.halos_received, served=v.halos_sent,
-                              halo_boxes=v.halo_boxes_exported)
-        else:
-            self.f_leaves, self.g_leaves = self.dom.f_leaves, self.dom.g_leaves
-            self.stats = dict(self.dom.stats)
+        v = self.dom.view()
+        self.f_leaves, self.g_leaves = v.num_focus_leaves, v.num_global_leaves
+        self.stats = dict(moved=v.particles_sent, halos=v.halos_received, served=v.halos_sent,
+                          halo_boxes=v.halo_boxes_exported)
 
     first_sync = step
 
@@ -546,11 +537,8 @@ def main():
                        "particles_per_gpu": n_local, "focus_leaves": pipe.f_leaves, "global_leaves": pipe.g_leaves,
                        **({"invariants_ok": invariants_ok, "rank0_assigned": pipe.assigned, "rank0_halos": pipe.halos,
                            "rank0_exchange": dict(pipe.stats),
-                           "orchestration": "libcstone_hip (cstone_hip_domain_mr_sync)" if pipe.native
-                           else "python (cstone_amd.distributed)",
-                           "transport": pipe.transport} if distributed else {}),
-                       **({"rank0_phase_ms": {k: v * 1e3 for k, v in pipe.dom.timing.items()}}
-                          if distributed and not pipe.native and pipe.dom.timing else {})},
+                           "orchestration": "libcstone_hip (cstone_hip_domain_mr_sync)",
+                           "transport": pipe.transport} if distributed else {})},
             "roofline": {"bound": "hbm", "kernel": "onesweepKernel (one 8-bit radix pass over key+index pairs)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic_per_launch, "traffic_source": traffic_source,

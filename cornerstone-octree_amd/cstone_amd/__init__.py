@@ -44,7 +44,7 @@ EXPORTS = [
     "cstone_hip_count_sfc_gaps", "cstone_hip_fill_sfc_gaps", "cstone_hip_geo_mac_spheres", "cstone_hip_set_mac",
     "cstone_hip_move_centers", "cstone_hip_leaf_source_centers", "cstone_hip_upsweep_centers",
     "cstone_hip_comm_rccl_unique_id", "cstone_hip_comm_rccl_create", "cstone_hip_comm_rccl_ops",
-    "cstone_hip_comm_rccl_destroy",
+    "cstone_hip_comm_rccl_destroy", "cstone_hip_create_binary_tree",
 ]
 
 

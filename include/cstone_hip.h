@@ -232,6 +232,13 @@ extern "C"
                                   void* tree, uint32_t* counts, int* num_leaves_host, int cap_leaves,
                                   uint32_t max_count, int* iterations_host);
 
+    /* createBinaryTreeGpu (R/tree/btree.cuh:41-52): the binary radix tree (Karras 2012) over the
+     * num_nodes + 1 keys of a cornerstone leaf array, num_nodes internal nodes of the reference's BinaryNode<KeyType>
+     * layout {int32 child[2]; KeyType prefix} (12 bytes for 32-bit keys, 16 for 64-bit keys).  A child that is a leaf is
+     * stored as (key index - 2^31) (R/tree/btree.hpp:48-66); prefix = common key prefix with the placeholder bit. */
+    int cstone_hip_create_binary_tree(cstone_hip_ctx* ctx, int key_bits, const void* tree, int num_nodes,
+                                      void* binary_nodes);
+
     /* ---------------------------------------------------------------------------------------------
      * linked octree: replaces buildOctreeGpu (R/tree/octree_gpu.h:47, R/tree/octree_gpu.cu:152-174).
      * Sizes with L = num_leaves, I = (L-1)/7, M = L+I:

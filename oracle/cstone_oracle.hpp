@@ -21,6 +21,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <limits>
 #include <numeric>
 #include <vector>
 
@@ -1298,6 +1299,56 @@ void gatherRanges(const I* scan, const I* offsets, int numRanges, const E* src, 
     {
         int r     = int(std::upper_bound(scan, scan + numRanges, I(i)) - scan) - 1;
         buffer[i] = src[offsets[r] + I(i) - scan[r]];
+    }
+}
+
+//! binary radix tree over the keys of a leaf array (Karras 2012), R/tree/btree.hpp:104-264: child[2 i], child[2 i + 1]
+//! and prefix[i] of internal node i; a leaf child is stored as index - 2^31 (:48-66)
+template<class K>
+void binaryTree(const K* codes, NodeIdx numCodes, NodeIdx* child, K* prefix)
+{
+    auto cpl = [&](NodeIdx a, NodeIdx b) { return sharedPrefixBits<K>(codes[a], codes[b]); };
+    for (NodeIdx first = 0; first < numCodes - 1; ++first)
+    {
+        int d = 1, minPrefix = -1;
+        if (first > 0)
+        {
+            d         = cpl(first, first + 1) > cpl(first, first - 1) ? 1 : -1;
+            minPrefix = cpl(first, first - d);
+        }
+        NodeIdx range = 2, second = first + range * d;
+        while (0 <= second && second < numCodes && cpl(first, second) > minPrefix)
+        {
+            range *= 2;
+            second = first + range * d;
+        }
+        second = first;
+        do
+        {
+            range        = (range + 1) / 2;
+            NodeIdx cand = second + range * d;
+            if (0 <= cand && cand < numCodes && cpl(first, cand) > minPrefix) second = cand;
+        } while (range > 1);
+        int nbits     = cpl(first, second);
+        K low         = (K(1) << (3 * maxLevel<K>() - nbits)) - 1;
+        prefix[first] = toPrefix<K>(codes[first] & ~low, nbits);
+        NodeIdx lo = std::min(first, second), hi = std::max(first, second), split;
+        if (codes[lo] == codes[hi]) { split = (lo + hi) >> 1; }
+        else
+        {
+            int common   = cpl(lo, hi);
+            split        = lo;
+            NodeIdx step = hi - lo;
+            do
+            {
+                step         = (step + 1) / 2;
+                NodeIdx cand = split + step;
+                if (cand < hi && cpl(lo, cand) > common) split = cand;
+            } while (step > 1);
+        }
+        const NodeIdx leafOffset = std::numeric_limits<NodeIdx>::min();
+        child[2 * first]     = lo == split ? split + leafOffset : split;
+        child[2 * first + 1] = hi == split + 1 ? split + 1 + leafOffset : split + 1;
     }
 }
 

@@ -409,6 +409,15 @@ class _CpuImpl:
         assert rc == 0, rc
         return out
 
+    def binary_tree(self, leaves):
+        """(child[n][2], prefix[n]) of the binary radix tree over a cornerstone leaf array (btree)"""
+        n = leaves.size - 1
+        child = np.zeros((n, 2), dtype=np.int32)
+        prefix = np.zeros(n, dtype=leaves.dtype)
+        rc = self._f("binary_tree")(C.c_int(leaves.dtype.itemsize * 8), _p(leaves), C.c_int(n), _p(child), _p(prefix))
+        assert rc == 0, rc
+        return child, prefix
+
     def num_threads(self):
         return int(self._f("num_threads")())
 

@@ -574,6 +574,17 @@ int cstone_oracle_random_uniform(int real_bits, unsigned seed, size_t n, const d
                     });
 }
 
+//! child[2 * num_nodes], prefix[num_nodes] of the binary radix tree over tree[0 .. num_nodes]
+int cstone_oracle_binary_tree(int key_bits, const void* tree, int num_nodes, int* child, void* prefix)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       binaryTree<K>((const K*)tree, num_nodes + 1, child, (K*)prefix);
+                   });
+}
+
 int cstone_oracle_num_threads()
 {
 #ifdef _OPENMP

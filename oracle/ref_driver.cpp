@@ -18,6 +18,7 @@
 #include "cstone/sfc/sfc.hpp"
 #include "cstone/traversal/collisions.hpp"
 #include "cstone/traversal/macs.hpp"
+#include "cstone/tree/btree.hpp"
 #include "cstone/tree/csarray.hpp"
 #include "cstone/tree/octree.hpp"
 
@@ -443,6 +444,23 @@ int cstone_ref_upsweep_centers(int real_bits, int num_levels, const int* level_r
                         upsweep({level_range, size_t(num_levels) + 1}, {child_offsets, size_t(level_range[num_levels])},
                                 (SourceCenterType<T>*)centers, CombineSourceCenter<T>{});
                     });
+}
+
+int cstone_ref_binary_tree(int key_bits, const void* tree, int num_nodes, int* child, void* prefix)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       std::vector<BinaryNode<K>> nodes(num_nodes);
+                       createBinaryTree((const K*)tree, num_nodes, nodes.data());
+                       for (int i = 0; i < num_nodes; ++i)
+                       {
+                           child[2 * i]     = nodes[i].child[0];
+                           child[2 * i + 1] = nodes[i].child[1];
+                           ((K*)prefix)[i]  = nodes[i].prefix;
+                       }
+                   });
 }
 
 int cstone_ref_num_threads()

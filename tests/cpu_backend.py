@@ -1,11 +1,11 @@
-"""TEST INFRASTRUCTURE: CPU stand-in for cstone_amd.distributed.HipBackend built on the oracle, so that the multi-rank
-orchestration (cstone_amd/distributed.py) can be rehearsed with gloo on machines without a GPU.  torch CPU tensors
+"""TEST INFRASTRUCTURE: CPU stand-in for py_domain.HipBackend built on the oracle, so that the multi-rank
+orchestration (tests/py_domain.py) can be rehearsed with gloo on machines without a GPU.  torch CPU tensors
 carry the data; keys travel as int64/int32 bit patterns exactly as on the device."""
 import numpy as np
 import torch
 
 from oracle import oracle as orc
-from cstone_amd.distributed import signed_key
+from py_domain import signed_key
 
 
 def _k(t, kb):  # torch int tensor -> numpy unsigned view

@@ -77,7 +77,7 @@ def make_native(backend, bucket, bucket_focus, lim, bc, curve=1, key_bits=64, re
 def golden(a, backend, dev, rank, P):
     """the reference's Domain on P MPI ranks (fixture) against DistributedDomain on P torch.distributed ranks: box,
     SFC ranges, global tree + counts and the assigned particles (keys, x, h) of every rank after every sync, bit for bit"""
-    from cstone_amd.distributed import Comm, DistributedDomain
+    from py_domain import Comm, DistributedDomain
     from oracle import oracle as orc
 
     g = np.load(a.golden)
@@ -173,14 +173,14 @@ def main():
     ap.add_argument("--curve", default="hilbert", choices=["hilbert", "morton"])
     ap.add_argument("--lopsided", type=int, default=0, help="1: the last rank starts without particles")
     ap.add_argument("--impl", default="python", choices=["python", "native"],
-                    help="python: cstone_amd.distributed.DistributedDomain; native: cstone_hip_domain_mr_* (hip only)")
+                    help="python: tests/py_domain.DistributedDomain; native: cstone_hip_domain_mr_* (hip only)")
     ap.add_argument("--fail-at", default="", help="native only: after one good sync, rank 1 is made to fail at this point "
                                                   "of the next sync (CSTONE_MR_FAIL_AT); every rank must get an error")
     a = ap.parse_args()
     dist.init_process_group("gloo")
     rank, P = dist.get_rank(), dist.get_world_size()
 
-    from cstone_amd.distributed import Comm, DistributedDomain, HipBackend
+    from py_domain import Comm, DistributedDomain, HipBackend
     from oracle import oracle as orc
 
     o = orc.Oracle()

@@ -11,7 +11,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cornerstone-octree_amd"))
 
-from cstone_amd.distributed import limit_boundary_shifts, signed_key, uniform_bins  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from py_domain import limit_boundary_shifts, signed_key, uniform_bins  # noqa: E402
 
 
 def test_uniform_bins_known_answers():
@@ -133,7 +134,7 @@ GOLDEN_MPI_CPU = GOLDEN_MPI + [("ref_domain_mpi_P6_uniform_pbc.npz", 6), ("ref_d
 
 def test_host_spanning_tree_against_oracle(oracle):
     """initial global tree of GlobalAssignment (assignment.hpp:42-53) against the pinned oracle"""
-    from cstone_amd.distributed import initial_domain_splits, log8ceil, spanning_tree
+    from py_domain import initial_domain_splits, log8ceil, spanning_tree
 
     assert [log8ceil(n) for n in (1, 8, 9, 100, 512, 513)] == [0, 1, 2, 3, 3, 4]
     for kb in (32, 64):

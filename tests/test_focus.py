@@ -408,3 +408,39 @@ def test_hip_small_primitives(hip, oracle):
         hip._chk(lib.cstone_hip_sort_keys(h, kb, _p(kd), C.c_size_t(k.size)), "sort_keys")
         assert np.array_equal(_host(kd, k.dtype), np.sort(k))
     hip.sync()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# binary radix tree (btree), SURVEY.md section 8f-4
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kb", [32, 64])
+def test_oracle_binary_tree_against_reference(oracle, reference, kb):
+    for seed, n, bucket in ((1, 20000, 16), (2, 500, 1), (3, 3000, 64)):
+        _, leaves, _, _, _, _ = _tree(oracle, kb, n, bucket, seed, clustered=seed % 2 == 0)
+        ca, pa = oracle.binary_tree(leaves)
+        cb, pb = reference.binary_tree(leaves)
+        assert np.array_equal(ca, cb) and np.array_equal(pa, pb)
+        # root covers everything: prefix 1 (placeholder bit only); every leaf (key index below the terminal key, whose set
+        # bit lies above the key bits) is some node's leaf child exactly once
+        assert int(pa[0]) == 1
+        leaf_children = ca[ca < 0].astype(np.int64) + 2**31
+        assert np.array_equal(np.sort(leaf_children), np.arange(leaves.size - 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kb", [32, 64])
+def test_hip_binary_tree(hip, oracle, kb):
+    import torch
+
+    for seed, n, bucket in ((1, 300000, 16), (2, 500, 1), (3, 30000, 64)):
+        _, leaves, _, _, _, _ = _tree(oracle, kb, n, bucket, seed, clustered=seed % 2 == 0)
+        m = leaves.size - 1
+        node_bytes = 12 if kb == 32 else 16
+        out = torch.zeros(m * node_bytes, dtype=torch.uint8, device="cuda")
+        hip._chk(hip.lib.cstone_hip_create_binary_tree(hip.h, kb, _p(_dev(leaves)), C.c_int(m), _p(out)), "binary_tree")
+        dt = np.dtype([("child", np.int32, 2), ("prefix", np.uint32 if kb == 32 else np.uint64)])
+        assert dt.itemsize == node_bytes
+        got = out.cpu().numpy().view(dt)
+        child, prefix = oracle.binary_tree(leaves)
+        assert np.array_equal(got["child"], child) and np.array_equal(got["prefix"], prefix)
+    hip.sync()
