@@ -305,13 +305,32 @@ __global__ __launch_bounds__(256) void gatherHaloRadiiKernel(const Th* __restric
     float out = 0.0f;
     if (b > a)
     {
-        Th m = h[order[a]];
-        for (uint32_t i = a + sub; i < b; i += 16)
+        // four slots per lane at a time (a leaf holds at most a bucket, typically 30-60 particles): all index loads go
+        // out together, then all value loads -- three dependent memory round trips per leaf instead of one per slot
+        Th m          = 0;
+        bool haveAny  = false;
+        for (uint32_t base = a + sub; base < b; base += 64)
         {
-            Th v    = h[order[i]];
-            hOut[i] = v;
-            m       = v > m ? v : m;
+            uint32_t idx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                idx[u] = base + 16 * u < b ? order[base + 16 * u] : 0u;
+            Th v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (base + 16 * u < b) v[u] = h[idx[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (base + 16 * u < b)
+                {
+                    hOut[base + 16 * u] = v[u];
+                    m                   = (!haveAny || v[u] > m) ? v[u] : m;
+                    haveAny             = true;
+                }
         }
+        // lanes without a particle of this leaf hold no candidate: take the first lane's (it always has one)
+        Th m0 = __shfl(m, int(threadIdx.x & 63u & ~15u));
+        if (!haveAny) m = m0;
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1)
         {

@@ -88,6 +88,34 @@ if perk:
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python bench.py --steps 3` (N = 1e8), largest grid "
                          "per kernel; FETCH_SIZE doubled (gfx950); durations are those of the counter runs",
                "kernels": table}, open(f"profiles/{tag}_kernel_hbm_traffic.json", "w"), indent=1)
+# the multi-rank sync at the per-GPU size of the 8-GPU point (tools/mr_bench.py --rccl --particles 1.25e7): kernels per
+# sync, averaged over the last 10 syncs of the trace (a sync starts with its one encodeHistogramKernel launch)
+for trace in glob.glob(os.path.join(src, "mr", "**", "*kernel_trace.csv"), recursive=True):
+    rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
+    starts = [i for i, r in enumerate(rows) if "encodeHistogramKernel" in r["Kernel_Name"]]
+    if len(starts) < 12:
+        continue
+    use = starts[-11:]
+    per = defaultdict(lambda: [0, 0.0])
+    wall = 0.0
+    for a, b in zip(use[:-1], use[1:]):
+        wall += (int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e6
+        for r in rows[a:b]:
+            name = re.sub(r"^void |cship::\(anonymous namespace\)::|cship::", "", r["Kernel_Name"]).split("(")[0]
+            if "at::native" in name or "elementwise" in name or "Cijk" in name:
+                name = "torch kernels of the particle displacement (bench jiggle)"
+            per[name][0] += 1
+            per[name][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    n = len(use) - 1
+    kernels = sorted(({"name": k, "launches_per_sync": v[0] / n, "us_per_sync": round(v[1] / n, 2)} for k, v in per.items()),
+                     key=lambda e: -e["us_per_sync"])
+    json.dump({"source": "rocprofv3 --kernel-trace of tools/mr_bench.py --rccl --particles 1.25e7 (cstone_hip_domain_mr_sync, "
+                         "one rank, RCCL collectives from inside the library, 1 % of the particles displaced before every "
+                         "sync), averages over the last 10 syncs",
+               "launches_per_sync": sum(e["launches_per_sync"] for e in kernels),
+               "kernel_time_ms_per_sync": sum(e["us_per_sync"] for e in kernels) / 1e3,
+               "wall_ms_per_sync_under_profiler": wall / n, "kernels": kernels},
+              open(f"profiles/{tag}_mr_sync_kernels.json", "w"), indent=1)
 print("wrote", sorted(os.listdir("profiles")))
 
 # the JSON line bench.py printed under the profiler (its live roofline number belongs next to the kernel stats)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""rehearsal of the multi-rank domain with several gloo ranks on ONE GPU (the collectives are host-staged and the ranks
-share the GPU, so only the relative phase costs mean anything): CSTONE_MR_TIMING=1 torchrun ... tools/mr_bench.py"""
+"""rehearsal of the multi-rank domain on ONE GPU: several gloo ranks (collectives host-staged, ranks share the GPU: only the
+relative phase costs mean anything; CSTONE_MR_TIMING=1 torchrun ... tools/mr_bench.py) or, with --rccl and no launcher,
+a world of ONE rank whose collectives are served by RCCL from C++ inside the library (the workload of
+profiles/r02_mr_sync_kernels.json: the per-GPU share of the 8-GPU point is --particles 1.25e7)"""
 import argparse
 import os
 import sys
@@ -15,8 +17,17 @@ import torch.distributed as dist  # noqa: E402
 p = argparse.ArgumentParser()
 p.add_argument("--particles", type=float, default=2e7, help="global")
 p.add_argument("--syncs", type=int, default=8)
+p.add_argument("--rccl", action="store_true", help="backend nccl: RCCL collectives from inside libcstone_hip")
 a = p.parse_args()
-dist.init_process_group("gloo")
+if a.rccl:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+else:
+    dist.init_process_group("gloo")
 rank, P = dist.get_rank(), dist.get_world_size()
 import cstone_amd  # noqa: E402
 from bench import DistributedPipeline  # noqa: E402
@@ -34,7 +45,7 @@ torch.cuda.synchronize()
 dist.barrier()
 dt = (time.perf_counter() - t0) / a.syncs
 if rank == 0:
-    print(f"{P} gloo ranks on one GPU, {n:.1e} particles: {dt*1e3:.2f} ms per sync; rank 0: assigned {pipe.assigned}, "
+    print(f"{P} {'RCCL' if a.rccl else 'gloo'} rank(s) on one GPU, {n:.1e} particles: {dt*1e3:.2f} ms per sync; rank 0: assigned {pipe.assigned}, "
           f"halos {pipe.halos}, {pipe.stats}", flush=True)
 del pipe
 dist.destroy_process_group()

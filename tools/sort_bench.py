@@ -17,6 +17,8 @@ p.add_argument("--n", type=float, default=1e8)
 p.add_argument("--key-bits", type=int, default=64)
 p.add_argument("--reps", type=int, default=3)
 p.add_argument("--sorted", action="store_true", help="input already sorted (steady-state sync)")
+p.add_argument("--alt-offset", type=int, default=0, help="byte offset of the alternate buffers inside their allocations "
+                                                         "(do the read and the write stream collide in the DRAM banks?)")
 a = p.parse_args()
 n = int(a.n)
 ctx = cstone_amd.Context(0)
@@ -29,7 +31,13 @@ if a.sorted:
     src = torch.sort(src).values
 keys = torch.empty_like(src)
 vals = torch.empty(n, dtype=torch.int32, device="cuda")
-ka, va = torch.empty_like(keys), torch.empty_like(vals)
+if a.alt_offset:
+    kraw = torch.empty(keys.numel() * keys.element_size() + a.alt_offset, dtype=torch.uint8, device="cuda")
+    vraw = torch.empty(vals.numel() * 4 + a.alt_offset, dtype=torch.uint8, device="cuda")
+    ka = kraw[a.alt_offset:].view(keys.dtype)
+    va = vraw[a.alt_offset:].view(torch.int32)
+else:
+    ka, va = torch.empty_like(keys), torch.empty_like(vals)
 tmp = torch.empty(ctx.sort_temp_bytes(a.key_bits, n), dtype=torch.uint8, device="cuda")
 ctx.profile_enable(True)
 for rep in range(a.reps + 1):
