@@ -1,6 +1,7 @@
 // runtime part of the C ABI: context, memory, copies, stage timers
 // replaces R/cuda/device_vector.{h,cu}, cuda_stubs.h:48-57, errorcheck.cuh (R = reference include/cstone)
 #include <algorithm>
+#include <cstdio>
 
 #include "ctx.hpp"
 #include "hilbert_tables.hpp"
@@ -83,6 +84,8 @@ static int drainBrackets(cstone_hip_ctx* ctx)
 
 using namespace cship;
 
+static thread_local char gCreateError[256] = "null context";
+
 extern "C"
 {
 
@@ -92,44 +95,42 @@ int cstone_hip_ctx_create(cstone_hip_ctx** out, int device, void* stream, int pr
     *out      = nullptr;
     auto* ctx = new cstone_hip_ctx;
     ctx->device = device;
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess)
+    // no context to hold the message yet: cstone_hip_last_error(NULL) returns it
+    auto giveUp = [&](const char* what, hipError_t e)
     {
+        std::snprintf(gCreateError, sizeof gCreateError, "cstone_hip_ctx_create: %s on device %d: %s", what, device,
+                      hipGetErrorString(e));
+        (void)hipGetLastError();
+        if (ctx->hilbertTables) (void)hipFree(ctx->hilbertTables);
+        if (ctx->devScalars) (void)hipFree(ctx->devScalars);
+        if (ctx->hostScalars) (void)hipHostFree(ctx->hostScalars);
+        if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return CSTONE_E_HIP;
-    }
+    };
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return giveUp("hipSetDevice", e);
     if (!private_stream) { ctx->stream = (hipStream_t)stream; }
     else
     {
         e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-        if (e != hipSuccess)
-        {
-            delete ctx;
-            return CSTONE_E_HIP;
-        }
+        if (e != hipSuccess) return giveUp("hipStreamCreateWithFlags", e);
         ctx->ownStream = true;
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->numCu = prop.multiProcessorCount;
-    if (hipHostMalloc((void**)&ctx->hostScalars, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-        hipMalloc((void**)&ctx->devScalars, 64 * sizeof(int)) != hipSuccess)
-    {
-        delete ctx;
-        return CSTONE_E_HIP;
-    }
-    if (hipMemset(ctx->devScalars, 0, 64 * sizeof(int)) != hipSuccess)
-    {
-        delete ctx;
-        return CSTONE_E_HIP;
-    }
+    e = hipHostMalloc((void**)&ctx->hostScalars, 64 * sizeof(int), hipHostMallocDefault);
+    if (e != hipSuccess) return giveUp("hipHostMalloc of the scalar page", e);
+    e = hipMalloc((void**)&ctx->devScalars, 64 * sizeof(int));
+    if (e != hipSuccess) return giveUp("hipMalloc of the device scalars", e);
+    e = hipMemset(ctx->devScalars, 0, 64 * sizeof(int));
+    if (e != hipSuccess) return giveUp("hipMemset of the device scalars", e);
     {
         HilbertTables t = makeHilbertTables();
-        if (hipMalloc(&ctx->hilbertTables, sizeof t) != hipSuccess ||
-            hipMemcpy(ctx->hilbertTables, &t, sizeof t, hipMemcpyHostToDevice) != hipSuccess)
-        {
-            delete ctx;
-            return CSTONE_E_HIP;
-        }
+        e = hipMalloc(&ctx->hilbertTables, sizeof t);
+        if (e != hipSuccess) return giveUp("hipMalloc of the Hilbert tables", e);
+        e = hipMemcpy(ctx->hilbertTables, &t, sizeof t, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return giveUp("upload of the Hilbert tables", e);
     }
     *out = ctx;
     return CSTONE_OK;
@@ -172,7 +173,7 @@ int cstone_hip_ctx_sync(cstone_hip_ctx* ctx)
     return CSTONE_OK;
 }
 
-const char* cstone_hip_last_error(cstone_hip_ctx* ctx) { return ctx ? ctx->lastError.c_str() : "null context"; }
+const char* cstone_hip_last_error(cstone_hip_ctx* ctx) { return ctx ? ctx->lastError.c_str() : gCreateError; }
 
 int cstone_hip_device_info(cstone_hip_ctx* ctx, int* num_cu, int* wave_size)
 {

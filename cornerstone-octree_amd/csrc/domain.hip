@@ -15,6 +15,7 @@
 #include "ctx.hpp"
 #include "devbuf.hpp"
 #include "device_keys.hpp"
+#include "resort.hpp"
 #include "scan.hpp"
 
 namespace cship
@@ -124,6 +125,7 @@ struct DomainBase
     virtual int view(cstone_hip_domain_view* out)        = 0;
     virtual void setHaloFactor(float factor)             = 0;
     virtual int reapplySync(const void* in, size_t n, int elemBytes, void* out) = 0;
+    virtual void stats(cstone_hip_domain_stats* out)     = 0;
 };
 
 template<class K, class T>
@@ -224,9 +226,91 @@ public:
             if (startPass == 0) CS_HIP(ctx_, hipMemsetAsync(ctx_->devScalars + 3, 0, sizeof(int), ctx_->stream));
             return CSTONE_OK;
         };
+        // the box the extents of this sync ask for (makeGlobalBox + limitBoxShrinking); true: it differs from box_
+        auto nextBox = [&](const double* ext, cstone_box& next)
+        {
+            double lim[6];
+            for (int d = 0; d < 3; ++d)
+            {
+                const bool pbc = box_.bc[d] == 1;
+                lim[2 * d]     = pbc ? box_.lim[2 * d] : ext[2 * d];
+                lim[2 * d + 1] = pbc ? box_.lim[2 * d + 1] : ext[2 * d + 1];
+            }
+            next = box_;
+            boxFromExtents(lim, next);
+            bool changed = false;
+            for (int k = 0; k < 6; ++k)
+                changed = changed || next.lim[k] != box_.lim[k];
+            return changed;
+        };
+
+        // ---- the incremental re-sort (resort.hpp): particles that are still inside the leaf their position belonged to
+        //      at the previous sync are ordered leaf by leaf, the others are binned into their new leaves.  Same result
+        //      as the sort of all keys; a box that changed, too many movers or an overfull leaf take the regular path.
+        const int tileLeaves = LeafResort<K>::leavesPerTile(bucketFocus_);
+        bool sorted          = false;
+        const bool tryResort = !firstCall_ && tileLeaves > 0 && layoutLeaves_ == fLeaves_ && fLeaves_ > 0 &&
+                               resortBackoff_ == 0 && std::getenv("CSTONE_NO_RESORT") == nullptr &&
+                               std::getenv("CSTONE_FULL_SORT") == nullptr;
+        if (resortBackoff_ > 0) --resortBackoff_;
+        if (tryResort)
+        {
+            CS_TRY(resort_.prepare(ctx_, fTree_.as<K>(), layout_.as<uint32_t>(), fLeaves_, n, keysAlt_.as<K>()));
+            const ResortArgs<K> ra = resort_.args();
+            bool done              = false;
+            CS_TRY(computeKeysResort(ctx_, curve_, kb, rb, *xPP, *yPP, *zPP, keys, n, box_, &ra,
+                                     speculate ? extentsDev : nullptr, &done));
+            if (done)
+            {
+                CS_TRY(resort_.binMovers(ctx_, tileLeaves));
+                // one read-back: the extents (slots 16..27) and what the re-sort found (28..31)
+                CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars + 16, ctx_->devScalars + 16, 16 * sizeof(int),
+                                            hipMemcpyDeviceToHost, ctx_->stream));
+                CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
+                bool boxChanged = false;
+                cstone_box next = box_;
+                if (speculate)
+                {
+                    double ext[6];
+                    for (int k = 0; k < 6; ++k)
+                        ext[k] = double(extentsHost[k]);
+                    boxChanged = nextBox(ext, next);
+                }
+                const uint32_t markers = uint32_t(ctx_->hostScalars[RESORT_SCALARS]);
+                const int flags        = ctx_->hostScalars[RESORT_SCALARS + 1];
+                const uint32_t J       = uint32_t(ctx_->hostScalars[RESORT_SCALARS + 2]);
+                const uint32_t movers  = uint32_t(ctx_->hostScalars[RESORT_SCALARS + 3]);
+                if (!boxChanged && flags == 0 && movers <= n / 16)
+                {
+                    CS_TRY(resort_.sortLeaves(ctx_, keysAlt_.as<K>(), keys, order_.as<uint32_t>(), movers, markers, J,
+                                              tileLeaves));
+                    CS_HIP(ctx_, hipMemsetAsync(ctx_->devScalars + 3, 0, sizeof(int), ctx_->stream));
+                    sorted      = true;
+                    lastMovers_ = movers;
+                    ++resorts_;
+                }
+                else
+                {
+                    // the caller's key array has not been touched: the regular path starts from scratch, with the box
+                    // this sync needs (the extents are known by now)
+                    if (boxChanged)
+                    {
+                        box_ = next;
+                        ++boxRedos_;
+                    }
+                    else
+                    {
+                        resortBackoff_ = 4;
+                        ++resortFallbacks_;
+                    }
+                    speculate = false;
+                }
+            }
+        }
+
         bool measured = false;
-        CS_TRY(encodeAndSort(speculate, &measured));
-        if (speculate)
+        if (!sorted) CS_TRY(encodeAndSort(speculate, &measured));
+        if (!sorted && speculate)
         {
             double lim[6];
             if (measured)
@@ -242,14 +326,8 @@ public:
                 const void* all[3] = {*xPP, *yPP, *zPP};
                 CS_TRY(minMaxCoordinates(ctx_, rb, all, 3, n, lim));
             }
-            for (int d = 0; d < 3; ++d)
-                if (box_.bc[d] == 1) lim[2 * d] = box_.lim[2 * d], lim[2 * d + 1] = box_.lim[2 * d + 1];
             cstone_box next = box_;
-            boxFromExtents(lim, next);
-            bool changed = false;
-            for (int k = 0; k < 6; ++k)
-                changed = changed || next.lim[k] != box_.lim[k];
-            if (changed)
+            if (nextBox(lim, next))
             {
                 // the particles have left the box (or shrunk away from it by more than 5 %): keys and order again
                 box_ = next;
@@ -375,6 +453,7 @@ public:
         endIndex_   = numAssigned;
         lastN_      = n;
         bufSize_    = numAssigned;
+        ++syncs_;
         firstCall_  = false;
         // the sticky device-side error word (look-back spin bail-out of the sort, traversal stack overflow ...): a sync
         // that tripped one of those checks must not report success (tests: CSTONE_FORCE_DEVICE_ERROR raises it)
@@ -421,9 +500,20 @@ public:
         return cstone_hip_gather(ctx_, elemBytes, order_.as<uint32_t>(), endIndex_, in, out);
     }
 
+    void stats(cstone_hip_domain_stats* out) override
+    {
+        out->syncs               = syncs_;
+        out->resorts             = uint32_t(resorts_);
+        out->resort_fallbacks    = uint32_t(resortFallbacks_);
+        out->box_redos           = uint32_t(boxRedos_);
+        out->full_sort_fallbacks = uint32_t(fullSortFallbacks_);
+        out->last_movers         = lastMovers_;
+    }
+
     float haloSearchExt_ = 1.0f;
 
 private:
+    uint32_t syncs_ = 0, lastMovers_ = 0;
     size_t lastN_ = 0; // input size of the last sync
     int boxRedos_ = 0; // syncs whose speculative keys had to be recomputed because the box changed
     int ensureTree(DevBuf& tree, DevBuf& counts, int& cap, int need)
@@ -547,6 +637,8 @@ private:
     uint32_t startIndex_ = 0, endIndex_ = 0, bufSize_ = 0;
 
     DevBuf order_, orderAlt_, keysAlt_, sortTmp_;
+    LeafResort<K> resort_;
+    int resortBackoff_ = 0, resorts_ = 0, resortFallbacks_ = 0;
     DevBuf gTree_, gCounts_;
     int gCap_ = 0, gLeaves_ = 0;
     DevBuf fTree_, fLeafCounts_, fCounts_, newTree_;
@@ -622,6 +714,13 @@ int cstone_hip_domain_view_get(cstone_hip_domain* dom, cstone_hip_domain_view* o
 {
     if (!dom || !out) return CSTONE_E_ARG;
     return dom->impl->view(out);
+}
+
+int cstone_hip_domain_stats_get(cstone_hip_domain* dom, cstone_hip_domain_stats* out)
+{
+    if (!dom || !out) return CSTONE_E_ARG;
+    dom->impl->stats(out);
+    return CSTONE_OK;
 }
 
 int cstone_hip_domain_reapply_sync(cstone_hip_domain* dom, const void* in, size_t n, int elem_bytes, void* out)

@@ -1,0 +1,400 @@
+// Incremental re-sort of Domain::sync: leaf table, mover binning and the leaf pass (see resort.hpp for the scheme).
+// Replaces, for a sync whose particles mostly stayed in their leaves, the reference's full sort of all keys
+// (sortByKeyGpu, R/primitives/primitives_gpu.cu:305-353).  gfx950: wave64, 160 KB LDS per CU.
+#include <algorithm>
+
+#include "device_keys.hpp"
+#include "resort.hpp"
+#include "scan.hpp"
+
+namespace cship
+{
+namespace
+{
+
+//! bit p of mask: a non-empty leaf starts at position p
+__global__ __launch_bounds__(256) void markLeafStartsKernel(const uint32_t* __restrict__ layout, int numLeaves,
+                                                            unsigned long long* __restrict__ mask)
+{
+    int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= numLeaves) return;
+    uint32_t a = layout[l], b = layout[l + 1];
+    if (b > a) atomicOr(&mask[a >> 6], 1ull << (a & 63u));
+}
+
+__global__ __launch_bounds__(256) void popcountWordsKernel(const uint64_t* __restrict__ mask, size_t words,
+                                                           uint32_t* __restrict__ out)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < words) out[i] = uint32_t(__popcll(mask[i]));
+}
+
+//! the j-th non-empty leaf: first key (0 for the first one: keys in front of it belong to it) and first position;
+//! entries J and J + 1 close the table: keys from endKey on (the remove markers) form a leaf of their own without positions
+template<class K>
+__global__ __launch_bounds__(256) void fillCompactLeavesKernel(const K* __restrict__ tree,
+                                                               const uint32_t* __restrict__ layout, int numLeaves,
+                                                               const uint64_t* __restrict__ mask,
+                                                               const uint32_t* __restrict__ rank,
+                                                               const uint32_t* __restrict__ numCompact, uint32_t n,
+                                                               K* __restrict__ leafLo, uint32_t* __restrict__ leafPos)
+{
+    int l = blockIdx.x * 256 + threadIdx.x;
+    if (l == 0)
+    {
+        uint32_t J     = *numCompact;
+        leafLo[J]      = endKey<K>();
+        leafLo[J + 1]  = ~K(0);
+        leafPos[J]     = n;
+        leafPos[J + 1] = n;
+    }
+    if (l >= numLeaves) return;
+    uint32_t a = layout[l], b = layout[l + 1];
+    if (b <= a) return;
+    uint32_t j = rank[a >> 6] + uint32_t(__popcll(mask[a >> 6] & ((1ull << (a & 63u)) - 1)));
+    leafLo[j]  = j == 0 ? K(0) : tree[l];
+    leafPos[j] = a;
+}
+
+//! leaf of a mover's new key, its slot among the movers arriving there
+template<class K>
+__global__ __launch_bounds__(256) void binMoversKernel(const K* __restrict__ moverKeys,
+                                                       const uint32_t* __restrict__ moverCount, uint32_t moverCap,
+                                                       const K* __restrict__ leafLo,
+                                                       const uint32_t* __restrict__ numCompact,
+                                                       uint32_t* __restrict__ incoming, uint32_t* __restrict__ dest,
+                                                       uint32_t* __restrict__ slot)
+{
+    const uint32_t M = *moverCount;
+    if (M > moverCap) return; // list incomplete: the caller falls back
+    const uint32_t J = *numCompact;
+    for (uint32_t m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256)
+    {
+        const K key = moverKeys[m];
+        // last j in [0, J] with leafLo[j] <= key (leafLo[0] = 0)
+        uint32_t lo = 0, hi = J + 1;
+        while (hi - lo > 1)
+        {
+            uint32_t mid = (lo + hi) / 2;
+            if (leafLo[mid] <= key) lo = mid;
+            else hi = mid;
+        }
+        dest[m] = lo;
+        slot[m] = atomicAdd(&incoming[lo], 1u);
+    }
+}
+
+//! size of every leaf after the moves; [1] |= 1: a leaf too long for the leaf pass
+__global__ __launch_bounds__(256) void newLeafSizesKernel(const uint32_t* __restrict__ leafPos,
+                                                          const uint32_t* __restrict__ outCount,
+                                                          const uint32_t* __restrict__ incoming,
+                                                          const uint32_t* __restrict__ numCompact, uint32_t entries,
+                                                          uint32_t* __restrict__ newCount, int* __restrict__ scalars)
+{
+    uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= entries) return;
+    const uint32_t J = *numCompact;
+    uint32_t c       = 0;
+    if (j <= J)
+    {
+        uint32_t old = j < J ? leafPos[j + 1] - leafPos[j] : 0u;
+        c            = old - outCount[j] + incoming[j];
+        // (entry J, the remove markers, does not go through the leaf pass)
+        if (j < J && old + incoming[j] > RESORT_LEAF_CAP) atomicOr(&scalars[1], 1);
+    }
+    newCount[j] = c;
+}
+
+//! [1] |= 2: the leaves of a workgroup of the leaf pass need more LDS slots than it has, |= 4: mover list overflow;
+//! [0]: particles carrying the remove marker
+__global__ __launch_bounds__(256) void checkTilesKernel(const uint32_t* __restrict__ leafPos,
+                                                        const uint32_t* __restrict__ inOffset,
+                                                        const uint32_t* __restrict__ numCompact,
+                                                        const uint32_t* __restrict__ moverCount, uint32_t moverCap,
+                                                        int leavesPerTile, int* __restrict__ scalars)
+{
+    const uint32_t J = *numCompact;
+    uint32_t t       = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0)
+    {
+        scalars[0] = int(inOffset[J + 1] - inOffset[J]);
+        if (*moverCount > moverCap) atomicOr(&scalars[1], 4);
+    }
+    uint32_t j0 = t * uint32_t(leavesPerTile);
+    if (j0 >= J) return;
+    uint32_t j1    = min(j0 + uint32_t(leavesPerTile), J);
+    uint32_t slots = (leafPos[j1] - leafPos[j0]) + (inOffset[j1] - inOffset[j0]);
+    if (slots > RESORT_TILE_SLOTS) atomicOr(&scalars[1], 2);
+}
+
+template<class K>
+__global__ __launch_bounds__(256) void placeMoversKernel(const K* __restrict__ moverKeys,
+                                                         const uint32_t* __restrict__ moverIdx,
+                                                         const uint32_t* __restrict__ dest,
+                                                         const uint32_t* __restrict__ slot, uint32_t M,
+                                                         const uint32_t* __restrict__ inOffset, K* __restrict__ binKeys,
+                                                         uint32_t* __restrict__ binIdx)
+{
+    uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    uint32_t at = inOffset[dest[m]] + slot[m];
+    binKeys[at] = moverKeys[m];
+    binIdx[at]  = moverIdx[m];
+}
+
+/*! The leaf pass.  A workgroup takes G consecutive (non-empty) leaves of the previous sync.  LDS slots of leaf k:
+ *  [its old positions | the movers arriving in it].  The old positions are filled in place -- a particle that left
+ *  becomes a hole (key ~0, sorts last) --, then one lane per leaf insertion-sorts its slots by (key, old index): the
+ *  stayers come in the order of the previous sync, i.e. almost sorted, so the sort is close to one comparison per
+ *  element.  The first newCount slots of every leaf are the leaf's new content, written to layoutNew[leaf] + r. */
+template<class K, int G>
+__global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keysIn, const uint64_t* __restrict__ mask,
+                                                      const uint32_t* __restrict__ rank, const K* __restrict__ leafLo,
+                                                      const uint32_t* __restrict__ leafPos,
+                                                      const uint32_t* __restrict__ inOffset,
+                                                      const uint32_t* __restrict__ layoutNew,
+                                                      const K* __restrict__ binKeys, const uint32_t* __restrict__ binIdx,
+                                                      uint32_t J, K* __restrict__ keysOut, uint32_t* __restrict__ orderOut)
+{
+    __shared__ K sKey[RESORT_TILE_SLOTS];
+    __shared__ uint32_t sIdx[RESORT_TILE_SLOTS];
+    __shared__ K loK[G + 1];
+    __shared__ uint32_t posK[G + 1], inK[G + 1], outK[G + 1], segK[G + 1];
+
+    const uint32_t j0 = blockIdx.x * uint32_t(G);
+    const uint32_t nl = min(uint32_t(G), J - j0);
+    const uint32_t t  = threadIdx.x;
+    if (t <= nl)
+    {
+        loK[t]  = leafLo[j0 + t];
+        posK[t] = leafPos[j0 + t];
+        inK[t]  = inOffset[j0 + t];
+        outK[t] = layoutNew[j0 + t];
+    }
+    __syncthreads();
+    if (t <= nl) segK[t] = (posK[t] - posK[0]) + (inK[t] - inK[0]);
+    __syncthreads();
+    const uint32_t p0 = posK[0], p1 = posK[nl];
+    const uint32_t slots = segK[nl];
+    // guarded by checkTilesKernel: a launch only happens when every workgroup fits
+    if (slots > RESORT_TILE_SLOTS) return;
+
+    for (uint32_t p = p0 + t; p < p1; p += 256)
+    {
+        const K key         = keysIn[p];
+        const uint64_t word = mask[p >> 6];
+        const uint32_t j    = rank[p >> 6] + uint32_t(__popcll(word & ((2ull << (p & 63u)) - 1))) - 1u;
+        const uint32_t k    = j - j0;
+        const bool stay     = key >= loK[k] && key < loK[k + 1];
+        const uint32_t at   = segK[k] + (p - posK[k]);
+        sKey[at]            = stay ? key : ~K(0);
+        sIdx[at]            = p;
+    }
+    for (uint32_t m = inK[0] + t; m < inK[nl]; m += 256)
+    {
+        // leaf of bin entry m: last k with inK[k] <= m
+        uint32_t lo = 0, hi = nl;
+        while (hi - lo > 1)
+        {
+            uint32_t mid = (lo + hi) / 2;
+            if (inK[mid] <= m) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t at = segK[lo] + (posK[lo + 1] - posK[lo]) + (m - inK[lo]);
+        sKey[at]          = binKeys[m];
+        sIdx[at]          = binIdx[m];
+    }
+    __syncthreads();
+
+    if (t < nl)
+    {
+        const uint32_t s = segK[t], e = segK[t + 1];
+        if (e - s > 1)
+        {
+            K pk        = sKey[s];
+            uint32_t pi = sIdx[s];
+            for (uint32_t a = s + 1; a < e; ++a)
+            {
+                const K ka        = sKey[a];
+                const uint32_t ia = sIdx[a];
+                if (ka > pk || (ka == pk && ia > pi))
+                {
+                    pk = ka, pi = ia;
+                    continue;
+                }
+                uint32_t b = a;
+                while (b > s)
+                {
+                    const K kb        = sKey[b - 1];
+                    const uint32_t ib = sIdx[b - 1];
+                    if (kb < ka || (kb == ka && ib < ia)) break;
+                    sKey[b] = kb;
+                    sIdx[b] = ib;
+                    --b;
+                }
+                sKey[b] = ka;
+                sIdx[b] = ia;
+            }
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t e = t; e < slots; e += 256)
+    {
+        uint32_t lo = 0, hi = nl;
+        while (hi - lo > 1)
+        {
+            uint32_t mid = (lo + hi) / 2;
+            if (segK[mid] <= e) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t r = e - segK[lo];
+        if (r < outK[lo + 1] - outK[lo])
+        {
+            keysOut[outK[lo] + r]  = sKey[e];
+            orderOut[outK[lo] + r] = sIdx[e];
+        }
+    }
+}
+
+//! the particles that carry the remove marker: behind every leaf, by ascending old position (idx sorted by the caller)
+template<class K>
+__global__ __launch_bounds__(256) void placeMarkersKernel(const uint32_t* __restrict__ idx, uint32_t count,
+                                                          const uint32_t* __restrict__ layoutNew,
+                                                          const uint32_t* __restrict__ numCompact,
+                                                          K* __restrict__ keysOut, uint32_t* __restrict__ orderOut)
+{
+    uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= count) return;
+    const uint32_t at = layoutNew[*numCompact] + r;
+    keysOut[at]       = endKey<K>();
+    orderOut[at]      = idx[r];
+}
+
+} // namespace
+
+template<class K>
+int LeafResort<K>::prepare(cstone_hip_ctx* ctx, const K* tree, const uint32_t* layout, int numLeaves, size_t n,
+                           K* keysOut)
+{
+    StageTimer timer(ctx, CSTONE_STAGE_RESORT_BINS);
+    numLeaves_         = numLeaves;
+    n_                 = n;
+    const size_t words = (n + 63) / 64 + 1;
+    const size_t ent   = size_t(numLeaves) + 3; // J + 2 <= numLeaves + 2 table entries, one more for the scans' totals
+    const size_t cap   = n / 8 + 1024;
+    CS_TRY(mask_.ensure(ctx, words * 8));
+    CS_TRY(rank_.ensure(ctx, words * 4));
+    CS_TRY(popc_.ensure(ctx, words * 4));
+    CS_TRY(leafLo_.ensure(ctx, ent * sizeof(K)));
+    CS_TRY(leafPos_.ensure(ctx, ent * 4));
+    CS_TRY(outCount_.ensure(ctx, ent * 4));
+    CS_TRY(incoming_.ensure(ctx, ent * 4));
+    CS_TRY(newCount_.ensure(ctx, ent * 4));
+    CS_TRY(layoutNew_.ensure(ctx, ent * 4));
+    CS_TRY(inOffset_.ensure(ctx, ent * 4));
+    CS_TRY(moverKeys_.ensure(ctx, cap * sizeof(K)));
+    CS_TRY(moverIdx_.ensure(ctx, cap * 4));
+    CS_TRY(moverDest_.ensure(ctx, cap * 4));
+    CS_TRY(moverSlot_.ensure(ctx, cap * 4));
+    CS_TRY(binKeys_.ensure(ctx, cap * sizeof(K)));
+    CS_TRY(binIdx_.ensure(ctx, cap * 4));
+
+    int* scalars = ctx->devScalars + RESORT_SCALARS;
+    CS_HIP(ctx, hipMemsetAsync(scalars, 0, 4 * sizeof(int), ctx->stream)); // [3]: the mover counter
+    CS_HIP(ctx, hipMemsetAsync(mask_.p, 0, words * 8, ctx->stream));
+    CS_HIP(ctx, hipMemsetAsync(outCount_.p, 0, ent * 4, ctx->stream));
+    CS_HIP(ctx, hipMemsetAsync(incoming_.p, 0, ent * 4, ctx->stream));
+    hipLaunchKernelGGL(markLeafStartsKernel, gridFor(numLeaves, 256), 256, 0, ctx->stream, layout, numLeaves,
+                       (unsigned long long*)mask_.p);
+    hipLaunchKernelGGL(popcountWordsKernel, gridFor(words, 256), 256, 0, ctx->stream, mask_.as<uint64_t>(), words,
+                       popc_.as<uint32_t>());
+    // rank of every word and, in scalars[2], the number of non-empty leaves
+    CS_TRY(arenaReserve(ctx, scanArenaBytes(words)));
+    int rc = scanU32(ctx, popc_.as<uint32_t>(), rank_.as<uint32_t>(), words, 0u, false, (uint32_t*)scalars + 2);
+    arenaReset(ctx);
+    CS_TRY(rc);
+    hipLaunchKernelGGL(fillCompactLeavesKernel<K>, gridFor(numLeaves, 256), 256, 0, ctx->stream, tree, layout, numLeaves,
+                       mask_.as<uint64_t>(), rank_.as<uint32_t>(), (const uint32_t*)scalars + 2, uint32_t(n),
+                       leafLo_.as<K>(), leafPos_.as<uint32_t>());
+    CS_HIP(ctx, hipGetLastError());
+
+    args_.keysOut    = keysOut;
+    args_.leafStart  = mask_.as<uint64_t>();
+    args_.leafRank   = rank_.as<uint32_t>();
+    args_.leafLo     = leafLo_.as<K>();
+    args_.outCount   = outCount_.as<uint32_t>();
+    args_.moverKeys  = moverKeys_.as<K>();
+    args_.moverIdx   = moverIdx_.as<uint32_t>();
+    args_.moverCount = (uint32_t*)scalars + 3;
+    args_.moverCap   = uint32_t(cap);
+    return CSTONE_OK;
+}
+
+template<class K>
+int LeafResort<K>::binMovers(cstone_hip_ctx* ctx, int leavesPerTile)
+{
+    StageTimer timer(ctx, CSTONE_STAGE_RESORT_BINS);
+    int* scalars          = ctx->devScalars + RESORT_SCALARS;
+    const uint32_t ent    = uint32_t(numLeaves_) + 3;
+    const uint32_t* numJ  = (const uint32_t*)scalars + 2;
+    const uint32_t* count = (const uint32_t*)scalars + 3;
+    hipLaunchKernelGGL(binMoversKernel<K>, unsigned(ctx->numCu) * 4, 256, 0, ctx->stream, moverKeys_.as<K>(), count,
+                       args_.moverCap, leafLo_.as<K>(), numJ, incoming_.as<uint32_t>(), moverDest_.as<uint32_t>(),
+                       moverSlot_.as<uint32_t>());
+    hipLaunchKernelGGL(newLeafSizesKernel, gridFor(ent, 256), 256, 0, ctx->stream, leafPos_.as<uint32_t>(),
+                       outCount_.as<uint32_t>(), incoming_.as<uint32_t>(), numJ, ent, newCount_.as<uint32_t>(), scalars);
+    CS_TRY(arenaReserve(ctx, 2 * scanArenaBytes(ent)));
+    int rc = scanU32(ctx, newCount_.as<uint32_t>(), layoutNew_.as<uint32_t>(), ent, 0u, false);
+    if (rc == CSTONE_OK) rc = scanU32(ctx, incoming_.as<uint32_t>(), inOffset_.as<uint32_t>(), ent, 0u, false);
+    arenaReset(ctx);
+    CS_TRY(rc);
+    hipLaunchKernelGGL(checkTilesKernel, gridFor(size_t(numLeaves_) / leavesPerTile + 1, 256), 256, 0, ctx->stream,
+                       leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), numJ, count, args_.moverCap, leavesPerTile,
+                       scalars);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+template<class K>
+int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, uint32_t* orderOut, uint32_t numMovers,
+                              uint32_t numMarkers, uint32_t J, int leavesPerTile)
+{
+    if (numMovers)
+    {
+        StageTimer timer(ctx, CSTONE_STAGE_RESORT_BINS);
+        hipLaunchKernelGGL(placeMoversKernel<K>, gridFor(numMovers, 256), 256, 0, ctx->stream, moverKeys_.as<K>(),
+                           moverIdx_.as<uint32_t>(), moverDest_.as<uint32_t>(), moverSlot_.as<uint32_t>(), numMovers,
+                           inOffset_.as<uint32_t>(), binKeys_.as<K>(), binIdx_.as<uint32_t>());
+    }
+    if (numMarkers)
+    {
+        // all markers are equal keys: their stable order is that of their old positions
+        StageTimer timer(ctx, CSTONE_STAGE_RESORT_BINS);
+        // their bin is the last one: it starts at movers - markers
+        uint32_t* idx = binIdx_.as<uint32_t>() + (numMovers - numMarkers);
+        CS_TRY(cstone_hip_sort_keys(ctx, 32, idx, numMarkers));
+        hipLaunchKernelGGL(placeMarkersKernel<K>, gridFor(numMarkers, 256), 256, 0, ctx->stream, idx, numMarkers,
+                           layoutNew_.as<uint32_t>(), (const uint32_t*)(ctx->devScalars + RESORT_SCALARS) + 2, keysOut,
+                           orderOut);
+    }
+    if (J == 0) return CSTONE_OK;
+    StageTimer timer(ctx, CSTONE_STAGE_RESORT_LEAVES);
+    const unsigned grid = (J + unsigned(leavesPerTile) - 1) / unsigned(leavesPerTile);
+#define CSTONE_LEAF_SORT(G)                                                                                            \
+    hipLaunchKernelGGL((leafSortKernel<K, G>), grid, 256, 0, ctx->stream, keysIn, mask_.as<uint64_t>(),                \
+                       rank_.as<uint32_t>(), leafLo_.as<K>(), leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(),       \
+                       layoutNew_.as<uint32_t>(), binKeys_.as<K>(), binIdx_.as<uint32_t>(), J, keysOut, orderOut)
+    if (leavesPerTile == 64) CSTONE_LEAF_SORT(64);
+    else if (leavesPerTile == 32) CSTONE_LEAF_SORT(32);
+    else if (leavesPerTile == 16) CSTONE_LEAF_SORT(16);
+    else return fail(ctx, CSTONE_E_INTERNAL, "resort: %d leaves per workgroup not instantiated", leavesPerTile);
+#undef CSTONE_LEAF_SORT
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+template class LeafResort<uint32_t>;
+template class LeafResort<uint64_t>;
+
+} // namespace cship

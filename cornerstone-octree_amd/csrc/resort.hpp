@@ -1,0 +1,84 @@
+// Incremental re-sort of Domain::sync ("leaf re-sort"): the SFC order of a sync, built from the order of the sync before.
+//
+// The reference sorts all particle keys from scratch in every sync (sortByKeyGpu, R/primitives/primitives_gpu.cu:305-353,
+// called from R/sfc/sfc_sorter.hpp).  Between two syncs of a time-stepping code most particles stay inside the leaf cell
+// of the focus tree they were in: their positions in the arrays still tell their leaf.  The re-sort uses that:
+//   1. the encode pass classifies every particle against the key range of the leaf its POSITION belongs to (previous
+//      layout): a "stayer" keeps its leaf, a "mover" is appended to a list (resort.hpp: ResortArgs, sfc.hip:
+//      encodeResortKernel)
+//   2. the movers are binned by the leaf their new key falls into (binary search, one atomic each)
+//   3. one pass over the leaves (leafSortKernel): the stayers of a leaf plus its incoming movers are ordered by
+//      (key, old index) inside LDS and written to the leaf's new place
+// The result is the stable sort of the keys (ties by old index), whatever the particles did: a particle is a stayer
+// only if its key lies in the range of the leaf its position claims, everything else goes through the bins, and the
+// leaf ranges are disjoint and ascending.  Too many movers or an overfull leaf make the caller fall back to the radix sort.
+// HBM traffic per particle: encode (3T + 2K) + leaf pass (K read, K + 4 written) instead of encode + 4..8 digit passes
+// of 2K + 8 each.
+#pragma once
+
+#include "ctx.hpp"
+#include "devbuf.hpp"
+
+namespace cship
+{
+
+//! what the classifying encode kernel needs (device pointers)
+template<class K>
+struct ResortArgs
+{
+    K* keysOut;                // new keys, at the particles' old positions
+    const uint64_t* leafStart; // bit p set: a non-empty leaf of the previous sync starts at position p
+    const uint32_t* leafRank;  // per 64 positions: number of set bits in front of the word
+    const K* leafLo;           // [J + 1]: first key of the j-th non-empty leaf; leafLo[0] = 0, leafLo[J] = endKey
+    uint32_t* outCount;        // [J + 1]: particles that left leaf j
+    K* moverKeys;              // [moverCap]
+    uint32_t* moverIdx;        // [moverCap] old position of the mover
+    uint32_t* moverCount;      // movers found (may exceed moverCap: then the list is incomplete)
+    uint32_t moverCap;
+};
+
+//! limits of the leaf pass
+constexpr uint32_t RESORT_TILE_SLOTS = 4224; // LDS slots (key + index) of a workgroup: three workgroups per CU
+constexpr uint32_t RESORT_LEAF_CAP   = 256;  // longest leaf the in-LDS insertion sort accepts
+
+//! device-side results a re-sort attempt reports (ctx->devScalars + RESORT_SCALARS, read back with the box extents)
+constexpr int RESORT_SCALARS = 28; // [0] particles with the remove marker, [1] flags (1: leaf too long, 2: tile too
+                                   // long, 4: mover list overflow), [2] J (non-empty leaves), [3] movers
+
+template<class K>
+class LeafResort
+{
+public:
+    //! leaves per workgroup of the leaf pass for a focus bucket size; 0: buckets this large are not re-sorted
+    static int leavesPerTile(uint32_t bucketFocus)
+    {
+        return bucketFocus <= 64 ? 64 : bucketFocus <= 128 ? 32 : bucketFocus <= RESORT_LEAF_CAP ? 16 : 0;
+    }
+
+    /*! compact leaf table of the previous sync (non-empty leaves of `tree` with their first positions) and cleared
+     *  counters; afterwards args() is valid.  layout[numLeaves] must equal n. */
+    int prepare(cstone_hip_ctx* ctx, const K* tree, const uint32_t* layout, int numLeaves, size_t n, K* keysOut);
+    ResortArgs<K> args() const { return args_; }
+    /*! bins the movers, new leaf sizes and offsets, limit checks; everything stays on the device: the three scalars at
+     *  ctx->devScalars + RESORT_SCALARS tell the host how it went */
+    int binMovers(cstone_hip_ctx* ctx, int leavesPerTile);
+    /*! the leaf pass: keysIn = new keys at old positions; keysOut / orderOut = sorted keys and their old positions.
+     *  numMovers, numMarkers, numCompactLeaves: the values read back after binMovers */
+    int sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, uint32_t* orderOut, uint32_t numMovers,
+                   uint32_t numMarkers, uint32_t numCompactLeaves, int leavesPerTile);
+
+private:
+    DevBuf mask_, rank_, popc_, leafLo_, leafPos_, outCount_, incoming_, newCount_, layoutNew_, inOffset_;
+    DevBuf moverKeys_, moverIdx_, moverDest_, moverSlot_, binKeys_, binIdx_;
+    ResortArgs<K> args_{};
+    int numLeaves_ = 0;
+    size_t n_      = 0;
+};
+
+//! encode with the box, write the keys to ra.keysOut and classify them (sfc.hip); *done = false: arrays not aligned
+//! for the vector kernel, nothing was launched
+int computeKeysResort(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
+                      const void* z, const void* keysIn, size_t n, const cstone_box& box, const void* resortArgs,
+                      void* extentsOut, bool* done);
+
+} // namespace cship

@@ -14,6 +14,7 @@
 
 #include "ctx.hpp"
 #include "device_keys.hpp"
+#include "resort.hpp"
 
 namespace cship
 {
@@ -96,6 +97,35 @@ __global__ __launch_bounds__(256) void encodeKernel(const T* __restrict__ x, con
             if (HILBERT) m = hilbertFromMorton<K>(m, enc);
             if (old != endKey<K>()) keys[i] = m;
         }
+    }
+}
+
+//! extents of a 256-thread workgroup: ext = {xmin, xmax, ymin, ymax, zmin, zmax} per lane -> partials[blockIdx.x][6]
+template<class T>
+__device__ __forceinline__ void foldBlockExtents(const T (&ext)[6], T* __restrict__ partials)
+{
+    __shared__ T wext[4][6];
+    const unsigned lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+    {
+        T v = ext[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+        {
+            T t = __shfl_xor(v, o);
+            v   = (k & 1) ? (t > v ? t : v) : (t < v ? t : v);
+        }
+        if (lane == 0) wext[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6)
+    {
+        const int k = threadIdx.x;
+        T v         = wext[0][k];
+        for (int w = 1; w < 4; ++w)
+            v = (k & 1) ? (wext[w][k] > v ? wext[w][k] : v) : (wext[w][k] < v ? wext[w][k] : v);
+        partials[size_t(blockIdx.x) * 6 + k] = v;
     }
 }
 
@@ -248,31 +278,7 @@ __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict
         uint32_t c = lh[i];
         if (c) atomicAdd(&hist[i], c);
     }
-    if (extentPartials)
-    {
-        __shared__ T wext[4][6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-        {
-            T v = ext[k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-            {
-                T t = __shfl_xor(v, o);
-                v   = (k & 1) ? (t > v ? t : v) : (t < v ? t : v);
-            }
-            if (lane == 0) wext[threadIdx.x >> 6][k] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < 6)
-        {
-            const int k = threadIdx.x;
-            T v         = wext[0][k];
-            for (int w = 1; w < 4; ++w)
-                v = (k & 1) ? (wext[w][k] > v ? wext[w][k] : v) : (wext[w][k] < v ? wext[w][k] : v);
-            extentPartials[size_t(blockIdx.x) * 6 + k] = v;
-        }
-    }
+    if (extentPartials) foldBlockExtents<T>(ext, extentPartials);
 }
 
 //! folds the per-workgroup extents of encodeHistogramKernel: out = {xmin, xmax, ymin, ymax, zmin, zmax}
@@ -308,6 +314,157 @@ __global__ __launch_bounds__(256) void foldExtentsKernel(const T* __restrict__ p
             v = (k & 1) ? (wext[w][k] > v ? wext[w][k] : v) : (wext[w][k] < v ? wext[w][k] : v);
         out[k] = v;
     }
+}
+
+/*! Encode for the incremental re-sort (resort.hpp): the keys go to ra.keysOut (the caller's key array is only read, for
+ *  its remove markers) and every particle is checked against the key range of the leaf its position belonged to at the
+ *  previous sync.  Particles that left their leaf are counted per leaf and appended to the mover list -- staged per wave
+ *  in LDS and flushed with one atomic per 128..256 movers.  The extents of x, y, z are measured like in
+ *  encodeHistogramKernel.  Grid-stride, whole waves walk the iterations together. */
+template<class K, class T, int VEC, bool HILBERT>
+__global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                          const T* __restrict__ z, const K* __restrict__ keysIn,
+                                                          size_t n, DBox<T> box, const uint16_t* __restrict__ encTable,
+                                                          ResortArgs<K> ra, T* __restrict__ extentPartials)
+{
+    constexpr unsigned STAGE = 64 * VEC * 2; // a wave flushes at half of this, one iteration adds at most 64 * VEC
+    __shared__ uint16_t enc[24 * 8];
+    __shared__ K stageKey[4][STAGE];
+    __shared__ uint32_t stageIdx[4][STAGE];
+    T ext[6] = {std::numeric_limits<T>::infinity(),  -std::numeric_limits<T>::infinity(),
+                std::numeric_limits<T>::infinity(),  -std::numeric_limits<T>::infinity(),
+                std::numeric_limits<T>::infinity(),  -std::numeric_limits<T>::infinity()};
+    auto widen = [&](T xv, T yv, T zv)
+    {
+        ext[0] = xv < ext[0] ? xv : ext[0], ext[1] = xv > ext[1] ? xv : ext[1];
+        ext[2] = yv < ext[2] ? yv : ext[2], ext[3] = yv > ext[3] ? yv : ext[3];
+        ext[4] = zv < ext[4] ? zv : ext[4], ext[5] = zv > ext[5] ? zv : ext[5];
+    };
+    if (threadIdx.x < 24 * 8) enc[threadIdx.x] = encTable[threadIdx.x];
+    __syncthreads();
+    constexpr unsigned g = 1u << maxLevel<K>();
+    const T mx = g * box.inv[0], my = g * box.inv[1], mz = g * box.inv[2]; // R/sfc/sfc.hpp:188-194
+    const T sx = box.lo[0] * mx, sy = box.lo[1] * my, sz = box.lo[2] * mz;
+    const unsigned lane   = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint64_t below  = (1ull << lane) - 1;
+    unsigned staged       = 0; // wave-uniform
+
+    auto flush = [&]()
+    {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(ra.moverCount, staged);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (unsigned k = lane; k < staged; k += 64)
+        {
+            if (base + k < ra.moverCap)
+            {
+                ra.moverKeys[base + k] = stageKey[w][k];
+                ra.moverIdx[base + k]  = stageIdx[w][k];
+            }
+        }
+        staged = 0;
+    };
+    // is the particle at position p still inside the leaf that position belonged to?  If not: count and stage it.
+    auto classify = [&](K key, size_t p, bool valid)
+    {
+        bool mover = false;
+        if (valid)
+        {
+            const uint64_t word = ra.leafStart[p >> 6];
+            const uint32_t j    = ra.leafRank[p >> 6] + uint32_t(__popcll(word & ((2ull << (p & 63)) - 1))) - 1u;
+            const K lo = ra.leafLo[j], hi = ra.leafLo[j + 1];
+            mover = !(key >= lo && key < hi);
+            if (mover) atomicAdd(&ra.outCount[j], 1u);
+        }
+        const uint64_t mm = __ballot(mover);
+        if (mm)
+        {
+            if (mover)
+            {
+                const unsigned off = staged + unsigned(__popcll(mm & below));
+                stageKey[w][off]   = key;
+                stageIdx[w][off]   = uint32_t(p);
+            }
+            staged += unsigned(__popcll(mm));
+        }
+    };
+
+    const size_t nVec   = n / VEC;
+    const size_t stride = size_t(gridDim.x) * 256;
+    const size_t iters  = (nVec + stride - 1) / stride;
+    size_t vi           = size_t(blockIdx.x) * 256 + threadIdx.x;
+    for (size_t it = 0; it < iters; ++it, vi += stride)
+    {
+        const bool valid = vi < nVec;
+        const size_t base = vi * VEC;
+        K out[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            out[v] = 0;
+        if (valid)
+        {
+            T vx[VEC], vy[VEC], vz[VEC];
+            K vk[VEC];
+            __builtin_memcpy(vx, __builtin_assume_aligned(x + base, sizeof(T) * VEC), sizeof vx);
+            __builtin_memcpy(vy, __builtin_assume_aligned(y + base, sizeof(T) * VEC), sizeof vy);
+            __builtin_memcpy(vz, __builtin_assume_aligned(z + base, sizeof(T) * VEC), sizeof vz);
+            __builtin_memcpy(vk, __builtin_assume_aligned(keysIn + base, sizeof(K) * VEC), sizeof vk);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+            {
+                out[v] = gridMorton<K, T>(vx[v], vy[v], vz[v], mx, my, mz, sx, sy, sz);
+                if (extentPartials) widen(vx[v], vy[v], vz[v]);
+            }
+            if (HILBERT)
+            {
+                K h[VEC];
+                unsigned st[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    h[v] = 0, st[v] = 0;
+#pragma unroll
+                for (int level = int(maxLevel<K>()) - 1; level >= 0; --level)
+                {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                    {
+                        unsigned e = enc[st[v] * 8 + (unsigned(out[v] >> (3 * level)) & 7u)];
+                        h[v]       = (h[v] << 3) | K(e & 7u);
+                        st[v]      = e >> 3;
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    out[v] = h[v];
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                if (vk[v] == endKey<K>()) out[v] = vk[v]; // particles flagged for removal keep their marker
+            __builtin_memcpy(__builtin_assume_aligned(ra.keysOut + base, sizeof(K) * VEC), out, sizeof out);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            classify(out[v], base + v, valid);
+        if (staged >= STAGE / 2) flush();
+    }
+    // elements behind the last full vector: first wave of block 0
+    if (blockIdx.x == 0 && threadIdx.x < 64)
+    {
+        size_t i   = nVec * VEC + threadIdx.x;
+        bool valid = i < n;
+        K key      = 0;
+        if (valid)
+        {
+            K m = gridMorton<K, T>(x[i], y[i], z[i], mx, my, mz, sx, sy, sz);
+            if (HILBERT) m = hilbertFromMorton<K>(m, enc);
+            key           = keysIn[i] == endKey<K>() ? endKey<K>() : m;
+            ra.keysOut[i] = key;
+            if (extentPartials) widen(x[i], y[i], z[i]);
+        }
+        classify(key, i, valid);
+    }
+    if (staged) flush();
+    if (extentPartials) foldBlockExtents<T>(ext, extentPartials);
 }
 
 template<class K, class T>
@@ -413,6 +570,64 @@ int computeKeysAndHistogram(cstone_hip_ctx* ctx, int curve, int key_bits, int re
         return computeKeysHist<uint64_t, double>(ctx, curve, (const double*)x, (const double*)y, (const double*)z,
                                                  (uint64_t*)keys, n, box, hist, fused, firstDigit, honourMarkers, extentsOut);
     return fail(ctx, CSTONE_E_ARG, "sfc_keys_and_ordering: unsupported type combination");
+}
+
+template<class K, class T>
+static int computeKeysResortT(cstone_hip_ctx* ctx, int curve, const T* x, const T* y, const T* z, const K* keysIn,
+                              size_t n, const cstone_box& hostBox, const ResortArgs<K>& ra, void* extentsOut, bool* done)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    bool aligned = (uintptr_t(x) % 16 == 0) && (uintptr_t(y) % 16 == 0) && (uintptr_t(z) % 16 == 0) &&
+                   (uintptr_t(keysIn) % (sizeof(K) * VEC) == 0) && (uintptr_t(ra.keysOut) % (sizeof(K) * VEC) == 0);
+    *done = aligned && n > 0;
+    if (!*done) return CSTONE_OK;
+    StageTimer timer(ctx, CSTONE_STAGE_ENCODE);
+    DBox<T> box   = makeDBox<T>(hostBox);
+    auto* enc     = (const uint16_t*)ctx->hilbertTables;
+    size_t nVec   = n / VEC;
+    unsigned grid = unsigned(std::max<size_t>(1, std::min<size_t>(size_t(ctx->numCu) * encodeBlocksPerCu(), (nVec + 255) / 256)));
+    T* partials   = nullptr;
+    if (extentsOut)
+    {
+        CS_TRY(arenaReserve(ctx, alignUp(size_t(grid) * 6 * sizeof(T)) + 256));
+        partials = (T*)arenaTake(ctx, size_t(grid) * 6 * sizeof(T));
+    }
+    if (curve == CSTONE_HILBERT)
+        hipLaunchKernelGGL((encodeResortKernel<K, T, VEC, true>), grid, 256, 0, ctx->stream, x, y, z, keysIn, n, box, enc,
+                           ra, partials);
+    else
+        hipLaunchKernelGGL((encodeResortKernel<K, T, VEC, false>), grid, 256, 0, ctx->stream, x, y, z, keysIn, n, box,
+                           enc, ra, partials);
+    if (extentsOut)
+    {
+        hipLaunchKernelGGL(foldExtentsKernel<T>, 1, 256, 0, ctx->stream, partials, grid, (T*)extentsOut);
+        arenaReset(ctx);
+    }
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int computeKeysResort(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* x, const void* y,
+                      const void* z, const void* keysIn, size_t n, const cstone_box& box, const void* resortArgs,
+                      void* extentsOut, bool* done)
+{
+    if (key_bits == 32 && real_bits == 32)
+        return computeKeysResortT<uint32_t, float>(ctx, curve, (const float*)x, (const float*)y, (const float*)z,
+                                                   (const uint32_t*)keysIn, n, box,
+                                                   *(const ResortArgs<uint32_t>*)resortArgs, extentsOut, done);
+    if (key_bits == 32 && real_bits == 64)
+        return computeKeysResortT<uint32_t, double>(ctx, curve, (const double*)x, (const double*)y, (const double*)z,
+                                                    (const uint32_t*)keysIn, n, box,
+                                                    *(const ResortArgs<uint32_t>*)resortArgs, extentsOut, done);
+    if (key_bits == 64 && real_bits == 32)
+        return computeKeysResortT<uint64_t, float>(ctx, curve, (const float*)x, (const float*)y, (const float*)z,
+                                                   (const uint64_t*)keysIn, n, box,
+                                                   *(const ResortArgs<uint64_t>*)resortArgs, extentsOut, done);
+    if (key_bits == 64 && real_bits == 64)
+        return computeKeysResortT<uint64_t, double>(ctx, curve, (const double*)x, (const double*)y, (const double*)z,
+                                                    (const uint64_t*)keysIn, n, box,
+                                                    *(const ResortArgs<uint64_t>*)resortArgs, extentsOut, done);
+    return fail(ctx, CSTONE_E_ARG, "resort encode: unsupported type combination");
 }
 
 } // namespace cship

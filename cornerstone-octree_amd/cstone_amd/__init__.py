@@ -18,7 +18,7 @@ MORTON, HILBERT = 0, 1
 
 STAGES = {
     "encode": 0, "sort_hist": 1, "sort_pass": 2, "gather": 3, "node_counts": 4, "rebalance": 5, "link_octree": 6,
-    "halos": 7, "neighbors": 8, "minmax": 9, "sort_pass_iota": 10,
+    "halos": 7, "neighbors": 8, "minmax": 9, "sort_pass_iota": 10, "resort_bins": 11, "resort_leaves": 12,
 }
 
 EXPORTS = [
@@ -36,7 +36,7 @@ EXPORTS = [
     "cstone_hip_domain_create", "cstone_hip_domain_destroy", "cstone_hip_domain_sync", "cstone_hip_domain_view_get",
     "cstone_hip_domain_set_halo_factor", "cstone_hip_domain_mr_create", "cstone_hip_domain_mr_destroy",
     "cstone_hip_domain_mr_sync", "cstone_hip_domain_mr_sync_props", "cstone_hip_domain_mr_sync_keys", "cstone_hip_domain_mr_view_get", "cstone_hip_domain_mr_set_halo_factor", "cstone_hip_domain_mr_exchange_halos", "cstone_hip_domain_mr_reapply_sync",
-    "cstone_hip_domain_reapply_sync", "cstone_hip_domain_mr_octree_get",
+    "cstone_hip_domain_reapply_sync", "cstone_hip_domain_stats_get", "cstone_hip_domain_mr_octree_get",
     "cstone_hip_fill", "cstone_hip_scale", "cstone_hip_increment", "cstone_hip_count_equal", "cstone_hip_reduce_sum",
     "cstone_hip_max_norm_square", "cstone_hip_segment_max", "cstone_hip_gather_ranges", "cstone_hip_lower_bound_value",
     "cstone_hip_sort_keys", "cstone_hip_rebalance_decision_essential", "cstone_hip_mac_refine_decision",
@@ -75,6 +75,10 @@ def load_library():
     if not os.path.exists(path):
         raise CstoneError(f"{LIBPATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           f"or `make -C cornerstone-octree_amd`")
+    # torch first: it brings its own libamdhip64, and a process must hold ONE HIP runtime -- with the library's
+    # /opt/rocm copy loaded before torch's, the second runtime finds no device ("no ROCm-capable device is detected")
+    import torch  # noqa: F401
+
     lib = C.CDLL(path)
     lib.cstone_hip_last_error.restype = C.c_char_p
     lib.cstone_hip_sort_pairs_temp_bytes.restype = C.c_size_t
@@ -126,7 +130,9 @@ class Context:
         rc = self.lib.cstone_hip_ctx_create(C.byref(self.h), C.c_int(self.device.index), C.c_void_p(stream),
                                             C.c_int(0 if use_torch_stream else 1))
         if rc != 0:
-            raise CstoneError(f"cstone_hip_ctx_create failed: {rc}")
+            self.lib.cstone_hip_last_error.restype = C.c_char_p
+            why = self.lib.cstone_hip_last_error(C.c_void_p(None))
+            raise CstoneError(f"cstone_hip_ctx_create failed: {rc} ({why.decode() if why else '?'})")
 
     def close(self):
         if getattr(self, "h", None):

@@ -19,6 +19,11 @@ class DomainView(C.Structure):
     ]
 
 
+class DomainStats(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("syncs", "resorts", "resort_fallbacks", "box_redos", "full_sort_fallbacks",
+                                          "last_movers")]
+
+
 class Domain:
     """cstone::Domain<KeyType, T, GpuTag> on one rank; arrays are torch tensors that the call may exchange"""
 
@@ -77,6 +82,12 @@ class Domain:
         v = DomainView()
         self.ctx._chk(self.ctx.lib.cstone_hip_domain_view_get(self.h, C.byref(v)), "domain_view_get")
         return v
+
+    def stats(self):
+        """counters of the syncs so far (cstone_hip_domain_stats) as a dict"""
+        st = DomainStats()
+        self.ctx._chk(self.ctx.lib.cstone_hip_domain_stats_get(self.h, C.byref(st)), "domain_stats_get")
+        return {k: getattr(st, k) for k, _ in DomainStats._fields_}
 
     def fetch(self, ptr, count, dtype):
         """device array behind a view pointer -> numpy"""

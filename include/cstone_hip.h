@@ -63,6 +63,7 @@ extern "C"
     int cstone_hip_ctx_create(cstone_hip_ctx** out, int device, void* stream, int private_stream);
     int cstone_hip_ctx_destroy(cstone_hip_ctx* ctx);
     int cstone_hip_ctx_sync(cstone_hip_ctx* ctx);
+    /* text of the last error of this context; ctx == NULL: the last failed cstone_hip_ctx_create of this thread */
     const char* cstone_hip_last_error(cstone_hip_ctx* ctx);
     /* number of compute units / wavefront size of the context's device (R/cuda/gpu_config.cuh:41-59) */
     int cstone_hip_device_info(cstone_hip_ctx* ctx, int* num_cu, int* wave_size);
@@ -88,6 +89,8 @@ extern "C"
 #define CSTONE_STAGE_NEIGHBORS 8
 #define CSTONE_STAGE_MINMAX 9
 #define CSTONE_STAGE_SORT_PASS_IOTA 10 /* a digit pass that produces the positions instead of reading values: K + (K+4) B/pair */
+#define CSTONE_STAGE_RESORT_BINS 11   /* incremental re-sort of Domain::sync: leaf table, mover bins (csrc/resort.hpp) */
+#define CSTONE_STAGE_RESORT_LEAVES 12 /* ... its pass over the leaves: K read, K + 4 written per particle */
 #define CSTONE_NUM_STAGES 16
     int cstone_hip_profile_enable(cstone_hip_ctx* ctx, int on);
     int cstone_hip_profile_reset(cstone_hip_ctx* ctx);
@@ -469,6 +472,20 @@ extern "C"
      * particles the last sync kept; in has the n elements (elem_bytes in {1,2,4,8,12,16,24,32}) of that call's arrays,
      * out must not alias in */
     int cstone_hip_domain_reapply_sync(cstone_hip_domain* dom, const void* in, size_t n, int elem_bytes, void* out);
+
+    /* How the syncs of a (single-rank) domain went so far: which of them took the incremental re-sort (the sorted order
+     * built from the previous sync's order, csrc/resort.hpp) instead of the radix sort of all keys, how often the
+     * speculatively used box had changed.  Counters only; the results of a sync do not depend on the path taken. */
+    typedef struct cstone_hip_domain_stats
+    {
+        uint32_t syncs;
+        uint32_t resorts;             /* syncs ordered by the incremental re-sort */
+        uint32_t resort_fallbacks;    /* re-sort attempts given up (too many movers, an overfull leaf) */
+        uint32_t box_redos;           /* syncs whose box differed from the one the keys were first computed with */
+        uint32_t full_sort_fallbacks; /* partial-digit sorts completed by a sort of the remaining digits */
+        uint32_t last_movers;         /* particles that had left their leaf at the last re-sort */
+    } cstone_hip_domain_stats;
+    int cstone_hip_domain_stats_get(cstone_hip_domain* dom, cstone_hip_domain_stats* out);
 
     /* ---------------------------------------------------------------------------------------------
      * Domain::sync on SEVERAL ranks, one process per GPU (R/domain/domain.hpp:196-243 with the exchange steps of

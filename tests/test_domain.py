@@ -80,6 +80,32 @@ def test_domain_argument_errors(hip):
 
 
 @pytest.mark.gpu
+def test_sync_reports_the_device_side_error_word(hip, monkeypatch):
+    """the sticky device-side check word (look-back spin bail-out of the sort, traversal stack overflow) must reach the
+    caller of sync: with the word forced, cstone_hip_domain_sync returns CSTONE_E_INTERNAL once, and the re-armed word
+    lets the next sync pass"""
+    import torch
+    import cstone_amd
+    from cstone_amd.domain import Domain
+
+    n = 5000
+    rng = np.random.default_rng(3)
+    cb = cstone_amd.make_cbox([0, 1, 0, 1, 0, 1], [0, 0, 0])
+    dom = Domain(hip, cstone_amd.HILBERT, 64, 64, 64, 16, 0.5, cb)
+    x, y, z = [torch.from_numpy(rng.uniform(0, 1, n)).cuda() for _ in range(3)]
+    h = torch.full((n,), 0.01, dtype=torch.float64, device="cuda")
+    keys = torch.zeros(n, dtype=torch.int64, device="cuda")
+    monkeypatch.setenv("CSTONE_FORCE_DEVICE_ERROR", "1")
+    with pytest.raises(cstone_amd.CstoneError, match="device-side check failed"):
+        dom.sync(keys, x.clone(), y.clone(), z.clone(), h.clone(), torch.empty_like(x))
+    monkeypatch.delenv("CSTONE_FORCE_DEVICE_ERROR")
+    dom2 = Domain(hip, cstone_amd.HILBERT, 64, 64, 64, 16, 0.5, cb)
+    out = dom2.sync(keys, x.clone(), y.clone(), z.clone(), h.clone(), torch.empty_like(x))
+    hip.sync()
+    assert out[0].numel() == n
+
+
+@pytest.mark.gpu
 def test_partial_sort_fallback_when_particles_collapse(hip, oracle):
     """Domain::sync radix-sorts only the key digits above the previous tree's depth and orders the rest inside runs of
     equal high digits; when the particles suddenly collapse into a tiny region those runs become too long and the

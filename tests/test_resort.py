@@ -1,0 +1,180 @@
+"""The incremental re-sort inside cstone_hip_domain_sync (csrc/resort.hpp): a sync that starts from the arrays the previous
+sync returned orders the particles leaf by leaf (stayers in LDS, movers through bins) instead of radix-sorting all keys.
+The reference always sorts from scratch (sortByKeyGpu, primitives_gpu.cu:305-353, via sfc_sorter.hpp), so the re-sort must
+give exactly the stable sort: every test runs the same time-stepping loop through a domain that may re-sort and through one
+that may not (CSTONE_NO_RESORT) and compares everything bit for bit, next to the oracle's keys under the domain's box."""
+import os
+
+import numpy as np
+import pytest
+
+
+class _Stepper:
+    """a client's time-stepping loop: the arrays a sync returns are moved in place and handed to the next sync"""
+
+    def __init__(self, hip, kb, rb, bucket_focus, curve, bc, n, seed, allow_resort):
+        import torch
+
+        import cstone_amd
+        from cstone_amd.domain import Domain
+
+        rng = np.random.default_rng(seed)
+        self.hip, self.kb, self.allow = hip, kb, allow_resort
+        rdt = torch.float64 if rb == 64 else torch.float32
+        kdt = torch.int64 if kb == 64 else torch.int32
+        box = cstone_amd.make_cbox([0, 1, 0, 1, 0, 1], bc)
+        self.dom = Domain(hip, curve, kb, rb, max(bucket_focus, 64) * 4, bucket_focus, 0.5, box)
+        centers = rng.uniform(0.2, 0.8, (5, 3))
+        pos = np.where(rng.uniform(size=(n, 1)) < 0.5, rng.uniform(0, 1, (n, 3)),
+                       centers[rng.integers(0, 5, n)] + rng.normal(0, 0.03, (n, 3)))
+        pos = np.clip(pos, 0.0, 1.0 - 1e-6)
+        self.x, self.y, self.z = [torch.from_numpy(np.ascontiguousarray(pos[:, d])).to(rdt).cuda() for d in range(3)]
+        self.h = torch.from_numpy(rng.uniform(0.001, 0.01, n)).to(rdt).cuda()
+        self.ident = torch.arange(n, dtype=rdt, device="cuda")  # follows its particle through every sync
+        self.keys = torch.zeros(n, dtype=kdt, device="cuda")
+        self.scratch = torch.empty_like(self.x)
+
+    def sync(self):
+        import torch
+
+        if self.allow:
+            os.environ.pop("CSTONE_NO_RESORT", None)
+        else:
+            os.environ["CSTONE_NO_RESORT"] = "1"
+        try:
+            self.keys, self.x, self.y, self.z, self.h, self.scratch, (self.ident,) = self.dom.sync(
+                self.keys, self.x, self.y, self.z, self.h, self.scratch, [self.ident])
+        finally:
+            os.environ.pop("CSTONE_NO_RESORT", None)
+        self.hip.sync()
+        m = self.x.numel()
+        if self.scratch.numel() != m:
+            # particles were removed: the client shrinks its arrays to the new size (views of the old buffers would do
+            # as well; fresh ones keep every array 16-byte aligned for this test)
+            self.keys, self.x, self.y, self.z, self.h, self.ident = [t.clone() for t in (
+                self.keys, self.x, self.y, self.z, self.h, self.ident)]
+            self.scratch = torch.empty_like(self.x)
+        return dict(keys=self.keys.cpu().numpy(), x=self.x.cpu().numpy(), y=self.y.cpu().numpy(),
+                    z=self.z.cpu().numpy(), h=self.h.cpu().numpy(), ident=self.ident.cpu().numpy(), view=self.dom.view())
+
+    def move(self, kind, mrng):
+        """in place, on the arrays the last sync returned"""
+        import torch
+
+        coords = (self.x, self.y, self.z)
+        m = self.x.numel()
+
+        def put(sel, values, a):
+            a[sel] = torch.from_numpy(values).to(a.dtype).cuda()
+
+        if kind == "none":
+            return
+        # nobody leaves the extents the particles have now: with open boundaries the box of the next sync stays what it
+        # is (a box that changes re-encodes every key and takes the regular path, covered by test_domain.py)
+        ext = [(float(a.min()), float(a.max())) for a in coords]
+        if kind == "jitter":  # everybody, by a fraction of a leaf
+            for a, (lo, hi) in zip(coords, ext):
+                a.add_(torch.from_numpy(mrng.normal(0, 2e-4, m)).to(a.dtype).cuda()).clamp_(lo, hi)
+        elif kind in ("few", "many"):  # 2 % (or every second particle: too many for the re-sort) jump anywhere
+            sel = torch.from_numpy(mrng.choice(m, max(1, m // (50 if kind == "few" else 2)), replace=False)).cuda()
+            for a, (lo, hi) in zip(coords, ext):
+                put(sel, mrng.uniform(lo, hi, sel.numel()), a)
+                a.clamp_(lo, hi)
+        elif kind == "collapse":  # a tenth of the particles onto three points: equal keys, overfull leaves
+            sel = torch.from_numpy(mrng.choice(m, m // 10, replace=False)).cuda()
+            pts = mrng.uniform(0.1, 0.9, (3, 3))
+            which = mrng.integers(0, 3, sel.numel())
+            for d, a in enumerate(coords):
+                put(sel, pts[which, d], a)
+        elif kind == "remove":  # flag 1 % with the remove marker (domain.hpp: particles with removeKey leave)
+            sel = torch.from_numpy(mrng.choice(m, max(1, m // 100), replace=False)).cuda()
+            self.keys[sel] = torch.iinfo(torch.int64).min if self.kb == 64 else (1 << 30)  # bit pattern of endKey
+        elif kind == "shuffle":  # the client reorders its arrays behind the domain's back
+            perm = torch.from_numpy(mrng.permutation(m)).cuda()
+            self.x, self.y, self.z, self.h, self.ident = [t[perm].contiguous() for t in (
+                self.x, self.y, self.z, self.h, self.ident)]
+        else:
+            raise ValueError(kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kb,rb,bucket_focus,curve,bc", [
+    (64, 64, 64, 1, (0, 0, 0)),
+    (64, 64, 16, 1, (1, 1, 1)),
+    (64, 32, 100, 1, (0, 1, 2)),
+    (32, 32, 64, 0, (0, 0, 0)),
+    (32, 64, 200, 1, (1, 1, 1)),
+    (64, 64, 1000, 1, (0, 0, 0)),  # buckets beyond the leaf pass: never re-sorted, same results
+])
+def test_resort_equals_full_sort_over_a_time_stepping_loop(hip, oracle, kb, rb, bucket_focus, curve, bc):
+    from oracle.oracle import Box
+
+    n, seed = 120_000, 7 + kb + bucket_focus
+    sa_, sb_ = (_Stepper(hip, kb, rb, bucket_focus, curve, bc, n, seed, allow) for allow in (True, False))
+    dom_a, dom_b = sa_.dom, sb_.dom
+    kdt = np.uint64 if kb == 64 else np.uint32
+    script = ["none", "none", "jitter", "few", "jitter", "remove", "few", "many", "none", "collapse", "jitter", "none",
+              "few", "none"]
+    for step, kind in enumerate(script):
+        if step:
+            sa_.move(kind, np.random.default_rng(1000 + step))
+            sb_.move(kind, np.random.default_rng(1000 + step))
+        a, b = sa_.sync(), sb_.sync()
+        va, vb = a["view"], b["view"]
+        assert (va.end_index, va.num_focus_leaves) == (vb.end_index, vb.num_focus_leaves), (step, kind)
+        for f in ("keys", "x", "y", "z", "h", "ident"):
+            assert np.array_equal(a[f], b[f]), (step, kind, f)
+        m, L = va.end_index, va.num_focus_leaves
+        assert np.array_equal(dom_a.fetch(va.sfc_order, m, np.uint32), dom_b.fetch(vb.sfc_order, m, np.uint32)), step
+        assert np.array_equal(dom_a.fetch(va.layout, L + 1, np.uint32), dom_b.fetch(vb.layout, L + 1, np.uint32)), step
+        assert np.array_equal(dom_a.fetch(va.focus_leaves, L + 1, kdt), dom_b.fetch(vb.focus_leaves, L + 1, kdt)), step
+        # and against the oracle: the keys of the returned coordinates under the domain's box, ascending
+        want = oracle.compute_sfc_keys(curve, kb, a["x"], a["y"], a["z"], Box(list(va.box.lim), bc))
+        assert np.array_equal(a["keys"].view(kdt), want), (step, kind)
+        assert np.all(want[1:] >= want[:-1]), (step, kind)
+    sa, sb = dom_a.stats(), dom_b.stats()
+    assert sb["resorts"] == 0
+    if bucket_focus <= 256:
+        # "none", "jitter", "few", "remove" steps re-sort; "many" and "collapse" are given up (and back off four syncs)
+        assert sa["resorts"] >= 5 and sa["resort_fallbacks"] >= 1, sa
+    else:
+        assert sa["resorts"] == 0, sa
+
+
+@pytest.mark.gpu
+def test_resort_ignores_what_the_caller_did_to_the_arrays(hip, oracle):
+    """the arrays of the previous sync are only a hint: a caller that hands in shuffled arrays (or new particles in the
+    old buffers) gets the same result as from a fresh domain -- every particle is then a mover, the attempt is given up"""
+    from oracle.oracle import Box
+
+    st_ = _Stepper(hip, 64, 64, 64, 1, (0, 0, 0), 80_000, 3, True)
+    dom = st_.dom
+    st_.sync()
+    a = st_.sync()
+    assert dom.stats()["resorts"] == 1 and dom.stats()["last_movers"] == 0
+    st_.move("shuffle", np.random.default_rng(5))
+    b = st_.sync()
+    st = dom.stats()
+    assert st["resort_fallbacks"] == 1, st
+    want = oracle.compute_sfc_keys(1, 64, b["x"], b["y"], b["z"], Box(list(b["view"].box.lim), (0, 0, 0)))
+    assert np.array_equal(b["keys"].view(np.uint64), want) and np.all(want[1:] >= want[:-1])
+    assert np.array_equal(np.sort(b["ident"]), np.sort(a["ident"]))
+
+
+@pytest.mark.gpu
+def test_resort_at_three_million_particles(hip, oracle):
+    """many workgroups of the leaf pass, movers in the hundred thousands, 63-bit keys"""
+    from oracle.oracle import Box
+
+    st_ = _Stepper(hip, 64, 64, 64, 1, (0, 0, 0), 3_000_000, 11, True)
+    dom = st_.dom
+    st_.sync()
+    for step, kind in enumerate(["none", "jitter", "few", "jitter"]):
+        st_.move(kind, np.random.default_rng(50 + step))
+        a = st_.sync()
+        want = oracle.compute_sfc_keys(1, 64, a["x"], a["y"], a["z"], Box(list(a["view"].box.lim), (0, 0, 0)))
+        assert np.array_equal(a["keys"].view(np.uint64), want), kind
+        assert np.all(want[1:] >= want[:-1]), kind
+        assert np.unique(a["ident"]).size == a["ident"].size
+    st = dom.stats()
+    assert st["resorts"] == 4 and st["resort_fallbacks"] == 0, st
