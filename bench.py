@@ -108,6 +108,18 @@ class SyncPipeline:
             d = (torch.rand(m, dtype=a.dtype, device=a.device, generator=self.g) - 0.5) * (4 * h0)
             a[idx] = (a[idx] + d).clamp_(0.0, 1.0)
 
+    def drift(self, frac=0.1):
+        """displace EVERY particle by up to frac * h per coordinate (a time step at a Courant number of that order)"""
+        import torch
+
+        if not hasattr(self, "g"):
+            self.g = torch.Generator(device=self.x.device).manual_seed(1234)
+        h0 = float(self.h[0])
+        for a in (self.x, self.y, self.z):
+            d = torch.rand(a.numel(), dtype=a.dtype, device=a.device, generator=self.g)
+            a.add_(d.sub_(0.5).mul_(2 * frac * h0)).clamp_(0.0, 1.0)
+            del d
+
     def find_neighbors(self, targets, ngmax):
         """cstone_hip_find_neighbors on the synced domain's own tree view (NOT part of the timed metric)"""
         import ctypes as C
@@ -364,11 +376,18 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
         n_sorted = pipe.assigned
-    pass_ms, pass_launches = ctx.profile_get("sort_pass")
-    iota_ms, iota_launches = ctx.profile_get("sort_pass_iota")
-    pass_spread, iota_spread = ctx.profile_spread("sort_pass"), ctx.profile_spread("sort_pass_iota")
-    stage_ms = {s: ctx.profile_get(s)[0] / args.steps for s in cstone_amd.STAGES}
-    roofline_source = "the digit passes of the timed syncs"
+    timed_stages = {s: ctx.profile_get(s) for s in cstone_amd.STAGES}
+    timed_spreads = {s: ctx.profile_spread(s) for s in cstone_amd.STAGES}
+    stage_ms = {s: timed_stages[s][0] / args.steps for s in cstone_amd.STAGES}
+    radix_stats = None
+    resorted = timed_stages["resort_leaves"][1] > 0
+    if resorted:
+        # what is left of the radix pass inside such syncs are the small sorts of the octree build: not the kernel's case
+        timed_stages["sort_pass"] = timed_stages["sort_pass_iota"] = (0.0, 0)
+    if timed_stages["sort_pass"][1]:
+        radix_stats = (timed_stages["sort_pass"][0], timed_stages["sort_pass"][1], timed_spreads["sort_pass"],
+                       timed_stages["sort_pass_iota"][0], timed_stages["sort_pass_iota"][1],
+                       timed_spreads["sort_pass_iota"], "the digit passes of the timed syncs")
     if distributed:
         # On several ranks a sync also launches the pass kernel on small inputs (the newcomers, the tree's node keys), so
         # the average over ALL launches says nothing about the dominant kernel: it is measured on its own, on as many
@@ -383,40 +402,69 @@ def main():
                 ctx.profile_reset()
             ctx.sort_pairs(work, rv)
         ctx.sync()
-        pass_ms, pass_launches = ctx.profile_get("sort_pass")
-        iota_ms, iota_launches = ctx.profile_get("sort_pass_iota")
-        pass_spread, iota_spread = ctx.profile_spread("sort_pass"), ctx.profile_spread("sort_pass_iota")
-        roofline_source = f"cstone_hip_sort_pairs of {n_sorted} random pairs (this rank's share), outside the timed region"
+        radix_stats = (*ctx.profile_get("sort_pass"), ctx.profile_spread("sort_pass"), *ctx.profile_get("sort_pass_iota"),
+                       ctx.profile_spread("sort_pass_iota"),
+                       f"cstone_hip_sort_pairs of {n_sorted} random pairs (this rank's share), outside the timed region")
+        # (the timed syncs' own pass launches include the small sorts: they stay out of the kernel table)
+        timed_stages["sort_pass"] = timed_stages["sort_pass_iota"] = (0.0, 0)
         del rk, rv, work
         invariants_ok = pipe.invariants(n_local * world)
     extras = {}
     if not distributed:
         # the same syncs with the radix sort forced over ALL key digits (what the reference's GPU path does every time;
         # by default Domain::sync sorts the digits above the previous tree's leaf level and finishes the rest in runs)
+        def timed_variant(before_step=None):
+            """args.steps syncs with their stage times and what the domain's counters say about them"""
+            ctx.profile_reset()
+            st0 = pipe.dom.stats()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                if before_step:
+                    before_step()
+                pipe.step()
+            barrier()
+            dt = (time.perf_counter() - t1) / args.steps
+            st1 = pipe.dom.stats()
+            nonlocal radix_stats
+            if radix_stats is None and ctx.profile_get("sort_pass")[1]:
+                radix_stats = (*ctx.profile_get("sort_pass"), ctx.profile_spread("sort_pass"),
+                               *ctx.profile_get("sort_pass_iota"), ctx.profile_spread("sort_pass_iota"),
+                               "the digit passes of the syncs of extras.all_digits_sorted (this run, radix sort forced)")
+            return {"ms_per_step": dt * 1e3, "value": n_local / dt, "unit": "particles/s",
+                    "stage_ms_per_step": {k: round(ctx.profile_get(k)[0] / args.steps, 4) for k in cstone_amd.STAGES
+                                          if ctx.profile_get(k)[1]},
+                    "syncs": {k: st1[k] - st0[k] for k in st1 if k != "last_movers"} | {"last_movers": st1["last_movers"]}}
+
         os.environ["CSTONE_FULL_SORT"] = "1"
         pipe.step()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            pipe.step()
-        barrier()
-        full = (time.perf_counter() - t1) / args.steps
+        extras["all_digits_sorted"] = timed_variant()
         del os.environ["CSTONE_FULL_SORT"]
+        # the sort of a sync from scratch, as the reference does it every time: radix passes over the digits above the
+        # previous tree's leaf level + run fix-up, no use of the previous order
+        os.environ["CSTONE_NO_RESORT"] = "1"
         pipe.step()
-        extras["all_digits_sorted"] = {"ms_per_step": full * 1e3, "value": n_local / full, "unit": "particles/s"}
+        extras["sorted_from_scratch"] = timed_variant()
+        del os.environ["CSTONE_NO_RESORT"]
+        pipe.step()
         # and with particles that move between the syncs (the tree changes a little every time; the displacement itself
         # is inside this timed loop, about 0.1 ms)
         pipe.jiggle()
         pipe.step()
-        barrier()
-        t2 = time.perf_counter()
+        extras["moving_particles"] = timed_variant(pipe.jiggle)
+        extras["moving_particles"]["note"] = "1% of the particles displaced by <= 2h before every sync"
+        # every particle drifts by up to 0.1 h per coordinate between the syncs (the displacement is timed with it: two
+        # passes over x, y, z, about 1.5 ms)
+        pipe.drift()
+        pipe.step()
+        extras["all_particles_drift"] = timed_variant(pipe.drift)
+        extras["all_particles_drift"]["note"] = ("every particle displaced by <= 0.1 h per coordinate before every sync; "
+                                                 "ms_per_step includes the displacement itself")
+        t3 = time.perf_counter()
         for _ in range(args.steps):
-            pipe.jiggle()
-            pipe.step()
+            pipe.drift()
         barrier()
-        moving = (time.perf_counter() - t2) / args.steps
-        extras["moving_particles"] = {"ms_per_step": moving * 1e3, "value": n_local / moving, "unit": "particles/s",
-                                      "note": "1% of the particles displaced by <= 2h before every sync"}
+        extras["all_particles_drift"]["displacement_ms"] = (time.perf_counter() - t3) / args.steps * 1e3
     if not distributed and args.neighbor_targets > 0:
         extras["find_neighbors"] = [pipe.find_neighbors(args.neighbor_targets, 0),
                                     pipe.find_neighbors(args.neighbor_targets, 128)]
@@ -482,37 +530,92 @@ def main():
     ctx.sync()  # raises if a device-side check tripped
 
     if rank == 0:
-        # HBM bytes of the dominant kernel from the PMC counters (FETCH_SIZE doubled per the gfx950 correction,
-        # + WRITE_SIZE), collected in their own rocprofv3 --pmc passes (tools/profile_r1.sh) and scaled per pair
-        traffic = None
-        traffic_per_launch, traffic_source = None, None
-        for tname in ("r02_onesweep_traffic.json", "r01_onesweep_traffic.json"):
+        kbytes, rbytes = args.key_bits // 8, args.real_bits // 8
+        # ---- roofline.  Every kernel that moves the particle arrays, with its ALGORITHMIC bytes per launch (DESIGN.md
+        # section 3) over its launch time measured live with HIP events on the context's stream (stage timers).  The
+        # top-level fields are those of the kernel with the largest total time inside the timed syncs.
+        models = [  # (kernel, stage, bytes per particle and launch, what the bytes are)
+            ("encodeResortKernel" if stage_ms.get("resort_leaves", 0) > 0 else "encodeHistogramKernel", "encode",
+             3 * rbytes + 2 * kbytes, "x, y, z and the old key read, the new key written"),
+            ("leafSortKernel", "resort_leaves", 2 * kbytes + 4, "key read; key + old index written"),
+            ("onesweepKernel", "sort_pass", 2 * (kbytes + 4), "key + index read and written"),
+            ("onesweepKernel (positions generated)", "sort_pass_iota", 2 * kbytes + 4, "key read; key + index written"),
+            ("gatherKernel", "gather", 4 + 2 * rbytes, "index + element read, element written; one launch per array"),
+        ]
+        tjson = None
+        for tname in ("r02_kernel_hbm_traffic.json",):
             tpath = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tpath) and args.key_bits == 64:
-                tj = json.load(open(tpath))
-                # NOT measured in this run: the committed rocprofv3 --pmc passes over tools/sort_bench.py (regular 24 B/pair
-                # launches), scaled to this run's pairs per launch
-                traffic_per_launch = tj["traffic_bytes_per_launch"] / tj["n_pairs"] * n_sorted
-                traffic_source = f"profiles/{tname} (separate --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)"
-                break
-        kbytes = args.key_bits // 8
-        # algorithmic bytes of one digit pass, SURVEY 8(d): read + write of (key, u32 value) = 2 (K + 4) B/pair; the pass
-        # that starts from the identity ordering produces the positions instead of reading them: K + (K + 4) B/pair
-        per_launch_bytes = 2.0 * (kbytes + 4) * n_sorted
-        iota_launch_bytes = (2.0 * kbytes + 4) * n_sorted
-        total_bytes = per_launch_bytes * pass_launches + iota_launch_bytes * iota_launches
-        total_s = (pass_ms + iota_ms) * 1e-3
-        launches = pass_launches + iota_launches
-        avg_s = total_s / max(1, launches)
-        achieved = total_bytes / total_s / 1e9 if total_s > 0 else 0.0
-        per_pass = {"regular": {"launches": pass_launches, "bytes_per_launch": per_launch_bytes,
-                                "avg_ms": pass_ms / max(1, pass_launches), "min_ms": pass_spread[0],
-                                "median_ms": pass_spread[1], "max_ms": pass_spread[2]},
-                    "positions_generated": {"launches": iota_launches, "bytes_per_launch": iota_launch_bytes,
-                                            "avg_ms": iota_ms / max(1, iota_launches), "min_ms": iota_spread[0],
-                                            "median_ms": iota_spread[1], "max_ms": iota_spread[2]}}
-        if traffic is not None:
-            traffic = None  # the PMC passes profile cstone_hip_sort_pairs (24 B/pair launches only): reported separately
+            if os.path.exists(tpath):
+                tjson = (tname, json.load(open(tpath)))
+
+        def pmc_traffic(kernel):
+            """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled + WRITE_SIZE), scaled to
+            this run's particles per launch; None when the profile does not hold the kernel"""
+            if not tjson:
+                return None
+            for row in tjson[1]["kernels"]:
+                if row["kernel"] == kernel.split(" ")[0]:
+                    return (row["hbm_read_bytes"] + row["hbm_write_bytes"]) * n_sorted / tjson[1].get("particles", 1e8)
+            return None
+
+        table = []
+        for kernel, stage, bpp, what in models:
+            ms, launches = timed_stages.get(stage, (0.0, 0))
+            if not launches:
+                continue
+            lo, med, hi = timed_spreads[stage]
+            bytes_launch = float(bpp) * n_sorted
+            gbs = bytes_launch * launches / (ms * 1e-3) / 1e9
+            table.append({"kernel": kernel, "stage": stage, "launches": launches, "bytes_per_particle": bpp,
+                          "bytes": what, "bytes_per_launch": bytes_launch, "avg_ms": ms / launches, "min_ms": lo,
+                          "median_ms": med, "max_ms": hi, "total_ms_per_step": ms / args.steps, "achieved": gbs,
+                          "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel)})
+        top = max(table, key=lambda r: r["total_ms_per_step"]) if table else None
+        sync_bytes = sum(r["bytes_per_launch"] * r["launches"] for r in table) / args.steps
+        # the radix pass the north star singles out: not part of a steady-state sync any more (the re-sort replaces it);
+        # measured live in this run on the syncs of extras.sorted_from_scratch / all_digits_sorted
+        onesweep = None
+        if radix_stats:
+            pass_ms, pass_launches, pass_spread, iota_ms, iota_launches, iota_spread, radix_source = radix_stats
+            per_launch_bytes = 2.0 * (kbytes + 4) * n_sorted
+            iota_launch_bytes = (2.0 * kbytes + 4) * n_sorted
+            total_bytes = per_launch_bytes * pass_launches + iota_launch_bytes * iota_launches
+            total_s = (pass_ms + iota_ms) * 1e-3
+            ach = total_bytes / total_s / 1e9 if total_s > 0 else 0.0
+            onesweep = {"kernel": "onesweepKernel (one 8-bit radix pass over key+index pairs)", "achieved": ach,
+                        "frac": ach / HBM_PEAK_GBS, "launches": pass_launches + iota_launches,
+                        "avg_launch_ms": total_s * 1e3 / max(1, pass_launches + iota_launches),
+                        "traffic": pmc_traffic("onesweepKernel"),
+                        "per_pass": {"regular": {"launches": pass_launches, "bytes_per_launch": per_launch_bytes,
+                                                 "avg_ms": pass_ms / max(1, pass_launches), "min_ms": pass_spread[0],
+                                                 "median_ms": pass_spread[1], "max_ms": pass_spread[2]},
+                                     "positions_generated": {"launches": iota_launches,
+                                                             "bytes_per_launch": iota_launch_bytes,
+                                                             "avg_ms": iota_ms / max(1, iota_launches),
+                                                             "min_ms": iota_spread[0], "median_ms": iota_spread[1],
+                                                             "max_ms": iota_spread[2]}},
+                        "measured_on": radix_source}
+        if distributed and onesweep:
+            # several ranks: the sync of a rank is measured as a whole (exchange included); the kernel singled out is the
+            # radix pass at this rank's share, measured on its own
+            top = {"kernel": onesweep["kernel"], "achieved": onesweep["achieved"], "frac": onesweep["frac"],
+                   "traffic": onesweep["traffic"], "bytes_per_launch": onesweep["per_pass"]["regular"]["bytes_per_launch"],
+                   "avg_ms": onesweep["avg_launch_ms"], "launches": onesweep["launches"]}
+        roofline = {"bound": "hbm", "kernel": top["kernel"] if top else None,
+                    "achieved": top["achieved"] if top else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": top["frac"] if top else 0.0, "traffic": top["traffic"] if top else None,
+                    "traffic_source": (f"profiles/{tjson[0]} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                       f"bench.py, not this run)") if tjson else None,
+                    "bytes_per_launch": top["bytes_per_launch"] if top else None,
+                    "avg_launch_ms": top["avg_ms"] if top else None, "launches": top["launches"] if top else 0,
+                    "dominant_by": "total time of the kernel's launches inside the timed syncs",
+                    "measured_on": "the timed syncs (HIP events around every launch, on the context's stream)",
+                    "kernels": table,
+                    "sync": {"algorithmic_bytes_per_step": sync_bytes,
+                             "achieved": sync_bytes / (elapsed / args.steps) / 1e9,
+                             "frac": sync_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                             "note": "bytes of the kernels listed here over the wall time of a whole sync"},
+                    "onesweep": onesweep}
         out = {
             "metric": "particles/sec domain.sync (encode+sort+tree+halo), 10^8 uniform, 1/2/4/8 GPU",
             "value": n_local * world * args.steps / elapsed,
@@ -528,9 +631,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{n_global:.0e} uniform particles, {args.key_bits}-bit {args.curve} keys, "
                                    f"f{args.real_bits} coordinates, bucketFocus {args.bucket_focus}, "
-                                   f"bucket {bucket_global}, steady-state cstone_hip_domain_sync (radix passes over the "
-                                   f"key digits above the previous tree's leaf level + run fix-up: same order as "
-                                   f"sorting all digits, see extras.all_digits_sorted)"
+                                   f"bucket {bucket_global}, steady-state cstone_hip_domain_sync: the arrays a sync "
+                                   f"returns go into the next one; particles still inside their leaf are ordered leaf by "
+                                   f"leaf, the others are binned (csrc/resort.hpp) -- the same order as sorting all keys; "
+                                   f"extras.sorted_from_scratch / all_digits_sorted: the radix sort instead"
                                    + ("" if not distributed else
                                       f"; {world} rank(s): SFC domain decomposition, particle + halo exchange with "
                                       f"all_to_all over RCCL, 1% of the particles displaced by <=2h before every sync"),
@@ -539,11 +643,7 @@ def main():
                            "rank0_exchange": dict(pipe.stats),
                            "orchestration": "libcstone_hip (cstone_hip_domain_mr_sync)",
                            "transport": pipe.transport} if distributed else {})},
-            "roofline": {"bound": "hbm", "kernel": "onesweepKernel (one 8-bit radix pass over key+index pairs)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic_per_launch, "traffic_source": traffic_source,
-                         "bytes_per_launch": total_bytes / max(1, launches), "avg_launch_ms": avg_s * 1e3,
-                         "launches": launches, "per_pass": per_pass, "measured_on": roofline_source},
+            "roofline": roofline,
             "stage_ms_per_step": stage_ms,
             "first_sync_ms": first_sync_ms,
             "extras": extras,

@@ -2,6 +2,7 @@
 // Replaces, for a sync whose particles mostly stayed in their leaves, the reference's full sort of all keys
 // (sortByKeyGpu, R/primitives/primitives_gpu.cu:305-353).  gfx950: wave64, 160 KB LDS per CU.
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_keys.hpp"
 #include "resort.hpp"
@@ -142,55 +143,190 @@ __global__ __launch_bounds__(256) void placeMoversKernel(const K* __restrict__ m
     binIdx[at]  = moverIdx[m];
 }
 
-/*! The leaf pass.  A workgroup takes G consecutive (non-empty) leaves of the previous sync.  LDS slots of leaf k:
- *  [its old positions | the movers arriving in it].  The old positions are filled in place -- a particle that left
- *  becomes a hole (key ~0, sorts last) --, then one lane per leaf insertion-sorts its slots by (key, old index): the
- *  stayers come in the order of the previous sync, i.e. almost sorted, so the sort is close to one comparison per
- *  element.  The first newCount slots of every leaf are the leaf's new content, written to layoutNew[leaf] + r. */
+/*! The leaf pass.  A workgroup takes G consecutive (non-empty) leaves of the previous sync.  Its LDS slots:
+ *  [the old positions of its leaves, in place | the movers arriving in its leaves, leaf by leaf].  The encode pass has
+ *  replaced the key of every particle that left its leaf by a hole (key ~0, sorts last), so the old positions are
+ *  copied as they are.  Then, per tile:
+ *   - nothing left or arrived (the common case of a quiet region): one lane per leaf insertion-sorts the leaf in LDS
+ *     -- the particles come in the order of the previous sync, i.e. almost sorted: one LDS read per element --, and the
+ *     tile is written back slot by slot;
+ *   - otherwise every particle counts the elements of its leaf (old positions and arrivals) that sort in front of it,
+ *     by (key, old index): LDS broadcast reads, all 256 lanes busy, cost independent of the disorder.  The count is the
+ *     particle's place in the leaf; holes rank last and are dropped.
+ *  Either way leaf j's new content lands at layoutNew[j]...: ascending keys, ties by old index = the stable sort. */
 template<class K, int G>
 __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keysIn, const uint64_t* __restrict__ mask,
-                                                      const uint32_t* __restrict__ rank, const K* __restrict__ leafLo,
+                                                      const uint32_t* __restrict__ rank,
                                                       const uint32_t* __restrict__ leafPos,
                                                       const uint32_t* __restrict__ inOffset,
                                                       const uint32_t* __restrict__ layoutNew,
                                                       const K* __restrict__ binKeys, const uint32_t* __restrict__ binIdx,
-                                                      uint32_t J, K* __restrict__ keysOut, uint32_t* __restrict__ orderOut)
+                                                      uint32_t J, bool alwaysCount, K* __restrict__ keysOut,
+                                                      uint32_t* __restrict__ orderOut)
 {
+    constexpr int ITER = (RESORT_TILE_SLOTS + 255) / 256;
+    constexpr K HOLE   = ~K(0);
     __shared__ K sKey[RESORT_TILE_SLOTS];
-    __shared__ uint32_t sIdx[RESORT_TILE_SLOTS];
-    __shared__ K loK[G + 1];
-    __shared__ uint32_t posK[G + 1], inK[G + 1], outK[G + 1], segK[G + 1];
+    __shared__ uint32_t sIdx[RESORT_TILE_SLOTS]; // old index; for the old positions only the quiet path fills it
+    __shared__ uint32_t posK[G + 1], inK[G + 1], outK[G + 1];
 
     const uint32_t j0 = blockIdx.x * uint32_t(G);
     const uint32_t nl = min(uint32_t(G), J - j0);
     const uint32_t t  = threadIdx.x;
     if (t <= nl)
     {
-        loK[t]  = leafLo[j0 + t];
         posK[t] = leafPos[j0 + t];
         inK[t]  = inOffset[j0 + t];
         outK[t] = layoutNew[j0 + t];
     }
     __syncthreads();
-    if (t <= nl) segK[t] = (posK[t] - posK[0]) + (inK[t] - inK[0]);
-    __syncthreads();
-    const uint32_t p0 = posK[0], p1 = posK[nl];
-    const uint32_t slots = segK[nl];
+    const uint32_t p0 = posK[0], p1 = posK[nl], in0 = inK[0], in1 = inK[nl];
+    const uint32_t nOldAll = p1 - p0, slots = nOldAll + (in1 - in0);
     // guarded by checkTilesKernel: a launch only happens when every workgroup fits
     if (slots > RESORT_TILE_SLOTS) return;
+    // quiet tile: no arrivals, and every leaf keeps its size (without arrivals: nobody left)
+    bool changed = in1 != in0 || alwaysCount;
+    if (t < nl) changed = changed || (outK[t + 1] - outK[t]) != (posK[t + 1] - posK[t]);
+    const bool quiet = !__syncthreads_or(changed);
 
-    for (uint32_t p = p0 + t; p < p1; p += 256)
+    // old positions: all loads of a thread are issued before the first is used
+    K key[ITER];
+    uint8_t leaf[ITER];
     {
-        const K key         = keysIn[p];
-        const uint64_t word = mask[p >> 6];
-        const uint32_t j    = rank[p >> 6] + uint32_t(__popcll(word & ((2ull << (p & 63u)) - 1))) - 1u;
-        const uint32_t k    = j - j0;
-        const bool stay     = key >= loK[k] && key < loK[k + 1];
-        const uint32_t at   = segK[k] + (p - posK[k]);
-        sKey[at]            = stay ? key : ~K(0);
-        sIdx[at]            = p;
+        uint64_t word[ITER];
+        uint32_t rk[ITER];
+#pragma unroll
+        for (int i = 0; i < ITER; ++i)
+        {
+            const uint32_t p = p0 + t + 256u * i;
+            if (p < p1)
+            {
+                key[i] = keysIn[p];
+                if (!quiet)
+                {
+                    word[i] = mask[p >> 6];
+                    rk[i]   = rank[p >> 6];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ITER; ++i)
+        {
+            const uint32_t p = p0 + t + 256u * i;
+            if (p < p1)
+            {
+                sKey[p - p0] = key[i];
+                if (quiet) sIdx[p - p0] = p;
+                else leaf[i] = uint8_t(rk[i] + uint32_t(__popcll(word[i] & ((2ull << (p & 63u)) - 1))) - 1u - j0);
+            }
+        }
     }
-    for (uint32_t m = inK[0] + t; m < inK[nl]; m += 256)
+    for (uint32_t m = in0 + t; m < in1; m += 256)
+    {
+        sKey[nOldAll + (m - in0)] = binKeys[m];
+        sIdx[nOldAll + (m - in0)] = binIdx[m];
+    }
+    __syncthreads();
+
+    if (quiet)
+    {
+        if (t < nl)
+        {
+            const uint32_t s = posK[t] - p0, nOld = posK[t + 1] - posK[t];
+            if (nOld > 1)
+            {
+                const uint32_t e = s + nOld;
+                K pk             = sKey[s];
+                K nk             = sKey[s + 1];
+                for (uint32_t a = s + 1; a < e; ++a)
+                {
+                    const K ka = nk;
+                    if (a + 1 < e) nk = sKey[a + 1];
+                    if (ka > pk)
+                    {
+                        pk = ka;
+                        continue;
+                    }
+                    const uint32_t ia = sIdx[a];
+                    if (ka == pk && ia > sIdx[a - 1]) continue;
+                    uint32_t b = a;
+                    while (b > s)
+                    {
+                        const K kb        = sKey[b - 1];
+                        const uint32_t ib = sIdx[b - 1];
+                        if (kb < ka || (kb == ka && ib < ia)) break;
+                        sKey[b] = kb;
+                        sIdx[b] = ib;
+                        --b;
+                    }
+                    sKey[b] = ka;
+                    sIdx[b] = ia;
+                }
+            }
+        }
+        __syncthreads();
+        // every leaf kept its size: slot e of the tile goes to layoutNew[first leaf] + e
+        const uint32_t out0 = outK[0];
+#pragma unroll
+        for (int i = 0; i < ITER; ++i)
+        {
+            const uint32_t e = t + 256u * i;
+            if (e < nOldAll)
+            {
+                keysOut[out0 + e]  = sKey[e];
+                orderOut[out0 + e] = sIdx[e];
+            }
+        }
+        return;
+    }
+
+    // place of (kx, ix) among the elements of leaf k: those with a smaller key, or the same key and a smaller old index.
+    // The old positions are scanned four at a time (independent LDS broadcast reads: the lanes of a wave sit in one or
+    // two leaves); equal keys are only counted there, their order is settled in a second look when there are any.
+    auto placeInLeaf = [&](uint32_t k, K kx, uint32_t ix, bool fromOld)
+    {
+        const uint32_t o0 = posK[k] - p0, nOld = posK[k + 1] - posK[k];
+        const uint32_t a0 = nOldAll + (inK[k] - in0), nInc = inK[k + 1] - inK[k];
+        uint32_t less = 0, same = 0;
+        uint32_t q = 0;
+        for (; q + 4 <= nOld; q += 4)
+        {
+            const K k0 = sKey[o0 + q], k1 = sKey[o0 + q + 1], k2 = sKey[o0 + q + 2], k3 = sKey[o0 + q + 3];
+            less += (k0 < kx) + (k1 < kx) + (k2 < kx) + (k3 < kx);
+            same += (k0 == kx) + (k1 == kx) + (k2 == kx) + (k3 == kx);
+        }
+        for (; q < nOld; ++q)
+        {
+            const K kq = sKey[o0 + q];
+            less += kq < kx;
+            same += kq == kx;
+        }
+        if (same > (fromOld ? 1u : 0u))
+        {
+            // equal keys among the old positions: those in front of ix count
+            for (q = 0; q < nOld; ++q)
+                less += (sKey[o0 + q] == kx && p0 + o0 + q < ix) ? 1u : 0u;
+        }
+        for (q = 0; q < nInc; ++q)
+        {
+            const K kq = sKey[a0 + q];
+            less += (kq < kx || (kq == kx && sIdx[a0 + q] < ix)) ? 1u : 0u;
+        }
+        return less;
+    };
+#pragma unroll
+    for (int i = 0; i < ITER; ++i)
+    {
+        const uint32_t e = t + 256u * i;
+        if (e < nOldAll && key[i] != HOLE)
+        {
+            const uint32_t k  = leaf[i];
+            const uint32_t to = outK[k] + placeInLeaf(k, key[i], p0 + e, true);
+            keysOut[to]       = key[i];
+            orderOut[to]      = p0 + e;
+        }
+    }
+    for (uint32_t m = in0 + t; m < in1; m += 256)
     {
         // leaf of bin entry m: last k with inK[k] <= m
         uint32_t lo = 0, hi = nl;
@@ -200,60 +336,11 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
             if (inK[mid] <= m) lo = mid;
             else hi = mid;
         }
-        const uint32_t at = segK[lo] + (posK[lo + 1] - posK[lo]) + (m - inK[lo]);
-        sKey[at]          = binKeys[m];
-        sIdx[at]          = binIdx[m];
-    }
-    __syncthreads();
-
-    if (t < nl)
-    {
-        const uint32_t s = segK[t], e = segK[t + 1];
-        if (e - s > 1)
-        {
-            K pk        = sKey[s];
-            uint32_t pi = sIdx[s];
-            for (uint32_t a = s + 1; a < e; ++a)
-            {
-                const K ka        = sKey[a];
-                const uint32_t ia = sIdx[a];
-                if (ka > pk || (ka == pk && ia > pi))
-                {
-                    pk = ka, pi = ia;
-                    continue;
-                }
-                uint32_t b = a;
-                while (b > s)
-                {
-                    const K kb        = sKey[b - 1];
-                    const uint32_t ib = sIdx[b - 1];
-                    if (kb < ka || (kb == ka && ib < ia)) break;
-                    sKey[b] = kb;
-                    sIdx[b] = ib;
-                    --b;
-                }
-                sKey[b] = ka;
-                sIdx[b] = ia;
-            }
-        }
-    }
-    __syncthreads();
-
-    for (uint32_t e = t; e < slots; e += 256)
-    {
-        uint32_t lo = 0, hi = nl;
-        while (hi - lo > 1)
-        {
-            uint32_t mid = (lo + hi) / 2;
-            if (segK[mid] <= e) lo = mid;
-            else hi = mid;
-        }
-        const uint32_t r = e - segK[lo];
-        if (r < outK[lo + 1] - outK[lo])
-        {
-            keysOut[outK[lo] + r]  = sKey[e];
-            orderOut[outK[lo] + r] = sIdx[e];
-        }
+        const K kx        = sKey[nOldAll + (m - in0)];
+        const uint32_t ix = sIdx[nOldAll + (m - in0)];
+        const uint32_t to = outK[lo] + placeInLeaf(lo, kx, ix, false);
+        keysOut[to]       = kx;
+        orderOut[to]      = ix;
     }
 }
 
@@ -380,11 +467,13 @@ int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, 
     }
     if (J == 0) return CSTONE_OK;
     StageTimer timer(ctx, CSTONE_STAGE_RESORT_LEAVES);
-    const unsigned grid = (J + unsigned(leavesPerTile) - 1) / unsigned(leavesPerTile);
+    const unsigned grid    = (J + unsigned(leavesPerTile) - 1) / unsigned(leavesPerTile);
+    const bool alwaysCount = std::getenv("CSTONE_RESORT_COUNT") != nullptr; // tuning/tests: no quiet-tile shortcut
 #define CSTONE_LEAF_SORT(G)                                                                                            \
     hipLaunchKernelGGL((leafSortKernel<K, G>), grid, 256, 0, ctx->stream, keysIn, mask_.as<uint64_t>(),                \
-                       rank_.as<uint32_t>(), leafLo_.as<K>(), leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(),       \
-                       layoutNew_.as<uint32_t>(), binKeys_.as<K>(), binIdx_.as<uint32_t>(), J, keysOut, orderOut)
+                       rank_.as<uint32_t>(), leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(),                        \
+                       layoutNew_.as<uint32_t>(), binKeys_.as<K>(), binIdx_.as<uint32_t>(), J, alwaysCount, keysOut,  \
+                       orderOut)
     if (leavesPerTile == 64) CSTONE_LEAF_SORT(64);
     else if (leavesPerTile == 32) CSTONE_LEAF_SORT(32);
     else if (leavesPerTile == 16) CSTONE_LEAF_SORT(16);

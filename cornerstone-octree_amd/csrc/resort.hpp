@@ -26,7 +26,7 @@ namespace cship
 template<class K>
 struct ResortArgs
 {
-    K* keysOut;                // new keys, at the particles' old positions
+    K* keysOut;                // new keys at the particles' old positions; ~0 (a hole) where the particle left its leaf
     const uint64_t* leafStart; // bit p set: a non-empty leaf of the previous sync starts at position p
     const uint32_t* leafRank;  // per 64 positions: number of set bits in front of the word
     const K* leafLo;           // [J + 1]: first key of the j-th non-empty leaf; leafLo[0] = 0, leafLo[J] = endKey

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void foldExtentsKernel(const T* __restrict__ p
 /*! Encode for the incremental re-sort (resort.hpp): the keys go to ra.keysOut (the caller's key array is only read, for
  *  its remove markers) and every particle is checked against the key range of the leaf its position belonged to at the
  *  previous sync.  Particles that left their leaf are counted per leaf and appended to the mover list -- staged per wave
- *  in LDS and flushed with one atomic per 128..256 movers.  The extents of x, y, z are measured like in
+ *  in LDS and flushed with one atomic per 128..256 movers; in ra.keysOut a hole (~0) takes their place.  The extents of x, y, z are measured like in
  *  encodeHistogramKernel.  Grid-stride, whole waves walk the iterations together. */
 template<class K, class T, int VEC, bool HILBERT>
 __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ x, const T* __restrict__ y,
@@ -364,8 +364,9 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
         }
         staged = 0;
     };
-    // is the particle at position p still inside the leaf that position belonged to?  If not: count and stage it.
-    auto classify = [&](K key, size_t p, bool valid)
+    // is the particle at position p still inside the leaf that position belonged to?  If not: count and stage it;
+    // returns what goes to keysOut: the key of a stayer, a hole (~0: sorts behind everything) for a mover
+    auto classify = [&](K key, size_t p, bool valid) -> K
     {
         bool mover = false;
         if (valid)
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
             }
             staged += unsigned(__popcll(mm));
         }
+        return mover ? ~K(0) : key;
     };
 
     const size_t nVec   = n / VEC;
@@ -440,11 +442,11 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
 #pragma unroll
             for (int v = 0; v < VEC; ++v)
                 if (vk[v] == endKey<K>()) out[v] = vk[v]; // particles flagged for removal keep their marker
-            __builtin_memcpy(__builtin_assume_aligned(ra.keysOut + base, sizeof(K) * VEC), out, sizeof out);
         }
 #pragma unroll
         for (int v = 0; v < VEC; ++v)
-            classify(out[v], base + v, valid);
+            out[v] = classify(out[v], base + v, valid);
+        if (valid) __builtin_memcpy(__builtin_assume_aligned(ra.keysOut + base, sizeof(K) * VEC), out, sizeof out);
         if (staged >= STAGE / 2) flush();
     }
     // elements behind the last full vector: first wave of block 0
@@ -457,11 +459,11 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
         {
             K m = gridMorton<K, T>(x[i], y[i], z[i], mx, my, mz, sx, sy, sz);
             if (HILBERT) m = hilbertFromMorton<K>(m, enc);
-            key           = keysIn[i] == endKey<K>() ? endKey<K>() : m;
-            ra.keysOut[i] = key;
+            key = keysIn[i] == endKey<K>() ? endKey<K>() : m;
             if (extentPartials) widen(x[i], y[i], z[i]);
         }
-        classify(key, i, valid);
+        key = classify(key, i, valid);
+        if (valid) ra.keysOut[i] = key;
     }
     if (staged) flush();
     if (extentPartials) foldBlockExtents<T>(ext, extentPartials);

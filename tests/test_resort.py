@@ -98,16 +98,22 @@ class _Stepper:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kb,rb,bucket_focus,curve,bc", [
-    (64, 64, 64, 1, (0, 0, 0)),
-    (64, 64, 16, 1, (1, 1, 1)),
-    (64, 32, 100, 1, (0, 1, 2)),
-    (32, 32, 64, 0, (0, 0, 0)),
-    (32, 64, 200, 1, (1, 1, 1)),
-    (64, 64, 1000, 1, (0, 0, 0)),  # buckets beyond the leaf pass: never re-sorted, same results
+@pytest.mark.parametrize("kb,rb,bucket_focus,curve,bc,always_count", [
+    (64, 64, 64, 1, (0, 0, 0), False),
+    (64, 64, 64, 1, (0, 0, 0), True),  # every tile of the leaf pass through the counting path, quiet or not
+    (64, 64, 16, 1, (1, 1, 1), False),
+    (64, 32, 100, 1, (0, 1, 2), False),
+    (32, 32, 64, 0, (0, 0, 0), False),
+    (32, 32, 64, 0, (0, 0, 0), True),
+    (32, 64, 200, 1, (1, 1, 1), False),
+    (64, 64, 1000, 1, (0, 0, 0), False),  # buckets beyond the leaf pass: never re-sorted, same results
 ])
-def test_resort_equals_full_sort_over_a_time_stepping_loop(hip, oracle, kb, rb, bucket_focus, curve, bc):
+def test_resort_equals_full_sort_over_a_time_stepping_loop(hip, oracle, monkeypatch, kb, rb, bucket_focus, curve, bc,
+                                                           always_count):
     from oracle.oracle import Box
+
+    if always_count:
+        monkeypatch.setenv("CSTONE_RESORT_COUNT", "1")
 
     n, seed = 120_000, 7 + kb + bucket_focus
     sa_, sb_ = (_Stepper(hip, kb, rb, bucket_focus, curve, bc, n, seed, allow) for allow in (True, False))
