@@ -71,10 +71,18 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             perk[key][c].append(float(row["Counter_Value"]))
             perk[key]["ns"].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
 if perk:
+    # the full-size launches of a kernel: grids within 10 % of its largest one (the grids of the leaf kernels follow the
+    # number of leaves, which differs a little from sync to sync and from run to run)
+    top = defaultdict(int)
+    for (short, grid) in perk:
+        top[short] = max(top[short], grid)
     biggest = {}
     for (short, grid), v in perk.items():
-        if short not in biggest or grid > biggest[short][0]:
-            biggest[short] = (grid, v)
+        if grid < 0.9 * top[short]:
+            continue
+        g, acc = biggest.setdefault(short, (top[short], defaultdict(list)))
+        for k, vals in v.items():
+            acc[k].extend(vals)
     table = []
     for short, (grid, v) in sorted(biggest.items()):
         if not v.get("FETCH_SIZE") or not v.get("WRITE_SIZE"):
@@ -85,8 +93,8 @@ if perk:
         table.append({"kernel": short, "grid_threads": grid, "launches": len(v["ns"]) // 2, "avg_us_under_pmc": us,
                       "hbm_read_bytes": fetch, "hbm_write_bytes": write,
                       "hbm_GBps": (fetch + write) / (us * 1e-6) / 1e9 if us > 0 else None})
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python bench.py --steps 3` (N = 1e8), largest grid "
-                         "per kernel; FETCH_SIZE doubled (gfx950); durations are those of the counter runs",
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python bench.py --steps 3` (N = 1e8), the full-size "
+                         "launches of every kernel; FETCH_SIZE doubled (gfx950); durations are those of the counter runs",
                "kernels": table}, open(f"profiles/{tag}_kernel_hbm_traffic.json", "w"), indent=1)
 # the multi-rank sync at the per-GPU size of the 8-GPU point (tools/mr_bench.py --rccl --particles 1.25e7): kernels per
 # sync, averaged over the last 10 syncs of the trace (a sync starts with its one encodeHistogramKernel launch)
