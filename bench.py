@@ -37,6 +37,7 @@ def parse():
     p.add_argument("--bucket-focus", type=int, default=64)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-plummer", action="store_true", help="skip extras.plummer (BASELINE configs[2])")
+    p.add_argument("--no-variants", action="store_true", help="skip the sort / movement variants of extras (tuning runs)")
     p.add_argument("--neighbor-targets", type=float, default=1e7,
                    help="after the timed region: findNeighbors for this many particles of the synced domain (0: skip)")
     p.add_argument("--cpu-sample", type=float, default=4e6, help="particles in the CPU baseline sample")
@@ -410,7 +411,7 @@ def main():
         del rk, rv, work
         invariants_ok = pipe.invariants(n_local * world)
     extras = {}
-    if not distributed:
+    if not distributed and not args.no_variants:
         # the same syncs with the radix sort forced over ALL key digits (what the reference's GPU path does every time;
         # by default Domain::sync sorts the digits above the previous tree's leaf level and finishes the rest in runs)
         def timed_variant(before_step=None):

@@ -126,6 +126,8 @@ class Context:
             raise CstoneError("no GPU visible: libcstone_hip needs an MI355X (there is no CPU path)")
         torch.cuda.set_device(self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else 0
+        # the stream the library's work is ordered on, as torch sees it (None: a private stream of the library)
+        self.stream_handle = stream if use_torch_stream else None
         self.h = C.c_void_p()
         rc = self.lib.cstone_hip_ctx_create(C.byref(self.h), C.c_int(self.device.index), C.c_void_p(stream),
                                             C.c_int(0 if use_torch_stream else 1))

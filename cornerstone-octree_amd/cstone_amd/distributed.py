@@ -73,7 +73,17 @@ class TorchCollectives:
 
     def _guard(self, fn):
         try:
+            # RCCL collectives of torch.distributed run on torch's CURRENT stream.  The contract of cstone_hip_comm_ops
+            # (cstone_hip.h) wants them ordered on the context's stream: that holds by itself while both are the same
+            # stream; otherwise the callback waits for the context's stream before and for torch's stream after
+            torch = _torch()
+            foreign = (not self.stage and
+                       getattr(self.ctx, "stream_handle", None) != torch.cuda.current_stream(self.ctx.device).cuda_stream)
+            if foreign:
+                self.ctx.sync()
             fn()
+            if foreign:
+                torch.cuda.current_stream(self.ctx.device).synchronize()
             return 0
         except Exception as e:  # surfaces as CSTONE_E_INTERNAL in the library; the text is kept for the caller
             self.error = e

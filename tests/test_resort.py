@@ -98,24 +98,28 @@ class _Stepper:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kb,rb,bucket_focus,curve,bc,always_count", [
-    (64, 64, 64, 1, (0, 0, 0), False),
-    (64, 64, 64, 1, (0, 0, 0), True),  # every tile of the leaf pass through the counting path, quiet or not
-    (64, 64, 16, 1, (1, 1, 1), False),
-    (64, 32, 100, 1, (0, 1, 2), False),
-    (32, 32, 64, 0, (0, 0, 0), False),
-    (32, 32, 64, 0, (0, 0, 0), True),
-    (32, 64, 200, 1, (1, 1, 1), False),
-    (64, 64, 1000, 1, (0, 0, 0), False),  # buckets beyond the leaf pass: never re-sorted, same results
+@pytest.mark.parametrize("kb,rb,bucket_focus,curve,bc,always_count,n", [
+    (64, 64, 64, 1, (0, 0, 0), False, 120_000),
+    (64, 64, 64, 1, (0, 0, 0), True, 120_000),  # every tile of the leaf pass through the counting path, quiet or not
+    (64, 64, 16, 1, (1, 1, 1), False, 120_000),
+    (64, 32, 100, 1, (0, 1, 2), False, 120_000),
+    (32, 32, 64, 0, (0, 0, 0), False, 120_000),
+    (32, 32, 64, 0, (0, 0, 0), True, 120_000),
+    (32, 64, 200, 1, (1, 1, 1), False, 120_000),
+    (64, 64, 1000, 1, (0, 0, 0), False, 120_000),  # buckets beyond the leaf pass: never re-sorted, same results
+    # a handful of leaves at levels 1-2: too wide for the packed (key, slot) entries of the counting path
+    (64, 64, 64, 1, (0, 0, 0), True, 700),
+    (32, 32, 64, 1, (1, 1, 1), True, 700),
+    (64, 64, 64, 0, (0, 0, 0), False, 700),
 ])
 def test_resort_equals_full_sort_over_a_time_stepping_loop(hip, oracle, monkeypatch, kb, rb, bucket_focus, curve, bc,
-                                                           always_count):
+                                                           always_count, n):
     from oracle.oracle import Box
 
     if always_count:
         monkeypatch.setenv("CSTONE_RESORT_COUNT", "1")
 
-    n, seed = 120_000, 7 + kb + bucket_focus
+    seed = 7 + kb + bucket_focus
     sa_, sb_ = (_Stepper(hip, kb, rb, bucket_focus, curve, bc, n, seed, allow) for allow in (True, False))
     dom_a, dom_b = sa_.dom, sb_.dom
     kdt = np.uint64 if kb == 64 else np.uint32
@@ -142,7 +146,10 @@ def test_resort_equals_full_sort_over_a_time_stepping_loop(hip, oracle, monkeypa
     assert sb["resorts"] == 0
     if bucket_focus <= 256:
         # "none", "jitter", "few", "remove" steps re-sort; "many" and "collapse" are given up (and back off four syncs)
-        assert sa["resorts"] >= 5 and sa["resort_fallbacks"] >= 1, sa
+        if n > 1000:
+            assert sa["resorts"] >= 5 and sa["resort_fallbacks"] >= 1, sa
+        else:
+            assert sa["resorts"] >= 3, sa  # (a few hundred particles: the box follows nearly every move)
     else:
         assert sa["resorts"] == 0, sa
 
