@@ -38,6 +38,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-plummer", action="store_true", help="skip extras.plummer (BASELINE configs[2])")
     p.add_argument("--no-variants", action="store_true", help="skip the sort / movement variants of extras (tuning runs)")
+    p.add_argument("--no-stage-timers", action="store_true",
+                   help="tuning runs: no HIP events around the launches (no roofline, no stage times): what do they cost?")
     p.add_argument("--neighbor-targets", type=float, default=1e7,
                    help="after the timed region: findNeighbors for this many particles of the synced domain (0: skip)")
     p.add_argument("--cpu-sample", type=float, default=4e6, help="particles in the CPU baseline sample")
@@ -362,7 +364,9 @@ def main():
     first_sync_ms = (time.perf_counter() - t_first) * 1e3
     for _ in range(args.warmup):
         pipe.step()
-    ctx.profile_enable(True)
+    # HIP events around the kernels that move the particle arrays only (roofline): every stage of a sync bracketed costs
+    # 0.1 ms of a 3.3 ms sync in event records; the full stage table comes from further syncs behind the timed region
+    ctx.profile_enable(0 if args.no_stage_timers else 2)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -379,7 +383,13 @@ def main():
         n_sorted = pipe.assigned
     timed_stages = {s: ctx.profile_get(s) for s in cstone_amd.STAGES}
     timed_spreads = {s: ctx.profile_spread(s) for s in cstone_amd.STAGES}
-    stage_ms = {s: timed_stages[s][0] / args.steps for s in cstone_amd.STAGES}
+    # every stage of a sync, on args.steps further syncs of the same kind (not part of `value`)
+    ctx.profile_enable(0 if args.no_stage_timers else 1)
+    ctx.profile_reset()
+    for _ in range(args.steps):
+        pipe.step()
+    barrier()
+    stage_ms = {s: ctx.profile_get(s)[0] / args.steps for s in cstone_amd.STAGES}
     radix_stats = None
     resorted = timed_stages["resort_leaves"][1] > 0
     if resorted:

@@ -50,6 +50,13 @@ StageTimer::StageTimer(cstone_hip_ctx* c, int stage)
 {
     if (!ctx->profiling) return;
     if (ctx->timerDepth++ > 0) return;
+    // level 2: only the kernels that move the particle arrays get their two event records (a record costs a few
+    // microseconds of stream time; a sync has about forty brackets, eight of them around such kernels)
+    const bool heavy = stage == CSTONE_STAGE_ENCODE || stage == CSTONE_STAGE_SORT_PASS ||
+                       stage == CSTONE_STAGE_SORT_PASS_IOTA || stage == CSTONE_STAGE_GATHER ||
+                       stage == CSTONE_STAGE_RESORT_LEAVES || stage == CSTONE_STAGE_HALOS ||
+                       stage == CSTONE_STAGE_NEIGHBORS;
+    if (ctx->profiling == 2 && !heavy) return;
     cstone_hip_ctx::Bracket b{stage, takeEvent(ctx), takeEvent(ctx)};
     (void)hipEventRecord(b.a, ctx->stream);
     idx = int(ctx->brackets.size());
@@ -239,7 +246,7 @@ int cstone_hip_profile_enable(cstone_hip_ctx* ctx, int on)
 {
     if (!ctx) return CSTONE_E_ARG;
     CS_TRY(drainBrackets(ctx));
-    ctx->profiling = on != 0;
+    ctx->profiling = on < 0 ? 0 : (on > 2 ? 1 : on);
     return CSTONE_OK;
 }
 

@@ -35,7 +35,7 @@ struct cstone_hip_ctx
     void* hilbertTables = nullptr;
 
     // stage timers
-    bool profiling = false;
+    int profiling  = 0; // 0 off, 1 every stage, 2 only the stages of the kernels that move the particle arrays
     int timerDepth = 0; // only the outermost StageTimer of a call records (nested helper launches are part of it)
     struct Bracket
     {

@@ -619,11 +619,20 @@ private:
                            fLeafCounts_.as<uint32_t>(), fLti_.as<NodeIdx>(), newI, newL, fCounts_.as<uint32_t>());
         CS_TRY(upsweepSumLevels(ctx_, int(maxLevel<K>()) + 2, levelRangeHost_.data(), fLevelRange_.as<int32_t>(),
                                 fChild_.as<int32_t>(), fCounts_.as<uint32_t>()));
-        // updateGeoCenters
-        CS_TRY(fCenters_.ensure(ctx_, size_t(newM) * 3 * sizeof(T)));
-        CS_TRY(fSizes_.ensure(ctx_, size_t(newM) * 3 * sizeof(T)));
-        CS_TRY(cstone_hip_node_centers(ctx_, curve_, 8 * sizeof(K), 8 * sizeof(T), fPrefixes_.p, newM, &box_,
-                                       fCenters_.p, fSizes_.p));
+        // updateGeoCenters: the geometry of the nodes follows from the tree and the box alone -- nothing to do for an
+        // unchanged tree inside an unchanged box (the reference recomputes it in every sync, octree_focus_mpi.hpp:259-273)
+        bool sameBox = centersNodes_ == newM;
+        for (int k = 0; k < 6; ++k)
+            sameBox = sameBox && centersBox_.lim[k] == box_.lim[k];
+        if (!(*converged && sameBox))
+        {
+            CS_TRY(fCenters_.ensure(ctx_, size_t(newM) * 3 * sizeof(T)));
+            CS_TRY(fSizes_.ensure(ctx_, size_t(newM) * 3 * sizeof(T)));
+            CS_TRY(cstone_hip_node_centers(ctx_, curve_, 8 * sizeof(K), 8 * sizeof(T), fPrefixes_.p, newM, &box_,
+                                           fCenters_.p, fSizes_.p));
+            centersBox_   = box_;
+            centersNodes_ = newM;
+        }
         CS_HIP(ctx_, hipGetLastError());
         return CSTONE_OK;
     }
@@ -644,6 +653,8 @@ private:
     DevBuf fTree_, fLeafCounts_, fCounts_, newTree_;
     int fCap_ = 0, fLeaves_ = 0;
     int layoutLeaves_ = -1; // number of leaves layout_ was computed for
+    cstone_box centersBox_{}; // box and node count fCenters_ / fSizes_ were computed for
+    NodeIdx centersNodes_ = -1;
     std::vector<NodeIdx> levelRangeHost_;
     int fullSortFallbacks_ = 0;
     DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_, fCenters_, fSizes_;

@@ -13,21 +13,45 @@ namespace cship
 namespace
 {
 
-//! bit p of mask: a non-empty leaf starts at position p
-__global__ __launch_bounds__(256) void markLeafStartsKernel(const uint32_t* __restrict__ layout, int numLeaves,
-                                                            unsigned long long* __restrict__ mask)
+/*! Leaf-start bitmask without atomics: bit p of mask is set when a non-empty leaf starts at position p.  The thread of
+ *  the first non-empty leaf that starts inside a 64-position word builds that word from the leaves that follow (a leaf
+ *  holds a few dozen particles: one or two starts per word), clears the words between the previous start and its own
+ *  and stores the words' bit counts for the rank scan.  The thread of the last non-empty leaf also clears the tail. */
+__global__ __launch_bounds__(256) void leafStartWordsKernel(const uint32_t* __restrict__ layout, int numLeaves,
+                                                            uint32_t n, uint64_t* __restrict__ mask,
+                                                            uint32_t* __restrict__ bits, uint32_t words)
 {
     int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= numLeaves) return;
-    uint32_t a = layout[l], b = layout[l + 1];
-    if (b > a) atomicOr(&mask[a >> 6], 1ull << (a & 63u));
-}
-
-__global__ __launch_bounds__(256) void popcountWordsKernel(const uint64_t* __restrict__ mask, size_t words,
-                                                           uint32_t* __restrict__ out)
-{
-    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
-    if (i < words) out[i] = uint32_t(__popcll(mask[i]));
+    const uint32_t a = layout[l];
+    if (layout[l + 1] <= a) return; // empty
+    const uint32_t w = a >> 6;
+    // the previous non-empty leaf (empty ones in between start at a as well)
+    int prev = l - 1;
+    while (prev >= 0 && layout[prev] == a)
+        --prev;
+    const bool first = prev < 0;
+    if (!first && (layout[prev] >> 6) == w) return; // not the first start inside this word
+    uint64_t word = 0;
+    uint32_t pos  = a;
+    int m         = l;
+    while (m < numLeaves && (pos >> 6) == w)
+    {
+        if (layout[m + 1] > pos) word |= 1ull << (pos & 63u);
+        ++m;
+        pos = m < numLeaves ? layout[m] : n;
+        // (empty leaves repeat the position of their successor: the bit is set once, by the non-empty one)
+    }
+    mask[w] = word;
+    bits[w] = uint32_t(__popcll(word));
+    for (uint32_t v = first ? 0u : (layout[prev] >> 6) + 1; v < w; ++v)
+        mask[v] = 0, bits[v] = 0;
+    if (m >= numLeaves || pos >= n)
+    {
+        // nothing starts behind this word
+        for (uint32_t v = w + 1; v < words; ++v)
+            mask[v] = 0, bits[v] = 0;
+    }
 }
 
 //! the j-th non-empty leaf: first key (0 for the first one: keys in front of it belong to it) and first position;
@@ -38,9 +62,12 @@ __global__ __launch_bounds__(256) void fillCompactLeavesKernel(const K* __restri
                                                                const uint64_t* __restrict__ mask,
                                                                const uint32_t* __restrict__ rank,
                                                                const uint32_t* __restrict__ numCompact, uint32_t n,
-                                                               K* __restrict__ leafLo, uint32_t* __restrict__ leafPos)
+                                                               K* __restrict__ leafLo, uint32_t* __restrict__ leafPos,
+                                                               uint32_t* __restrict__ outCount,
+                                                               uint32_t* __restrict__ incoming)
 {
     int l = blockIdx.x * 256 + threadIdx.x;
+    if (l < numLeaves + 3) outCount[l] = 0, incoming[l] = 0; // the departure / arrival counters of this sync
     if (l == 0)
     {
         uint32_t J     = *numCompact;
@@ -389,21 +416,16 @@ int LeafResort<K>::prepare(cstone_hip_ctx* ctx, const K* tree, const uint32_t* l
 
     int* scalars = ctx->devScalars + RESORT_SCALARS;
     CS_HIP(ctx, hipMemsetAsync(scalars, 0, 4 * sizeof(int), ctx->stream)); // [3]: the mover counter
-    CS_HIP(ctx, hipMemsetAsync(mask_.p, 0, words * 8, ctx->stream));
-    CS_HIP(ctx, hipMemsetAsync(outCount_.p, 0, ent * 4, ctx->stream));
-    CS_HIP(ctx, hipMemsetAsync(incoming_.p, 0, ent * 4, ctx->stream));
-    hipLaunchKernelGGL(markLeafStartsKernel, gridFor(numLeaves, 256), 256, 0, ctx->stream, layout, numLeaves,
-                       (unsigned long long*)mask_.p);
-    hipLaunchKernelGGL(popcountWordsKernel, gridFor(words, 256), 256, 0, ctx->stream, mask_.as<uint64_t>(), words,
-                       popc_.as<uint32_t>());
+    hipLaunchKernelGGL(leafStartWordsKernel, gridFor(numLeaves, 256), 256, 0, ctx->stream, layout, numLeaves, uint32_t(n),
+                       mask_.as<uint64_t>(), popc_.as<uint32_t>(), uint32_t(words));
     // rank of every word and, in scalars[2], the number of non-empty leaves
     CS_TRY(arenaReserve(ctx, scanArenaBytes(words)));
     int rc = scanU32(ctx, popc_.as<uint32_t>(), rank_.as<uint32_t>(), words, 0u, false, (uint32_t*)scalars + 2);
     arenaReset(ctx);
     CS_TRY(rc);
-    hipLaunchKernelGGL(fillCompactLeavesKernel<K>, gridFor(numLeaves, 256), 256, 0, ctx->stream, tree, layout, numLeaves,
-                       mask_.as<uint64_t>(), rank_.as<uint32_t>(), (const uint32_t*)scalars + 2, uint32_t(n),
-                       leafLo_.as<K>(), leafPos_.as<uint32_t>());
+    hipLaunchKernelGGL(fillCompactLeavesKernel<K>, gridFor(size_t(numLeaves) + 3, 256), 256, 0, ctx->stream, tree, layout,
+                       numLeaves, mask_.as<uint64_t>(), rank_.as<uint32_t>(), (const uint32_t*)scalars + 2, uint32_t(n),
+                       leafLo_.as<K>(), leafPos_.as<uint32_t>(), outCount_.as<uint32_t>(), incoming_.as<uint32_t>());
     CS_HIP(ctx, hipGetLastError());
 
     args_.keysOut    = keysOut;
@@ -432,8 +454,8 @@ int LeafResort<K>::binMovers(cstone_hip_ctx* ctx, int leavesPerTile)
     hipLaunchKernelGGL(newLeafSizesKernel, gridFor(ent, 256), 256, 0, ctx->stream, leafPos_.as<uint32_t>(),
                        outCount_.as<uint32_t>(), incoming_.as<uint32_t>(), numJ, ent, newCount_.as<uint32_t>(), scalars);
     CS_TRY(arenaReserve(ctx, 2 * scanArenaBytes(ent)));
-    int rc = scanU32(ctx, newCount_.as<uint32_t>(), layoutNew_.as<uint32_t>(), ent, 0u, false);
-    if (rc == CSTONE_OK) rc = scanU32(ctx, incoming_.as<uint32_t>(), inOffset_.as<uint32_t>(), ent, 0u, false);
+    int rc = scanU32Pair(ctx, newCount_.as<uint32_t>(), layoutNew_.as<uint32_t>(), incoming_.as<uint32_t>(),
+                         inOffset_.as<uint32_t>(), ent);
     arenaReset(ctx);
     CS_TRY(rc);
     hipLaunchKernelGGL(checkTilesKernel, gridFor(size_t(numLeaves_) / leavesPerTile + 1, 256), 256, 0, ctx->stream,

@@ -9,10 +9,20 @@ constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE  = SCAN_BLOCK * SCAN_ITEMS;
 
-__global__ __launch_bounds__(SCAN_BLOCK) void blockSumKernel(const uint32_t* __restrict__ in, size_t n,
-                                                             uint32_t* __restrict__ sums)
+//! up to two independent scans of equally long arrays in one set of launches (blockIdx.y picks the array)
+struct ScanJobs
+{
+    const uint32_t* in[2];
+    uint32_t* out[2];
+    uint32_t* sums[2];
+    uint32_t* total[2];
+    uint32_t init[2];
+};
+
+__global__ __launch_bounds__(SCAN_BLOCK) void blockSumKernel(ScanJobs jobs, size_t n)
 {
     __shared__ uint32_t ws[4];
+    const uint32_t* __restrict__ in = jobs.in[blockIdx.y];
     size_t base = size_t(blockIdx.x) * SCAN_TILE + size_t(threadIdx.x) * SCAN_ITEMS;
     uint32_t s  = 0;
 #pragma unroll
@@ -20,15 +30,15 @@ __global__ __launch_bounds__(SCAN_BLOCK) void blockSumKernel(const uint32_t* __r
         if (base + k < n) s += in[base + k];
     uint32_t total;
     blockExclusiveScan256(s, ws, &total);
-    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+    if (threadIdx.x == 0) jobs.sums[blockIdx.y][blockIdx.x] = total;
 }
 
-//! single workgroup: sums[0..m) -> exclusive scan in place (+init); grand total to *totalOut
-__global__ __launch_bounds__(SCAN_BLOCK) void scanSumsKernel(uint32_t* __restrict__ sums, unsigned m, uint32_t init,
-                                                             uint32_t* __restrict__ totalOut)
+//! one workgroup per array: sums[0..m) -> exclusive scan in place (+init); grand total to *total
+__global__ __launch_bounds__(SCAN_BLOCK) void scanSumsKernel(ScanJobs jobs, unsigned m)
 {
     __shared__ uint32_t ws[4];
-    uint32_t carry = init;
+    uint32_t* __restrict__ sums = jobs.sums[blockIdx.x];
+    uint32_t carry              = jobs.init[blockIdx.x];
     for (unsigned base = 0; base < m; base += SCAN_BLOCK)
     {
         unsigned i = base + threadIdx.x;
@@ -38,14 +48,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scanSumsKernel(uint32_t* __restric
         if (i < m) sums[i] = carry + ex;
         carry += total;
     }
-    if (threadIdx.x == 0 && totalOut) *totalOut = carry;
+    if (threadIdx.x == 0 && jobs.total[blockIdx.x]) *jobs.total[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void blockScanKernel(const uint32_t* __restrict__ in,
-                                                              uint32_t* __restrict__ out, size_t n,
-                                                              const uint32_t* __restrict__ offsets, bool inclusive)
+__global__ __launch_bounds__(SCAN_BLOCK) void blockScanKernel(ScanJobs jobs, size_t n, bool inclusive)
 {
     __shared__ uint32_t ws[4];
+    const uint32_t* in = jobs.in[blockIdx.y]; // in == out is allowed
+    uint32_t* out      = jobs.out[blockIdx.y];
     size_t base = size_t(blockIdx.x) * SCAN_TILE + size_t(threadIdx.x) * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
@@ -55,7 +65,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void blockScanKernel(const uint32_t* __
         v[k] = (base + k < n) ? in[base + k] : 0u;
         s += v[k];
     }
-    uint32_t run = offsets[blockIdx.x] + blockExclusiveScan256(s, ws, nullptr);
+    uint32_t run = jobs.sums[blockIdx.y][blockIdx.x] + blockExclusiveScan256(s, ws, nullptr);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k)
     {
@@ -65,26 +75,44 @@ __global__ __launch_bounds__(SCAN_BLOCK) void blockScanKernel(const uint32_t* __
 }
 } // namespace
 
-int scanU32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t init, bool inclusive,
-            uint32_t* totalOut)
+static int scanJobs(cstone_hip_ctx* ctx, ScanJobs jobs, int count, size_t n, bool inclusive)
 {
     if (n == 0)
     {
-        // nothing to scan: the grand total is the initial value (written by the sums kernel over zero blocks)
-        if (totalOut) hipLaunchKernelGGL(scanSumsKernel, 1, SCAN_BLOCK, 0, ctx->stream, (uint32_t*)nullptr, 0u, init, totalOut);
+        // nothing to scan: the grand totals are the initial values (written by the sums kernel over zero blocks)
+        hipLaunchKernelGGL(scanSumsKernel, count, SCAN_BLOCK, 0, ctx->stream, jobs, 0u);
         CS_HIP(ctx, hipGetLastError());
         return CSTONE_OK;
     }
     unsigned blocks = unsigned((n + SCAN_TILE - 1) / SCAN_TILE);
-    // block sums live in a private slice at the END of the arena so callers may hold arena slices of their own
+    // block sums live in private slices at the END of the arena so callers may hold arena slices of their own
     size_t bytes = alignUp(size_t(blocks) * sizeof(uint32_t));
-    auto* sums   = (uint32_t*)arenaTake(ctx, bytes);
-    if (!sums) return fail(ctx, CSTONE_E_INTERNAL, "scan: arena exhausted (caller must reserve %zu extra bytes)", bytes);
-    hipLaunchKernelGGL(blockSumKernel, blocks, SCAN_BLOCK, 0, ctx->stream, in, n, sums);
-    hipLaunchKernelGGL(scanSumsKernel, 1, SCAN_BLOCK, 0, ctx->stream, sums, blocks, init, totalOut);
-    hipLaunchKernelGGL(blockScanKernel, blocks, SCAN_BLOCK, 0, ctx->stream, in, out, n, sums, inclusive);
+    for (int j = 0; j < count; ++j)
+    {
+        jobs.sums[j] = (uint32_t*)arenaTake(ctx, bytes);
+        if (!jobs.sums[j])
+            return fail(ctx, CSTONE_E_INTERNAL, "scan: arena exhausted (caller must reserve %zu extra bytes)", bytes * count);
+    }
+    hipLaunchKernelGGL(blockSumKernel, dim3(blocks, count), SCAN_BLOCK, 0, ctx->stream, jobs, n);
+    hipLaunchKernelGGL(scanSumsKernel, count, SCAN_BLOCK, 0, ctx->stream, jobs, blocks);
+    hipLaunchKernelGGL(blockScanKernel, dim3(blocks, count), SCAN_BLOCK, 0, ctx->stream, jobs, n, inclusive);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
+}
+
+int scanU32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t init, bool inclusive,
+            uint32_t* totalOut)
+{
+    ScanJobs jobs{};
+    jobs.in[0] = in, jobs.out[0] = out, jobs.total[0] = totalOut, jobs.init[0] = init;
+    return scanJobs(ctx, jobs, 1, n, inclusive);
+}
+
+int scanU32Pair(cstone_hip_ctx* ctx, const uint32_t* inA, uint32_t* outA, const uint32_t* inB, uint32_t* outB, size_t n)
+{
+    ScanJobs jobs{};
+    jobs.in[0] = inA, jobs.out[0] = outA, jobs.in[1] = inB, jobs.out[1] = outB;
+    return scanJobs(ctx, jobs, 2, n, false);
 }
 
 //! bytes scanU32 takes from the arena for n elements

@@ -13,6 +13,9 @@ namespace cship
 int scanU32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t init, bool inclusive,
             uint32_t* totalOut = nullptr);
 
+//! two exclusive scans (init 0) of arrays of n elements in one set of launches; arena: 2 * scanArenaBytes(n)
+int scanU32Pair(cstone_hip_ctx* ctx, const uint32_t* inA, uint32_t* outA, const uint32_t* inB, uint32_t* outB, size_t n);
+
 //! bytes scanU32 takes from the arena for n elements (callers reserve this much on top of their own slices)
 size_t scanArenaBytes(size_t n);
 

@@ -157,7 +157,8 @@ class Context:
 
     # ---- profiling
     def profile_enable(self, on=True):
-        self._chk(self.lib.cstone_hip_profile_enable(self.h, C.c_int(1 if on else 0)), "profile_enable")
+        """True / 1: every stage; 2: only the stages of the kernels that move the particle arrays; False: off"""
+        self._chk(self.lib.cstone_hip_profile_enable(self.h, C.c_int(int(on))), "profile_enable")
 
     def profile_reset(self):
         self._chk(self.lib.cstone_hip_profile_reset(self.h), "profile_reset")

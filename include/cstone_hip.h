@@ -92,6 +92,8 @@ extern "C"
 #define CSTONE_STAGE_RESORT_BINS 11   /* incremental re-sort of Domain::sync: leaf table, mover bins (csrc/resort.hpp) */
 #define CSTONE_STAGE_RESORT_LEAVES 12 /* ... its pass over the leaves: K read, K + 4 written per particle */
 #define CSTONE_NUM_STAGES 16
+    /* on: 0 off, 1 every stage, 2 only ENCODE, SORT_PASS(_IOTA), RESORT_LEAVES, GATHER, HALOS, NEIGHBORS (the kernels that
+     * move the particle arrays: eight brackets per sync instead of forty) */
     int cstone_hip_profile_enable(cstone_hip_ctx* ctx, int on);
     int cstone_hip_profile_reset(cstone_hip_ctx* ctx);
     /* synchronises the stream; total_ms and launches accumulated since the last reset */
