@@ -80,6 +80,11 @@ class _Stepper:
             for a, (lo, hi) in zip(coords, ext):
                 put(sel, mrng.uniform(lo, hi, sel.numel()), a)
                 a.clamp_(lo, hi)
+        elif kind == "pairs":  # 2 % of the particles onto the position of another one: equal keys inside ordinary leaves
+            sel = torch.from_numpy(mrng.choice(m, max(2, m // 50), replace=False)).cuda()
+            onto = torch.from_numpy(mrng.choice(m, sel.numel(), replace=True)).cuda()
+            for a in coords:
+                a[sel] = a[onto]
         elif kind == "collapse":  # a tenth of the particles onto three points: equal keys, overfull leaves
             sel = torch.from_numpy(mrng.choice(m, m // 10, replace=False)).cuda()
             pts = mrng.uniform(0.1, 0.9, (3, 3))
@@ -123,8 +128,8 @@ def test_resort_equals_full_sort_over_a_time_stepping_loop(hip, oracle, monkeypa
     sa_, sb_ = (_Stepper(hip, kb, rb, bucket_focus, curve, bc, n, seed, allow) for allow in (True, False))
     dom_a, dom_b = sa_.dom, sb_.dom
     kdt = np.uint64 if kb == 64 else np.uint32
-    script = ["none", "none", "jitter", "few", "jitter", "remove", "few", "many", "none", "collapse", "jitter", "none",
-              "few", "none"]
+    script = ["none", "none", "jitter", "few", "pairs", "jitter", "remove", "pairs", "few", "many", "none", "collapse",
+              "jitter", "none", "few", "none"]
     for step, kind in enumerate(script):
         if step:
             sa_.move(kind, np.random.default_rng(1000 + step))
