@@ -30,6 +30,7 @@
 #include "ctx.hpp"
 #include "devbuf.hpp"
 #include "device_keys.hpp"
+#include "resort.hpp"
 #include "scan.hpp"
 
 namespace cship
@@ -517,7 +518,48 @@ public:
         if (keysIn && n)
             CS_HIP(ctx_, hipMemcpyAsync(keys_.p, keysIn, n * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
         bool partialSort = false;
-        if (n)
+        // ---- the incremental re-sort (resort.hpp), as in the single-rank domain: the input arrays are the assigned block
+        //      the previous sync handed out, ordered by the leaves of this rank's tree (layout_); particles still inside
+        //      their leaf are ordered leaf by leaf, the others are binned.  Rank-local: no collective depends on it.
+        bool resorted         = false;
+        const int tileLeaves  = LeafResort<K>::leavesPerTile(bucketFocus_);
+        bool sameBox          = true;
+        for (int k = 0; k < 6; ++k)
+            sameBox = sameBox && box_.lim[k] == layoutBox_.lim[k];
+        // (below some 10^7 particles per rank the chain of small launches of the re-sort and its read-back cost what the
+        //  four digit passes cost: measured 1.39 against 1.32 ms per sync at 1.25e7, 3.20 against 3.43 ms at 5e7)
+        static const size_t resortMin = []
+        {
+            const char* e = std::getenv("CSTONE_MR_RESORT_MIN");
+            return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(1) << 24;
+        }();
+        const bool tryResort = !firstCall_ && n >= resortMin && n == layoutParticles_ && tileLeaves > 0 && sameBox && fLeaves_ > 0 &&
+                               resortBackoff_ == 0 && !pending_ && std::getenv("CSTONE_NO_RESORT") == nullptr &&
+                               std::getenv("CSTONE_FULL_SORT") == nullptr;
+        if (resortBackoff_ > 0) --resortBackoff_;
+        if (tryResort)
+        {
+            CS_TRY(resort_.prepare(ctx_, fTree_.as<K>(), layout_.as<uint32_t>(), fLeaves_, n, keysAlt_.as<K>()));
+            const ResortArgs<K> ra = resort_.args();
+            bool done              = false;
+            CS_TRY(computeKeysResort(ctx_, curve_, kb, rb, x, y, z, keysIn ? keys_.p : nullptr, n, box_, &ra, nullptr, &done));
+            if (done)
+            {
+                CS_TRY(resort_.binMovers(ctx_, tileLeaves));
+                int found[4];
+                CS_TRY(toHost(found, ctx_->devScalars + RESORT_SCALARS, sizeof found));
+                const uint32_t markers = uint32_t(found[0]), J = uint32_t(found[2]), movers = uint32_t(found[3]);
+                if (found[1] == 0 && movers <= n / 8)
+                {
+                    CS_TRY(resort_.sortLeaves(ctx_, keysAlt_.as<K>(), keys_.as<K>(), order_.as<uint32_t>(), movers, markers,
+                                              J, tileLeaves));
+                    resorted = true;
+                    ++resorts_;
+                }
+                else { resortBackoff_ = 4; }
+            }
+        }
+        if (n && !resorted)
         {
             // radix passes only over the digits above the leaf level (+1) of the previous tree, runs of equal high digits
             // are finished by a fix-up pass; a run that is too long raises a flag and the regular sort completes the job
@@ -754,6 +796,8 @@ public:
         CS_TRY(layout_.ensure(ctx_, size_t(L + 1) * sizeof(uint32_t)));
         CS_HIP(ctx_, hipMemsetAsync(layout_.p, 0, sizeof(uint32_t), ctx_->stream));
         CS_TRY(cstone_hip_inclusive_scan_u32(ctx_, fCounts_.as<uint32_t>(), layout_.as<uint32_t>() + 1, size_t(L)));
+        layoutParticles_ = nm; // the next sync's re-sort starts from this layout: nm particles in this box
+        layoutBox_       = box_;
         tick("5 focus tree");
 
         // ---- C4: owner-side halo discovery
@@ -988,6 +1032,7 @@ public:
         view_.halos_received      = nlo + nhi;
         view_.halos_sent          = selTotal;
         view_.halo_boxes_exported = numMyBoxes;
+        view_.resorts             = uint64_t(resorts_);
         // the sticky device-side error word: a sync that tripped a device-side check must not report success
         return cstone_hip_ctx_sync(ctx_);
     }
@@ -1447,6 +1492,10 @@ private:
     DevBuf leaving_, sendRows_, recvRows_, rcol_[4], rcolS_[4], rk_, ro_, posA_, posB_, moveTmp_;
     DevBuf propRecv_[MAX_PROPS], propRecvS_[MAX_PROPS];
     uint64_t prevLo_ = 0, prevHi_ = 0;
+    LeafResort<K> resort_;
+    int resortBackoff_ = 0, resorts_ = 0;
+    uint64_t layoutParticles_ = 0; // particles and box layout_ was made for
+    cstone_box layoutBox_{};
     std::vector<K> coverHost_; // leaf keys inserted at the range boundaries, staged for the copy to the device
     // tree over all local particles incl. halos (octree()), built on request
     DevBuf nsTree_, nsCounts_, nsLayout_, nsPrefixes_, nsChild_, nsParents_, nsLevelRange_, nsItl_, nsLti_, nsCenters_,

@@ -410,7 +410,14 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
             __builtin_memcpy(vx, __builtin_assume_aligned(x + base, sizeof(T) * VEC), sizeof vx);
             __builtin_memcpy(vy, __builtin_assume_aligned(y + base, sizeof(T) * VEC), sizeof vy);
             __builtin_memcpy(vz, __builtin_assume_aligned(z + base, sizeof(T) * VEC), sizeof vz);
-            __builtin_memcpy(vk, __builtin_assume_aligned(keysIn + base, sizeof(K) * VEC), sizeof vk);
+            // keysIn == nullptr: the caller has no key array, i.e. no remove markers
+            if (keysIn) { __builtin_memcpy(vk, __builtin_assume_aligned(keysIn + base, sizeof(K) * VEC), sizeof vk); }
+            else
+            {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    vk[v] = 0;
+            }
 #pragma unroll
             for (int v = 0; v < VEC; ++v)
             {
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
         {
             K m = gridMorton<K, T>(x[i], y[i], z[i], mx, my, mz, sx, sy, sz);
             if (HILBERT) m = hilbertFromMorton<K>(m, enc);
-            key = keysIn[i] == endKey<K>() ? endKey<K>() : m;
+            key = (keysIn && keysIn[i] == endKey<K>()) ? endKey<K>() : m;
             if (extentPartials) widen(x[i], y[i], z[i]);
         }
         key = classify(key, i, valid);
@@ -581,6 +588,7 @@ static int computeKeysResortT(cstone_hip_ctx* ctx, int curve, const T* x, const 
     constexpr int VEC = 16 / sizeof(T);
     bool aligned = (uintptr_t(x) % 16 == 0) && (uintptr_t(y) % 16 == 0) && (uintptr_t(z) % 16 == 0) &&
                    (uintptr_t(keysIn) % (sizeof(K) * VEC) == 0) && (uintptr_t(ra.keysOut) % (sizeof(K) * VEC) == 0);
+    // (keysIn may be null: no key array of the caller's, no remove markers)
     *done = aligned && n > 0;
     if (!*done) return CSTONE_OK;
     StageTimer timer(ctx, CSTONE_STAGE_ENCODE);

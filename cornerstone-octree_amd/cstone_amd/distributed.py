@@ -33,7 +33,8 @@ class MrView(C.Structure):
                 ("global_leaves", C.c_void_p), ("global_counts", C.c_void_p), ("focus_leaves", C.c_void_p),
                 ("focus_leaf_counts", C.c_void_p), ("range_start", C.c_uint64), ("range_end", C.c_uint64),
                 ("particles_sent", C.c_uint64), ("halos_received", C.c_uint64), ("halos_sent", C.c_uint64),
-                ("halo_boxes_exported", C.c_uint64), ("props", C.c_void_p * 16)]
+                ("halo_boxes_exported", C.c_uint64), ("props", C.c_void_p * 16),
+                ("resorts", C.c_uint64)]
 
 
 class MrOctree(C.Structure):

@@ -543,6 +543,8 @@ extern "C"
         uint64_t particles_sent, halos_received, halos_sent, halo_boxes_exported;
         const void* props[16];           /* the conserved properties of the last sync_props call, same layout; their
                                             halo ranges are NOT filled (exchange_halos does that on request) */
+        uint64_t resorts;                /* syncs so far whose local particles were ordered by the incremental re-sort
+                                            (csrc/resort.hpp) instead of the radix sort; same results either way */
     } cstone_hip_domain_mr_view;
 
     int cstone_hip_domain_mr_create(cstone_hip_ctx* ctx, cstone_hip_domain_mr** out, int curve, int key_bits,

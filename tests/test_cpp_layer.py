@@ -12,6 +12,15 @@ EXE = os.path.join(ROOT, "cornerstone-octree_amd", "build", "domain_example")
 SEAM_EXE = os.path.join(ROOT, "cornerstone-octree_amd", "build", "seam_check")
 
 
+def _stale(exe):
+    """the client binary is older than the headers it was compiled against (the ABI structs may have grown since)"""
+    if not os.path.exists(exe):
+        return True
+    heads = [os.path.join(ROOT, "include", "cstone_hip.h"),
+             os.path.join(ROOT, "cornerstone-octree_amd", "include", "cstone_amd", "cstone_amd.hpp")]
+    return any(os.path.getmtime(h) > os.path.getmtime(exe) for h in heads)
+
+
 def _compile(source="domain_example.cpp", exe=EXE):
     lib = os.path.join(ROOT, "cornerstone-octree_amd", "lib")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
@@ -42,7 +51,7 @@ def test_cpp_layer_compiles_with_host_compiler():
 
 @pytest.mark.gpu
 def test_cpp_domain_example_runs():
-    if not os.path.exists(EXE):
+    if _stale(EXE):
         _compile()
     out = subprocess.run([EXE, "300000"], check=True, capture_output=True, text=True, timeout=120).stdout
     assert "keys sorted: yes" in out
@@ -78,7 +87,7 @@ def test_cpp_mpi_example_compiles():
 @pytest.mark.skipif(not have_mpi, reason="no MPI in this image")
 @pytest.mark.parametrize("ranks", [2, 3])
 def test_cpp_mpi_example_runs(ranks):
-    if not os.path.exists(MPI_EXE):
+    if _stale(MPI_EXE):
         _compile_mpi()
     r = subprocess.run([MPIEXEC, "-n", str(ranks), MPI_EXE, "100000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

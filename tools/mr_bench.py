@@ -46,6 +46,6 @@ dist.barrier()
 dt = (time.perf_counter() - t0) / a.syncs
 if rank == 0:
     print(f"{P} {'RCCL' if a.rccl else 'gloo'} rank(s) on one GPU, {n:.1e} particles: {dt*1e3:.2f} ms per sync; rank 0: assigned {pipe.assigned}, "
-          f"halos {pipe.halos}, {pipe.stats}", flush=True)
+          f"halos {pipe.halos}, {pipe.stats}, syncs re-sorted: {pipe.dom.view().resorts}", flush=True)
 del pipe
 dist.destroy_process_group()
