@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void placeMoversKernel(const K* __restrict__ m
  *  Either way leaf j's new content lands at layoutNew[j]...: ascending keys, ties by old index = the stable sort. */
 template<class K, int G>
 __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keysIn, const uint64_t* __restrict__ mask,
-                                                      const uint32_t* __restrict__ rank,
+                                                      const uint32_t* __restrict__ rank, const K* __restrict__ leafLo,
                                                       const uint32_t* __restrict__ leafPos,
                                                       const uint32_t* __restrict__ inOffset,
                                                       const uint32_t* __restrict__ layoutNew,
@@ -196,6 +196,11 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
     __shared__ K sKey[RESORT_TILE_SLOTS];
     __shared__ uint32_t sIdx[RESORT_TILE_SLOTS]; // old index; for the old positions only the quiet path fills it
     __shared__ uint32_t posK[G + 1], inK[G + 1], outK[G + 1];
+    // tiles that count: first key of every leaf, the low key bits a digest leaves out, first 4-slot chunk of every leaf
+    __shared__ K loK[G + 1];
+    __shared__ uint8_t cutK[G];
+    __shared__ uint32_t chunkK[G + 1];
+    static_assert(G <= 64, "the chunk prefix of a tile is one wave scan");
 
     const uint32_t j0 = blockIdx.x * uint32_t(G);
     const uint32_t nl = min(uint32_t(G), J - j0);
@@ -205,8 +210,24 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
         posK[t] = leafPos[j0 + t];
         inK[t]  = inOffset[j0 + t];
         outK[t] = layoutNew[j0 + t];
+        loK[t]  = leafLo[j0 + t];
     }
     __syncthreads();
+    if (t < 64)
+    {
+        // chunks of four old slots, leaf by leaf: a lane of the counting path takes one chunk at a time
+        const uint32_t mine = t < nl ? (posK[t + 1] - posK[t] + 3) / 4 : 0u;
+        const uint32_t incl = waveInclusiveScan(mine, t);
+        if (t < nl) chunkK[t] = incl - mine;
+        if (t == 63) chunkK[nl] = incl;
+        if (t < nl)
+        {
+            // 24 leading bits of key - loK[t] tell the particles of a leaf apart in all but a few cases
+            const K span   = loK[t + 1] - loK[t] - 1;
+            const int bits = span ? int(8 * sizeof(K)) - clzKey(span) : 0;
+            cutK[t]        = uint8_t(bits > 24 ? bits - 24 : 0);
+        }
+    }
     const uint32_t p0 = posK[0], p1 = posK[nl], in0 = inK[0], in1 = inK[nl];
     const uint32_t nOldAll = p1 - p0, slots = nOldAll + (in1 - in0);
     // guarded by checkTilesKernel: a launch only happens when every workgroup fits
@@ -216,10 +237,28 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
     if (t < nl) changed = changed || (outK[t + 1] - outK[t]) != (posK[t + 1] - posK[t]);
     const bool quiet = !__syncthreads_or(changed);
 
-    // old positions: all loads of a thread are issued before the first is used
-    K key[ITER];
-    uint8_t leaf[ITER];
+    // Tiles that count keep no keys in LDS, only 32-bit digests: 24 leading bits of (key - first key of the leaf), then
+    // the slot in the leaf (old slots first, then arrivals; at most 256).  The digests of a leaf are distinct, and
+    // ordered like (key, old index) as long as the leading key bits of its elements differ -- checked afterwards.
+    uint32_t* const sDig = sIdx;                              // the index array is free in such a tile
+    uint32_t* const sNew = reinterpret_cast<uint32_t*>(sKey); // and so is the key array: key bits in the NEW order
+    auto digest          = [&](K key, uint32_t k, uint32_t slot)
+    { return (uint32_t((key - loK[k]) >> cutK[k]) << 8) | slot; };
+    // leaf of bin entry m: last k with inK[k] <= m
+    auto leafOfArrival = [&](uint32_t m)
     {
+        uint32_t lo = 0, hi = nl;
+        while (hi - lo > 1)
+        {
+            uint32_t mid = (lo + hi) / 2;
+            if (inK[mid] <= m) lo = mid;
+            else hi = mid;
+        }
+        return lo;
+    };
+    {
+        // old positions: all loads of a thread are issued before the first is used
+        K key[ITER];
         uint64_t word[ITER];
         uint32_t rk[ITER];
 #pragma unroll
@@ -242,16 +281,24 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
             const uint32_t p = p0 + t + 256u * i;
             if (p < p1)
             {
-                sKey[p - p0] = key[i];
-                if (quiet) sIdx[p - p0] = p;
-                else leaf[i] = uint8_t(rk[i] + uint32_t(__popcll(word[i] & ((2ull << (p & 63u)) - 1))) - 1u - j0);
+                if (quiet)
+                {
+                    sKey[p - p0] = key[i];
+                    sIdx[p - p0] = p;
+                }
+                else
+                {
+                    const uint32_t k = rk[i] + uint32_t(__popcll(word[i] & ((2ull << (p & 63u)) - 1))) - 1u - j0;
+                    sDig[p - p0]     = key[i] == HOLE ? ~0u : digest(key[i], k, p - posK[k]);
+                }
             }
         }
     }
     for (uint32_t m = in0 + t; m < in1; m += 256)
     {
-        sKey[nOldAll + (m - in0)] = binKeys[m];
-        sIdx[nOldAll + (m - in0)] = binIdx[m];
+        // (only tiles that count have arrivals)
+        const uint32_t k          = leafOfArrival(m);
+        sDig[nOldAll + (m - in0)] = digest(binKeys[m], k, (posK[k + 1] - posK[k]) + (m - inK[k]));
     }
     __syncthreads();
 
@@ -307,67 +354,139 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
         return;
     }
 
-    // place of (kx, ix) among the elements of leaf k: those with a smaller key, or the same key and a smaller old index.
-    // The old positions are scanned four at a time (independent LDS broadcast reads: the lanes of a wave sit in one or
-    // two leaves); equal keys are only counted there, their order is settled in a second look when there are any.
-    auto placeInLeaf = [&](uint32_t k, K kx, uint32_t ix, bool fromOld)
+    // ---- counting.  A lane takes a chunk of four consecutive old slots of ONE leaf and scans the leaf's digests once
+    // for all four: LDS reads / 4, two 32-bit vector instructions per comparison.
+    constexpr int CHUNK_ITER = (RESORT_TILE_SLOTS / 4 + G + 255) / 256;
+    const uint32_t numChunks = chunkK[nl];
+    uint32_t chunkLeaf[CHUNK_ITER], chunkSlot[CHUNK_ITER], place[CHUNK_ITER][4];
+#pragma unroll
+    for (int i = 0; i < CHUNK_ITER; ++i)
+    {
+        const uint32_t c = t + 256u * i;
+        if (c < numChunks)
+        {
+            uint32_t lo = 0, hi = nl; // leaf of the chunk: last k with chunkK[k] <= c
+            while (hi - lo > 1)
+            {
+                uint32_t mid = (lo + hi) / 2;
+                if (chunkK[mid] <= c) lo = mid;
+                else hi = mid;
+            }
+            const uint32_t k  = lo;
+            const uint32_t o0 = posK[k] - p0, nOld = posK[k + 1] - posK[k];
+            const uint32_t a0 = nOldAll + (inK[k] - in0), nInc = inK[k + 1] - inK[k];
+            const uint32_t s0 = 4 * (c - chunkK[k]); // first slot of the chunk inside the leaf
+            chunkLeaf[i] = k, chunkSlot[i] = s0;
+            uint32_t d[4], cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d[j] = s0 + j < nOld ? sDig[o0 + s0 + j] : ~0u; // (slots behind the leaf's end count as holes)
+            uint32_t q = 0;
+            for (; q + 4 <= nOld; q += 4)
+            {
+                const uint32_t v0 = sDig[o0 + q], v1 = sDig[o0 + q + 1], v2 = sDig[o0 + q + 2], v3 = sDig[o0 + q + 3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    cnt[j] += (v0 < d[j]) + (v1 < d[j]) + (v2 < d[j]) + (v3 < d[j]);
+            }
+            for (; q < nOld; ++q)
+            {
+                const uint32_t v0 = sDig[o0 + q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    cnt[j] += v0 < d[j];
+            }
+            for (q = 0; q < nInc; ++q)
+            {
+                const uint32_t v0 = sDig[a0 + q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    cnt[j] += v0 < d[j];
+            }
+            const uint32_t base = outK[k] - outK[0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                place[i][j] = cnt[j];
+                if (d[j] != ~0u) sNew[base + cnt[j]] = d[j] >> 8;
+            }
+        }
+    }
+    auto placeByDigest = [&](uint32_t k, uint32_t dx)
     {
         const uint32_t o0 = posK[k] - p0, nOld = posK[k + 1] - posK[k];
         const uint32_t a0 = nOldAll + (inK[k] - in0), nInc = inK[k + 1] - inK[k];
-        uint32_t less = 0, same = 0;
-        uint32_t q = 0;
-        for (; q + 4 <= nOld; q += 4)
+        uint32_t less = 0;
+        for (uint32_t q = 0; q < nOld; ++q)
+            less += sDig[o0 + q] < dx;
+        for (uint32_t q = 0; q < nInc; ++q)
+            less += sDig[a0 + q] < dx;
+        return less;
+    };
+    for (uint32_t m = in0 + t; m < in1; m += 256)
+    {
+        const uint32_t k = leafOfArrival(m), d = sDig[nOldAll + (m - in0)];
+        sNew[(outK[k] - outK[0]) + placeByDigest(k, d)] = d >> 8;
+    }
+    __syncthreads();
+
+    // an element whose neighbour in the new order of its leaf has the same leading key bits is placed again, by key and
+    // old index proper, from global memory (the others are where they belong: leading bits that differ decide)
+    auto clashes = [&](uint32_t k, uint32_t pl, uint32_t bitsX)
+    {
+        const uint32_t base = outK[k] - outK[0], cnt = outK[k + 1] - outK[k];
+        return (pl > 0 && sNew[base + pl - 1] == bitsX) || (pl + 1 < cnt && sNew[base + pl + 1] == bitsX);
+    };
+    auto placeExact = [&](uint32_t k, K kx, uint32_t ix)
+    {
+        const uint32_t nOld = posK[k + 1] - posK[k], nInc = inK[k + 1] - inK[k];
+        uint32_t less = 0;
+        for (uint32_t q = 0; q < nOld; ++q)
         {
-            const K k0 = sKey[o0 + q], k1 = sKey[o0 + q + 1], k2 = sKey[o0 + q + 2], k3 = sKey[o0 + q + 3];
-            less += (k0 < kx) + (k1 < kx) + (k2 < kx) + (k3 < kx);
-            same += (k0 == kx) + (k1 == kx) + (k2 == kx) + (k3 == kx);
+            const K kq = keysIn[posK[k] + q]; // (a hole is larger than any key)
+            less += (kq < kx || (kq == kx && posK[k] + q < ix)) ? 1u : 0u;
         }
-        for (; q < nOld; ++q)
+        for (uint32_t q = 0; q < nInc; ++q)
         {
-            const K kq = sKey[o0 + q];
-            less += kq < kx;
-            same += kq == kx;
-        }
-        if (same > (fromOld ? 1u : 0u))
-        {
-            // equal keys among the old positions: those in front of ix count
-            for (q = 0; q < nOld; ++q)
-                less += (sKey[o0 + q] == kx && p0 + o0 + q < ix) ? 1u : 0u;
-        }
-        for (q = 0; q < nInc; ++q)
-        {
-            const K kq = sKey[a0 + q];
-            less += (kq < kx || (kq == kx && sIdx[a0 + q] < ix)) ? 1u : 0u;
+            const K kq = binKeys[inK[k] + q];
+            less += (kq < kx || (kq == kx && binIdx[inK[k] + q] < ix)) ? 1u : 0u;
         }
         return less;
     };
 #pragma unroll
-    for (int i = 0; i < ITER; ++i)
+    for (int i = 0; i < CHUNK_ITER; ++i)
     {
-        const uint32_t e = t + 256u * i;
-        if (e < nOldAll && key[i] != HOLE)
+        const uint32_t c = t + 256u * i;
+        if (c < numChunks)
         {
-            const uint32_t k  = leaf[i];
-            const uint32_t to = outK[k] + placeInLeaf(k, key[i], p0 + e, true);
-            keysOut[to]       = key[i];
-            orderOut[to]      = p0 + e;
+            const uint32_t k = chunkLeaf[i], nOld = posK[k + 1] - posK[k];
+            const uint32_t p = posK[k] + chunkSlot[i]; // position of the chunk's first slot
+            K kx[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                kx[j] = chunkSlot[i] + j < nOld ? keysIn[p + j] : HOLE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                if (kx[j] != HOLE)
+                {
+                    uint32_t pl = place[i][j];
+                    if (clashes(k, pl, sDig[p - p0 + j] >> 8)) pl = placeExact(k, kx[j], p + j);
+                    keysOut[outK[k] + pl]  = kx[j];
+                    orderOut[outK[k] + pl] = p + j;
+                }
+            }
         }
     }
     for (uint32_t m = in0 + t; m < in1; m += 256)
     {
-        // leaf of bin entry m: last k with inK[k] <= m
-        uint32_t lo = 0, hi = nl;
-        while (hi - lo > 1)
-        {
-            uint32_t mid = (lo + hi) / 2;
-            if (inK[mid] <= m) lo = mid;
-            else hi = mid;
-        }
-        const K kx        = sKey[nOldAll + (m - in0)];
-        const uint32_t ix = sIdx[nOldAll + (m - in0)];
-        const uint32_t to = outK[lo] + placeInLeaf(lo, kx, ix, false);
-        keysOut[to]       = kx;
-        orderOut[to]      = ix;
+        const uint32_t k = leafOfArrival(m), d = sDig[nOldAll + (m - in0)];
+        const K kx        = binKeys[m];
+        const uint32_t ix = binIdx[m];
+        uint32_t pl       = placeByDigest(k, d);
+        if (clashes(k, pl, d >> 8)) pl = placeExact(k, kx, ix);
+        keysOut[outK[k] + pl]  = kx;
+        orderOut[outK[k] + pl] = ix;
     }
 }
 
@@ -493,7 +612,7 @@ int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, 
     const bool alwaysCount = std::getenv("CSTONE_RESORT_COUNT") != nullptr; // tuning/tests: no quiet-tile shortcut
 #define CSTONE_LEAF_SORT(G)                                                                                            \
     hipLaunchKernelGGL((leafSortKernel<K, G>), grid, 256, 0, ctx->stream, keysIn, mask_.as<uint64_t>(),                \
-                       rank_.as<uint32_t>(), leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(),                        \
+                       rank_.as<uint32_t>(), leafLo_.as<K>(), leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(),       \
                        layoutNew_.as<uint32_t>(), binKeys_.as<K>(), binIdx_.as<uint32_t>(), J, alwaysCount, keysOut,  \
                        orderOut)
     if (leavesPerTile == 64) CSTONE_LEAF_SORT(64);
