@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void placeMoversKernel(const K* __restrict__ m
  *     by (key, old index): LDS broadcast reads, all 256 lanes busy, cost independent of the disorder.  The count is the
  *     particle's place in the leaf; holes rank last and are dropped.
  *  Either way leaf j's new content lands at layoutNew[j]...: ascending keys, ties by old index = the stable sort. */
-template<class K, int G>
+template<class K, int G, bool COUNTING>
 __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keysIn, const uint64_t* __restrict__ mask,
                                                       const uint32_t* __restrict__ rank, const K* __restrict__ leafLo,
                                                       const uint32_t* __restrict__ leafPos,
@@ -193,8 +193,13 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
 {
     constexpr int ITER = (RESORT_TILE_SLOTS + 255) / 256;
     constexpr K HOLE   = ~K(0);
-    __shared__ K sKey[RESORT_TILE_SLOTS];
-    __shared__ uint32_t sIdx[RESORT_TILE_SLOTS]; // old index; for the old positions only the quiet path fills it
+    // Two instantiations share this body and the grid: COUNTING = false takes the quiet tiles (keys and old indices in
+    // LDS, 52 KB: three workgroups per CU), COUNTING = true the tiles in which something moved (digests and the new
+    // order's key bits, 35 KB: four per CU); a workgroup whose tile is of the other kind leaves after the setup.
+    __shared__ __attribute__((aligned(8))) uint32_t sWordsA[COUNTING ? RESORT_TILE_SLOTS : RESORT_TILE_SLOTS * sizeof(K) / 4];
+    __shared__ uint32_t sWordsB[RESORT_TILE_SLOTS];
+    K* const sKey        = reinterpret_cast<K*>(sWordsA); // quiet tiles: the keys ...
+    uint32_t* const sIdx = sWordsB;                       // ... and their old indices
     __shared__ uint32_t posK[G + 1], inK[G + 1], outK[G + 1];
     // tiles that count: first key of every leaf, the low key bits a digest leaves out, first 4-slot chunk of every leaf
     __shared__ K loK[G + 1];
@@ -210,10 +215,10 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
         posK[t] = leafPos[j0 + t];
         inK[t]  = inOffset[j0 + t];
         outK[t] = layoutNew[j0 + t];
-        loK[t]  = leafLo[j0 + t];
+        if constexpr (COUNTING) loK[t] = leafLo[j0 + t];
     }
     __syncthreads();
-    if (t < 64)
+    if (COUNTING && t < 64)
     {
         // chunks of four old slots, leaf by leaf: a lane of the counting path takes one chunk at a time
         const uint32_t mine = t < nl ? (posK[t + 1] - posK[t] + 3) / 4 : 0u;
@@ -236,12 +241,13 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
     bool changed = in1 != in0 || alwaysCount;
     if (t < nl) changed = changed || (outK[t + 1] - outK[t]) != (posK[t + 1] - posK[t]);
     const bool quiet = !__syncthreads_or(changed);
+    if (quiet == COUNTING) return; // the other instantiation's tile
 
     // Tiles that count keep no keys in LDS, only 32-bit digests: 24 leading bits of (key - first key of the leaf), then
     // the slot in the leaf (old slots first, then arrivals; at most 256).  The digests of a leaf are distinct, and
     // ordered like (key, old index) as long as the leading key bits of its elements differ -- checked afterwards.
-    uint32_t* const sDig = sIdx;                              // the index array is free in such a tile
-    uint32_t* const sNew = reinterpret_cast<uint32_t*>(sKey); // and so is the key array: key bits in the NEW order
+    uint32_t* const sDig = sWordsB; // digests by slot
+    uint32_t* const sNew = sWordsA; // leading key bits in the NEW order
     auto digest          = [&](K key, uint32_t k, uint32_t slot)
     { return (uint32_t((key - loK[k]) >> cutK[k]) << 8) | slot; };
     // leaf of bin entry m: last k with inK[k] <= m
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
             if (p < p1)
             {
                 key[i] = keysIn[p];
-                if (!quiet)
+                if constexpr (COUNTING)
                 {
                     word[i] = mask[p >> 6];
                     rk[i]   = rank[p >> 6];
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
             const uint32_t p = p0 + t + 256u * i;
             if (p < p1)
             {
-                if (quiet)
+                if constexpr (!COUNTING)
                 {
                     sKey[p - p0] = key[i];
                     sIdx[p - p0] = p;
@@ -294,15 +300,17 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
             }
         }
     }
-    for (uint32_t m = in0 + t; m < in1; m += 256)
+    if constexpr (COUNTING)
     {
-        // (only tiles that count have arrivals)
-        const uint32_t k          = leafOfArrival(m);
-        sDig[nOldAll + (m - in0)] = digest(binKeys[m], k, (posK[k + 1] - posK[k]) + (m - inK[k]));
+        for (uint32_t m = in0 + t; m < in1; m += 256)
+        {
+            const uint32_t k          = leafOfArrival(m);
+            sDig[nOldAll + (m - in0)] = digest(binKeys[m], k, (posK[k + 1] - posK[k]) + (m - inK[k]));
+        }
     }
     __syncthreads();
 
-    if (quiet)
+    if constexpr (!COUNTING)
     {
         if (t < nl)
         {
@@ -354,6 +362,8 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
         return;
     }
 
+    if constexpr (COUNTING)
+    {
     // ---- counting.  A lane takes a chunk of four consecutive old slots of ONE leaf and scans the leaf's digests once
     // for all four: LDS reads / 4, two 32-bit vector instructions per comparison.
     constexpr int CHUNK_ITER = (RESORT_TILE_SLOTS / 4 + G + 255) / 256;
@@ -488,6 +498,7 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
         keysOut[outK[k] + pl]  = kx;
         orderOut[outK[k] + pl] = ix;
     }
+    }
 }
 
 //! the particles that carry the remove marker: behind every leaf, by ascending old position (idx sorted by the caller)
@@ -610,14 +621,29 @@ int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, 
     StageTimer timer(ctx, CSTONE_STAGE_RESORT_LEAVES);
     const unsigned grid    = (J + unsigned(leavesPerTile) - 1) / unsigned(leavesPerTile);
     const bool alwaysCount = std::getenv("CSTONE_RESORT_COUNT") != nullptr; // tuning/tests: no quiet-tile shortcut
-#define CSTONE_LEAF_SORT(G)                                                                                            \
-    hipLaunchKernelGGL((leafSortKernel<K, G>), grid, 256, 0, ctx->stream, keysIn, mask_.as<uint64_t>(),                \
+#define CSTONE_LEAF_SORT(G, COUNTING)                                                                                  \
+    hipLaunchKernelGGL((leafSortKernel<K, G, COUNTING>), grid, 256, 0, ctx->stream, keysIn, mask_.as<uint64_t>(),      \
                        rank_.as<uint32_t>(), leafLo_.as<K>(), leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(),       \
                        layoutNew_.as<uint32_t>(), binKeys_.as<K>(), binIdx_.as<uint32_t>(), J, alwaysCount, keysOut,  \
                        orderOut)
-    if (leavesPerTile == 64) CSTONE_LEAF_SORT(64);
-    else if (leavesPerTile == 32) CSTONE_LEAF_SORT(32);
-    else if (leavesPerTile == 16) CSTONE_LEAF_SORT(16);
+    // quiet tiles and tiles in which something moved: one launch each over all tiles (without movers there are none of
+    // the second kind)
+    const bool someMoved = numMovers > 0 || alwaysCount;
+    if (leavesPerTile == 64)
+    {
+        CSTONE_LEAF_SORT(64, false);
+        if (someMoved) CSTONE_LEAF_SORT(64, true);
+    }
+    else if (leavesPerTile == 32)
+    {
+        CSTONE_LEAF_SORT(32, false);
+        if (someMoved) CSTONE_LEAF_SORT(32, true);
+    }
+    else if (leavesPerTile == 16)
+    {
+        CSTONE_LEAF_SORT(16, false);
+        if (someMoved) CSTONE_LEAF_SORT(16, true);
+    }
     else return fail(ctx, CSTONE_E_INTERNAL, "resort: %d leaves per workgroup not instantiated", leavesPerTile);
 #undef CSTONE_LEAF_SORT
     CS_HIP(ctx, hipGetLastError());
