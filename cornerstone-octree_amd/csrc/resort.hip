@@ -195,8 +195,9 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
     constexpr K HOLE   = ~K(0);
     // Two instantiations share this body and the grid: COUNTING = false takes the quiet tiles (keys and old indices in
     // LDS, 52 KB: three workgroups per CU), COUNTING = true the tiles in which something moved (digests and the new
-    // order's key bits, 35 KB: four per CU); a workgroup whose tile is of the other kind leaves after the setup.
-    __shared__ __attribute__((aligned(8))) uint32_t sWordsA[COUNTING ? RESORT_TILE_SLOTS : RESORT_TILE_SLOTS * sizeof(K) / 4];
+    // order's key bits folded to 16, 27 KB: five per CU); a workgroup whose tile is of the other kind leaves after the
+    // setup.
+    __shared__ __attribute__((aligned(8))) uint32_t sWordsA[COUNTING ? RESORT_TILE_SLOTS / 2 : RESORT_TILE_SLOTS * sizeof(K) / 4];
     __shared__ uint32_t sWordsB[RESORT_TILE_SLOTS];
     K* const sKey        = reinterpret_cast<K*>(sWordsA); // quiet tiles: the keys ...
     uint32_t* const sIdx = sWordsB;                       // ... and their old indices
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
     // the slot in the leaf (old slots first, then arrivals; at most 256).  The digests of a leaf are distinct, and
     // ordered like (key, old index) as long as the leading key bits of its elements differ -- checked afterwards.
     uint32_t* const sDig = sWordsB; // digests by slot
-    uint32_t* const sNew = sWordsA; // leading key bits in the NEW order
+    uint16_t* const sNew = reinterpret_cast<uint16_t*>(sWordsA); // leading key bits in the NEW order, folded to 16 bits
+    auto fold            = [](uint32_t dig) { return uint16_t((dig >> 8) ^ (dig >> 24)); }; // equal bits -> equal folds
     auto digest          = [&](K key, uint32_t k, uint32_t slot)
     { return (uint32_t((key - loK[k]) >> cutK[k]) << 8) | slot; };
     // leaf of bin entry m: last k with inK[k] <= m
@@ -262,24 +264,15 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
         }
         return lo;
     };
+    if constexpr (!COUNTING)
     {
         // old positions: all loads of a thread are issued before the first is used
         K key[ITER];
-        uint64_t word[ITER];
-        uint32_t rk[ITER];
 #pragma unroll
         for (int i = 0; i < ITER; ++i)
         {
             const uint32_t p = p0 + t + 256u * i;
-            if (p < p1)
-            {
-                key[i] = keysIn[p];
-                if constexpr (COUNTING)
-                {
-                    word[i] = mask[p >> 6];
-                    rk[i]   = rank[p >> 6];
-                }
-            }
+            if (p < p1) key[i] = keysIn[p];
         }
 #pragma unroll
         for (int i = 0; i < ITER; ++i)
@@ -287,12 +280,37 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
             const uint32_t p = p0 + t + 256u * i;
             if (p < p1)
             {
-                if constexpr (!COUNTING)
+                sKey[p - p0] = key[i];
+                sIdx[p - p0] = p;
+            }
+        }
+    }
+    else
+    {
+        // old positions -> digests, in two batches (registers: key, leaf-start word and rank of every load in flight)
+        constexpr int HALF = (ITER + 1) / 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+        {
+            K key[HALF];
+            uint64_t word[HALF];
+            uint32_t rk[HALF];
+#pragma unroll
+            for (int i = 0; i < HALF; ++i)
+            {
+                const uint32_t p = p0 + t + 256u * (h * HALF + i);
+                if (p < p1)
                 {
-                    sKey[p - p0] = key[i];
-                    sIdx[p - p0] = p;
+                    key[i]  = keysIn[p];
+                    word[i] = mask[p >> 6];
+                    rk[i]   = rank[p >> 6];
                 }
-                else
+            }
+#pragma unroll
+            for (int i = 0; i < HALF; ++i)
+            {
+                const uint32_t p = p0 + t + 256u * (h * HALF + i);
+                if (p < p1)
                 {
                     const uint32_t k = rk[i] + uint32_t(__popcll(word[i] & ((2ull << (p & 63u)) - 1))) - 1u - j0;
                     sDig[p - p0]     = key[i] == HOLE ? ~0u : digest(key[i], k, p - posK[k]);
@@ -418,7 +436,7 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
             for (int j = 0; j < 4; ++j)
             {
                 place[i][j] = cnt[j];
-                if (d[j] != ~0u) sNew[base + cnt[j]] = d[j] >> 8;
+                if (d[j] != ~0u) sNew[base + cnt[j]] = fold(d[j]);
             }
         }
     }
@@ -436,13 +454,13 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
     for (uint32_t m = in0 + t; m < in1; m += 256)
     {
         const uint32_t k = leafOfArrival(m), d = sDig[nOldAll + (m - in0)];
-        sNew[(outK[k] - outK[0]) + placeByDigest(k, d)] = d >> 8;
+        sNew[(outK[k] - outK[0]) + placeByDigest(k, d)] = fold(d);
     }
     __syncthreads();
 
-    // an element whose neighbour in the new order of its leaf has the same leading key bits is placed again, by key and
-    // old index proper, from global memory (the others are where they belong: leading bits that differ decide)
-    auto clashes = [&](uint32_t k, uint32_t pl, uint32_t bitsX)
+    // an element whose neighbour in the new order of its leaf has the same (folded) leading key bits is placed again, by
+    // key and old index proper, from global memory (the others are where they belong: leading bits that differ decide)
+    auto clashes = [&](uint32_t k, uint32_t pl, uint16_t bitsX)
     {
         const uint32_t base = outK[k] - outK[0], cnt = outK[k + 1] - outK[k];
         return (pl > 0 && sNew[base + pl - 1] == bitsX) || (pl + 1 < cnt && sNew[base + pl + 1] == bitsX);
@@ -481,7 +499,7 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
                 if (kx[j] != HOLE)
                 {
                     uint32_t pl = place[i][j];
-                    if (clashes(k, pl, sDig[p - p0 + j] >> 8)) pl = placeExact(k, kx[j], p + j);
+                    if (clashes(k, pl, fold(sDig[p - p0 + j]))) pl = placeExact(k, kx[j], p + j);
                     keysOut[outK[k] + pl]  = kx[j];
                     orderOut[outK[k] + pl] = p + j;
                 }
@@ -494,7 +512,7 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
         const K kx        = binKeys[m];
         const uint32_t ix = binIdx[m];
         uint32_t pl       = placeByDigest(k, d);
-        if (clashes(k, pl, d >> 8)) pl = placeExact(k, kx, ix);
+        if (clashes(k, pl, fold(d))) pl = placeExact(k, kx, ix);
         keysOut[outK[k] + pl]  = kx;
         orderOut[outK[k] + pl] = ix;
     }
