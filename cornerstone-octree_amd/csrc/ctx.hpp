@@ -126,6 +126,12 @@ int sfcKeysAndOrderingHint(cstone_hip_ctx* ctx, int curve, int key_bits, int rea
 int gatherWithHaloRadii(cstone_hip_ctx* ctx, int h_bits, const void* h, const uint32_t* order, void* hOut,
                         const uint32_t* layout, int numLeaves, float ext, float* radii);
 
+//! cstone_hip_build_octree with a bound on the level of the leaves (tree.hip): the sort of the node keys then skips the
+//! digit passes above 3 * deepestLevel + 1 bits
+int buildLinkedOctree(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int numLeaves, void* prefixes,
+                      int32_t* childOffsets, int32_t* parents, int32_t* levelRange, int32_t* internalToLeaf,
+                      int32_t* leafToInternal, int deepestLevel);
+
 //! bottom-up saturating sum over the linked octree, launching only the levels that exist (tree.hip)
 int upsweepSumLevels(cstone_hip_ctx* ctx, int numLevelsPlus2, const int32_t* levelRangeHost, const int32_t* levelRange,
                      const int32_t* childOffsets, uint32_t* counts);

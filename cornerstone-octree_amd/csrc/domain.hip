@@ -554,9 +554,19 @@ private:
         CS_TRY(fLevelRange_.ensure(ctx_, (maxLevel<K>() + 2) * sizeof(NodeIdx)));
         CS_TRY(fItl_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
         CS_TRY(fLti_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
-        CS_TRY(cstone_hip_build_octree(ctx_, 8 * sizeof(K), fTree_.p, L, fPrefixes_.p, fChild_.as<int32_t>(),
-                                       fParents_.as<int32_t>(), fLevelRange_.as<int32_t>(), fItl_.as<int32_t>(),
-                                       fLti_.as<int32_t>()));
+        // a focus update refines by one level at most: the leaves of the new tree are no deeper than the deepest of the
+        // tree before + 1 (levelRangeHost_ still describes that one)
+        int deepest = int(maxLevel<K>());
+        if (!levelRangeHost_.empty())
+        {
+            int prev = 0;
+            for (int l = 0; l <= int(maxLevel<K>()); ++l)
+                if (levelRangeHost_[l + 1] > levelRangeHost_[l]) prev = l;
+            deepest = std::min(deepest, prev + 1);
+        }
+        CS_TRY(buildLinkedOctree(ctx_, 8 * sizeof(K), fTree_.p, L, fPrefixes_.p, fChild_.as<int32_t>(),
+                                 fParents_.as<int32_t>(), fLevelRange_.as<int32_t>(), fItl_.as<int32_t>(),
+                                 fLti_.as<int32_t>(), deepest));
         // the level ranges also on the host (the tree is rebuilt rarely): the upsweep then launches existing levels only
         levelRangeHost_.resize(maxLevel<K>() + 2);
         CS_HIP(ctx_, hipMemcpyAsync(levelRangeHost_.data(), fLevelRange_.p, levelRangeHost_.size() * sizeof(NodeIdx),

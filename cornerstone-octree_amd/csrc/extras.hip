@@ -10,7 +10,7 @@
 namespace cship
 {
 template<class K>
-int sortPairsArena(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n);
+int sortPairsArena(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, int keyBits);
 
 namespace
 {
@@ -411,8 +411,8 @@ int cstone_hip_sort_keys(cstone_hip_ctx* ctx, int key_bits, void* keys, size_t n
     // rare and small (injectKeys, R/focus/inject.hpp:97): the pair sort with a throw-away payload
     uint32_t* payload = nullptr;
     CS_HIP(ctx, hipMalloc((void**)&payload, n * sizeof(uint32_t)));
-    int rc = key_bits == 32 ? sortPairsArena<uint32_t>(ctx, (uint32_t*)keys, payload, n)
-                            : sortPairsArena<uint64_t>(ctx, (uint64_t*)keys, payload, n);
+    int rc = key_bits == 32 ? sortPairsArena<uint32_t>(ctx, (uint32_t*)keys, payload, n, 32)
+                            : sortPairsArena<uint64_t>(ctx, (uint64_t*)keys, payload, n, 64);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(payload);
     if (rc == CSTONE_OK && e != hipSuccess) return fail(ctx, CSTONE_E_HIP, "sort_keys: %s", hipGetErrorString(e));

@@ -596,7 +596,7 @@ int LeafResort<K>::binMovers(cstone_hip_ctx* ctx, int leavesPerTile)
     const uint32_t ent    = uint32_t(numLeaves_) + 3;
     const uint32_t* numJ  = (const uint32_t*)scalars + 2;
     const uint32_t* count = (const uint32_t*)scalars + 3;
-    hipLaunchKernelGGL(binMoversKernel<K>, unsigned(ctx->numCu) * 4, 256, 0, ctx->stream, moverKeys_.as<K>(), count,
+    hipLaunchKernelGGL(binMoversKernel<K>, unsigned(ctx->numCu) * 16, 256, 0, ctx->stream, moverKeys_.as<K>(), count,
                        args_.moverCap, leafLo_.as<K>(), numJ, incoming_.as<uint32_t>(), moverDest_.as<uint32_t>(),
                        moverSlot_.as<uint32_t>());
     hipLaunchKernelGGL(newLeafSizesKernel, gridFor(ent, 256), 256, 0, ctx->stream, leafPos_.as<uint32_t>(),

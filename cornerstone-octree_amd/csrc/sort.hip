@@ -1044,7 +1044,7 @@ size_t sortTempBytes(size_t n)
 
 template<class K, int BLOCK, bool BALLOT>
 void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* vals, size_t n, K* keysAlt,
-                  uint32_t* valsAlt, bool iotaValues, int startPass)
+                  uint32_t* valsAlt, bool iotaValues, int startPass, int endPass)
 {
     using Cfg             = SortCfg<K, BLOCK>;
     constexpr int P       = Cfg::PASSES;
@@ -1054,7 +1054,7 @@ void launchPasses(cstone_hip_ctx* ctx, const SortTemp& t, K* keys, uint32_t* val
     uint32_t* vIn  = iotaValues ? nullptr : vals;
     K* kOut        = keysAlt;
     uint32_t* vOut = valsAlt;
-    for (int p = startPass; p < P; ++p)
+    for (int p = startPass; p < std::min(P, endPass); ++p)
     {
         StageTimer timer(ctx, vIn == nullptr ? CSTONE_STAGE_SORT_PASS_IOTA : CSTONE_STAGE_SORT_PASS);
         const uint32_t* bases = t.hist + size_t(p) * RADIX;
@@ -1083,7 +1083,8 @@ template<class K>
 int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt, uint32_t* valsAlt, void* temp,
               size_t tempBytes, bool iotaValues = false, int histogramState = 0 /* 0: do all, 1: only clear the
               temp (the caller counts into it next), 2: temp cleared and digit counts present */,
-              int startPass = 0 /* even: digits below 8 * startPass bits are left to the caller (fixupRuns) */)
+              int startPass = 0 /* even: digits below 8 * startPass bits are left to the caller (fixupRuns) */,
+              int endPass = 64 /* even: the caller knows that all keys are zero from bit 8 * endPass on */)
 {
     if (n == 0) return CSTONE_OK;
     if (n >= (size_t(1) << 30)) return fail(ctx, CSTONE_E_ARG, "sort_pairs: n = %zu exceeds 2^30 - 1", n);
@@ -1138,11 +1139,11 @@ int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt
 #endif
     if (ballot)
     {
-        if (large) launchPasses<K, LARGE_BLOCK, true>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass);
-        else launchPasses<K, SMALL_BLOCK, true>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass);
+        if (large) launchPasses<K, LARGE_BLOCK, true>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass, endPass);
+        else launchPasses<K, SMALL_BLOCK, true>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass, endPass);
     }
-    else if (large) launchPasses<K, LARGE_BLOCK, false>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass);
-    else launchPasses<K, SMALL_BLOCK, false>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass);
+    else if (large) launchPasses<K, LARGE_BLOCK, false>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass, endPass);
+    else launchPasses<K, SMALL_BLOCK, false>(ctx, t, keys, vals, n, keysAlt, valsAlt, iotaValues, startPass, endPass);
     CS_HIP(ctx, hipGetLastError());
 #ifdef CSTONE_SORT_TRACE
     if (traceFile)
@@ -1166,19 +1167,21 @@ int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt
 } // namespace
 
 template<class K>
-int sortPairsArena(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n)
+int sortPairsArena(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, int keyBits)
 {
     size_t tb = sortTempBytes<K>(n);
     CS_TRY(arenaReserve(ctx, alignUp(n * sizeof(K)) + alignUp(n * sizeof(uint32_t)) + tb + 1024));
     K* ka        = (K*)arenaTake(ctx, n * sizeof(K));
     uint32_t* va = (uint32_t*)arenaTake(ctx, n * sizeof(uint32_t));
     void* tmp    = arenaTake(ctx, tb);
-    int rc       = sortPairs<K>(ctx, keys, vals, n, ka, va, tmp, tb);
+    // keyBits: the caller's bound on the significant bits of the keys (digit passes above them would be the identity)
+    const int endPass = std::min(int(sizeof(K)), ((keyBits + 7) / 8 + 1) & ~1);
+    int rc            = sortPairs<K>(ctx, keys, vals, n, ka, va, tmp, tb, false, 0, 0, endPass);
     arenaReset(ctx);
     return rc;
 }
-template int sortPairsArena<uint32_t>(cstone_hip_ctx*, uint32_t*, uint32_t*, size_t);
-template int sortPairsArena<uint64_t>(cstone_hip_ctx*, uint64_t*, uint32_t*, size_t);
+template int sortPairsArena<uint32_t>(cstone_hip_ctx*, uint32_t*, uint32_t*, size_t, int);
+template int sortPairsArena<uint64_t>(cstone_hip_ctx*, uint64_t*, uint32_t*, size_t, int);
 
 } // namespace cship
 
@@ -1247,8 +1250,8 @@ int cstone_hip_sort_pairs(cstone_hip_ctx* ctx, int key_bits, void* keys, uint32_
         return fail(ctx, CSTONE_E_ARG, "sort_pairs: pass all of keys_alt/values_alt/temp or none");
     if (own)
     {
-        return key_bits == 32 ? sortPairsArena<uint32_t>(ctx, (uint32_t*)keys, values, n)
-                              : sortPairsArena<uint64_t>(ctx, (uint64_t*)keys, values, n);
+        return key_bits == 32 ? sortPairsArena<uint32_t>(ctx, (uint32_t*)keys, values, n, 32)
+                              : sortPairsArena<uint64_t>(ctx, (uint64_t*)keys, values, n, 64);
     }
     return key_bits == 32
                ? sortPairs<uint32_t>(ctx, (uint32_t*)keys, values, n, (uint32_t*)keys_alt, values_alt, temp, temp_bytes)

@@ -14,7 +14,7 @@ namespace cship
 {
 
 template<class K>
-int sortPairsArena(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n); // sort.hip
+int sortPairsArena(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, int keyBits); // sort.hip
 
 namespace
 {
@@ -386,7 +386,8 @@ int updateOctree(cstone_hip_ctx* ctx, const K* keys, size_t n, uint32_t bucket, 
 
 template<class K>
 int buildOctree(cstone_hip_ctx* ctx, const K* leaves, NodeIdx numLeaves, K* prefixes, NodeIdx* childOffsets,
-                NodeIdx* parents, NodeIdx* levelRange, NodeIdx* internalToLeaf, NodeIdx* leafToInternal)
+                NodeIdx* parents, NodeIdx* levelRange, NodeIdx* internalToLeaf, NodeIdx* leafToInternal,
+                int deepestLevel = int(maxLevel<K>()) /* bound on the level of the leaves, if the caller has one */)
 {
     if (numLeaves < 1) return fail(ctx, CSTONE_E_ARG, "build_octree: need at least one leaf");
     NodeIdx numInternal = (numLeaves - 1) / 7;
@@ -396,7 +397,8 @@ int buildOctree(cstone_hip_ctx* ctx, const K* leaves, NodeIdx numLeaves, K* pref
     auto* order = reinterpret_cast<uint32_t*>(internalToLeaf);
     hipLaunchKernelGGL(unsortedLayoutKernel<K>, gridFor(numLeaves, 256), 256, 0, ctx->stream, leaves, numInternal,
                        numLeaves, prefixes, order);
-    CS_TRY(sortPairsArena<K>(ctx, prefixes, order, size_t(numNodes)));
+    // a node key of level l has its sentinel bit at 3 l: no digit pass over the zeros above the deepest level
+    CS_TRY(sortPairsArena<K>(ctx, prefixes, order, size_t(numNodes), 3 * std::min(deepestLevel, int(maxLevel<K>())) + 1));
     // order -> (leafToInternal, internalToLeaf); reading and writing internalToLeaf[i] in the same lane is safe
     hipLaunchKernelGGL(invertOrderKernel, gridFor(numNodes, 256), 256, 0, ctx->stream, order, numNodes, numInternal,
                        internalToLeaf, leafToInternal);
@@ -415,6 +417,17 @@ int buildOctree(cstone_hip_ctx* ctx, const K* leaves, NodeIdx numLeaves, K* pref
 
 namespace cship
 {
+int buildLinkedOctree(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int numLeaves, void* prefixes,
+                      int32_t* childOffsets, int32_t* parents, int32_t* levelRange, int32_t* internalToLeaf,
+                      int32_t* leafToInternal, int deepestLevel)
+{
+    if (key_bits == 32)
+        return buildOctree<uint32_t>(ctx, (const uint32_t*)leaves, numLeaves, (uint32_t*)prefixes, childOffsets, parents,
+                                     levelRange, internalToLeaf, leafToInternal, deepestLevel);
+    return buildOctree<uint64_t>(ctx, (const uint64_t*)leaves, numLeaves, (uint64_t*)prefixes, childOffsets, parents,
+                                 levelRange, internalToLeaf, leafToInternal, deepestLevel);
+}
+
 //! upsweep with the level ranges known on the host as well: empty levels are not launched
 int upsweepSumLevels(cstone_hip_ctx* ctx, int numLevelsPlus2, const int32_t* levelRangeHost, const int32_t* levelRange,
                      const int32_t* childOffsets, uint32_t* counts)
