@@ -89,13 +89,35 @@ class SyncPipeline:
         self.f_leaves = self.g_leaves = 0
 
     def step(self):
-        """one Domain::sync (domain.hpp:196-243); the first call also converges both trees from the root"""
-        self.keys, self.x, self.y, self.z, self.h, self.scratch, _ = self.dom.sync(self.keys, self.x, self.y, self.z,
-                                                                                   self.h, self.scratch)
-        v = self.dom.view()
-        self.f_leaves, self.g_leaves = v.num_focus_leaves, v.num_global_leaves
+        """one Domain::sync (domain.hpp:196-243); the first call also converges both trees from the root.  Straight
+        through the C ABI, as a C++ client would call it: five pointers the library may exchange among themselves; the
+        tensors follow their buffers (no particle is removed here, so every array keeps its length)"""
+        import ctypes as C
 
-    first_sync = step
+        arrays = (self.x, self.y, self.z, self.h, self.scratch)
+        if not hasattr(self, "_ptrs"):
+            self._keys_ptr = C.c_void_p(self.keys.data_ptr())
+            self._ptrs = [C.c_void_p() for _ in range(5)]
+            self._n = C.c_size_t(self.x.numel())
+            self._none = C.c_void_p(None)
+        by_ptr = {}
+        for p, t in zip(self._ptrs, arrays):
+            p.value = t.data_ptr()
+            by_ptr[p.value] = t
+        rc = self.ctx.lib.cstone_hip_domain_sync(self.dom.h, C.byref(self._keys_ptr), C.byref(self._ptrs[0]),
+                                                 C.byref(self._ptrs[1]), C.byref(self._ptrs[2]), C.byref(self._ptrs[3]),
+                                                 self._n, C.byref(self._ptrs[4]), self._none, self._none, C.c_int(0))
+        self.ctx._chk(rc, "domain_sync")
+        self.x, self.y, self.z, self.h, self.scratch = [by_ptr[p.value] for p in self._ptrs]
+
+    def first_sync(self):
+        self.step()
+        self.note_leaves()
+
+    def note_leaves(self):
+        v = self.dom.view()
+        assert v.num_particles_with_halos == self.x.numel()
+        self.f_leaves, self.g_leaves = v.num_focus_leaves, v.num_global_leaves
 
     def jiggle(self):
         """displace a random 1 % of the particles by up to 2h (what a time step of a simulation does to the order)"""
@@ -374,6 +396,8 @@ def main():
         pipe.step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if not distributed:
+        pipe.note_leaves()
     n_sorted = n_local
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64,
@@ -530,6 +554,7 @@ def main():
             pl.step()
         barrier()
         per = (time.perf_counter() - t4) / args.steps
+        pl.note_leaves()
         extras["plummer"] = {"workload": f"{n_local:.0e} Plummer-sphere particles (r <= 10), bucketFocus {args.bucket_focus}",
                              "first_sync_ms": first_pl * 1e3, "ms_per_step": per * 1e3, "value": n_local / per,
                              "unit": "particles/s", "focus_leaves": pl.f_leaves,
