@@ -196,3 +196,43 @@ def test_resort_at_three_million_particles(hip, oracle):
         assert np.unique(a["ident"]).size == a["ident"].size
     st = dom.stats()
     assert st["resorts"] == 4 and st["resort_fallbacks"] == 0, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 7, 63, 64, 65, 1000])
+def test_resort_with_a_handful_of_particles(hip, oracle, n):
+    """one leaf, one 64-position word of the leaf table, fewer particles than a wave"""
+    from oracle.oracle import Box
+
+    st_ = _Stepper(hip, 64, 64, 64, 1, (1, 1, 1), n, 21, True)
+    for step, kind in enumerate(["none", "none", "jitter", "few", "none"]):
+        if step:
+            st_.move(kind, np.random.default_rng(70 + step))
+        a = st_.sync()
+        want = oracle.compute_sfc_keys(1, 64, a["x"], a["y"], a["z"], Box(list(a["view"].box.lim), (1, 1, 1)))
+        assert np.array_equal(a["keys"].view(np.uint64), want) and np.all(want[1:] >= want[:-1]), (n, kind)
+        assert np.array_equal(np.sort(a["ident"]), np.arange(n)), (n, kind)
+    assert st_.dom.stats()["resorts"] >= 2, st_.dom.stats()
+
+
+@pytest.mark.gpu
+def test_unaligned_arrays_take_the_regular_path(hip, oracle):
+    """coordinate arrays that do not start on a 16-byte boundary cannot go through the vector encode kernels: the sync
+    falls back to the plain encode and the radix sort, same results"""
+    import torch
+    from oracle.oracle import Box
+
+    st_ = _Stepper(hip, 64, 64, 64, 1, (1, 1, 1), 50_001, 22, True)
+    st_.sync()
+    # views shifted by one element (8 bytes): the client dropped its first particle
+    st_.x, st_.y, st_.z, st_.h, st_.ident = [t[1:] for t in (st_.x, st_.y, st_.z, st_.h, st_.ident)]
+    st_.keys, st_.scratch = st_.keys[1:], torch.empty(50_001, dtype=st_.x.dtype, device="cuda")[1:]
+    from cstone_amd.domain import Domain
+    import cstone_amd
+
+    # a new domain: the old one insists on the size of its last sync
+    st_.dom = Domain(hip, 1, 64, 64, 256, 64, 0.5, cstone_amd.make_cbox([0, 1, 0, 1, 0, 1], (1, 1, 1)))
+    for _ in range(3):
+        a = st_.sync()
+        want = oracle.compute_sfc_keys(1, 64, a["x"], a["y"], a["z"], Box(list(a["view"].box.lim), (1, 1, 1)))
+        assert np.array_equal(a["keys"].view(np.uint64), want) and np.all(want[1:] >= want[:-1])
