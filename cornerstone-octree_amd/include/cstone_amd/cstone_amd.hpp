@@ -28,6 +28,7 @@
 #include <string>
 #include <memory>
 #include <span>
+#include <cmath>
 #include <tuple>
 #include <type_traits>
 #include <utility>
@@ -472,6 +473,90 @@ void computeGeoCentersGpu(const KeyType* prefixes, TreeNodeIndex numNodes, T* ce
     Context::check(cstone_hip_node_centers(Context::get(), int(curve), detail::keyBits<KeyType>(), detail::realBits<T>(),
                                            prefixes, numNodes, &box.pod(), centers, sizes),
                    "computeGeoCentersGpu");
+}
+
+/*! Cornerstone leaf array of a particle CONCENTRATION given as a function (R/tree/continuum.hpp:41-116: continuumCount,
+ *  computeContinuumCounts, updateContinuumCsarray, computeContinuumCsarray), for initial conditions.  The rebalance
+ *  decisions, the new leaf array and the node geometry are computed on the device by the same kernels the particle
+ *  trees use; the concentration -- host code of the caller -- is evaluated on the host at the eight points
+ *  center +- size / 2 of every leaf (size = half edge lengths, as centerAndSize returns them) and summed in double like
+ *  the reference does: count = round(sum of concentration * sx * sy * sz).
+ *  Returns (leaf array, counts) after at most eleven update steps, converged or not (reference: maxIteration = 10). */
+template<class KeyType, class F, class T>
+std::tuple<std::vector<KeyType>, std::vector<unsigned>>
+computeContinuumCsarray(F&& concentration, const Box<T>& box, unsigned bucketSize, Curve curve = Curve::hilbert)
+{
+    constexpr unsigned maxLevel = sizeof(KeyType) == 8 ? 21 : 10;
+    std::vector<KeyType> tree{0, KeyType(1) << (3 * maxLevel)};
+    std::vector<unsigned> counts{bucketSize + 1};
+
+    DeviceVector<KeyType> dTree, dNewTree, dPrefixes;
+    DeviceVector<unsigned> dCounts;
+    DeviceVector<TreeNodeIndex> dOps;
+    DeviceVector<T> dCenters, dSizes;
+    std::vector<KeyType> prefixes;
+    std::vector<T> centers, sizes;
+
+    int maxIteration = 10;
+    bool converged   = false;
+    do
+    {
+        const TreeNodeIndex numNodes = TreeNodeIndex(tree.size()) - 1;
+        dTree.resize(tree.size());
+        dCounts.resize(counts.size());
+        dOps.resize(tree.size());
+        memcpyH2D(tree.data(), tree.size(), dTree.data());
+        memcpyH2D(counts.data(), counts.size(), dCounts.data());
+        const TreeNodeIndex newNumNodes =
+            computeNodeOpsGpu(dTree.data(), numNodes, dCounts.data(), bucketSize, dOps.data(), &converged);
+        dNewTree.resize(std::size_t(newNumNodes) + 1);
+        rebalanceTreeGpu(dTree.data(), numNodes, newNumNodes, dOps.data(), dNewTree.data());
+        tree.resize(std::size_t(newNumNodes) + 1);
+        memcpyD2H(dNewTree.data(), tree.size(), tree.data());
+
+        // node keys of the leaves (level + start, R/sfc/common.hpp:163-171) -> centers and half sizes on the device
+        prefixes.resize(newNumNodes);
+        for (TreeNodeIndex i = 0; i < newNumNodes; ++i)
+        {
+            const KeyType span = tree[i + 1] - tree[i];
+            unsigned level     = 0;
+            while ((KeyType(1) << (3 * (maxLevel - level))) > span)
+                ++level;
+            prefixes[i] = (KeyType(1) << (3 * level)) | (tree[i] >> (3 * (maxLevel - level)));
+        }
+        dPrefixes.resize(newNumNodes);
+        dCenters.resize(std::size_t(newNumNodes) * 3);
+        dSizes.resize(std::size_t(newNumNodes) * 3);
+        memcpyH2D(prefixes.data(), prefixes.size(), dPrefixes.data());
+        computeGeoCentersGpu(dPrefixes.data(), newNumNodes, dCenters.data(), dSizes.data(), box, curve);
+        centers.resize(dCenters.size());
+        sizes.resize(dSizes.size());
+        memcpyD2H(dCenters.data(), centers.size(), centers.data());
+        memcpyD2H(dSizes.data(), sizes.size(), sizes.data());
+
+        counts.resize(newNumNodes);
+        for (TreeNodeIndex i = 0; i < newNumNodes; ++i)
+        {
+            const T* c   = &centers[3 * std::size_t(i)];
+            const T* sz  = &sizes[3 * std::size_t(i)];
+            const T vol  = sz[0] * sz[1] * sz[2];
+            double count = 0;
+            for (int ix = -1; ix <= 1; ix += 2)
+                for (int iy = -1; iy <= 1; iy += 2)
+                    for (int iz = -1; iz <= 1; iz += 2)
+                    {
+                        const T cx = c[0] + T(0.5) * (T(ix) * sz[0]);
+                        const T cy = c[1] + T(0.5) * (T(iy) * sz[1]);
+                        const T cz = c[2] + T(0.5) * (T(iz) * sz[2]);
+                        count += concentration(cx, cy, cz) * vol;
+                    }
+            const double r = std::round(count);
+            counts[i]      = r >= double(std::numeric_limits<unsigned>::max()) ? std::numeric_limits<unsigned>::max()
+                                                                               : unsigned(r);
+        }
+    } while (!converged && maxIteration--);
+
+    return std::make_tuple(std::move(tree), std::move(counts));
 }
 
 //! segmentMax + scaleGpu as Halos::discover uses them (R/halos/halos.hpp:150-160): radii[i] = 2 ext max(h) over leaf i

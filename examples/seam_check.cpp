@@ -3,6 +3,7 @@
 // code: keys sorted and consistent, permutation, tree counts, linked octree, halo flags of a two-part split, neighbour
 // counts against an O(n^2) loop, target groups.  Exit code 0 = every check passed.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <numeric>
 #include <random>
@@ -181,8 +182,45 @@ bool runAll(const char* name, Curve curve)
     return ok;
 }
 
+//! computeContinuumCsarray for the two concentration functions the oracle's reference build can name (oracle/ref_driver.cpp,
+//! cstone_ref_continuum): leaves, particles and an FNV-1a digest of leaf keys and counts, for tests/test_cpp_layer.py
+template<class KeyType>
+void continuumDigest(const char* name, int kind)
+{
+    const double n0 = 1e6, lo = -1, hi = 1;
+    Box<double> box(lo, hi);
+    const double vol = box.lx() * box.ly() * box.lz();
+    const double eps = box.lx() / double(1u << (sizeof(KeyType) == 8 ? 21 : 10));
+    auto constant    = [=](double, double, double) { return n0 / vol; };
+    auto oneOverR    = [=](double x, double y, double z)
+    {
+        double r = std::max(std::sqrt(x * x + y * y + z * z), eps);
+        return r > 1.0 ? 0.0 : n0 / (2 * M_PI * r);
+    };
+    std::vector<KeyType> tree;
+    std::vector<unsigned> counts;
+    if (kind == 0) std::tie(tree, counts) = computeContinuumCsarray<KeyType>(constant, box, 64u);
+    else std::tie(tree, counts) = computeContinuumCsarray<KeyType>(oneOverR, box, 64u);
+    std::uint64_t h = 1469598103934665603ull, sum = 0;
+    auto mix = [&](std::uint64_t v)
+    {
+        for (int b = 0; b < 8; ++b)
+            h = (h ^ ((v >> (8 * b)) & 0xff)) * 1099511628211ull;
+    };
+    for (auto k : tree)
+        mix(std::uint64_t(k));
+    for (auto c : counts)
+        mix(c), sum += c;
+    std::printf("continuum %s kind %d: leaves %zu particles %llu digest %016llx\n", name, kind, counts.size(),
+                (unsigned long long)sum, (unsigned long long)h);
+}
+
 int main()
 {
+    continuumDigest<std::uint64_t>("u64", 0);
+    continuumDigest<std::uint64_t>("u64", 1);
+    continuumDigest<std::uint32_t>("u32", 0);
+    continuumDigest<std::uint32_t>("u32", 1);
     bool ok = runAll<std::uint64_t, double>("u64/f64 hilbert", Curve::hilbert);
     ok      = runAll<std::uint64_t, float>("u64/f32 morton", Curve::morton) && ok;
     ok      = runAll<std::uint32_t, double>("u32/f64 morton", Curve::morton) && ok;

@@ -19,6 +19,7 @@
 #include "cstone/traversal/collisions.hpp"
 #include "cstone/traversal/macs.hpp"
 #include "cstone/tree/btree.hpp"
+#include "cstone/tree/continuum.hpp"
 #include "cstone/tree/csarray.hpp"
 #include "cstone/tree/octree.hpp"
 
@@ -461,6 +462,39 @@ int cstone_ref_binary_tree(int key_bits, const void* tree, int num_nodes, int* c
                            ((K*)prefix)[i]  = nodes[i].prefix;
                        }
                    });
+}
+
+/*! computeContinuumCsarray (R/tree/continuum.hpp:103-116) for two concentration functions a C interface can name:
+ *  kind 0: constant n0 / box volume; kind 1: n0 / (2 pi r) inside the unit sphere, 0 outside, r floored at one grid cell
+ *  (the function of T/unit/tree/continuum.cpp:54-75).  Box = [lo, hi]^3, double coordinates, Hilbert keys.
+ *  Returns the number of leaves (tree: that many + 1 keys) or -1 if cap is too small. */
+int cstone_ref_continuum(int key_bits, int kind, double n0, unsigned bucket, double lo, double hi, void* tree,
+                         unsigned* counts, int cap)
+{
+    int leaves = -1;
+    withKey(key_bits,
+            [&](auto k)
+            {
+                using K = decltype(k);
+                Box<double> box(lo, hi);
+                const double vol = box.lx() * box.ly() * box.lz();
+                const double eps = box.lx() / double(1u << maxTreeLevel<K>{});
+                auto constant    = [=](double, double, double) { return n0 / vol; };
+                auto oneOverR    = [=](double x, double y, double z)
+                {
+                    double r = std::max(std::sqrt(x * x + y * y + z * z), eps);
+                    return r > 1.0 ? 0.0 : n0 / (2 * M_PI * r);
+                };
+                std::vector<K> t;
+                std::vector<unsigned> c;
+                if (kind == 0) std::tie(t, c) = computeContinuumCsarray<K>(constant, box, bucket);
+                else std::tie(t, c) = computeContinuumCsarray<K>(oneOverR, box, bucket);
+                if (int(c.size()) > cap) return;
+                std::copy(t.begin(), t.end(), (K*)tree);
+                std::copy(c.begin(), c.end(), counts);
+                leaves = int(c.size());
+            });
+    return leaves;
 }
 
 int cstone_ref_num_threads()

@@ -21,6 +21,40 @@ def _stale(exe):
     return any(os.path.getmtime(h) > os.path.getmtime(exe) for h in heads)
 
 
+def _check_continuum(stdout):
+    """computeContinuumCsarray of the C++ layer (R/tree/continuum.hpp: rebalance and node geometry on the device, the
+    concentration on the host) against the reference's own function, built from its headers into oracle/_ref: same
+    leaf array, same counts (FNV-1a over both), 32- and 64-bit keys, a constant and a 1/r concentration"""
+    import ctypes as C
+    import re
+
+    import numpy as np
+
+    ref = os.path.join(ROOT, "oracle", "_ref", "libcstone_ref.so")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/libcstone_ref.so not built")
+    lib = C.CDLL(ref)
+    if not hasattr(lib, "cstone_ref_continuum"):
+        pytest.skip("oracle/_ref predates cstone_ref_continuum")
+    lib.cstone_ref_continuum.argtypes = [C.c_int, C.c_int, C.c_double, C.c_uint, C.c_double, C.c_double, C.c_void_p,
+                                         C.c_void_p, C.c_int]
+    for kb, name in ((64, "u64"), (32, "u32")):
+        for kind in (0, 1):
+            cap = 1 << 20
+            tree = np.zeros(cap + 1, dtype=np.uint64 if kb == 64 else np.uint32)
+            counts = np.zeros(cap, dtype=np.uint32)
+            L = lib.cstone_ref_continuum(kb, kind, 1e6, 64, -1.0, 1.0, tree.ctypes.data, counts.ctypes.data, cap)
+            assert L > 0
+            h = 1469598103934665603
+            for v in list(tree[:L + 1].astype(np.uint64)) + list(counts[:L].astype(np.uint64)):
+                v = int(v)
+                for b in range(8):
+                    h = ((h ^ ((v >> (8 * b)) & 0xff)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+            m = re.search(rf"continuum {name} kind {kind}: leaves (\d+) particles (\d+) digest ([0-9a-f]+)", stdout)
+            assert m, stdout[-1500:]
+            assert (int(m.group(1)), int(m.group(2)), int(m.group(3), 16)) == (L, int(counts[:L].sum()), h), (name, kind)
+
+
 def _compile(source="domain_example.cpp", exe=EXE):
     lib = os.path.join(ROOT, "cornerstone-octree_amd", "lib")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
@@ -40,7 +74,10 @@ def test_cpp_seam_check_compiles():
 def test_cpp_seam_check_runs():
     if not os.path.exists(SEAM_EXE):
         _compile("seam_check.cpp", SEAM_EXE)
+    if _stale(SEAM_EXE):
+        _compile("seam_check.cpp", SEAM_EXE)
     r = subprocess.run([SEAM_EXE], capture_output=True, text=True, timeout=300)
+    _check_continuum(r.stdout)
     assert r.returncode == 0 and "seam check: all passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
 
 
