@@ -7,8 +7,9 @@
 //      layout): a "stayer" keeps its leaf, a "mover" is appended to a list (resort.hpp: ResortArgs, sfc.hip:
 //      encodeResortKernel)
 //   2. the movers are binned by the leaf their new key falls into (binary search, one atomic each)
-//   3. one pass over the leaves (leafSortKernel): the stayers of a leaf plus its incoming movers are ordered by
-//      (key, old index) inside LDS and written to the leaf's new place
+//   3. one pass over the leaves (leafSortKernel): the stayers of a leaf plus its incoming movers are brought into the
+//      order of (key, old index) -- tiles in which nothing moved by one lane per leaf sorting in LDS, the others by
+//      counting on 32-bit digests -- and written to the leaf's new place
 // The result is the stable sort of the keys (ties by old index), whatever the particles did: a particle is a stayer
 // only if its key lies in the range of the leaf its position claims, everything else goes through the bins, and the
 // leaf ranges are disjoint and ascending.  Too many movers or an overfull leaf make the caller fall back to the radix sort.
@@ -38,8 +39,9 @@ struct ResortArgs
 };
 
 //! limits of the leaf pass
-constexpr uint32_t RESORT_TILE_SLOTS = 4224; // LDS slots (key + index) of a workgroup: three workgroups per CU
-constexpr uint32_t RESORT_LEAF_CAP   = 256;  // longest leaf the in-LDS insertion sort accepts
+constexpr uint32_t RESORT_TILE_SLOTS = 4224; // slots (old positions + arrivals) of a workgroup's leaves: key + index in
+                                             // LDS for quiet tiles (three workgroups per CU), digests for the others
+constexpr uint32_t RESORT_LEAF_CAP   = 256;  // most slots of ONE leaf (the slot number is the low byte of a digest)
 
 //! device-side results a re-sort attempt reports (ctx->devScalars + RESORT_SCALARS, read back with the box extents)
 constexpr int RESORT_SCALARS = 28; // [0] particles with the remove marker, [1] flags (1: leaf too long, 2: tile too
