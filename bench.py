@@ -555,9 +555,11 @@ def main():
         barrier()
         per = (time.perf_counter() - t4) / args.steps
         pl.note_leaves()
+        pl_stats = pl.dom.stats()
         extras["plummer"] = {"workload": f"{n_local:.0e} Plummer-sphere particles (r <= 10), bucketFocus {args.bucket_focus}",
                              "first_sync_ms": first_pl * 1e3, "ms_per_step": per * 1e3, "value": n_local / per,
                              "unit": "particles/s", "focus_leaves": pl.f_leaves,
+                             "syncs": {k: pl_stats[k] for k in ("syncs", "resorts", "resort_fallbacks", "box_redos")},
                              "find_neighbors": pl.find_neighbors(args.neighbor_targets, 0)
                              if args.neighbor_targets > 0 else None}
         pipe = pl
