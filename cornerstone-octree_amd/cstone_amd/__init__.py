@@ -7,6 +7,7 @@ There is NO fallback: if the library is missing or a call fails, an exception is
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -142,6 +143,10 @@ class Context:
             self.h = None
 
     def __del__(self):
+        # not during interpreter shutdown: the HIP runtime may be gone by then (objects kept alive by a traceback are
+        # collected that late), and the process is about to release everything anyway
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

@@ -4,6 +4,7 @@ inside the library, csrc/comm_rccl.hip) and TorchCollectives (callbacks into tor
 rehearsals of several ranks on one GPU) -- and NativeDistributedDomain, which hands torch tensors to the library and wraps
 its result arrays.  Used by tests/ and bench.py only; torch is plumbing here, not part of the product.
 """
+import sys
 import numpy as np
 
 
@@ -170,6 +171,10 @@ class RcclCollectives:
             self.h = None
 
     def __del__(self):
+        # not during interpreter shutdown: the HIP runtime may be gone by then (objects kept alive by a traceback are
+        # collected that late), and the process is about to release everything anyway
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -202,6 +207,10 @@ class NativeDistributedDomain:
             self.h = None
 
     def __del__(self):
+        # not during interpreter shutdown: the HIP runtime may be gone by then (objects kept alive by a traceback are
+        # collected that late), and the process is about to release everything anyway
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

@@ -1,4 +1,5 @@
 """ctypes plumbing for the cstone_hip_domain_* entry points (tests / bench only)."""
+import sys
 import ctypes as C
 
 import numpy as np
@@ -42,6 +43,10 @@ class Domain:
             self.h = None
 
     def __del__(self):
+        # not during interpreter shutdown: the HIP runtime may be gone by then (objects kept alive by a traceback are
+        # collected that late), and the process is about to release everything anyway
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
