@@ -1269,10 +1269,12 @@ private:
                     continue;
                 }
                 CS_TRY(rc);
-                fLeaves_ = leaves;
+                fLeaves_   = leaves;
+                treeSteps_ = 0;
                 return CSTONE_OK;
             }
         }
+        ++treeSteps_;
         while (true)
         {
             int leaves = fLeaves_, conv = 0;
@@ -1322,6 +1324,7 @@ private:
         }
         // position of a boundary key in the new leaf array: leaves before it in the old array + what the covers add
         coverHost_.clear();
+        coverDeepest_ = 0;
         std::vector<int> coverBegin, coverSize;
         for (const Cut& c : cuts)
         {
@@ -1334,6 +1337,18 @@ private:
             }
             appendCover(coverHost_, a, c.e);
             coverSize.push_back(int(coverHost_.size()) - coverBegin.back());
+            // how deep the inserted leaves go (the sort of the node keys in buildFocusOctree leaves out the digit passes
+            // above the deepest level of the tree)
+            for (int i = 0; i < coverSize.back(); ++i)
+            {
+                const uint64_t lo   = uint64_t(coverHost_[coverBegin.back() + i]);
+                const uint64_t hi   = i + 1 < coverSize.back() ? uint64_t(coverHost_[coverBegin.back() + i + 1]) : c.e;
+                const uint64_t span = hi - lo;
+                int level           = 0;
+                while (level < int(maxLevel<K>()) && (uint64_t(1) << (3 * (maxLevel<K>() - level))) > span)
+                    ++level;
+                coverDeepest_ = std::max(coverDeepest_, level);
+            }
         }
         auto newIndexOf = [&](uint64_t key, int containing, bool aligned) -> int
         {
@@ -1398,9 +1413,12 @@ private:
         CS_TRY(fLevelRange_.ensure(ctx_, (maxLevel<K>() + 2) * sizeof(NodeIdx)));
         CS_TRY(fItl_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
         CS_TRY(fLti_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
-        return cstone_hip_build_octree(ctx_, kb, fTree_.p, L, fPrefixes_.p, fChild_.as<int32_t>(),
-                                       fParents_.as<int32_t>(), fLevelRange_.as<int32_t>(), fItl_.as<int32_t>(),
-                                       fLti_.as<int32_t>());
+        // leaves of the new tree: at most one level below the deepest of the previous sync's tree (one update step), or as
+        // deep as the leaves inserted at the range boundaries; the first tree of a domain may be of any depth
+        const int deepest = (treeSteps_ > 0 && prevMaxLeafLevel_ >= 0) ? std::max(prevMaxLeafLevel_ + 1, coverDeepest_)
+                                                                       : int(maxLevel<K>());
+        return buildLinkedOctree(ctx_, kb, fTree_.p, L, fPrefixes_.p, fChild_.as<int32_t>(), fParents_.as<int32_t>(),
+                                 fLevelRange_.as<int32_t>(), fItl_.as<int32_t>(), fLti_.as<int32_t>(), deepest);
     }
 
     int buildNsTree()
@@ -1497,6 +1515,8 @@ private:
     uint64_t layoutParticles_ = 0; // particles and box layout_ was made for
     cstone_box layoutBox_{};
     std::vector<K> coverHost_; // leaf keys inserted at the range boundaries, staged for the copy to the device
+    int coverDeepest_ = 0;     // level of the deepest of them
+    int treeSteps_    = 0;     // single update steps of the focus tree so far (0: the tree was just built from scratch)
     // tree over all local particles incl. halos (octree()), built on request
     DevBuf nsTree_, nsCounts_, nsLayout_, nsPrefixes_, nsChild_, nsParents_, nsLevelRange_, nsItl_, nsLti_, nsCenters_,
         nsSizes_;
