@@ -526,12 +526,13 @@ public:
         bool sameBox          = true;
         for (int k = 0; k < 6; ++k)
             sameBox = sameBox && box_.lim[k] == layoutBox_.lim[k];
-        // (below some 10^7 particles per rank the chain of small launches of the re-sort and its read-back cost what the
-        //  four digit passes cost: measured 1.39 against 1.32 ms per sync at 1.25e7, 3.20 against 3.43 ms at 5e7)
+        // (below some 3e7 particles per rank the chain of small launches of the re-sort and its read-back cost what the
+        //  four digit passes cost: measured, with 1 % movers, 1.35 against 1.25 ms per sync at 1.25e7, 2.16 against
+        //  2.19 ms at 2.5e7, 3.20 against 3.43 ms at 5e7)
         static const size_t resortMin = []
         {
             const char* e = std::getenv("CSTONE_MR_RESORT_MIN");
-            return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(1) << 24;
+            return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(1) << 25;
         }();
         const bool tryResort = !firstCall_ && n >= resortMin && n == layoutParticles_ && tileLeaves > 0 && sameBox && fLeaves_ > 0 &&
                                resortBackoff_ == 0 && !pending_ && std::getenv("CSTONE_NO_RESORT") == nullptr &&
