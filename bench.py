@@ -591,8 +591,9 @@ def main():
             this run's particles per launch; None when the profile does not hold the kernel"""
             if not tjson:
                 return None
+            wanted = {"leafSortKernel": "leafSortKernel/quiet"}.get(kernel.split(" ")[0], kernel.split(" ")[0])
             for row in tjson[1]["kernels"]:
-                if row["kernel"] == kernel.split(" ")[0]:
+                if row["kernel"] == wanted:
                     return (row["hbm_read_bytes"] + row["hbm_write_bytes"]) * n_sorted / tjson[1].get("particles", 1e8)
             return None
 
