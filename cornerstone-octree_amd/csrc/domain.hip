@@ -255,7 +255,8 @@ public:
         if (resortBackoff_ > 0) --resortBackoff_;
         if (tryResort)
         {
-            CS_TRY(resort_.prepare(ctx_, fTree_.as<K>(), layout_.as<uint32_t>(), fLeaves_, n, keysAlt_.as<K>()));
+            CS_TRY(resort_.prepare(ctx_, fTree_.as<K>(), layout_.as<uint32_t>(), fLeaves_, n, keysAlt_.as<K>(),
+                                   lastMovers_ > 100000));
             const ResortArgs<K> ra = resort_.args();
             bool done              = false;
             CS_TRY(computeKeysResort(ctx_, curve_, kb, rb, *xPP, *yPP, *zPP, keys, n, box_, &ra,

@@ -540,7 +540,8 @@ public:
         if (resortBackoff_ > 0) --resortBackoff_;
         if (tryResort)
         {
-            CS_TRY(resort_.prepare(ctx_, fTree_.as<K>(), layout_.as<uint32_t>(), fLeaves_, n, keysAlt_.as<K>()));
+            CS_TRY(resort_.prepare(ctx_, fTree_.as<K>(), layout_.as<uint32_t>(), fLeaves_, n, keysAlt_.as<K>(),
+                                   lastMovers_ > 100000));
             const ResortArgs<K> ra = resort_.args();
             bool done              = false;
             CS_TRY(computeKeysResort(ctx_, curve_, kb, rb, x, y, z, keysIn ? keys_.p : nullptr, n, box_, &ra, nullptr, &done));
@@ -554,7 +555,8 @@ public:
                 {
                     CS_TRY(resort_.sortLeaves(ctx_, keysAlt_.as<K>(), keys_.as<K>(), order_.as<uint32_t>(), movers, markers,
                                               J, tileLeaves));
-                    resorted = true;
+                    resorted    = true;
+                    lastMovers_ = movers;
                     ++resorts_;
                 }
                 else { resortBackoff_ = 4; }
@@ -1513,6 +1515,7 @@ private:
     uint64_t prevLo_ = 0, prevHi_ = 0;
     LeafResort<K> resort_;
     int resortBackoff_ = 0, resorts_ = 0;
+    uint32_t lastMovers_ = 0;
     uint64_t layoutParticles_ = 0; // particles and box layout_ was made for
     cstone_box layoutBox_{};
     std::vector<K> coverHost_; // leaf keys inserted at the range boundaries, staged for the copy to the device

@@ -84,12 +84,35 @@ __global__ __launch_bounds__(256) void fillCompactLeavesKernel(const K* __restri
     leafPos[j] = a;
 }
 
+//! coarse[c] = last leaf j with leafLo[j] <= c << RESORT_COARSE_SHIFT, for the 2^RESORT_COARSE_BITS + 1 values of c that
+//! keys have in their leading bits: the search for a mover's leaf then starts from a handful of candidates
+template<class K>
+__global__ __launch_bounds__(256) void coarseLeafTableKernel(const K* __restrict__ leafLo,
+                                                             const uint32_t* __restrict__ numCompact,
+                                                             uint32_t* __restrict__ coarse)
+{
+    constexpr int shift = 3 * int(maxLevel<K>()) - RESORT_COARSE_BITS;
+    const uint32_t c    = blockIdx.x * 256 + threadIdx.x;
+    if (c > (1u << RESORT_COARSE_BITS)) return;
+    const K key      = K(c) << shift; // c = 2^bits: endKey, the markers' entry
+    const uint32_t J = *numCompact;
+    uint32_t lo = 0, hi = J + 1;
+    while (hi - lo > 1)
+    {
+        uint32_t mid = (lo + hi) / 2;
+        if (leafLo[mid] <= key) lo = mid;
+        else hi = mid;
+    }
+    coarse[c] = lo;
+}
+
 //! leaf of a mover's new key, its slot among the movers arriving there
 template<class K>
 __global__ __launch_bounds__(256) void binMoversKernel(const K* __restrict__ moverKeys,
                                                        const uint32_t* __restrict__ moverCount, uint32_t moverCap,
                                                        const K* __restrict__ leafLo,
                                                        const uint32_t* __restrict__ numCompact,
+                                                       const uint32_t* __restrict__ coarse,
                                                        uint32_t* __restrict__ incoming, uint32_t* __restrict__ dest,
                                                        uint32_t* __restrict__ slot)
 {
@@ -101,6 +124,15 @@ __global__ __launch_bounds__(256) void binMoversKernel(const K* __restrict__ mov
         const K key = moverKeys[m];
         // last j in [0, J] with leafLo[j] <= key (leafLo[0] = 0)
         uint32_t lo = 0, hi = J + 1;
+        if (coarse)
+        {
+            // the leaves of the key's coarse cell: from the last leaf at or before the cell's first key to the last one
+            // at or before the next cell's
+            constexpr int shift = 3 * int(maxLevel<K>()) - RESORT_COARSE_BITS;
+            const uint32_t c    = uint32_t(key >> shift); // (a marker: 2^bits)
+            lo                  = coarse[c];
+            hi                  = c < (1u << RESORT_COARSE_BITS) ? coarse[c + 1] + 1 : J + 1;
+        }
         while (hi - lo > 1)
         {
             uint32_t mid = (lo + hi) / 2;
@@ -537,7 +569,7 @@ __global__ __launch_bounds__(256) void placeMarkersKernel(const uint32_t* __rest
 
 template<class K>
 int LeafResort<K>::prepare(cstone_hip_ctx* ctx, const K* tree, const uint32_t* layout, int numLeaves, size_t n,
-                           K* keysOut)
+                           K* keysOut, bool expectMovers)
 {
     StageTimer timer(ctx, CSTONE_STAGE_RESORT_BINS);
     numLeaves_         = numLeaves;
@@ -574,6 +606,15 @@ int LeafResort<K>::prepare(cstone_hip_ctx* ctx, const K* tree, const uint32_t* l
     hipLaunchKernelGGL(fillCompactLeavesKernel<K>, gridFor(size_t(numLeaves) + 3, 256), 256, 0, ctx->stream, tree, layout,
                        numLeaves, mask_.as<uint64_t>(), rank_.as<uint32_t>(), (const uint32_t*)scalars + 2, uint32_t(n),
                        leafLo_.as<K>(), leafPos_.as<uint32_t>(), outCount_.as<uint32_t>(), incoming_.as<uint32_t>());
+    // many movers expected (the previous sync had them): the coarse table that shortens their searches
+    haveCoarse_ = expectMovers;
+    if (haveCoarse_)
+    {
+        constexpr uint32_t cells = (1u << RESORT_COARSE_BITS) + 1;
+        CS_TRY(coarse_.ensure(ctx, size_t(cells) * 4));
+        hipLaunchKernelGGL(coarseLeafTableKernel<K>, gridFor(cells, 256), 256, 0, ctx->stream, leafLo_.as<K>(),
+                           (const uint32_t*)scalars + 2, coarse_.as<uint32_t>());
+    }
     CS_HIP(ctx, hipGetLastError());
 
     args_.keysOut    = keysOut;
@@ -597,8 +638,8 @@ int LeafResort<K>::binMovers(cstone_hip_ctx* ctx, int leavesPerTile)
     const uint32_t* numJ  = (const uint32_t*)scalars + 2;
     const uint32_t* count = (const uint32_t*)scalars + 3;
     hipLaunchKernelGGL(binMoversKernel<K>, unsigned(ctx->numCu) * 16, 256, 0, ctx->stream, moverKeys_.as<K>(), count,
-                       args_.moverCap, leafLo_.as<K>(), numJ, incoming_.as<uint32_t>(), moverDest_.as<uint32_t>(),
-                       moverSlot_.as<uint32_t>());
+                       args_.moverCap, leafLo_.as<K>(), numJ, haveCoarse_ ? coarse_.as<uint32_t>() : nullptr,
+                       incoming_.as<uint32_t>(), moverDest_.as<uint32_t>(), moverSlot_.as<uint32_t>());
     hipLaunchKernelGGL(newLeafSizesKernel, gridFor(ent, 256), 256, 0, ctx->stream, leafPos_.as<uint32_t>(),
                        outCount_.as<uint32_t>(), incoming_.as<uint32_t>(), numJ, ent, newCount_.as<uint32_t>(), scalars);
     CS_TRY(arenaReserve(ctx, 2 * scanArenaBytes(ent)));

@@ -41,6 +41,7 @@ struct ResortArgs
 //! limits of the leaf pass
 constexpr uint32_t RESORT_TILE_SLOTS = 4224; // slots (old positions + arrivals) of a workgroup's leaves: key + index in
                                              // LDS for quiet tiles (three workgroups per CU), digests for the others
+constexpr int RESORT_COARSE_BITS      = 20;  // leading key bits of the movers' search table (binMoversKernel)
 constexpr uint32_t RESORT_LEAF_CAP   = 256;  // most slots of ONE leaf (the slot number is the low byte of a digest)
 
 //! device-side results a re-sort attempt reports (ctx->devScalars + RESORT_SCALARS, read back with the box extents)
@@ -58,8 +59,11 @@ public:
     }
 
     /*! compact leaf table of the previous sync (non-empty leaves of `tree` with their first positions) and cleared
-     *  counters; afterwards args() is valid.  layout[numLeaves] must equal n. */
-    int prepare(cstone_hip_ctx* ctx, const K* tree, const uint32_t* layout, int numLeaves, size_t n, K* keysOut);
+     *  counters; afterwards args() is valid.  layout[numLeaves] must equal n.  expectMovers: also a table from the
+     *  leading key bits to the leaves, which shortens the search of every mover for its new leaf (worth its 20 us from
+     *  some 10^5 movers on) */
+    int prepare(cstone_hip_ctx* ctx, const K* tree, const uint32_t* layout, int numLeaves, size_t n, K* keysOut,
+                bool expectMovers = false);
     ResortArgs<K> args() const { return args_; }
     /*! bins the movers, new leaf sizes and offsets, limit checks; everything stays on the device: the three scalars at
      *  ctx->devScalars + RESORT_SCALARS tell the host how it went */
@@ -71,7 +75,8 @@ public:
 
 private:
     DevBuf mask_, rank_, popc_, leafLo_, leafPos_, outCount_, incoming_, newCount_, layoutNew_, inOffset_;
-    DevBuf moverKeys_, moverIdx_, moverDest_, moverSlot_, binKeys_, binIdx_;
+    DevBuf moverKeys_, moverIdx_, moverDest_, moverSlot_, binKeys_, binIdx_, coarse_;
+    bool haveCoarse_ = false;
     ResortArgs<K> args_{};
     int numLeaves_ = 0;
     size_t n_      = 0;
