@@ -255,8 +255,7 @@ public:
         if (resortBackoff_ > 0) --resortBackoff_;
         if (tryResort)
         {
-            CS_TRY(resort_.prepare(ctx_, fTree_.as<K>(), layout_.as<uint32_t>(), fLeaves_, n, keysAlt_.as<K>(),
-                                   lastMovers_ > 100000));
+            CS_TRY(resort_.prepare(ctx_, fTree_.as<K>(), layout_.as<uint32_t>(), fLeaves_, n, keysAlt_.as<K>(), true));
             const ResortArgs<K> ra = resort_.args();
             bool done              = false;
             CS_TRY(computeKeysResort(ctx_, curve_, kb, rb, *xPP, *yPP, *zPP, keys, n, box_, &ra,
@@ -309,7 +308,8 @@ public:
             }
         }
 
-        bool measured = false;
+        resortedThisSync_ = sorted;
+        bool measured     = false;
         if (!sorted) CS_TRY(encodeAndSort(speculate, &measured));
         if (!sorted && speculate)
         {
@@ -623,8 +623,13 @@ private:
         const NodeIdx newI = (newL - 1) / 7, newM = newL + newI;
         // the leaf boundaries of an unchanged tree are searched from where they were at the previous sync (layout_)
         const uint32_t* guess = (*converged && layoutLeaves_ == newL) ? layout_.as<uint32_t>() : nullptr;
-        CS_TRY(cstone_hip_compute_node_counts_guided(ctx_, 8 * sizeof(K), fTree_.p, fLeafCounts_.as<uint32_t>(), newL,
-                                                     keys, n, 0xFFFFFFFFu, guess));
+        // a sync that was re-sorted knows where the particles of every old leaf went: a boundary that an old leaf had
+        // already is looked up, any other is searched inside one old leaf (resort.hip, countLeaves)
+        if (resortedThisSync_)
+            CS_TRY(resort_.countLeaves(ctx_, fTree_.as<K>(), newL, keys, 0xFFFFFFFFu, fLeafCounts_.as<uint32_t>()));
+        else
+            CS_TRY(cstone_hip_compute_node_counts_guided(ctx_, 8 * sizeof(K), fTree_.p, fLeafCounts_.as<uint32_t>(), newL,
+                                                         keys, n, 0xFFFFFFFFu, guess));
         CS_TRY(fCounts_.ensure(ctx_, size_t(newM) * sizeof(uint32_t)));
         hipLaunchKernelGGL(scatterLeafCountsKernel, gridFor(newL, 256), 256, 0, ctx_->stream,
                            fLeafCounts_.as<uint32_t>(), fLti_.as<NodeIdx>(), newI, newL, fCounts_.as<uint32_t>());
@@ -659,6 +664,7 @@ private:
     DevBuf order_, orderAlt_, keysAlt_, sortTmp_;
     LeafResort<K> resort_;
     int resortBackoff_ = 0, resorts_ = 0, resortFallbacks_ = 0;
+    bool resortedThisSync_ = false;
     DevBuf gTree_, gCounts_;
     int gCap_ = 0, gLeaves_ = 0;
     DevBuf fTree_, fLeafCounts_, fCounts_, newTree_;

@@ -551,6 +551,57 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
     }
 }
 
+/*! Positions of the leaf boundaries of ANOTHER tree (the focus tree after its rebalance) in the keys this re-sort has just
+ *  ordered: the leaf table knows where every old leaf starts now (layoutNew), so the search for a boundary key only
+ *  covers the particles of the one old leaf whose key range holds it -- a few dozen keys instead of all of them. */
+template<class K>
+__global__ __launch_bounds__(256) void bracketedPositionsKernel(const K* __restrict__ tree, NodeIdx numNodes,
+                                                                const K* __restrict__ keys,
+                                                                const K* __restrict__ leafLo,
+                                                                const uint32_t* __restrict__ numCompact,
+                                                                const uint32_t* __restrict__ coarse,
+                                                                const uint32_t* __restrict__ layoutNew,
+                                                                uint32_t* __restrict__ pos)
+{
+    NodeIdx i = blockIdx.x * 256 + threadIdx.x;
+    if (i > numNodes) return;
+    const K key      = tree[i];
+    const uint32_t J = *numCompact;
+    uint32_t lo = 0, hi = J + 1; // last j in [0, J] with leafLo[j] <= key
+    if (coarse)
+    {
+        constexpr int shift = 3 * int(maxLevel<K>()) - RESORT_COARSE_BITS;
+        const uint32_t c    = uint32_t(key >> shift);
+        lo                  = coarse[c];
+        hi                  = c < (1u << RESORT_COARSE_BITS) ? coarse[c + 1] + 1 : J + 1;
+    }
+    while (hi - lo > 1)
+    {
+        uint32_t mid = (lo + hi) / 2;
+        if (leafLo[mid] <= key) lo = mid;
+        else hi = mid;
+    }
+    // first index with keys[index] >= key, inside that leaf's new range -- its start, without looking at any key, when
+    // the boundary is that of the old leaf itself (most leaves of a tree outlive an update)
+    uint32_t a = layoutNew[lo], len = leafLo[lo] == key ? 0u : layoutNew[lo + 1] - a;
+    while (len > 0)
+    {
+        uint32_t half = len >> 1;
+        if (keys[a + half] < key) { a += half + 1, len -= half + 1; }
+        else { len = half; }
+    }
+    pos[i] = a;
+}
+
+__global__ __launch_bounds__(256) void countsOfPositionsKernel(const uint32_t* __restrict__ pos, NodeIdx numNodes,
+                                                               uint32_t maxCount, uint32_t* __restrict__ counts)
+{
+    NodeIdx i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= numNodes) return;
+    uint32_t c = pos[i + 1] - pos[i];
+    counts[i]  = c < maxCount ? c : maxCount;
+}
+
 //! the particles that carry the remove marker: behind every leaf, by ascending old position (idx sorted by the caller)
 template<class K>
 __global__ __launch_bounds__(256) void placeMarkersKernel(const uint32_t* __restrict__ idx, uint32_t count,
@@ -608,10 +659,10 @@ int LeafResort<K>::prepare(cstone_hip_ctx* ctx, const K* tree, const uint32_t* l
                        leafLo_.as<K>(), leafPos_.as<uint32_t>(), outCount_.as<uint32_t>(), incoming_.as<uint32_t>());
     // many movers expected (the previous sync had them): the coarse table that shortens their searches
     haveCoarse_ = expectMovers;
+    constexpr uint32_t cells = (1u << RESORT_COARSE_BITS) + 1;
+    CS_TRY(coarse_.ensure(ctx, size_t(cells) * 4)); // (4 MB, once: no allocation in the middle of a run)
     if (haveCoarse_)
     {
-        constexpr uint32_t cells = (1u << RESORT_COARSE_BITS) + 1;
-        CS_TRY(coarse_.ensure(ctx, size_t(cells) * 4));
         hipLaunchKernelGGL(coarseLeafTableKernel<K>, gridFor(cells, 256), 256, 0, ctx->stream, leafLo_.as<K>(),
                            (const uint32_t*)scalars + 2, coarse_.as<uint32_t>());
     }
@@ -705,6 +756,24 @@ int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, 
     }
     else return fail(ctx, CSTONE_E_INTERNAL, "resort: %d leaves per workgroup not instantiated", leavesPerTile);
 #undef CSTONE_LEAF_SORT
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+template<class K>
+int LeafResort<K>::countLeaves(cstone_hip_ctx* ctx, const K* tree, int numNodes, const K* keys, uint32_t maxCount,
+                               uint32_t* counts)
+{
+    if (numNodes <= 0) return CSTONE_OK;
+    StageTimer timer(ctx, CSTONE_STAGE_NODE_COUNTS);
+    CS_TRY(arenaReserve(ctx, alignUp(size_t(numNodes + 1) * sizeof(uint32_t)) + 1024));
+    auto* pos = (uint32_t*)arenaTake(ctx, size_t(numNodes + 1) * sizeof(uint32_t));
+    hipLaunchKernelGGL(bracketedPositionsKernel<K>, gridFor(size_t(numNodes) + 1, 256), 256, 0, ctx->stream, tree,
+                       NodeIdx(numNodes), keys, leafLo_.as<K>(), (const uint32_t*)(ctx->devScalars + RESORT_SCALARS) + 2,
+                       haveCoarse_ ? coarse_.as<uint32_t>() : nullptr, layoutNew_.as<uint32_t>(), pos);
+    hipLaunchKernelGGL(countsOfPositionsKernel, gridFor(numNodes, 256), 256, 0, ctx->stream, pos, NodeIdx(numNodes),
+                       maxCount, counts);
+    arenaReset(ctx);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

@@ -73,6 +73,11 @@ public:
     int sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, uint32_t* orderOut, uint32_t numMovers,
                    uint32_t numMarkers, uint32_t numCompactLeaves, int leavesPerTile);
 
+    /*! computeNodeCounts for any cornerstone leaf array over the keys the last sortLeaves ordered (valid until the next
+     *  prepare): every boundary is searched inside the one old leaf that holds its key.  counts[i] = min(#keys in
+     *  [tree[i], tree[i + 1]), maxCount) */
+    int countLeaves(cstone_hip_ctx* ctx, const K* tree, int numNodes, const K* keys, uint32_t maxCount, uint32_t* counts);
+
 private:
     DevBuf mask_, rank_, popc_, leafLo_, leafPos_, outCount_, incoming_, newCount_, layoutNew_, inOffset_;
     DevBuf moverKeys_, moverIdx_, moverDest_, moverSlot_, binKeys_, binIdx_, coarse_;
