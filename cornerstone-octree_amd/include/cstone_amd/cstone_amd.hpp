@@ -908,6 +908,63 @@ public:
         std::apply([&](auto&... vec) { (vec.rebind(pp[i], m, capOf(pp[i])), ..., void(++i)); }, properties);
     }
 
+    /*! the reference's signature (R/domain/domain.hpp:196-203): the scratch buffers come as a tuple; the first one with
+     *  elements of type T takes the role of the scratch vector above (the others are left alone: the orderings the
+     *  reference parks in them live inside the library) */
+    template<class... Props, class... Scratch>
+    void sync(DeviceVector<KeyType>& keys, DeviceVector<T>& x, DeviceVector<T>& y, DeviceVector<T>& z,
+              DeviceVector<T>& h, std::tuple<DeviceVector<Props>&...> properties, std::tuple<Scratch&...> scratchBuffers)
+    {
+        static_assert((std::is_same_v<Scratch, DeviceVector<T>> || ...),
+                      "one of the scratch buffers must be a DeviceVector<T>");
+        DeviceVector<T>* first = nullptr;
+        std::apply(
+            [&](auto&... s)
+            {
+                auto pick = [&](auto& v)
+                {
+                    if constexpr (std::is_same_v<std::decay_t<decltype(v)>, DeviceVector<T>>)
+                        if (!first) first = &v;
+                };
+                (pick(s), ...);
+            },
+            scratchBuffers);
+        sync(keys, x, y, z, h, properties, *first);
+    }
+
+    /*! Domain::globalTree() (R/domain/domain.hpp:388-392): the leaves of the global (assignment) tree, device pointer,
+     *  numGlobalLeaves + 1 keys; globalCounts(): their particle counts */
+    std::span<const KeyType> globalTree() const
+    {
+        if (mr_)
+        {
+            const auto& v = mr_->view();
+            return {static_cast<const KeyType*>(v.global_leaves), std::size_t(v.num_global_leaves) + 1};
+        }
+        auto v = view();
+        return {static_cast<const KeyType*>(v.global_leaves), std::size_t(v.num_global_leaves) + 1};
+    }
+    //! what clients read from Domain::focusTree() (R/domain/domain.hpp:394-398): leaves and leaf counts, device pointers
+    struct FocusTreeView
+    {
+        std::span<const KeyType> leaves;
+        std::span<const unsigned> counts;
+        std::span<const KeyType> treeLeaves() const { return leaves; }
+        std::span<const unsigned> leafCounts() const { return counts; }
+    };
+    FocusTreeView focusTree() const
+    {
+        if (mr_)
+        {
+            const auto& v = mr_->view();
+            return {{static_cast<const KeyType*>(v.focus_leaves), std::size_t(v.num_focus_leaves) + 1},
+                    {v.focus_leaf_counts, std::size_t(v.num_focus_leaves)}};
+        }
+        auto v = view();
+        return {{static_cast<const KeyType*>(v.focus_leaves), std::size_t(v.num_focus_leaves) + 1},
+                {v.focus_leaf_counts, std::size_t(v.num_focus_leaves)}};
+    }
+
     //! single-rank mode only: the raw view of the C ABI (multi-rank: multiRank().view())
     cstone_hip_domain_view view() const
     {

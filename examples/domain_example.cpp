@@ -50,8 +50,30 @@ int main(int argc, char** argv)
         hid[i] = T(i);
     DeviceVector<T> id(hid.data(), hid.data() + hid.size()), idScratch;
     auto xBefore = toHost(x);
-    domain.sync(keys, x, y, z, h, std::tie(mass), scratch);
+    // (the reference's signature: the scratch buffers as a tuple)
+    DeviceVector<KeyType> keyScratch;
+    domain.sync(keys, x, y, z, h, std::tie(mass), std::tie(keyScratch, scratch));
     domain.reapplySync(std::tie(id), idScratch);
+    {
+        // Domain::globalTree() / focusTree(): cornerstone arrays from 0 to the end of the key space whose counts add up
+        auto fromDevice = [](auto span)
+        {
+            std::vector<std::remove_const_t<typename decltype(span)::element_type>> v(span.size());
+            memcpyD2H(span.data(), span.size(), v.data());
+            return v;
+        };
+        auto ft = domain.focusTree();
+        auto gt = fromDevice(domain.globalTree());
+        auto fl = fromDevice(ft.treeLeaves());
+        auto fc = fromDevice(ft.leafCounts());
+        unsigned long long total = 0;
+        for (auto c : fc)
+            total += c;
+        bool fine = gt.front() == 0 && fl.front() == 0 && gt.back() == fl.back() && std::is_sorted(fl.begin(), fl.end()) &&
+                    total == domain.nParticles();
+        std::printf("globalTree / focusTree: %zu and %zu leaves, counts add up: %s\n", gt.size() - 1, fl.size() - 1,
+                    fine ? "yes" : "NO");
+    }
     auto xAfter = toHost(x);
     auto idAfter = toHost(id);
     bool followed = idAfter.size() == xAfter.size();

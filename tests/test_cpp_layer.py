@@ -94,6 +94,7 @@ def test_cpp_domain_example_runs():
     assert "keys sorted: yes" in out
     assert out.count("focus leaves") == 3
     assert "field followed its particles: yes" in out
+    assert "counts add up: yes" in out  # Domain::globalTree() / focusTree(), the scratch-tuple signature of sync
     assert "target groups:" in out and "BAD" not in out
 
 
