@@ -280,10 +280,10 @@ public:
                 const int flags        = ctx_->hostScalars[RESORT_SCALARS + 1];
                 const uint32_t J       = uint32_t(ctx_->hostScalars[RESORT_SCALARS + 2]);
                 const uint32_t movers  = uint32_t(ctx_->hostScalars[RESORT_SCALARS + 3]);
-                if (!boxChanged && flags == 0 && movers <= n / 8)
+                if (!boxChanged && (flags & 7) == 0 && movers <= n / 8)
                 {
                     CS_TRY(resort_.sortLeaves(ctx_, keysAlt_.as<K>(), keys, order_.as<uint32_t>(), movers, markers, J,
-                                              tileLeaves));
+                                              tileLeaves, (flags & 8) != 0));
                     CS_HIP(ctx_, hipMemsetAsync(ctx_->devScalars + 3, 0, sizeof(int), ctx_->stream));
                     sorted      = true;
                     lastMovers_ = movers;

@@ -551,10 +551,10 @@ public:
                 int found[4];
                 CS_TRY(toHost(found, ctx_->devScalars + RESORT_SCALARS, sizeof found));
                 const uint32_t markers = uint32_t(found[0]), J = uint32_t(found[2]), movers = uint32_t(found[3]);
-                if (found[1] == 0 && movers <= n / 8)
+                if ((found[1] & 7) == 0 && movers <= n / 8)
                 {
                     CS_TRY(resort_.sortLeaves(ctx_, keysAlt_.as<K>(), keys_.as<K>(), order_.as<uint32_t>(), movers, markers,
-                                              J, tileLeaves));
+                                              J, tileLeaves, (found[1] & 8) != 0));
                     resorted    = true;
                     lastMovers_ = movers;
                     ++resorts_;

@@ -165,10 +165,11 @@ __global__ __launch_bounds__(256) void newLeafSizesKernel(const uint32_t* __rest
     newCount[j] = c;
 }
 
-//! [1] |= 2: the leaves of a workgroup of the leaf pass need more LDS slots than it has, |= 4: mover list overflow;
-//! [0]: particles carrying the remove marker
+//! [1] |= 2: the leaves of a workgroup of the leaf pass need more LDS slots than it has, |= 4: mover list overflow,
+//! |= 8 (no failure): a large quiet tile; [0]: particles carrying the remove marker
 __global__ __launch_bounds__(256) void checkTilesKernel(const uint32_t* __restrict__ leafPos,
                                                         const uint32_t* __restrict__ inOffset,
+                                                        const uint32_t* __restrict__ layoutNew,
                                                         const uint32_t* __restrict__ numCompact,
                                                         const uint32_t* __restrict__ moverCount, uint32_t moverCap,
                                                         int leavesPerTile, int* __restrict__ scalars)
@@ -183,8 +184,11 @@ __global__ __launch_bounds__(256) void checkTilesKernel(const uint32_t* __restri
     uint32_t j0 = t * uint32_t(leavesPerTile);
     if (j0 >= J) return;
     uint32_t j1    = min(j0 + uint32_t(leavesPerTile), J);
-    uint32_t slots = (leafPos[j1] - leafPos[j0]) + (inOffset[j1] - inOffset[j0]);
-    if (slots > RESORT_TILE_SLOTS) atomicOr(&scalars[1], 2);
+    const uint32_t old = leafPos[j1] - leafPos[j0], arrivals = inOffset[j1] - inOffset[j0];
+    if (old + arrivals > RESORT_TILE_SLOTS) atomicOr(&scalars[1], 2);
+    // a tile in which nothing moved but with more slots than the quiet instantiation of the leaf pass has: the other
+    // instantiation has to be launched for it even without movers
+    if (arrivals == 0 && layoutNew[j1] - layoutNew[j0] == old && old > RESORT_QUIET_SLOTS) atomicOr(&scalars[1], 8);
 }
 
 template<class K>
@@ -226,13 +230,14 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
     constexpr int ITER = (RESORT_TILE_SLOTS + 255) / 256;
     constexpr K HOLE   = ~K(0);
     // Two instantiations share this body and the grid: COUNTING = false takes the quiet tiles (keys and old indices in
-    // LDS, 52 KB: three workgroups per CU), COUNTING = true the tiles in which something moved (digests and the new
+    // LDS, up to RESORT_QUIET_SLOTS of them = 39 KB: four workgroups per CU), COUNTING = true the tiles in which something
+    // moved, and the few quiet ones with more slots than that (digests and the new
     // order's key bits folded to 16, 27 KB: five per CU); a workgroup whose tile is of the other kind leaves after the
     // setup.
-    __shared__ __attribute__((aligned(8))) uint32_t sWordsA[COUNTING ? RESORT_TILE_SLOTS / 2 : RESORT_TILE_SLOTS * sizeof(K) / 4];
-    __shared__ uint32_t sWordsB[RESORT_TILE_SLOTS];
-    K* const sKey        = reinterpret_cast<K*>(sWordsA); // quiet tiles: the keys ...
-    uint32_t* const sIdx = sWordsB;                       // ... and their old indices
+    __shared__ __attribute__((aligned(8))) uint32_t sWordsA[COUNTING ? RESORT_TILE_SLOTS / 2 : RESORT_QUIET_SLOTS * sizeof(K) / 4];
+    __shared__ uint32_t sWordsB[COUNTING ? RESORT_TILE_SLOTS : RESORT_QUIET_SLOTS / 2];
+    K* const sKey        = reinterpret_cast<K*>(sWordsA);        // quiet tiles: the keys ...
+    uint16_t* const sIdx = reinterpret_cast<uint16_t*>(sWordsB); // ... and the slots of the tile they came from
     __shared__ uint32_t posK[G + 1], inK[G + 1], outK[G + 1];
     // tiles that count: first key of every leaf, the low key bits a digest leaves out, first 4-slot chunk of every leaf
     __shared__ K loK[G + 1];
@@ -273,7 +278,8 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
     // quiet tile: no arrivals, and every leaf keeps its size (without arrivals: nobody left)
     bool changed = in1 != in0 || alwaysCount;
     if (t < nl) changed = changed || (outK[t + 1] - outK[t]) != (posK[t + 1] - posK[t]);
-    const bool quiet = !__syncthreads_or(changed);
+    // (a quiet tile beyond the slots of the quiet instantiation goes the other way: it can hold RESORT_TILE_SLOTS)
+    const bool quiet = !__syncthreads_or(changed) && nOldAll <= RESORT_QUIET_SLOTS;
     if (quiet == COUNTING) return; // the other instantiation's tile
 
     // Tiles that count keep no keys in LDS, only 32-bit digests: 24 leading bits of (key - first key of the leaf), then
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
             if (p < p1)
             {
                 sKey[p - p0] = key[i];
-                sIdx[p - p0] = p;
+                sIdx[p - p0] = uint16_t(p - p0);
             }
         }
     }
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
             if (e < nOldAll)
             {
                 keysOut[out0 + e]  = sKey[e];
-                orderOut[out0 + e] = sIdx[e];
+                orderOut[out0 + e] = p0 + sIdx[e];
             }
         }
         return;
@@ -699,15 +705,15 @@ int LeafResort<K>::binMovers(cstone_hip_ctx* ctx, int leavesPerTile)
     arenaReset(ctx);
     CS_TRY(rc);
     hipLaunchKernelGGL(checkTilesKernel, gridFor(size_t(numLeaves_) / leavesPerTile + 1, 256), 256, 0, ctx->stream,
-                       leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), numJ, count, args_.moverCap, leavesPerTile,
-                       scalars);
+                       leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), layoutNew_.as<uint32_t>(), numJ, count,
+                       args_.moverCap, leavesPerTile, scalars);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }
 
 template<class K>
 int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, uint32_t* orderOut, uint32_t numMovers,
-                              uint32_t numMarkers, uint32_t J, int leavesPerTile)
+                              uint32_t numMarkers, uint32_t J, int leavesPerTile, bool largeQuietTiles)
 {
     if (numMovers)
     {
@@ -738,7 +744,7 @@ int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, 
                        orderOut)
     // quiet tiles and tiles in which something moved: one launch each over all tiles (without movers there are none of
     // the second kind)
-    const bool someMoved = numMovers > 0 || alwaysCount;
+    const bool someMoved = numMovers > 0 || alwaysCount || largeQuietTiles;
     if (leavesPerTile == 64)
     {
         CSTONE_LEAF_SORT(64, false);

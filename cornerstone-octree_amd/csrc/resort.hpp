@@ -41,12 +41,15 @@ struct ResortArgs
 //! limits of the leaf pass
 constexpr uint32_t RESORT_TILE_SLOTS = 4224; // slots (old positions + arrivals) of a workgroup's leaves: key + index in
                                              // LDS for quiet tiles (three workgroups per CU), digests for the others
+constexpr uint32_t RESORT_QUIET_SLOTS = 3840; // a tile in which nothing moved is sorted in LDS if it has at most this many
+                                              // slots: key + 16-bit slot number, 39 KB, four workgroups per CU
 constexpr int RESORT_COARSE_BITS      = 20;  // leading key bits of the movers' search table (binMoversKernel)
 constexpr uint32_t RESORT_LEAF_CAP   = 256;  // most slots of ONE leaf (the slot number is the low byte of a digest)
 
 //! device-side results a re-sort attempt reports (ctx->devScalars + RESORT_SCALARS, read back with the box extents)
 constexpr int RESORT_SCALARS = 28; // [0] particles with the remove marker, [1] flags (1: leaf too long, 2: tile too
-                                   // long, 4: mover list overflow), [2] J (non-empty leaves), [3] movers
+                                   // long, 4: mover list overflow: the attempt fails; 8: a quiet tile beyond
+                                   // RESORT_QUIET_SLOTS: both leaf-pass launches needed), [2] J (non-empty leaves), [3] movers
 
 template<class K>
 class LeafResort
@@ -71,7 +74,7 @@ public:
     /*! the leaf pass: keysIn = new keys at old positions; keysOut / orderOut = sorted keys and their old positions.
      *  numMovers, numMarkers, numCompactLeaves: the values read back after binMovers */
     int sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, uint32_t* orderOut, uint32_t numMovers,
-                   uint32_t numMarkers, uint32_t numCompactLeaves, int leavesPerTile);
+                   uint32_t numMarkers, uint32_t numCompactLeaves, int leavesPerTile, bool largeQuietTiles);
 
     /*! computeNodeCounts for any cornerstone leaf array over the keys the last sortLeaves ordered (valid until the next
      *  prepare): every boundary is searched inside the one old leaf that holds its key.  counts[i] = min(#keys in

@@ -265,3 +265,28 @@ def test_resort_random_walk(hip, oracle, seed):
         assert np.array_equal(sa_.dom.fetch(va.sfc_order, m, np.uint32), sb_.dom.fetch(vb.sfc_order, m, np.uint32)), step
     # (how often it re-sorted depends on the draw: collapses leave overfull leaves behind; the other tests pin that down)
     assert sb_.dom.stats()["resorts"] == 0 and sa_.dom.stats()["resorts"] >= 1, sa_.dom.stats()
+
+
+@pytest.mark.gpu
+def test_full_leaves_everywhere(hip, oracle):
+    """a regular 64^3 lattice with bucket 64: every leaf holds exactly 64 particles, a tile of 64 leaves has 4096 old
+    slots -- more than the quiet instantiation of the leaf pass takes, so the other one orders them although nothing
+    moves; then a jitter, which sends arrivals into full leaves"""
+    import torch
+    from oracle.oracle import Box
+
+    st_ = _Stepper(hip, 64, 64, 64, 1, (1, 1, 1), 64 ** 3, 41, True)
+    g = (np.arange(64) + 0.5) / 64
+    gx, gy, gz = np.meshgrid(g, g, g, indexing="ij")
+    st_.x, st_.y, st_.z = [torch.from_numpy(a.ravel().copy()).cuda() for a in (gx, gy, gz)]
+    for step, kind in enumerate(["none", "none", "none", "jitter", "none", "few", "none"]):
+        if step:
+            st_.move(kind, np.random.default_rng(80 + step))
+        a = st_.sync()
+        want = oracle.compute_sfc_keys(1, 64, a["x"], a["y"], a["z"], Box(list(a["view"].box.lim), (1, 1, 1)))
+        assert np.array_equal(a["keys"].view(np.uint64), want) and np.all(want[1:] >= want[:-1]), (step, kind)
+        assert np.array_equal(np.sort(a["ident"]), np.arange(64 ** 3)), (step, kind)
+        if step == 2:
+            counts = st_.dom.fetch(a["view"].focus_leaf_counts, a["view"].num_focus_leaves, np.uint32)
+            assert counts.min() == 64 and counts.max() == 64  # the premise of this test
+    assert st_.dom.stats()["resorts"] >= 3, st_.dom.stats()
