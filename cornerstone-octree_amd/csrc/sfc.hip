@@ -366,13 +366,13 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
     };
     // is the particle at position p still inside the leaf that position belonged to?  If not: count and stage it;
     // returns what goes to keysOut: the key of a stayer, a hole (~0: sorts behind everything) for a mover
-    auto classify = [&](K key, size_t p, bool valid) -> K
+    // (word, rank: the leaf-start bits of the 64 positions around p and the number of starts in front of them)
+    auto classify = [&](K key, size_t p, bool valid, uint64_t word, uint32_t rank) -> K
     {
         bool mover = false;
         if (valid)
         {
-            const uint64_t word = ra.leafStart[p >> 6];
-            const uint32_t j    = ra.leafRank[p >> 6] + uint32_t(__popcll(word & ((2ull << (p & 63)) - 1))) - 1u;
+            const uint32_t j = rank + uint32_t(__popcll(word & ((2ull << (p & 63)) - 1))) - 1u;
             const K lo = ra.leafLo[j], hi = ra.leafLo[j + 1];
             mover = !(key >= lo && key < hi);
             if (mover) atomicAdd(&ra.outCount[j], 1u);
@@ -450,9 +450,12 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
             for (int v = 0; v < VEC; ++v)
                 if (vk[v] == endKey<K>()) out[v] = vk[v]; // particles flagged for removal keep their marker
         }
+        // the VEC positions of a lane lie in one 64-position word of the leaf table (base is a multiple of VEC)
+        const uint64_t word = valid ? ra.leafStart[base >> 6] : 0;
+        const uint32_t rank = valid ? ra.leafRank[base >> 6] : 0;
 #pragma unroll
         for (int v = 0; v < VEC; ++v)
-            out[v] = classify(out[v], base + v, valid);
+            out[v] = classify(out[v], base + v, valid, word, rank);
         if (valid) __builtin_memcpy(__builtin_assume_aligned(ra.keysOut + base, sizeof(K) * VEC), out, sizeof out);
         if (staged >= STAGE / 2) flush();
     }
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
             key = (keysIn && keysIn[i] == endKey<K>()) ? endKey<K>() : m;
             if (extentPartials) widen(x[i], y[i], z[i]);
         }
-        key = classify(key, i, valid);
+        key = classify(key, i, valid, valid ? ra.leafStart[i >> 6] : 0, valid ? ra.leafRank[i >> 6] : 0);
         if (valid) ra.keysOut[i] = key;
     }
     if (staged) flush();
