@@ -137,8 +137,10 @@ static void run(int rank, int numRanks, LocalIndex numParticles, int numSyncs, c
     {
         cpu.sync(keys, x, y, z, h, std::tie(m, tag), std::tie(hs1, hs2, hs3));
         progress(name, "cpu sync done", sync);
+        MPI_Barrier(MPI_COMM_WORLD); // (the point-to-point tails of the two domains' syncs kept apart, see below)
         gpu.sync(d_keys, d_x, d_y, d_z, d_h, std::tie(d_m, d_tag), std::tie(s1, s2, s3));
         progress(name, "gpu sync done", sync);
+        MPI_Barrier(MPI_COMM_WORLD);
 
         expectSame("nParticles", cpu.nParticles(), gpu.nParticles(), sync);
         expectSame("startIndex", cpu.startIndex(), gpu.startIndex(), sync);
@@ -203,8 +205,15 @@ static void run(int rank, int numRanks, LocalIndex numParticles, int numSyncs, c
             DeviceVector<T> d_f = fg;
             std::vector<T> sb, rb;
             DeviceVector<T> dsb, drb;
+            // The two domains of a rank talk over the same communicator with the same tags and receive from any source:
+            // without a fence a fast rank's message of the NEXT exchange can be taken for a slow peer's message of this
+            // one (seen once on 5 ranks: a halo range of f left at -1).  The syncs themselves are fenced by their
+            // collectives; the bare halo exchanges are not.
+            MPI_Barrier(MPI_COMM_WORLD);
             cpu.exchangeHalos(std::tie(f), sb, rb);
+            MPI_Barrier(MPI_COMM_WORLD);
             gpu.exchangeHalos(std::tie(d_f), dsb, drb);
+            MPI_Barrier(MPI_COMM_WORLD);
             if (keys.size() == gkeys.size() && gx.size() == x.size())
                 expectEqual("exchangeHalos field", permuted(f, canonicalOrder(keys, x, y, z)),
                             permuted(download(d_f), canonicalOrder(gkeys, gx, gy, gz)), sync);
@@ -273,8 +282,10 @@ static void runGrav(int rank, int numRanks, LocalIndex numParticles, int numSync
         }
         cpu.syncGrav(keys, x, y, z, h, m, std::tuple<>{}, std::tie(hs1, hs2, hs3));
         progress(name, "cpu syncGrav done", sync);
+        MPI_Barrier(MPI_COMM_WORLD);
         gpu.syncGrav(d_keys, d_x, d_y, d_z, d_h, d_m, std::tuple<>{}, std::tie(s1, s2, s3));
         progress(name, "gpu syncGrav done", sync);
+        MPI_Barrier(MPI_COMM_WORLD);
         expectSame("grav nParticles", cpu.nParticles(), gpu.nParticles(), sync);
         expectSame("grav startIndex", cpu.startIndex(), gpu.startIndex(), sync);
         expectSame("grav nParticlesWithHalos", cpu.nParticlesWithHalos(), gpu.nParticlesWithHalos(), sync);
