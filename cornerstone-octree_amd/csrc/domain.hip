@@ -174,9 +174,13 @@ public:
             }
         };
         const bool anyOpen = box_.bc[0] != 1 || box_.bc[1] != 1 || box_.bc[2] != 1;
-        bool speculate     = anyOpen && !firstCall_ && std::getenv("CSTONE_NO_SPECULATIVE_BOX") == nullptr;
+        // (adaptive: a sync whose speculation failed -- the outermost particles of an open box move -- makes the following
+        //  syncs measure first, until one of them finds the box unchanged again)
+        bool speculate     = anyOpen && !firstCall_ && !measureFirst_ && std::getenv("CSTONE_NO_SPECULATIVE_BOX") == nullptr;
+        bool boxMoved      = false; // measured first and found a new box: every key changes, nothing to re-sort from
         if (anyOpen && !speculate)
         {
+            const cstone_box before = box_;
             double lim[6];
             // extents of the open dimensions in one launch and one read-back (MinMaxGpu x3 in the reference)
             const void* open[3];
@@ -192,6 +196,9 @@ public:
             for (int i = 0; i < numOpen; ++i)
                 lim[2 * dims[i]] = ext[2 * i], lim[2 * dims[i] + 1] = ext[2 * i + 1];
             boxFromExtents(lim, box_);
+            for (int k = 0; k < 6; ++k)
+                boxMoved = boxMoved || box_.lim[k] != before.lim[k];
+            if (!firstCall_) measureFirst_ = boxMoved;
         }
         // computeSfcKeys + setMapFromCodes (assignment.hpp:81-86) in one call: the sort's digits are counted while the keys
         // are still in the encode kernel's registers, its first pass produces the positions instead of reading an iota
@@ -250,7 +257,7 @@ public:
         const int tileLeaves = LeafResort<K>::leavesPerTile(bucketFocus_);
         bool sorted          = false;
         const bool tryResort = !firstCall_ && tileLeaves > 0 && layoutLeaves_ == fLeaves_ && fLeaves_ > 0 &&
-                               resortBackoff_ == 0 && std::getenv("CSTONE_NO_RESORT") == nullptr &&
+                               resortBackoff_ == 0 && !boxMoved && std::getenv("CSTONE_NO_RESORT") == nullptr &&
                                std::getenv("CSTONE_FULL_SORT") == nullptr;
         if (resortBackoff_ > 0) --resortBackoff_;
         if (tryResort)
@@ -297,6 +304,7 @@ public:
                     {
                         box_ = next;
                         ++boxRedos_;
+                        measureFirst_ = true;
                     }
                     else
                     {
@@ -333,6 +341,7 @@ public:
                 // the particles have left the box (or shrunk away from it by more than 5 %): keys and order again
                 box_ = next;
                 ++boxRedos_;
+                measureFirst_ = true;
                 // the key array is sorted by now: put every entry back to its particle first (the remove markers of the
                 // caller must meet their own particles again), then encode with the new box
                 CS_TRY(cstone_hip_scatter(ctx_, sizeof(K), order_.as<uint32_t>(), n, keys, keysAlt_.p));
@@ -517,6 +526,7 @@ private:
     uint32_t syncs_ = 0, lastMovers_ = 0;
     size_t lastN_ = 0; // input size of the last sync
     int boxRedos_ = 0; // syncs whose speculative keys had to be recomputed because the box changed
+    bool measureFirst_ = false; // the last box was not the one before it: measure the extents before encoding
     int ensureTree(DevBuf& tree, DevBuf& counts, int& cap, int need)
     {
         if (need <= cap) return CSTONE_OK;

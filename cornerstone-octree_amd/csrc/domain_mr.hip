@@ -518,6 +518,16 @@ public:
         if (keysIn && n)
             CS_HIP(ctx_, hipMemcpyAsync(keys_.p, keysIn, n * sizeof(K), hipMemcpyDeviceToDevice, ctx_->stream));
         bool partialSort = false;
+        // the level ranges of the previous sync's tree (copied to the pinned block behind its build, many stream
+        // synchronisations ago): refreshed at EVERY sync -- buildFocusOctree() bounds its digit passes by it, also on
+        // the syncs that re-sort
+        if (levelRangePending_)
+        {
+            prevMaxLeafLevel_ = 0;
+            for (int l = 0; l <= int(maxLevel<K>()); ++l)
+                if (hostLevelRange_[l + 1] > hostLevelRange_[l]) prevMaxLeafLevel_ = l;
+            levelRangePending_ = false;
+        }
         // ---- the incremental re-sort (resort.hpp), as in the single-rank domain: the input arrays are the assigned block
         //      the previous sync handed out, ordered by the leaves of this rank's tree (layout_); particles still inside
         //      their leaf are ordered leaf by leaf, the others are binned.  Rank-local: no collective depends on it.
@@ -567,13 +577,6 @@ public:
             // radix passes only over the digits above the leaf level (+1) of the previous tree, runs of equal high digits
             // are finished by a fix-up pass; a run that is too long raises a flag and the regular sort completes the job
             int startPass = 0;
-            if (levelRangePending_)
-            {
-                prevMaxLeafLevel_ = 0;
-                for (int l = 0; l <= int(maxLevel<K>()); ++l)
-                    if (hostLevelRange_[l + 1] > hostLevelRange_[l]) prevMaxLeafLevel_ = l;
-                levelRangePending_ = false;
-            }
             if (!firstCall_ && prevMaxLeafLevel_ >= 0 && std::getenv("CSTONE_FULL_SORT") == nullptr)
                 startPass = std::max(0, (3 * int(maxLevel<K>()) -
                                          3 * (prevMaxLeafLevel_ + 1 + (bucketFocus_ > 128) + (bucketFocus_ > 1024))) / 8) & ~1;
@@ -619,8 +622,8 @@ public:
             {
                 // word P of every row: the status of that rank (0 = fine), see the top of sync()
                 injectFailure("assign");
-                const uint64_t status = pending_ ? 1 : 0;
-                CS_HIP(ctx_, hipMemcpyAsync(send + P_, &status, 8, hipMemcpyHostToDevice, ctx_->stream));
+                statusW64_ = pending_ ? 1 : 0; // a member: outlives the asynchronous copy
+                CS_HIP(ctx_, hipMemcpyAsync(send + P_, &statusW64_, 8, hipMemcpyHostToDevice, ctx_->stream));
                 CS_TRY(callComm(comm_.all_gather(comm_.user, send, recv, size_t(P_ + 1) * 8), "all_gather (counts)"));
                 CS_HIP(ctx_, hipMemcpyAsync(rows.data(), recv, rows.size() * 8, hipMemcpyDeviceToHost, ctx_->stream));
             }
@@ -829,8 +832,8 @@ public:
             {
                 uint32_t* recv = reinterpret_cast<uint32_t*>(scal_.as<char>() + 4096);
                 injectFailure("exchange");
-                const uint32_t status = pending_ ? 1u : 0u; // second word: the status of this rank
-                CS_HIP(ctx_, hipMemcpyAsync(total + 1, &status, 4, hipMemcpyHostToDevice, ctx_->stream));
+                statusW32_ = pending_ ? 1u : 0u; // second word: the status of this rank (a member, see above)
+                CS_HIP(ctx_, hipMemcpyAsync(total + 1, &statusW32_, 4, hipMemcpyHostToDevice, ctx_->stream));
                 CS_TRY(callComm(comm_.all_gather(comm_.user, total, recv, 8), "all_gather (box counts)"));
                 std::vector<uint32_t> c32(size_t(P_) * 2);
                 CS_TRY(toHost(c32.data(), recv, c32.size() * 4));
@@ -1152,8 +1155,8 @@ private:
         }
         else { CS_HIP(ctx_, hipMemcpyAsync(dev, nothing, sizeof nothing, hipMemcpyHostToDevice, ctx_->stream)); }
         // seventh value: the status of this rank (0, or -(rank + 1) if it has a failure pending); MIN over the ranks
-        const double status = pending_ ? -double(rank_ + 1) : 0.0;
-        CS_HIP(ctx_, hipMemcpyAsync(dev + 6, &status, sizeof status, hipMemcpyHostToDevice, ctx_->stream));
+        statusD_ = pending_ ? -double(rank_ + 1) : 0.0;
+        CS_HIP(ctx_, hipMemcpyAsync(dev + 6, &statusD_, sizeof statusD_, hipMemcpyHostToDevice, ctx_->stream));
         if (P_ > 1) CS_TRY(callComm(comm_.all_reduce(comm_.user, dev, 7, 0, 1), "all_reduce (box)"));
         double ext[7];
         CS_TRY(toHost(ext, dev, sizeof ext));
@@ -1493,6 +1496,9 @@ private:
     bool firstCall_ = true;
     bool toggled_   = false; // this sync has switched to the other output buffer set already
     int pending_    = 0; // status of this rank inside sync(): 0, or the error code the peers have to learn about
+    uint64_t statusW64_ = 0; // staging of the status words that ride on the collectives (asynchronous copies read them)
+    uint32_t statusW32_ = 0;
+    double statusD_     = 0;
     std::string pendingMsg_;
     bool timing_    = std::getenv("CSTONE_MR_TIMING") != nullptr;
     bool noMargin_  = std::getenv("CSTONE_MR_NO_MARGIN") != nullptr; // tests: no room left for halos, the block is moved

@@ -160,7 +160,9 @@ __global__ __launch_bounds__(256) void newLeafSizesKernel(const uint32_t* __rest
         uint32_t old = j < J ? leafPos[j + 1] - leafPos[j] : 0u;
         c            = old - outCount[j] + incoming[j];
         // (entry J, the remove markers, does not go through the leaf pass)
-        if (j < J && old + incoming[j] > RESORT_LEAF_CAP) atomicOr(&scalars[1], 1);
+        // (slot numbers 0 .. RESORT_LEAF_CAP - 2 only: the digest of slot 255 behind 24 set key bits would equal the
+        //  hole's ~0u)
+        if (j < J && old + incoming[j] >= RESORT_LEAF_CAP) atomicOr(&scalars[1], 1);
     }
     newCount[j] = c;
 }

@@ -44,7 +44,8 @@ constexpr uint32_t RESORT_TILE_SLOTS = 4224; // slots (old positions + arrivals)
 constexpr uint32_t RESORT_QUIET_SLOTS = 3840; // a tile in which nothing moved is sorted in LDS if it has at most this many
                                               // slots: key + 16-bit slot number, 39 KB, four workgroups per CU
 constexpr int RESORT_COARSE_BITS      = 20;  // leading key bits of the movers' search table (binMoversKernel)
-constexpr uint32_t RESORT_LEAF_CAP   = 256;  // most slots of ONE leaf (the slot number is the low byte of a digest)
+constexpr uint32_t RESORT_LEAF_CAP   = 256;  // a leaf must hold FEWER slots than this (the slot number is the low byte of a
+                                             // digest, and slot 255 is left to the hole's digest ~0u)
 
 //! device-side results a re-sort attempt reports (ctx->devScalars + RESORT_SCALARS, read back with the box extents)
 constexpr int RESORT_SCALARS = 28; // [0] particles with the remove marker, [1] flags (1: leaf too long, 2: tile too
@@ -58,7 +59,7 @@ public:
     //! leaves per workgroup of the leaf pass for a focus bucket size; 0: buckets this large are not re-sorted
     static int leavesPerTile(uint32_t bucketFocus)
     {
-        return bucketFocus <= 64 ? 64 : bucketFocus <= 128 ? 32 : bucketFocus <= RESORT_LEAF_CAP ? 16 : 0;
+        return bucketFocus <= 64 ? 64 : bucketFocus <= 128 ? 32 : bucketFocus < RESORT_LEAF_CAP ? 16 : 0;
     }
 
     /*! compact leaf table of the previous sync (non-empty leaves of `tree` with their first positions) and cleared
