@@ -11,6 +11,7 @@
 //   * markMacs: a wave walks the tree for one target at a time, 8 nodes popped and their 64 children tested per step
 //     (LDS stack), like findHalos; the MAC arithmetic keeps the reference's operation order (-ffp-contract=off)
 #include <algorithm>
+#include <vector>
 
 #include "ctx.hpp"
 #include "device_keys.hpp"
@@ -591,6 +592,237 @@ int macSpheres(cstone_hip_ctx* ctx, int curve, const void* prefixes, int numNode
     return CSTONE_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// findPeersMac, R/traversal/peers.hpp:63-118: dual traversal (R/traversal/traversal.hpp:135-188) of the replicated
+// global tree against itself, started from each of the nodes that span the rank's key range.  One wave per start
+// node; up to 8 node pairs are popped per step and their 64 child pairs tested one per lane (LDS stack of pairs), like
+// markMacs above.  The set of pairs visited is that of the reference's serial walk (a pair is expanded iff it was
+// reached and fails the MAC), so the order in which they are visited does not matter: the result is a set of flags.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PEER_STACK_CAP = 4096;
+
+template<class K, class T, bool HILBERT>
+__global__ __launch_bounds__(64) void findPeersKernel(const K* __restrict__ prefixes,
+                                                      const NodeIdx* __restrict__ childOffsets,
+                                                      const NodeIdx* __restrict__ levelRange,
+                                                      const K* __restrict__ spanKeys, int numSpan,
+                                                      const K* __restrict__ assignment, int numRanks, DBox<T> box,
+                                                      float invThetaEff, int32_t* __restrict__ peerFlags,
+                                                      const uint16_t* __restrict__ tables, int* __restrict__ errors)
+{
+    __shared__ uint16_t dec[24 * 8];
+    __shared__ NodeIdx stackA[PEER_STACK_CAP], stackB[PEER_STACK_CAP];
+    for (unsigned i = threadIdx.x; i < 24 * 8; i += 64)
+        dec[i] = tables[48 * 8 + i];
+    __syncthreads();
+    const unsigned lane = threadIdx.x;
+    const int span      = blockIdx.x;
+    if (span >= numSpan) return;
+    const K domainStart = spanKeys[0], domainEnd = spanKeys[numSpan];
+
+    T pbcLen[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        pbcLen[d] = T(box.bc[d] == 1) * box.len[d];
+
+    auto geometry = [&](NodeIdx n, T (&c)[3], T (&s)[3])
+    {
+        const K prefix       = prefixes[n];
+        const unsigned level = prefixBits(prefix) / 3;
+        int lo[3], hi[3];
+        cornerOf<K, HILBERT>(fromPrefix(prefix), level, dec, lo);
+        const int edge = 1 << (maxLevel<K>() - level);
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            hi[d] = lo[d] + edge;
+        centerAndSize<K, T>(lo, hi, box, c, s);
+    };
+    // minDistance(X, bCenter, bSize, box), R/traversal/boxoverlap.hpp:208-218, squared norm
+    auto dist2 = [&](const T (&X)[3], const T (&bc)[3], const T (&bs)[3])
+    {
+        T dX[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+        {
+            T dx = bc[d] - X[d];
+            dx -= pbcLen[d] * rint(dx * box.inv[d]);
+            dx = fabs(dx);
+            dx -= bs[d];
+            dx += fabs(dx);
+            dx *= T(0.5);
+            dX[d] = dx;
+        }
+        return dX[0] * dX[0] + (dX[1] * dX[1] + dX[2] * dX[2]);
+    };
+    // crossFocusPairs, peers.hpp:72-86: true = the pair fails the MAC and is followed
+    auto follows = [&](NodeIdx a, NodeIdx b) -> bool
+    {
+        const K pa = prefixes[a], pb = prefixes[b];
+        const K aStart = fromPrefix(pa), aEnd = aStart + nodeSpan<K>(prefixBits(pa) / 3);
+        const K bStart = fromPrefix(pb), bEnd = bStart + nodeSpan<K>(prefixBits(pb) / 3);
+        const bool aFocusOverlap = domainStart < aEnd && aStart < domainEnd; // overlapTwoRanges
+        const bool bInFocus      = bStart >= domainStart && bEnd <= domainEnd; // containedIn
+        if (!aFocusOverlap || bInFocus) return false;
+        T ac[3], as[3], bc[3], bs[3];
+        geometry(a, ac, as);
+        geometry(b, bc, bs);
+        // minVecMacMutual, R/traversal/macs.hpp:171-194
+        const T macA = max3(bs) * 2 * invThetaEff;
+        const bool passA = dist2(bc, ac, as) > macA * macA;
+        const T macB = max3(as) * 2 * invThetaEff;
+        const bool passB = dist2(ac, bc, bs) > macB * macB;
+        return !(passA && passB);
+    };
+    auto mark = [&](NodeIdx b)
+    {
+        const K key = fromPrefix(prefixes[b]);
+        int lo = 0, len = numRanks + 1; // findRank: upper_bound(assignment, key) - 1
+        while (len > 0)
+        {
+            int half   = len >> 1;
+            bool right = assignment[lo + half] <= key;
+            lo         = right ? lo + half + 1 : lo;
+            len        = right ? len - half - 1 : half;
+        }
+        const int rank = lo - 1;
+        if (rank >= 0 && rank < numRanks) peerFlags[rank] = 1;
+    };
+
+    // the start node: locateNode(spanKeys[span], spanKeys[span + 1]), R/tree/octree.hpp:216-241
+    NodeIdx a0 = 0;
+    {
+        const K start = spanKeys[span], end = spanKeys[span + 1];
+        const int bits       = clzKey(K(end - start - 1)) - int(KeyInfo<K>::spare);
+        const unsigned level = unsigned(bits) / 3u;
+        const K want         = toPrefix<K>(start, bits);
+        NodeIdx lo = levelRange[level], len = levelRange[level + 1] - lo;
+        while (len > 0)
+        {
+            NodeIdx half = len >> 1;
+            bool right   = prefixes[lo + half] < want;
+            lo           = right ? lo + half + 1 : lo;
+            len          = right ? len - half - 1 : half;
+        }
+        a0 = lo;
+        if (lo >= levelRange[maxLevel<K>() + 1] || prefixes[lo] != want)
+        {
+            if (lane == 0) atomicOr(errors, 8);
+            return;
+        }
+    }
+    if (childOffsets[a0] == 0 && childOffsets[0] == 0)
+    {
+        if (lane == 0 && follows(a0, 0)) mark(0);
+        return;
+    }
+    int top = 1;
+    if (lane == 0) stackA[0] = a0, stackB[0] = 0;
+    while (top > 0)
+    {
+        const int take  = min(top, 8);
+        const int slot  = int(lane >> 3);
+        const bool mine = slot < take;
+        NodeIdx ta = 0, tb = 0;
+        if (mine) ta = stackA[top - 1 - slot], tb = stackB[top - 1 - slot];
+        top -= take;
+        bool push  = false;
+        NodeIdx na = 0, nb = 0;
+        if (mine)
+        {
+            const bool leafT = childOffsets[ta] == 0, leafS = childOffsets[tb] == 0;
+            const unsigned levelT = prefixBits(prefixes[ta]) / 3, levelS = prefixBits(prefixes[tb]) / 3;
+            const bool splitTarget = (levelT < levelS && !leafT) || leafS;
+            bool have = false;
+            if (splitTarget)
+            {
+                if (!leafT) na = childOffsets[ta] + NodeIdx(lane & 7u), nb = tb, have = true;
+            }
+            else if (!leafS) { na = ta, nb = childOffsets[tb] + NodeIdx(lane & 7u), have = true; }
+            if (have && follows(na, nb))
+            {
+                if (childOffsets[na] == 0 && childOffsets[nb] == 0) mark(nb);
+                else push = true;
+            }
+        }
+        const uint64_t pm = __ballot(push);
+        const int numPush = __popcll(pm);
+        if (top + numPush > PEER_STACK_CAP)
+        {
+            if (lane == 0) atomicOr(errors, 8);
+            return;
+        }
+        if (push)
+        {
+            const int at = top + __popcll(pm & ((1ull << lane) - 1ull));
+            stackA[at] = na, stackB[at] = nb;
+        }
+        top += numPush;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+//! the keys of the coarsest nodes that cover [a, b) (spanSfcRange, R/sfc/common.hpp:376-438), b appended
+template<class K>
+std::vector<K> spanningKeys(uint64_t a, uint64_t b)
+{
+    std::vector<K> out;
+    const uint64_t end = uint64_t(endKey<K>());
+    while (a < b)
+    {
+        uint64_t size = end;
+        while (size > 1 && (a % size != 0 || size > b - a))
+            size /= 8;
+        out.push_back(K(a));
+        a += size;
+    }
+    out.push_back(K(b));
+    return out;
+}
+
+template<class K, class T>
+int findPeers(cstone_hip_ctx* ctx, int curve, const void* prefixes, const int32_t* childOffsets,
+              const int32_t* levelRange, const uint64_t* assignment, int numRanks, int myRank, const cstone_box& box,
+              float invThetaEff, int32_t* peerFlagsHost)
+{
+    std::vector<K> span = spanningKeys<K>(assignment[myRank], assignment[myRank + 1]);
+    const int numSpan   = int(span.size()) - 1;
+    std::fill(peerFlagsHost, peerFlagsHost + numRanks, 0);
+    if (numSpan <= 0) return CSTONE_OK;
+    std::vector<K> asg(numRanks + 1);
+    for (int r = 0; r <= numRanks; ++r)
+        asg[r] = K(assignment[r]);
+    const size_t spanBytes = alignUp(span.size() * sizeof(K)), asgBytes = alignUp(asg.size() * sizeof(K));
+    const size_t flagBytes = alignUp(size_t(numRanks) * 4);
+    CS_TRY(arenaReserve(ctx, spanBytes + asgBytes + flagBytes + 1024));
+    K* dSpan    = (K*)arenaTake(ctx, spanBytes);
+    K* dAsg     = (K*)arenaTake(ctx, asgBytes);
+    auto* dFlag = (int32_t*)arenaTake(ctx, flagBytes);
+    auto body   = [&]() -> int
+    {
+        CS_HIP(ctx, hipMemcpyAsync(dSpan, span.data(), span.size() * sizeof(K), hipMemcpyHostToDevice, ctx->stream));
+        CS_HIP(ctx, hipMemcpyAsync(dAsg, asg.data(), asg.size() * sizeof(K), hipMemcpyHostToDevice, ctx->stream));
+        CS_HIP(ctx, hipMemsetAsync(dFlag, 0, size_t(numRanks) * 4, ctx->stream));
+        auto* tables  = (const uint16_t*)ctx->hilbertTables;
+        int* errors   = ctx->devScalars + 63;
+        DBox<T> b     = makeDBox<T>(box);
+        if (curve == CSTONE_HILBERT)
+            hipLaunchKernelGGL((findPeersKernel<K, T, true>), unsigned(numSpan), 64, 0, ctx->stream, (const K*)prefixes,
+                               childOffsets, levelRange, dSpan, numSpan, dAsg, numRanks, b, invThetaEff, dFlag, tables,
+                               errors);
+        else
+            hipLaunchKernelGGL((findPeersKernel<K, T, false>), unsigned(numSpan), 64, 0, ctx->stream, (const K*)prefixes,
+                               childOffsets, levelRange, dSpan, numSpan, dAsg, numRanks, b, invThetaEff, dFlag, tables,
+                               errors);
+        CS_HIP(ctx, hipGetLastError());
+        CS_HIP(ctx, hipMemcpyAsync(peerFlagsHost, dFlag, size_t(numRanks) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return CSTONE_OK;
+    };
+    int rc = body();
+    arenaReset(ctx);
+    return rc;
+}
+
 //! one int from the device scalars to the host (synchronises the stream)
 int readScalar(cstone_hip_ctx* ctx, int slot, int* out)
 {
@@ -753,6 +985,31 @@ int cstone_hip_mark_macs(cstone_hip_ctx* ctx, int curve, int key_bits, int real_
                                                        focus_nodes, num_focus_nodes, limit_source, markings)
                            : markMacs<uint64_t, double>(ctx, curve, prefixes, child_offsets, centers, *box_host,
                                                         focus_nodes, num_focus_nodes, limit_source, markings);
+}
+
+int cstone_hip_find_peers_mac(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* prefixes,
+                              const int32_t* child_offsets, const int32_t* level_range, const uint64_t* assignment_host,
+                              int num_ranks, int my_rank, const cstone_box* box_host, float inv_theta_eff,
+                              int32_t* peer_flags_host)
+{
+    if (!ctx || badKeyBits(key_bits) || badCurve(curve) || (real_bits != 32 && real_bits != 64) || !box_host ||
+        !prefixes || !child_offsets || !level_range || !assignment_host || !peer_flags_host || num_ranks < 1 ||
+        my_rank < 0 || my_rank >= num_ranks)
+        return fail(ctx, CSTONE_E_ARG, "find_peers_mac: bad argument");
+    StageTimer timer(ctx, CSTONE_STAGE_HALOS);
+    if (key_bits == 32)
+        return real_bits == 32 ? findPeers<uint32_t, float>(ctx, curve, prefixes, child_offsets, level_range,
+                                                            assignment_host, num_ranks, my_rank, *box_host,
+                                                            inv_theta_eff, peer_flags_host)
+                               : findPeers<uint32_t, double>(ctx, curve, prefixes, child_offsets, level_range,
+                                                             assignment_host, num_ranks, my_rank, *box_host,
+                                                             inv_theta_eff, peer_flags_host);
+    return real_bits == 32 ? findPeers<uint64_t, float>(ctx, curve, prefixes, child_offsets, level_range,
+                                                        assignment_host, num_ranks, my_rank, *box_host, inv_theta_eff,
+                                                        peer_flags_host)
+                           : findPeers<uint64_t, double>(ctx, curve, prefixes, child_offsets, level_range,
+                                                         assignment_host, num_ranks, my_rank, *box_host, inv_theta_eff,
+                                                         peer_flags_host);
 }
 
 static int macSpheresEntry(cstone_hip_ctx* ctx, const char* name, int mode, int curve, int key_bits, int real_bits,

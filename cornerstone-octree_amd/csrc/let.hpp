@@ -1,0 +1,1081 @@
+// The locally essential tree (LET) of one rank and its halo layout: the host state machine of the reference's
+// FocusedOctree (R/focus/octree_focus_mpi.hpp) and Halos (R/halos/halos.hpp) on top of the C ABI of cstone_hip.h.
+//
+// PLAIN HOST C++20: this file includes no HIP header and launches nothing itself.  Every device operation is a call of
+// the C ABI (device pointers + sizes), every exchange goes through cstone_hip_comm_ops (RCCL inside the library, or
+// whatever the application provides).  What the reference does with MPI_Isend / MPI_Probe loops between peers is done
+// here with a count pre-exchange (one all-gather of a row per rank) followed by ONE all-to-all-v per step: xGMI links
+// are point to point, a grouped ncclSend/ncclRecv per peer is what an all-to-all-v is there.
+//
+//   reference step                                   R/ file:line                          here
+//   findPeersMac                                     traversal/peers.hpp:63-118            findPeers()
+//   FocusedOctree::updateMinMac / updateMacs         focus/octree_focus_mpi.hpp:457-531    updateMinMac()
+//   FocusedOctree::updateTree                        :108-187                              updateTree()
+//     focusTransfer                                  focus/exchange_focus.hpp:364-433      focusTransfer()
+//     CombinedUpdate::updateFocus                    focus/octree_focus.hpp:83-136         updateFocus()
+//     macRefine / updateMacRefine                    :218-279                              macRefine()
+//     translateAssignment                            domain/domaindecomp.hpp:183-206       translateAssignment()
+//     syncTreelets (exchange, check, reject, prune)  focus/exchange_focus.hpp:61-217       syncTreelets()
+//     indexTreelets                                  :266-287                              indexTreelets()
+//   FocusedOctree::updateCounts (+ peerExchange)     focus/octree_focus_mpi.hpp:205-286    updateCounts()
+//   FocusedOctree::converge                          :535-553                              converge()
+//   Halos::discover                                  halos/halos.hpp:128-189               discoverHalos()
+//   Halos::computeLayout, exchangeRequestKeys        :205-222, domain/exchange_keys.hpp    computeLayout()
+//   Halos::exchangeHalos                             :232-253                              exchangeHalos()
+//
+// The tree stays on the device between the steps; the host sees a few scalars per step (new leaf counts, status words,
+// per-peer counts).  The results -- leaf array, leaf counts, focus assignment, layout, halo flags and halo ranges -- are
+// the reference's, bit for bit (tests/test_let.py: this file against the reference's own classes under MPI).
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cstone_hip.h"
+
+namespace cship
+{
+
+#define LET_TRY(expr)                                                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        int rc_ = (expr);                                                                                              \
+        if (rc_ != CSTONE_OK) return rc_;                                                                              \
+    } while (0)
+
+//! grow-only device buffer on the C ABI
+struct LetBuf
+{
+    cstone_hip_ctx* ctx = nullptr;
+    void* p             = nullptr;
+    size_t bytes        = 0;
+
+    LetBuf() = default;
+    explicit LetBuf(cstone_hip_ctx* c)
+        : ctx(c)
+    {
+    }
+    LetBuf(const LetBuf&)            = delete;
+    LetBuf& operator=(const LetBuf&) = delete;
+    ~LetBuf()
+    {
+        if (p) (void)cstone_hip_free(ctx, p);
+    }
+    int ensure(size_t need, bool keep = false)
+    {
+        if (need <= bytes) return CSTONE_OK;
+        size_t want = size_t(double(need) * 1.05) + 256;
+        void* q     = nullptr;
+        LET_TRY(cstone_hip_malloc(ctx, &q, want));
+        if (p)
+        {
+            if (keep) LET_TRY(cstone_hip_memcpy_d2d(ctx, q, p, bytes));
+            LET_TRY(cstone_hip_free(ctx, p)); // synchronises the stream first
+        }
+        p     = q;
+        bytes = want;
+        return CSTONE_OK;
+    }
+    void swap(LetBuf& o)
+    {
+        std::swap(p, o.p);
+        std::swap(bytes, o.bytes);
+    }
+    template<class V>
+    V* as() const
+    {
+        return static_cast<V*>(p);
+    }
+};
+
+//! TreeIndexPair of the reference (R/domain/index_ranges.hpp:30-60)
+struct LetRange
+{
+    int32_t start = 0, end = 0;
+    int32_t count() const { return end - start; }
+};
+
+template<class K, class T>
+class FocusLet
+{
+    static constexpr int kb = 8 * sizeof(K), rb = 8 * sizeof(T);
+    static constexpr int maxLevel = sizeof(K) == 4 ? 10 : 21;
+    static constexpr K endKey() { return K(1) << (3 * maxLevel); }
+
+public:
+    FocusLet(cstone_hip_ctx* ctx, int curve, int rank, int numRanks, uint32_t bucketFocus, float theta,
+             const cstone_hip_comm_ops& comm)
+        : ctx_(ctx)
+        , curve_(curve)
+        , rank_(rank)
+        , P_(numRanks)
+        , bucket_(bucketFocus)
+        , theta_(theta)
+        , comm_(comm)
+        , assignment_(numRanks)
+        , globAssignment_(numRanks + 1, K(0))
+        , tlCount_(numRanks, 0)
+        , tlOffset_(numRanks + 1, 0)
+    {
+        for (LetBuf* b : allBufs())
+            b->ctx = ctx;
+        box_.lim[0] = box_.lim[2] = box_.lim[4] = 0.0; // Box<T>{0, 1} (octree_focus_mpi.hpp:689)
+        box_.lim[1] = box_.lim[3] = box_.lim[5] = 1.0;
+        box_.bc[0] = box_.bc[1] = box_.bc[2] = 0;
+        box_.pad_                            = 0;
+    }
+
+    /*! The focus-tree part of Domain::sync (R/domain/domain.hpp:217-237) followed by Halos::discover / computeLayout.
+     *  keys: the rank's assigned particles, sorted (device); h: their smoothing lengths in the same order (device);
+     *  assignment: numRanks + 1 keys (host); globalLeaves / globalCounts: the replicated global tree (device).
+     *  Collective: every rank calls it. */
+    int update(const cstone_box& box, const K* keys, size_t numKeys, const K* assignment, const K* globalLeaves,
+               const uint32_t* globalCounts, int numGlobalLeaves, const T* h, float haloSearchExt)
+    {
+        const float invThetaEff = 1.0f / theta_ + 0.5f; // invThetaMinMac, R/traversal/macs.hpp:44
+        LET_TRY(init());
+        LET_TRY(findPeers(assignment, globalLeaves, numGlobalLeaves, box, invThetaEff));
+        if (firstCall_)
+            LET_TRY(converge(box, keys, numKeys, assignment, globalLeaves, globalCounts, numGlobalLeaves, invThetaEff));
+        LET_TRY(updateMinMac(assignment, invThetaEff));
+        bool converged = false;
+        LET_TRY(updateTree(assignment, box, &converged));
+        LET_TRY(updateCounts(keys, numKeys, globalLeaves, globalCounts, numGlobalLeaves));
+        LET_TRY(discoverHalos(box, h, haloSearchExt));
+        LET_TRY(computeLayout());
+        firstCall_ = false;
+        return CSTONE_OK;
+    }
+
+    /*! Halos::exchangeHalos (R/halos/halos.hpp:232-253): array is laid out like the particle buffers of the last
+     *  update (numParticlesWithHalos() elements of elemBytes bytes): its assigned range is read, the halo ranges are
+     *  overwritten with the owners' values.  Collective. */
+    int exchangeHalos(void* array, int elemBytes)
+    {
+        if (P_ == 1) return CSTONE_OK;
+        const size_t e = size_t(elemBytes);
+        LET_TRY(haloSend_.ensure(std::max<uint64_t>(sendTotal_, 1) * e));
+        LET_TRY(haloRecv_.ensure(std::max<uint64_t>(recvTotal_, 1) * e));
+        if (numSendRanges_)
+            LET_TRY(cstone_hip_gather_ranges(ctx_, elemBytes, 32, rangeScan_.p, rangeOffsets_.p, numSendRanges_, array,
+                                             haloSend_.p, size_t(sendTotal_)));
+        std::vector<size_t> sb(P_), rbv(P_);
+        for (int p = 0; p < P_; ++p)
+            sb[p] = size_t(haloSendCounts_[p]) * e, rbv[p] = size_t(haloRecvCounts_[p]) * e;
+        LET_TRY(commCall(comm_.all_to_all_v(comm_.user, haloSend_.p, sb.data(), haloRecv_.p, rbv.data()),
+                         "all_to_all_v (halos)"));
+        // incoming ranges: [layout[start_p], layout[end_p]) per peer, back to back in rank order on both sides of the
+        // assigned block (R/domain/layout.hpp:175-190)
+        char* a       = static_cast<char*>(array);
+        uint64_t done = 0;
+        for (int p = 0; p < P_; ++p)
+        {
+            if (!haloRecvCounts_[p]) continue;
+            LET_TRY(cstone_hip_memcpy_d2d(ctx_, a + size_t(haloRecvOffsets_[p]) * e, haloRecv_.template as<char>() + done * e,
+                                          size_t(haloRecvCounts_[p]) * e));
+            done += haloRecvCounts_[p];
+        }
+        return CSTONE_OK;
+    }
+
+    // ---- results of the last update ------------------------------------------------------------------------------
+    int numLeaves() const { return L_; }
+    int numNodes() const { return numNodesOf(L_); }
+    const K* leaves() const { return leaves_.as<K>(); }
+    const uint32_t* leafCounts() const { return leafCounts_.as<uint32_t>(); }
+    const uint32_t* layout() const { return layout_.as<uint32_t>(); }
+    const int32_t* haloFlags() const { return flags_.as<int32_t>(); }
+    const K* prefixes() const { return prefixes_.as<K>(); }
+    const int32_t* childOffsets() const { return child_.as<int32_t>(); }
+    const int32_t* parents() const { return parents_.as<int32_t>(); }
+    const int32_t* levelRange() const { return levelRange_.as<int32_t>(); }
+    const int32_t* internalToLeaf() const { return itl_.as<int32_t>(); }
+    const int32_t* leafToInternal() const { return lti_.as<int32_t>(); }
+    const T* geoCenters() const { return geoCenters_.as<T>(); }
+    const T* geoSizes() const { return geoSizes_.as<T>(); }
+    const uint32_t* nodeCounts() const { return counts_.as<uint32_t>(); }
+    const std::vector<LetRange>& assignment() const { return assignment_; }
+    const std::vector<int>& peers() const { return peers_; }
+    int startCell() const { return assignment_[rank_].start; }
+    int endCell() const { return assignment_[rank_].end; }
+    //! Domain::startIndex / endIndex / nParticlesWithHalos (R/domain/domain.hpp:388-397) of the layout just computed
+    uint32_t startIndex() const { return particleStart_; }
+    uint32_t endIndex() const { return particleEnd_; }
+    uint32_t numParticlesWithHalos() const { return particleTotal_; }
+    //! which of the rarer paths the updates so far have taken (diagnostics and tests)
+    struct Stats
+    {
+        uint64_t treeUpdates = 0, treeBuilds = 0, focusTransfers = 0, keysTransferred = 0, macRefineSteps = 0,
+                 keysInjected = 0, keysRejected = 0, leavesFromGlobal = 0, convergeSteps = 0;
+    };
+    const Stats& stats() const { return stats_; }
+    uint64_t halosSent() const { return sendTotal_; }
+    uint64_t halosReceived() const { return recvTotal_; }
+
+private:
+    static int numNodesOf(int L) { return L + (L - 1) / 7; }
+    static int numInternalOf(int L) { return (L - 1) / 7; }
+
+    std::vector<LetBuf*> allBufs()
+    {
+        return {&leaves_, &leavesNew_, &prefixes_, &child_, &parents_, &levelRange_, &itl_, &lti_, &counts_, &leafCounts_,
+                &macs_, &centers_, &geoCenters_, &geoSizes_, &opsAll_, &ops_, &scratchKeys_, &scratchKeys2_, &scratchIdx_,
+                &scratchIdx2_, &scratchU64_, &gPrefixes_, &gChild_, &gParents_, &gLevelRange_, &gItl_, &gLti_, &treelets_,
+                &treeletIdx_, &tlFlags_, &tlScan_, &sendBuf_, &recvBuf_, &layout_, &flags_, &radii_, &rangeOffsets_,
+                &rangeScan_, &haloSend_, &haloRecv_, &rowBuf_};
+    }
+
+    int fail(int code, const char* fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        return cstone_hip_raise(ctx_, code, buf);
+    }
+
+    int commCall(int rc, const char* what)
+    {
+        if (rc != 0) return fail(CSTONE_E_INTERNAL, "collective %s failed with code %d", what, rc);
+        return CSTONE_OK;
+    }
+
+    // ---- small helpers on the C ABI --------------------------------------------------------------------------------
+
+    //! result[q] = index of the first of keys[0 .. n) that is >= queries[q] (host in, host out)
+    int lowerBounds(const K* keys, size_t n, const std::vector<K>& queries, std::vector<int64_t>& result)
+    {
+        const size_t m = queries.size();
+        result.assign(m, 0);
+        if (m == 0) return CSTONE_OK;
+        LET_TRY(scratchU64_.ensure(m * (sizeof(K) + 8) + 64));
+        K* dq        = scratchU64_.as<K>();
+        uint64_t* dr = reinterpret_cast<uint64_t*>(scratchU64_.as<char>() + ((m * sizeof(K) + 63) / 64) * 64);
+        LET_TRY(cstone_hip_memcpy_h2d(ctx_, dq, queries.data(), m * sizeof(K)));
+        LET_TRY(cstone_hip_lower_bound(ctx_, kb, keys, n, dq, int(m), dr));
+        std::vector<uint64_t> r(m);
+        LET_TRY(cstone_hip_memcpy_d2h(ctx_, r.data(), dr, m * 8));
+        for (size_t i = 0; i < m; ++i)
+            result[i] = int64_t(r[i]);
+        return CSTONE_OK;
+    }
+
+    //! one 32-bit value from the device
+    template<class V>
+    int readBack(const V* dev, V* out, size_t count = 1)
+    {
+        return cstone_hip_memcpy_d2h(ctx_, out, dev, count * sizeof(V));
+    }
+
+    //! the rows of everybody: matrix[src * width + i] = row of rank src (host in, host out)
+    int gatherRows(const std::vector<uint64_t>& mine, std::vector<uint64_t>& matrix)
+    {
+        const size_t w = mine.size();
+        matrix.assign(w * P_, 0);
+        if (P_ == 1)
+        {
+            std::copy(mine.begin(), mine.end(), matrix.begin());
+            return CSTONE_OK;
+        }
+        LET_TRY(rowBuf_.ensure(w * 8 * (P_ + 1)));
+        uint64_t* send = rowBuf_.as<uint64_t>();
+        uint64_t* recv = send + w;
+        LET_TRY(cstone_hip_memcpy_h2d(ctx_, send, mine.data(), w * 8));
+        LET_TRY(commCall(comm_.all_gather(comm_.user, send, recv, w * 8), "all_gather (counts)"));
+        return cstone_hip_memcpy_d2h(ctx_, matrix.data(), recv, w * 8 * P_);
+    }
+
+    /*! variable all-to-all of elements of elemBytes: sendCounts[p] elements for rank p lie back to back in send (device);
+     *  the counts the others send me are exchanged first (the reference probes the message sizes, MPI_Probe /
+     *  MPI_Get_count).  anyGlobal = false on return: nobody sends anything, the data collective was skipped */
+    int exchangeV(const void* send, const std::vector<uint64_t>& sendCounts, int elemBytes, LetBuf& recv,
+                  std::vector<uint64_t>& recvCounts, bool* anyGlobal = nullptr)
+    {
+        std::vector<uint64_t> matrix;
+        LET_TRY(gatherRows(sendCounts, matrix));
+        recvCounts.assign(P_, 0);
+        uint64_t total = 0, any = 0;
+        for (int p = 0; p < P_; ++p)
+        {
+            recvCounts[p] = matrix[size_t(p) * P_ + rank_];
+            total += recvCounts[p];
+            for (int q = 0; q < P_; ++q)
+                any += matrix[size_t(p) * P_ + q];
+        }
+        if (anyGlobal) *anyGlobal = any != 0;
+        if (any == 0) return CSTONE_OK;
+        LET_TRY(recv.ensure(std::max<uint64_t>(total, 1) * elemBytes));
+        return allToAll(send, sendCounts, elemBytes, recv.p, recvCounts);
+    }
+
+    int allToAll(const void* send, const std::vector<uint64_t>& sendCounts, int elemBytes, void* recv,
+                 const std::vector<uint64_t>& recvCounts)
+    {
+        std::vector<size_t> sb(P_), rbv(P_);
+        for (int p = 0; p < P_; ++p)
+            sb[p] = size_t(sendCounts[p]) * elemBytes, rbv[p] = size_t(recvCounts[p]) * elemBytes;
+        if (P_ == 1) return CSTONE_OK;
+        return commCall(comm_.all_to_all_v(comm_.user, send, sb.data(), recv, rbv.data()), "all_to_all_v");
+    }
+
+    //! linked octree of leaves_[0 .. L_]
+    int buildOctree()
+    {
+        const int L = L_, M = numNodesOf(L);
+        LET_TRY(prefixes_.ensure(size_t(M) * sizeof(K)));
+        LET_TRY(child_.ensure(size_t(M + 1) * 4));
+        LET_TRY(parents_.ensure(size_t(std::max(1, (M - 1) / 8)) * 4));
+        LET_TRY(levelRange_.ensure(size_t(maxLevel + 2) * 4));
+        LET_TRY(itl_.ensure(size_t(M) * 4));
+        LET_TRY(lti_.ensure(size_t(M) * 4));
+        ++stats_.treeBuilds;
+        return cstone_hip_build_octree(ctx_, kb, leaves_.p, L, prefixes_.p, child_.as<int32_t>(), parents_.as<int32_t>(),
+                                       levelRange_.as<int32_t>(), itl_.as<int32_t>(), lti_.as<int32_t>());
+    }
+
+    //! the leaf-order part of leafToInternal (leafToInternal(tree) of R/tree/octree.hpp:366-375)
+    const uint32_t* leafMap() const { return lti_.as<uint32_t>() + numInternalOf(L_); }
+
+    /*! rebalanceTree (R/tree/csarray.hpp:396-409) with the node ops in ops_[0 .. L_] (entry L_ is ignored): exclusive
+     *  scan, new leaf array, swap.  The ops array is overwritten by its scan. */
+    int rebalanceFromOps()
+    {
+        const int L = L_;
+        LET_TRY(cstone_hip_exclusive_scan_u32(ctx_, ops_.as<uint32_t>(), ops_.as<uint32_t>(), size_t(L) + 1, 0u));
+        int32_t newL = 0;
+        LET_TRY(readBack(ops_.as<int32_t>() + L, &newL));
+        if (newL < 1) return fail(CSTONE_E_INTERNAL, "focus tree: rebalance produced %d leaves", newL);
+        LET_TRY(leavesNew_.ensure(size_t(newL + 1) * sizeof(K)));
+        LET_TRY(cstone_hip_rebalance_tree(ctx_, kb, leaves_.p, L, newL, ops_.as<int32_t>(), leavesNew_.p));
+        leaves_.swap(leavesNew_);
+        L_ = newL;
+        return CSTONE_OK;
+    }
+
+    // ---- state of a fresh FocusedOctree (octree_focus_mpi.hpp:69-98) ------------------------------------------------
+    int init()
+    {
+        if (L_ != 0) return CSTONE_OK;
+        const K root[2] = {K(0), endKey()};
+        LET_TRY(leaves_.ensure(2 * sizeof(K)));
+        LET_TRY(cstone_hip_memcpy_h2d(ctx_, leaves_.p, root, sizeof root));
+        L_ = 1;
+        LET_TRY(buildOctree());
+        const uint32_t c0 = bucket_ + 1; // counts_{bucketSize + 1}
+        const char m0     = 1;           // macs_{1}
+        LET_TRY(counts_.ensure(4));
+        LET_TRY(macs_.ensure(1));
+        LET_TRY(cstone_hip_memcpy_h2d(ctx_, counts_.p, &c0, 4));
+        LET_TRY(cstone_hip_memcpy_h2d(ctx_, macs_.p, &m0, 1));
+        haveLeafCounts_ = false;
+        return CSTONE_OK;
+    }
+
+    // ---- peers ---------------------------------------------------------------------------------------------------
+    int findPeers(const K* assignment, const K* globalLeaves, int numGlobalLeaves, const cstone_box& box, float invThetaEff)
+    {
+        peers_.clear();
+        if (P_ == 1) return CSTONE_OK;
+        const int GL = numGlobalLeaves, GM = numNodesOf(GL);
+        LET_TRY(gPrefixes_.ensure(size_t(GM) * sizeof(K)));
+        LET_TRY(gChild_.ensure(size_t(GM + 1) * 4));
+        LET_TRY(gParents_.ensure(size_t(std::max(1, (GM - 1) / 8)) * 4));
+        LET_TRY(gLevelRange_.ensure(size_t(maxLevel + 2) * 4));
+        LET_TRY(gItl_.ensure(size_t(GM) * 4));
+        LET_TRY(gLti_.ensure(size_t(GM) * 4));
+        LET_TRY(cstone_hip_build_octree(ctx_, kb, globalLeaves, GL, gPrefixes_.p, gChild_.as<int32_t>(),
+                                        gParents_.as<int32_t>(), gLevelRange_.as<int32_t>(), gItl_.as<int32_t>(),
+                                        gLti_.as<int32_t>()));
+        std::vector<uint64_t> a64(P_ + 1);
+        for (int r = 0; r <= P_; ++r)
+            a64[r] = uint64_t(assignment[r]);
+        std::vector<int32_t> flags(P_, 0);
+        LET_TRY(cstone_hip_find_peers_mac(ctx_, curve_, kb, rb, gPrefixes_.p, gChild_.as<int32_t>(),
+                                          gLevelRange_.as<int32_t>(), a64.data(), P_, rank_, &box, invThetaEff,
+                                          flags.data()));
+        for (int r = 0; r < P_; ++r)
+            if (flags[r] && r != rank_) peers_.push_back(r);
+        return CSTONE_OK;
+    }
+
+    // ---- MAC criteria (updateMinMac + updateMacs, octree_focus_mpi.hpp:457-531) ----------------------------------------
+    int updateMinMac(const K* assignment, float invThetaEff)
+    {
+        const int M = numNodesOf(L_);
+        LET_TRY(centers_.ensure(size_t(M) * 4 * sizeof(T)));
+        // centers_[i] = computeMinMacR2(prefix, invThetaEff, box_) with the box of the LAST updateTree; the radius that
+        // setMacRadius then derives from these centres is the same number (distance to the geometric centre = 0)
+        LET_TRY(cstone_hip_geo_mac_spheres(ctx_, curve_, kb, rb, prefixes_.p, M, centers_.p, invThetaEff, &box_));
+        LET_TRY(macs_.ensure(size_t(M)));
+        LET_TRY(cstone_hip_memset(ctx_, macs_.p, 0, size_t(M)));
+        // the assignment may have changed: its start and end in the CURRENT leaves, searched among the first L keys
+        std::vector<int64_t> idx;
+        LET_TRY(lowerBounds(leaves_.as<K>(), size_t(L_), {assignment[rank_], assignment[rank_ + 1]}, idx));
+        const int fStart = int(idx[0]), fEnd = int(idx[1]);
+        if (fEnd > fStart)
+            LET_TRY(cstone_hip_mark_macs(ctx_, curve_, kb, rb, prefixes_.p, child_.as<int32_t>(), centers_.p, &box_,
+                                         leaves_.as<K>() + fStart, fEnd - fStart, 0, macs_.as<char>()));
+        haveMacs_ = true;
+        return CSTONE_OK;
+    }
+
+    // ---- updateTree (octree_focus_mpi.hpp:108-187) ---------------------------------------------------------------------
+    int updateTree(const K* assignment, const cstone_box& box, bool* convergedOut)
+    {
+        if (!(haveMacs_ && haveCounts_)) // rebalanceStatus_ != valid (:110-113)
+            return fail(CSTONE_E_INTERNAL, "update of criteria required before updating the tree structure");
+        const K focusStart = assignment[rank_], focusEnd = assignment[rank_ + 1];
+        const bool firstUpdate = prevFocusStart_ == 0 && prevFocusEnd_ == 0;
+        if (firstUpdate) prevFocusStart_ = focusStart, prevFocusEnd_ = focusEnd;
+
+        std::vector<K> enforced;
+        LET_TRY(focusTransfer(assignment, firstUpdate, enforced));
+        for (int peer : peers_)
+        {
+            enforced.push_back(assignment[peer]);
+            enforced.push_back(assignment[peer + 1]);
+        }
+        enforced.erase(std::unique(enforced.begin(), enforced.end()), enforced.end());
+
+        bool converged = false;
+        LET_TRY(updateFocus(focusStart, focusEnd, enforced, &converged));
+        const float invThetaRefine = std::sqrt(3.0f) / 2 + 1e-6f; // octree_focus_mpi.hpp:139: float(sqrt(3)/2 + 1e-6)
+        bool refined                = false;
+        int guard                   = 0;
+        while (!refined)
+        {
+            LET_TRY(macRefine(prevFocusStart_, prevFocusEnd_, focusStart, focusEnd, invThetaRefine, box, &refined));
+            if (++guard > 8 * maxLevel) return fail(CSTONE_E_INTERNAL, "focus tree: MAC refinement does not end");
+        }
+        LET_TRY(translateAssignment(assignment));
+        LET_TRY(syncTreelets());
+        LET_TRY(indexTreelets());
+        LET_TRY(translateAssignment(assignment));
+        std::copy(assignment, assignment + P_ + 1, globAssignment_.begin());
+
+        box_            = box;
+        prevFocusStart_ = focusStart;
+        prevFocusEnd_   = focusEnd;
+        haveMacs_ = haveCounts_ = false;
+        ++stats_.treeUpdates;
+        // updateGeoCenters (:614-625)
+        const int M = numNodesOf(L_);
+        LET_TRY(geoCenters_.ensure(size_t(M) * 3 * sizeof(T)));
+        LET_TRY(geoSizes_.ensure(size_t(M) * 3 * sizeof(T)));
+        LET_TRY(cstone_hip_node_centers(ctx_, curve_, kb, rb, prefixes_.p, M, &box_, geoCenters_.p, geoSizes_.p));
+        *convergedOut = converged;
+        return CSTONE_OK;
+    }
+
+    /*! focusTransfer (exchange_focus.hpp:364-433): a rank whose range shrank hands the part of its tree that covers the
+     *  lost key range to the new owner (one rebalance step with the last leaf counts applied, updateTreelet
+     *  R/tree/csarray.hpp:477-488); the keys a rank receives become mandatory keys of its next tree.  Every rank knows
+     *  the old and the new assignment of everybody, so all of them agree on whether anything is handed over at all. */
+    int focusTransfer(const K* assignment, bool firstUpdate, std::vector<K>& buffer)
+    {
+        if (firstUpdate || P_ == 1) return CSTONE_OK;
+        bool anyChange = false;
+        for (int r = 0; r <= P_; ++r)
+            anyChange = anyChange || assignment[r] != globAssignment_[r];
+        if (!anyChange) return CSTONE_OK;
+        if (!haveLeafCounts_) return fail(CSTONE_E_INTERNAL, "focus transfer without leaf counts");
+
+        const K oldStart = prevFocusStart_, oldEnd = prevFocusEnd_;
+        const K newStart = assignment[rank_], newEnd = assignment[rank_ + 1];
+        std::vector<int64_t> idx;
+        LET_TRY(lowerBounds(leaves_.as<K>(), size_t(L_) + 1, {oldStart, newStart, newEnd, oldEnd}, idx));
+        // what I lost: [oldStart, newStart) to the rank below, [newEnd, oldEnd) to the rank above
+        struct Part
+        {
+            int dest;
+            int64_t first, last;
+        };
+        std::vector<Part> parts;
+        if (oldStart < newStart) parts.push_back({rank_ - 1, idx[0], idx[1]});
+        if (newEnd < oldEnd) parts.push_back({rank_ + 1, idx[2], idx[3]});
+        std::vector<uint64_t> sendCounts(P_, 0);
+        // the rebalanced treelets, back to back in the order [to the rank below | to the rank above] = rank order
+        std::vector<std::pair<int, int>> produced; // (dest, number of keys to send)
+        size_t used = 0;
+        for (const Part& part : parts)
+        {
+            const int numNodes = int(part.last - part.first);
+            int newNum         = 0;
+            if (numNodes > 0)
+            {
+                int conv = 0;
+                LET_TRY(ops_.ensure(size_t(numNodes + 2) * 4));
+                LET_TRY(cstone_hip_compute_node_ops(ctx_, kb, leaves_.as<K>() + part.first, numNodes,
+                                                    leafCounts_.as<uint32_t>() + part.first, bucket_, ops_.as<int32_t>(),
+                                                    &newNum, &conv));
+                LET_TRY(sendBuf_.ensure((used + size_t(newNum) + 1) * sizeof(K), true));
+                LET_TRY(cstone_hip_rebalance_tree(ctx_, kb, leaves_.as<K>() + part.first, numNodes, newNum,
+                                                  ops_.as<int32_t>(), sendBuf_.as<K>() + used));
+            }
+            // the last key of the treelet is not sent (mpiSendAsync(treelet.data(), treelet.size() - 1, ...)): the next
+            // treelet overwrites it
+            produced.push_back({part.dest, newNum});
+            used += size_t(newNum);
+        }
+        for (auto [dest, count] : produced)
+        {
+            if (dest < 0 || dest >= P_) return fail(CSTONE_E_INTERNAL, "focus transfer to rank %d", dest);
+            sendCounts[dest] = uint64_t(count);
+        }
+        LET_TRY(sendBuf_.ensure(std::max<size_t>(used, 1) * sizeof(K), true));
+        std::vector<uint64_t> recvCounts;
+        bool any = false;
+        LET_TRY(exchangeV(sendBuf_.p, sendCounts, int(sizeof(K)), recvBuf_, recvCounts, &any));
+        if (!any) return CSTONE_OK;
+        // received keys: from the rank below first, then from the rank above (rank order = the order of the buffer)
+        uint64_t recvTotal = 0;
+        for (int p = 0; p < P_; ++p)
+        {
+            if (recvCounts[p] && p != rank_ - 1 && p != rank_ + 1)
+                return fail(CSTONE_E_INTERNAL, "focus transfer from rank %d", p);
+            recvTotal += recvCounts[p];
+        }
+        const size_t at = buffer.size();
+        buffer.resize(at + recvTotal);
+        if (recvTotal) LET_TRY(readBack(recvBuf_.as<K>(), buffer.data() + at, size_t(recvTotal)));
+        ++stats_.focusTransfers;
+        stats_.keysTransferred += recvTotal;
+        return CSTONE_OK;
+    }
+
+    /*! CombinedUpdate::updateFocus (octree_focus.hpp:83-136): ops from counts and MACs, mandatory keys enforced,
+     *  ancestors protected, rebalance, keys that one step cannot resolve injected */
+    int updateFocus(K focusStart, K focusEnd, const std::vector<K>& mandatory, bool* convergedOut)
+    {
+        const int L = L_, M = numNodesOf(L), I = numInternalOf(L);
+        LET_TRY(opsAll_.ensure(size_t(M + 1) * 4));
+        LET_TRY(ops_.ensure(size_t(L + 2) * 4));
+        LET_TRY(cstone_hip_rebalance_decision_essential(ctx_, kb, prefixes_.p, child_.as<int32_t>(),
+                                                        parents_.as<int32_t>(), counts_.as<uint32_t>(),
+                                                        macs_.as<char>(), uint64_t(focusStart), uint64_t(focusEnd),
+                                                        bucket_, opsAll_.as<int32_t>(), M));
+        std::vector<K> all{focusStart, focusEnd};
+        all.insert(all.end(), mandatory.begin(), mandatory.end());
+        LET_TRY(scratchKeys_.ensure(all.size() * sizeof(K)));
+        LET_TRY(cstone_hip_memcpy_h2d(ctx_, scratchKeys_.p, all.data(), all.size() * sizeof(K)));
+        int status = 0, converged = 0;
+        LET_TRY(cstone_hip_enforce_keys(ctx_, kb, scratchKeys_.p, int(all.size()), prefixes_.p, child_.as<int32_t>(),
+                                        parents_.as<int32_t>(), opsAll_.as<int32_t>(), &status));
+        LET_TRY(cstone_hip_protect_ancestors(ctx_, kb, prefixes_.p, parents_.as<int32_t>(), opsAll_.as<int32_t>(), M,
+                                             &converged));
+        // the leaves' decisions in leaf order
+        LET_TRY(cstone_hip_gather(ctx_, 4, lti_.as<uint32_t>() + I, size_t(L), opsAll_.p, ops_.p));
+        LET_TRY(cstone_hip_memset(ctx_, ops_.as<int32_t>() + L, 0, 4));
+        if (status == 1) // cancelMerge
+        {
+            uint64_t ones = 0;
+            LET_TRY(cstone_hip_count_equal(ctx_, 32, ops_.p, size_t(L), 1, &ones));
+            converged = ones == uint64_t(L);
+        }
+        else if (status == 2) { converged = 0; } // rebalance
+        if (status == 3) converged = 0;          // failed
+
+        // (every op "keep" and nothing to inject: the leaf array and the linked octree stay what they are; the reference
+        //  rebuilds regardless because it parks the ops in the tree's arrays)
+        bool allKeep = status != 3 && converged;
+        if (status == 2)
+        {
+            uint64_t ones = 0;
+            LET_TRY(cstone_hip_count_equal(ctx_, 32, ops_.p, size_t(L), 1, &ones));
+            allKeep = ones == uint64_t(L);
+        }
+        else if (status == 0 && !converged)
+        {
+            // an inner node wants to change although every leaf keeps: nothing happens to the leaf array
+            uint64_t ones = 0;
+            LET_TRY(cstone_hip_count_equal(ctx_, 32, ops_.p, size_t(L), 1, &ones));
+            allKeep = ones == uint64_t(L);
+        }
+        if (!allKeep)
+        {
+            LET_TRY(rebalanceFromOps());
+            if (status == 3)
+            {
+                LET_TRY(injectKeys(all));
+                stats_.keysInjected += all.size();
+            }
+            LET_TRY(buildOctree());
+        }
+        *convergedOut = converged != 0;
+        return CSTONE_OK;
+    }
+
+    /*! injectKeys (R/focus/inject.hpp:52-113): the keys join the leaf array, and every gap between two consecutive
+     *  keys that is not a power-of-8 node is filled with the coarsest nodes that cover it */
+    int injectKeys(const std::vector<K>& keys)
+    {
+        const size_t n = size_t(L_) + 1 + keys.size();
+        LET_TRY(leaves_.ensure(n * sizeof(K), true));
+        LET_TRY(cstone_hip_memcpy_h2d(ctx_, leaves_.as<K>() + L_ + 1, keys.data(), keys.size() * sizeof(K)));
+        LET_TRY(cstone_hip_sort_keys(ctx_, kb, leaves_.p, n));
+        LET_TRY(ops_.ensure((n + 1) * 4));
+        LET_TRY(cstone_hip_count_sfc_gaps(ctx_, kb, leaves_.p, int(n) - 1, ops_.as<int32_t>()));
+        LET_TRY(cstone_hip_memset(ctx_, ops_.as<int32_t>() + (n - 1), 0, 4));
+        LET_TRY(cstone_hip_exclusive_scan_u32(ctx_, ops_.as<uint32_t>(), ops_.as<uint32_t>(), n, 0u));
+        int32_t numGap = 0;
+        LET_TRY(readBack(ops_.as<int32_t>() + (n - 1), &numGap));
+        if (numGap < 1) return fail(CSTONE_E_INTERNAL, "focus tree: key injection produced %d leaves", numGap);
+        LET_TRY(leavesNew_.ensure(size_t(numGap + 1) * sizeof(K)));
+        LET_TRY(cstone_hip_fill_sfc_gaps(ctx_, kb, leaves_.p, int(n) - 1, ops_.as<int32_t>(), leavesNew_.p));
+        leaves_.swap(leavesNew_);
+        L_ = numGap;
+        return CSTONE_OK;
+    }
+
+    /*! macRefine + updateMacRefine (octree_focus.hpp:218-279): when the focus has moved, the leaves that the vector MAC
+     *  (relative to the newly gained part of the focus) asks for are split, one level per call */
+    int macRefine(K oldStart, K oldEnd, K focusStart, K focusEnd, float invTheta, const cstone_box& box, bool* done)
+    {
+        *done = true;
+        if (oldStart == focusStart && oldEnd == focusEnd) return CSTONE_OK;
+        const int L = L_, M = numNodesOf(L), I = numInternalOf(L);
+        LET_TRY(centers_.ensure(size_t(M) * 4 * sizeof(T)));
+        LET_TRY(cstone_hip_geo_mac_spheres(ctx_, curve_, kb, rb, prefixes_.p, M, centers_.p, invTheta, &box));
+        LET_TRY(macs_.ensure(size_t(M)));
+        LET_TRY(cstone_hip_memset(ctx_, macs_.p, 0, size_t(M)));
+        const K growthLower = focusStart < oldStart ? oldStart : focusStart;
+        const K growthUpper = oldEnd < focusEnd ? oldEnd : focusEnd;
+        std::vector<int64_t> idx;
+        LET_TRY(lowerBounds(leaves_.as<K>(), size_t(L), {growthLower, growthUpper, focusStart, focusEnd}, idx));
+        const int fGrowL = int(idx[0]), fGrowU = int(idx[1]), fStart = int(idx[2]), fEnd = int(idx[3]);
+        if (fGrowL - fStart > 0)
+            LET_TRY(cstone_hip_mark_macs(ctx_, curve_, kb, rb, prefixes_.p, child_.as<int32_t>(), centers_.p, &box,
+                                         leaves_.as<K>() + fStart, fGrowL - fStart, 1, macs_.as<char>()));
+        if (fEnd - fGrowU > 0)
+            LET_TRY(cstone_hip_mark_macs(ctx_, curve_, kb, rb, prefixes_.p, child_.as<int32_t>(), centers_.p, &box,
+                                         leaves_.as<K>() + fGrowU, fEnd - fGrowU, 1, macs_.as<char>()));
+        LET_TRY(ops_.ensure(size_t(L + 2) * 4));
+        LET_TRY(cstone_hip_mac_refine_decision(ctx_, kb, prefixes_.p, macs_.as<char>(), lti_.as<int32_t>() + I, L,
+                                               fStart, fEnd, ops_.as<int32_t>()));
+        LET_TRY(cstone_hip_memset(ctx_, ops_.as<int32_t>() + L, 0, 4));
+        uint64_t ones = 0;
+        LET_TRY(cstone_hip_count_equal(ctx_, 32, ops_.p, size_t(L), 1, &ones));
+        *done = ones == uint64_t(L);
+        if (*done) return CSTONE_OK; // nothing to split: leaves and octree are unchanged
+        ++stats_.macRefineSteps;
+        LET_TRY(rebalanceFromOps());
+        return buildOctree();
+    }
+
+    /*! translateAssignment (domaindecomp.hpp:183-206): the leaf index ranges of the peers' and my own key ranges; a range
+     *  whose boundary keys are not in the tree is narrowed */
+    int translateAssignment(const K* assignment)
+    {
+        std::vector<K> q;
+        q.reserve(2 * (P_ + 1));
+        for (int r = 0; r <= P_; ++r)
+            q.push_back(assignment[r]);
+        for (int r = 0; r <= P_; ++r)
+            q.push_back(K(assignment[r] + 1)); // upper_bound(key) = lower_bound(key + 1)
+        std::vector<int64_t> idx;
+        LET_TRY(lowerBounds(leaves_.as<K>(), size_t(L_) + 1, q, idx));
+        auto above = [&](int r) { return int32_t(idx[r]); };              // findNodeAbove(assignment[r])
+        auto below = [&](int r) { return int32_t(idx[P_ + 1 + r]) - 1; }; // findNodeBelow(assignment[r])
+        std::fill(assignment_.begin(), assignment_.end(), LetRange{});
+        for (int peer : peers_)
+        {
+            int32_t s = above(peer), e = below(peer + 1);
+            if (e < s) e = s;
+            assignment_[peer] = LetRange{s, e};
+        }
+        assignment_[rank_] = LetRange{above(rank_), below(rank_ + 1)};
+        return CSTONE_OK;
+    }
+
+    /*! syncTreelets (exchange_focus.hpp:196-217): every peer gets my view of ITS key range (exchangeTreelets :61-96);
+     *  keys of such a treelet that the owner does not have are sent back (checkTreelets, exchangeRejectedKeys :98-194)
+     *  and removed from the sender's tree; what remains of a treelet (pruneTreelets :118-129) is the node list the owner
+     *  serves counts for */
+    int syncTreelets()
+    {
+        std::fill(tlCount_.begin(), tlCount_.end(), 0);
+        std::fill(tlOffset_.begin(), tlOffset_.end(), 0);
+        if (P_ == 1 || peers_.empty())
+        {
+            // (a rank without peers still takes part in the count exchanges of the others)
+            if (P_ == 1) return CSTONE_OK;
+        }
+        // ---- my leaves over each peer's range, including the upper boundary key
+        std::vector<uint64_t> sendCounts(P_, 0), recvCounts;
+        uint64_t sendTotal = 0;
+        for (int peer : peers_)
+        {
+            sendCounts[peer] = uint64_t(assignment_[peer].count()) + 1;
+            sendTotal += sendCounts[peer];
+        }
+        LET_TRY(sendBuf_.ensure(std::max<uint64_t>(sendTotal, 1) * sizeof(K)));
+        uint64_t at = 0;
+        for (int peer : peers_)
+        {
+            LET_TRY(cstone_hip_memcpy_d2d(ctx_, sendBuf_.as<K>() + at, leaves_.as<K>() + assignment_[peer].start,
+                                          size_t(sendCounts[peer]) * sizeof(K)));
+            at += sendCounts[peer];
+        }
+        bool any = false;
+        LET_TRY(exchangeV(sendBuf_.p, sendCounts, int(sizeof(K)), treelets_, recvCounts, &any));
+        if (!any) return CSTONE_OK;
+        uint64_t recvTotal = 0;
+        std::vector<uint64_t> rOff(P_ + 1, 0);
+        for (int p = 0; p < P_; ++p)
+        {
+            rOff[p + 1] = rOff[p] + recvCounts[p];
+            recvTotal += recvCounts[p];
+        }
+
+        // ---- keys of the treelets that are not in my tree (all but the last key of every treelet are checked)
+        std::vector<uint64_t> rejCounts(P_, 0), keepCounts(recvCounts);
+        if (recvTotal)
+        {
+            LET_TRY(tlFlags_.ensure((recvTotal + 1) * 4));
+            LET_TRY(tlScan_.ensure((recvTotal + 1) * 4));
+            LET_TRY(cstone_hip_keys_missing(ctx_, kb, leaves_.p, L_, treelets_.p, size_t(recvTotal),
+                                            tlFlags_.as<uint32_t>()));
+            for (int p = 0; p < P_; ++p)
+                if (recvCounts[p]) LET_TRY(cstone_hip_memset(ctx_, tlFlags_.as<uint32_t>() + rOff[p + 1] - 1, 0, 4));
+            LET_TRY(cstone_hip_memset(ctx_, tlFlags_.as<uint32_t>() + recvTotal, 0, 4));
+            LET_TRY(cstone_hip_exclusive_scan_u32(ctx_, tlFlags_.as<uint32_t>(), tlScan_.as<uint32_t>(),
+                                                  size_t(recvTotal) + 1, 0u));
+            // rejected keys per peer = differences of the scan at the treelet boundaries
+            std::vector<uint32_t> map(P_ + 1), at32(P_ + 1);
+            for (int p = 0; p <= P_; ++p)
+                map[p] = uint32_t(rOff[p]);
+            LET_TRY(scratchIdx_.ensure(size_t(P_ + 1) * 8));
+            uint32_t* dmap = scratchIdx_.as<uint32_t>();
+            uint32_t* dval = dmap + (P_ + 1);
+            LET_TRY(cstone_hip_memcpy_h2d(ctx_, dmap, map.data(), size_t(P_ + 1) * 4));
+            LET_TRY(cstone_hip_gather(ctx_, 4, dmap, size_t(P_) + 1, tlScan_.p, dval));
+            LET_TRY(readBack(dval, at32.data(), size_t(P_) + 1));
+            for (int p = 0; p < P_; ++p)
+            {
+                rejCounts[p]  = at32[p + 1] - at32[p];
+                keepCounts[p] = recvCounts[p] - rejCounts[p];
+            }
+        }
+        uint64_t rejTotal = 0;
+        for (int p = 0; p < P_; ++p)
+            rejTotal += rejCounts[p];
+        // rejected keys back to their senders, kept keys packed (both keep the rank order of the treelets)
+        LET_TRY(scratchKeys_.ensure(std::max<uint64_t>(rejTotal, 1) * sizeof(K)));
+        LET_TRY(scratchKeys2_.ensure(std::max<uint64_t>(recvTotal, 1) * sizeof(K)));
+        if (recvTotal)
+            LET_TRY(cstone_hip_partition_keys(ctx_, kb, treelets_.p, tlFlags_.as<uint32_t>(), tlScan_.as<uint32_t>(),
+                                              size_t(recvTotal), scratchKeys_.p, scratchKeys2_.p));
+        std::vector<uint64_t> rejRecv;
+        bool anyRejected = false;
+        LET_TRY(exchangeV(scratchKeys_.p, rejCounts, int(sizeof(K)), recvBuf_, rejRecv, &anyRejected));
+        // the pruned treelets
+        treelets_.swap(scratchKeys2_);
+        for (int p = 0; p < P_; ++p)
+        {
+            tlOffset_[p + 1] = tlOffset_[p] + keepCounts[p];
+            tlCount_[p]      = keepCounts[p] ? keepCounts[p] - 1 : 0; // nodes = keys - 1
+        }
+        uint64_t rejRecvTotal = 0;
+        for (int p = 0; p < P_; ++p)
+            rejRecvTotal += rejRecv[p];
+        stats_.keysRejected += rejRecvTotal;
+        if (rejRecvTotal)
+        {
+            // nodeOps (one per key of the leaf array, all 1) with a 0 at every leaf that starts at a rejected key, then
+            // rebalanceTree: those leaves merge into their predecessors
+            const int L = L_;
+            LET_TRY(ops_.ensure(size_t(L + 2) * 4));
+            const int32_t one = 1;
+            LET_TRY(cstone_hip_fill(ctx_, 4, ops_.p, size_t(L) + 1, &one));
+            LET_TRY(cstone_hip_zero_ops_at_keys(ctx_, kb, leaves_.p, L, recvBuf_.p, size_t(rejRecvTotal),
+                                                ops_.as<int32_t>()));
+            LET_TRY(rebalanceFromOps());
+            LET_TRY(buildOctree());
+        }
+        return CSTONE_OK;
+    }
+
+    //! indexTreelets (exchange_focus.hpp:266-287): node index in MY tree of every node of the peers' treelets
+    int indexTreelets()
+    {
+        uint64_t nodes = 0;
+        tlIdxOffset_.assign(P_ + 1, 0);
+        for (int p = 0; p < P_; ++p)
+        {
+            tlIdxOffset_[p + 1] = tlIdxOffset_[p] + tlCount_[p];
+            nodes += tlCount_[p];
+        }
+        LET_TRY(treeletIdx_.ensure(std::max<uint64_t>(nodes, 1) * 4));
+        for (int peer : peers_)
+        {
+            if (!tlCount_[peer]) continue;
+            LET_TRY(cstone_hip_locate_nodes(ctx_, kb, treelets_.as<K>() + tlOffset_[peer], size_t(tlCount_[peer]) + 1,
+                                            prefixes_.p, levelRange_.as<int32_t>(),
+                                            treeletIdx_.as<int32_t>() + tlIdxOffset_[peer]));
+        }
+        return CSTONE_OK;
+    }
+
+    // ---- updateCounts (octree_focus_mpi.hpp:205-273) ---------------------------------------------------------------------
+    int updateCounts(const K* keys, size_t numKeys, const K* globalLeaves, const uint32_t* globalCounts,
+                     int numGlobalLeaves)
+    {
+        const int L = L_, M = numNodesOf(L), I = numInternalOf(L);
+        LET_TRY(leafCounts_.ensure(size_t(L) * 4));
+        LET_TRY(cstone_hip_compute_node_counts(ctx_, kb, leaves_.p, leafCounts_.as<uint32_t>(), L, keys, numKeys,
+                                               0xFFFFFFFFu));
+        // leaves that neither I nor a peer own: counts from the global tree (invertRanges + enumerateRanges,
+        // R/domain/layout.hpp:57-89, rangeCount R/focus/rebalance.hpp:279-301)
+        std::vector<int32_t> fromGlobal;
+        {
+            int32_t cur = 0;
+            for (const LetRange& r : assignment_)
+            {
+                if (r.start == r.end) continue;
+                for (int32_t i = cur; i < r.start; ++i)
+                    fromGlobal.push_back(i);
+                cur = r.end;
+            }
+            for (int32_t i = cur; i < L; ++i)
+                fromGlobal.push_back(i);
+        }
+        stats_.leavesFromGlobal += fromGlobal.size();
+        if (!fromGlobal.empty())
+        {
+            LET_TRY(scratchIdx_.ensure(fromGlobal.size() * 4));
+            LET_TRY(cstone_hip_memcpy_h2d(ctx_, scratchIdx_.p, fromGlobal.data(), fromGlobal.size() * 4));
+            LET_TRY(cstone_hip_range_count(ctx_, kb, globalLeaves, numGlobalLeaves, globalCounts, leaves_.p,
+                                           scratchIdx_.as<int32_t>(), int(fromGlobal.size()),
+                                           leafCounts_.as<uint32_t>()));
+        }
+        // first upsweep with local and global data
+        LET_TRY(counts_.ensure(size_t(M) * 4));
+        LET_TRY(cstone_hip_scatter(ctx_, 4, lti_.as<uint32_t>() + I, size_t(L), leafCounts_.p, counts_.p));
+        LET_TRY(cstone_hip_upsweep_sum(ctx_, maxLevel + 2, levelRange_.as<int32_t>(), child_.as<int32_t>(),
+                                       counts_.as<uint32_t>()));
+        // counts of the peers' regions from their owners (peerExchange -> exchangeTreeletGeneral, exchange_focus.hpp:289-344)
+        if (P_ > 1)
+        {
+            std::vector<uint64_t> sendCounts(P_, 0), recvCounts(P_, 0);
+            uint64_t sendTotal = 0, recvTotal = 0;
+            for (int peer : peers_)
+            {
+                sendCounts[peer] = tlCount_[peer];
+                recvCounts[peer] = uint64_t(assignment_[peer].count());
+                sendTotal += sendCounts[peer];
+                recvTotal += recvCounts[peer];
+            }
+            LET_TRY(sendBuf_.ensure(std::max<uint64_t>(sendTotal, 1) * 4));
+            LET_TRY(recvBuf_.ensure(std::max<uint64_t>(recvTotal, 1) * 4));
+            // (the node indices of the peers' treelets lie in rank order, like the send segments)
+            if (sendTotal)
+                LET_TRY(cstone_hip_gather(ctx_, 4, treeletIdx_.as<uint32_t>(), size_t(sendTotal), counts_.p, sendBuf_.p));
+            LET_TRY(allToAll(sendBuf_.p, sendCounts, 4, recvBuf_.p, recvCounts));
+            uint64_t at = 0;
+            for (int peer : peers_)
+            {
+                if (recvCounts[peer])
+                    LET_TRY(cstone_hip_scatter(ctx_, 4, lti_.as<uint32_t>() + I + assignment_[peer].start,
+                                               size_t(recvCounts[peer]), recvBuf_.as<uint32_t>() + at, counts_.p));
+                at += recvCounts[peer];
+            }
+            // second upsweep with the peer data present
+            LET_TRY(cstone_hip_upsweep_sum(ctx_, maxLevel + 2, levelRange_.as<int32_t>(), child_.as<int32_t>(),
+                                           counts_.as<uint32_t>()));
+        }
+        LET_TRY(cstone_hip_gather(ctx_, 4, lti_.as<uint32_t>() + I, size_t(L), counts_.p, leafCounts_.p));
+        haveCounts_ = haveLeafCounts_ = true;
+        return CSTONE_OK;
+    }
+
+    //! converge (octree_focus_mpi.hpp:535-553): update until the tree of EVERY rank has stopped changing
+    int converge(const cstone_box& box, const K* keys, size_t numKeys, const K* assignment, const K* globalLeaves,
+                 const uint32_t* globalCounts, int numGlobalLeaves, float invThetaEff)
+    {
+        int guard = 0;
+        while (true)
+        {
+            LET_TRY(updateMinMac(assignment, invThetaEff));
+            bool converged = false;
+            LET_TRY(updateTree(assignment, box, &converged));
+            LET_TRY(updateCounts(keys, numKeys, globalLeaves, globalCounts, numGlobalLeaves));
+            // (updateGeoCenters: done at the end of updateTree, the tree has not changed since)
+            uint32_t sum = converged ? 1u : 0u;
+            if (P_ > 1)
+            {
+                LET_TRY(rowBuf_.ensure(64));
+                LET_TRY(cstone_hip_memcpy_h2d(ctx_, rowBuf_.p, &sum, 4));
+                LET_TRY(commCall(comm_.all_reduce(comm_.user, rowBuf_.p, 1, 1, 0), "all_reduce (converged)"));
+                LET_TRY(readBack(rowBuf_.as<uint32_t>(), &sum));
+            }
+            ++stats_.convergeSteps;
+            if (int(sum) == P_) return CSTONE_OK;
+            if (++guard > 128) return fail(CSTONE_E_INTERNAL, "focus tree does not converge");
+        }
+    }
+
+    // ---- Halos::discover (halos.hpp:128-189) -----------------------------------------------------------------------------
+    int discoverHalos(const cstone_box& box, const T* h, float searchExt)
+    {
+        const int L = L_, first = assignment_[rank_].start, last = assignment_[rank_].end;
+        if (first < 0 || last > L || last < first)
+            return fail(CSTONE_E_INTERNAL, "focus tree: bad leaf range [%d, %d) of %d", first, last, L);
+        LET_TRY(layout_.ensure(size_t(L + 2) * 4));
+        LET_TRY(radii_.ensure(size_t(L) * 4));
+        LET_TRY(flags_.ensure(size_t(L) * 4));
+        // layout[0 .. last - first] = offsets of the assigned leaves among the assigned particles
+        LET_TRY(cstone_hip_memset(ctx_, layout_.p, 0, 4));
+        if (last > first)
+            LET_TRY(cstone_hip_inclusive_scan_u32(ctx_, leafCounts_.as<uint32_t>() + first, layout_.as<uint32_t>() + 1,
+                                                  size_t(last - first)));
+        LET_TRY(cstone_hip_halo_radii(ctx_, rb, h, layout_.as<uint32_t>(), first, last, L, searchExt, radii_.as<float>()));
+        LET_TRY(cstone_hip_memset(ctx_, flags_.p, 0, size_t(L) * 4));
+        if (last > first)
+            LET_TRY(cstone_hip_find_halos(ctx_, curve_, kb, rb, prefixes_.p, child_.as<int32_t>(), itl_.as<int32_t>(),
+                                          leaves_.p, radii_.as<float>(), &box, first, last, flags_.as<int32_t>()));
+        return CSTONE_OK;
+    }
+
+    /*! Halos::computeLayout (halos.hpp:205-222): offsets of every leaf in the particle buffers (computeNodeLayout,
+     *  R/domain/layout.hpp:150-165), the key ranges I want from every peer (exchangeRequestKeys,
+     *  R/domain/exchange_keys.hpp:63-119) and the index ranges the peers want from me, the ranges the halos arrive in
+     *  (computeHaloRecvList, layout.hpp:175-190) */
+    int computeLayout()
+    {
+        const int L = L_, first = assignment_[rank_].start, last = assignment_[rank_].end;
+        LET_TRY(cstone_hip_node_layout(ctx_, leafCounts_.as<uint32_t>(), flags_.as<int32_t>(), first, last, L,
+                                       layout_.as<uint32_t>()));
+        // the halo key ranges I request, peer by peer
+        std::vector<int32_t> ranges(2 * size_t(P_), 0);
+        for (int peer : peers_)
+            ranges[2 * peer] = assignment_[peer].start, ranges[2 * peer + 1] = assignment_[peer].end;
+        std::vector<uint32_t> pairCounts(P_, 0);
+        uint32_t unmatched = 0;
+        LET_TRY(scratchKeys_.ensure(size_t(L + 2) * sizeof(K))); // at most (L + 1) / 2 runs of flagged leaves, 2 keys each
+        LET_TRY(cstone_hip_halo_requests(ctx_, kb, leaves_.p, flags_.as<int32_t>(), L, first, last, ranges.data(), P_,
+                                         scratchKeys_.p, pairCounts.data(), &unmatched));
+        // counts of everybody (+ a status word: a halo cell that no peer owns fails the sync on every rank, checkHalos
+        // halos.hpp:59-95)
+        std::vector<uint64_t> row(P_ + 1, 0), matrix;
+        for (int p = 0; p < P_; ++p)
+            row[p] = 2 * uint64_t(pairCounts[p]);
+        row[P_] = unmatched ? 1 : 0;
+        LET_TRY(gatherRows(row, matrix));
+        for (int p = 0; p < P_; ++p)
+            if (matrix[size_t(p) * (P_ + 1) + P_] != 0)
+                return fail(CSTONE_E_INTERNAL,
+                            "halo discovery: rank %d found halo cells that belong to none of its peers (the sync was "
+                            "abandoned on every rank)",
+                            p);
+        std::vector<uint64_t> sendCounts(P_, 0), recvCounts(P_, 0);
+        uint64_t recvKeys = 0;
+        for (int p = 0; p < P_; ++p)
+        {
+            sendCounts[p] = row[p];
+            recvCounts[p] = matrix[size_t(p) * (P_ + 1) + rank_];
+            recvKeys += recvCounts[p];
+        }
+        LET_TRY(recvBuf_.ensure(std::max<uint64_t>(recvKeys, 1) * sizeof(K)));
+        LET_TRY(allToAll(scratchKeys_.p, sendCounts, int(sizeof(K)), recvBuf_.p, recvCounts));
+
+        // what the peers want from me: index ranges of my particle buffers, peer after peer
+        numSendRanges_ = int(recvKeys / 2);
+        LET_TRY(rangeOffsets_.ensure(size_t(numSendRanges_ + 1) * 4));
+        LET_TRY(rangeScan_.ensure(size_t(numSendRanges_ + 2) * 4));
+        haloSendCounts_.assign(P_, 0);
+        sendTotal_ = 0;
+        if (numSendRanges_)
+        {
+            LET_TRY(cstone_hip_ranges_from_keys(ctx_, kb, leaves_.p, L, layout_.as<uint32_t>(), recvBuf_.p,
+                                                size_t(numSendRanges_), rangeOffsets_.as<uint32_t>(),
+                                                rangeScan_.as<uint32_t>()));
+            // particles per peer = differences of the range scan at the peers' first ranges
+            std::vector<uint32_t> map(P_ + 1, 0), at32(P_ + 1, 0);
+            for (int p = 0; p < P_; ++p)
+                map[p + 1] = map[p] + uint32_t(recvCounts[p] / 2);
+            LET_TRY(scratchIdx_.ensure(size_t(P_ + 1) * 8));
+            uint32_t* dmap = scratchIdx_.as<uint32_t>();
+            uint32_t* dval = dmap + (P_ + 1);
+            LET_TRY(cstone_hip_memcpy_h2d(ctx_, dmap, map.data(), size_t(P_ + 1) * 4));
+            LET_TRY(cstone_hip_gather(ctx_, 4, dmap, size_t(P_) + 1, rangeScan_.p, dval));
+            LET_TRY(readBack(dval, at32.data(), size_t(P_) + 1));
+            for (int p = 0; p < P_; ++p)
+            {
+                haloSendCounts_[p] = at32[p + 1] - at32[p];
+                sendTotal_ += haloSendCounts_[p];
+            }
+        }
+        // where the halos arrive and the extent of the buffers: layout at the assignment boundaries
+        {
+            std::vector<uint32_t> map, val;
+            for (int p = 0; p < P_; ++p)
+            {
+                map.push_back(uint32_t(assignment_[p].start));
+                map.push_back(uint32_t(assignment_[p].end));
+            }
+            map.push_back(uint32_t(L));
+            val.resize(map.size());
+            LET_TRY(scratchIdx_.ensure(map.size() * 8));
+            uint32_t* dmap = scratchIdx_.as<uint32_t>();
+            uint32_t* dval = dmap + map.size();
+            LET_TRY(cstone_hip_memcpy_h2d(ctx_, dmap, map.data(), map.size() * 4));
+            LET_TRY(cstone_hip_gather(ctx_, 4, dmap, map.size(), layout_.p, dval));
+            LET_TRY(readBack(dval, val.data(), val.size()));
+            haloRecvCounts_.assign(P_, 0);
+            haloRecvOffsets_.assign(P_, 0);
+            recvTotal_ = 0;
+            for (int peer : peers_)
+            {
+                haloRecvOffsets_[peer] = val[2 * peer];
+                haloRecvCounts_[peer]  = val[2 * peer + 1] - val[2 * peer];
+                recvTotal_ += haloRecvCounts_[peer];
+            }
+            particleStart_ = val[2 * rank_];
+            particleEnd_   = val[2 * rank_ + 1];
+            particleTotal_ = val.back();
+        }
+        return CSTONE_OK;
+    }
+
+    cstone_hip_ctx* ctx_;
+    int curve_, rank_, P_;
+    uint32_t bucket_;
+    float theta_;
+    cstone_hip_comm_ops comm_;
+
+    bool firstCall_ = true;
+    cstone_box box_{}; // the box of the last updateTree (octree_focus_mpi.hpp:689)
+    K prevFocusStart_ = 0, prevFocusEnd_ = 0;
+    bool haveMacs_ = true, haveCounts_ = true, haveLeafCounts_ = false; // rebalanceStatus_ (:669-677, :733)
+    Stats stats_;
+
+    int L_ = 0; // leaves of the focus tree
+    LetBuf leaves_, leavesNew_, prefixes_, child_, parents_, levelRange_, itl_, lti_;
+    LetBuf counts_, leafCounts_, macs_, centers_, geoCenters_, geoSizes_;
+    LetBuf opsAll_, ops_, scratchKeys_, scratchKeys2_, scratchIdx_, scratchIdx2_, scratchU64_;
+    LetBuf gPrefixes_, gChild_, gParents_, gLevelRange_, gItl_, gLti_; // linked octree of the global tree (peer search)
+
+    std::vector<int> peers_;
+    std::vector<LetRange> assignment_; // leaf index range of every peer's (and my) key range
+    std::vector<K> globAssignment_;    // the key ranges of the last updateTree
+
+    // treelets: the peers' views of my range, pruned to the keys I have; node counts, key offsets, node-index offsets
+    LetBuf treelets_, treeletIdx_, tlFlags_, tlScan_, sendBuf_, recvBuf_, rowBuf_;
+    std::vector<uint64_t> tlCount_, tlOffset_, tlIdxOffset_;
+
+    // halo layout
+    LetBuf layout_, flags_, radii_, rangeOffsets_, rangeScan_, haloSend_, haloRecv_;
+    int numSendRanges_ = 0;
+    std::vector<uint64_t> haloSendCounts_, haloRecvCounts_, haloRecvOffsets_;
+    uint64_t sendTotal_ = 0, recvTotal_ = 0;
+    uint32_t particleStart_ = 0, particleEnd_ = 0, particleTotal_ = 0;
+};
+
+} // namespace cship

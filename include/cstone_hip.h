@@ -373,6 +373,63 @@ extern "C"
                                    const int32_t* child_offsets, void* centers);
 
     /* ---------------------------------------------------------------------------------------------
+     * Building blocks of the locally essential tree on SEVERAL ranks: the device work behind the host state machine of
+     * FocusedOctree (R/focus/octree_focus_mpi.hpp:108-273), its treelet exchanges (R/focus/exchange_focus.hpp:98-287) and
+     * of Halos::computeLayout (R/halos/halos.hpp:205-222, R/domain/layout.hpp:91-190, R/domain/exchange_keys.hpp:63-119).
+     * The state machine itself is plain host C++ on top of this ABI (cornerstone-octree_amd/csrc/let.hpp).
+     * raise         : records `message` as the context's last error and returns `code` (host layers above the ABI
+     *                 report their own failures through the same channel as the library's)
+     * find_peers_mac : findPeersMac (R/traversal/peers.hpp:63-118): peer_flags_host[r] = 1 for every rank r whose SFC
+     *                 range [assignment[r], assignment[r+1]) holds a leaf of the replicated global tree that fails the
+     *                 mutual min-distance MAC (minVecMacMutual, R/traversal/macs.hpp:171-194) paired with a leaf inside
+     *                 my_rank's range, found by the reference's dual traversal (R/traversal/traversal.hpp:135-188) from
+     *                 the nodes that span my_rank's range; prefixes / child_offsets / level_range: the linked octree
+     *                 of the global leaves (device), assignment_host: num_ranks + 1 keys (as uint64)
+     * keys_missing  : flags[i] = 1 if keys[i] is not one of leaves[0 .. num_leaves] (the test of checkTreelets,
+     *                 exchange_focus.hpp:104-115: k != leaves[findNodeAbove(leaves, num_leaves, k)]), else 0
+     * partition_keys : with scan = exclusive scan of flags: keys with flag 1 go to set_out[scan[i]], the others to
+     *                 unset_out[i - scan[i]] (either output may be NULL): pruneTreelets / the rejected keys (:118-171)
+     * zero_ops_at_keys : node_ops[findNodeAbove(leaves, num_keys_in_leaves, keys[i])] = 0 (exchangeRejectedKeys, :186-190);
+     *                 leaves has num_leaves + 1 keys, all of them are searched
+     * locate_nodes  : idx[i] = locateNode(keys[i], keys[i+1], prefixes, level_range) for i < num_keys - 1
+     *                 (indexTreelets, :266-287; R/tree/octree.hpp:216-241): the node with exactly that key range, or
+     *                 num_nodes if there is none
+     * node_layout   : computeNodeLayout (R/domain/layout.hpp:150-165): layout[num_leaves + 1] = exclusive scan of
+     *                 (first <= i < last || flags[i]) ? counts[i] : 0
+     * halo_requests : extractMarkedElements for every peer at once (R/domain/layout.hpp:104-139, as called by
+     *                 exchangeRequestKeys, R/domain/exchange_keys.hpp:76-83): ranges_host = num_ranks pairs
+     *                 {first leaf, last leaf} in ascending order ({0,0} for ranks that are no peers); for each run of
+     *                 flagged leaves inside a peer's range the pair (leaves[run start], leaves[run end]) is written to
+     *                 pairs_out (2 keys per run, peer after peer); pair_counts_host[r] = number of runs of rank r;
+     *                 *unmatched_host = flagged leaves outside [first, last) that lie in no peer's range (checkHalos,
+     *                 R/halos/halos.hpp:59-95).  pairs_out needs room for 2 * (flagged leaves) keys
+     * ranges_from_keys : the serving side of exchangeRequestKeys (:98-108): range r = [layout[findNodeAbove(leaves,
+     *                 pairs[2r])], layout[findNodeAbove(leaves, pairs[2r+1])]) -> range_offsets[r] = its start,
+     *                 range_scan[num_pairs + 1] = exclusive scan of the lengths (what gather_ranges takes)
+     * ------------------------------------------------------------------------------------------- */
+    int cstone_hip_raise(cstone_hip_ctx* ctx, int code, const char* message);
+    int cstone_hip_find_peers_mac(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* prefixes,
+                                  const int32_t* child_offsets, const int32_t* level_range,
+                                  const uint64_t* assignment_host, int num_ranks, int my_rank,
+                                  const cstone_box* box_host, float inv_theta_eff, int32_t* peer_flags_host);
+    int cstone_hip_keys_missing(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int num_leaves, const void* keys,
+                                size_t num_keys, uint32_t* flags);
+    int cstone_hip_partition_keys(cstone_hip_ctx* ctx, int key_bits, const void* keys, const uint32_t* flags,
+                                  const uint32_t* scan, size_t num_keys, void* set_out, void* unset_out);
+    int cstone_hip_zero_ops_at_keys(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int num_leaves,
+                                    const void* keys, size_t num_keys, int32_t* node_ops);
+    int cstone_hip_locate_nodes(cstone_hip_ctx* ctx, int key_bits, const void* keys, size_t num_keys,
+                                const void* prefixes, const int32_t* level_range, int32_t* idx);
+    int cstone_hip_node_layout(cstone_hip_ctx* ctx, const uint32_t* counts, const int32_t* flags, int first, int last,
+                               int num_leaves, uint32_t* layout);
+    int cstone_hip_halo_requests(cstone_hip_ctx* ctx, int key_bits, const void* leaves, const int32_t* flags,
+                                 int num_leaves, int first, int last, const int32_t* ranges_host, int num_ranks,
+                                 void* pairs_out, uint32_t* pair_counts_host, uint32_t* unmatched_host);
+    int cstone_hip_ranges_from_keys(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int num_leaves,
+                                    const uint32_t* layout, const void* pairs, size_t num_pairs,
+                                    uint32_t* range_offsets, uint32_t* range_scan);
+
+    /* ---------------------------------------------------------------------------------------------
      * neighbor search: replaces findNeighbors (R/findneighbors.hpp:160-188) / the traverseNeighbors
      * device function (R/traversal/find_neighbors.cuh:436-506) on an OctreeNsView
      * (R/tree/octree.hpp:297-317).  For i in [first,last): counts[i-first] = number of j != i with

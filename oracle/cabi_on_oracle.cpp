@@ -1,0 +1,583 @@
+// TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+// The part of the C ABI of include/cstone_hip.h that the host state machine of the locally essential tree
+// (cornerstone-octree_amd/csrc/let.hpp) calls, served by the CPU restatement (cstone_oracle.hpp) on HOST memory: a
+// "device pointer" is a host pointer here, the stream is the program order.  It exists so that let.hpp -- product
+// code that is plain host C++ over the ABI -- can be run and compared with the reference's own FocusedOctree / Halos
+// classes in this container, which has no GPU (oracle/let_check.cpp, tests/test_let.py), and under sanitizers.
+// Never linked into libcstone_hip.so, never shipped.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cstone_hip.h"
+#include "cstone_oracle.hpp"
+
+using namespace orc;
+
+struct cstone_hip_ctx
+{
+    std::string lastError;
+};
+
+namespace
+{
+template<class T>
+Box<T> mkBox(const cstone_box* b)
+{
+    return Box<T>(T(b->lim[0]), T(b->lim[1]), T(b->lim[2]), T(b->lim[3]), T(b->lim[4]), T(b->lim[5]), b->bc[0],
+                  b->bc[1], b->bc[2]);
+}
+
+template<class F>
+int withKey(int keyBits, F&& f)
+{
+    if (keyBits == 32) { f(uint32_t{}); }
+    else if (keyBits == 64) { f(uint64_t{}); }
+    else { return CSTONE_E_ARG; }
+    return CSTONE_OK;
+}
+template<class F>
+int withReal(int realBits, F&& f)
+{
+    if (realBits == 32) { f(float{}); }
+    else if (realBits == 64) { f(double{}); }
+    else { return CSTONE_E_ARG; }
+    return CSTONE_OK;
+}
+} // namespace
+
+extern "C"
+{
+
+int cstone_fake_ctx_create(cstone_hip_ctx** out)
+{
+    *out = new cstone_hip_ctx;
+    return CSTONE_OK;
+}
+int cstone_fake_ctx_destroy(cstone_hip_ctx* ctx)
+{
+    delete ctx;
+    return CSTONE_OK;
+}
+const char* cstone_hip_last_error(cstone_hip_ctx* ctx) { return ctx ? ctx->lastError.c_str() : ""; }
+int cstone_hip_raise(cstone_hip_ctx* ctx, int code, const char* message)
+{
+    if (ctx) ctx->lastError = message ? message : "";
+    return code;
+}
+int cstone_hip_ctx_sync(cstone_hip_ctx*) { return CSTONE_OK; }
+
+int cstone_hip_malloc(cstone_hip_ctx*, void** ptr, size_t bytes)
+{
+    *ptr = bytes ? std::malloc(bytes) : nullptr;
+    // fresh device memory holds anything: make reads of unwritten bytes visible
+    if (*ptr) std::memset(*ptr, 0xA5, bytes);
+    return (*ptr || !bytes) ? CSTONE_OK : CSTONE_E_HIP;
+}
+int cstone_hip_free(cstone_hip_ctx*, void* ptr)
+{
+    std::free(ptr);
+    return CSTONE_OK;
+}
+int cstone_hip_memcpy_h2d(cstone_hip_ctx*, void* dst, const void* src, size_t bytes)
+{
+    if (bytes) std::memcpy(dst, src, bytes);
+    return CSTONE_OK;
+}
+int cstone_hip_memcpy_d2h(cstone_hip_ctx*, void* dst, const void* src, size_t bytes)
+{
+    if (bytes) std::memcpy(dst, src, bytes);
+    return CSTONE_OK;
+}
+int cstone_hip_memcpy_d2d(cstone_hip_ctx*, void* dst, const void* src, size_t bytes)
+{
+    if (bytes) std::memmove(dst, src, bytes);
+    return CSTONE_OK;
+}
+int cstone_hip_memset(cstone_hip_ctx*, void* dst, int value, size_t bytes)
+{
+    if (bytes) std::memset(dst, value, bytes);
+    return CSTONE_OK;
+}
+
+int cstone_hip_gather(cstone_hip_ctx*, int elem_bytes, const uint32_t* map, size_t n, const void* src, void* dst)
+{
+    for (size_t i = 0; i < n; ++i)
+        std::memcpy((char*)dst + i * elem_bytes, (const char*)src + size_t(map[i]) * elem_bytes, elem_bytes);
+    return CSTONE_OK;
+}
+int cstone_hip_scatter(cstone_hip_ctx*, int elem_bytes, const uint32_t* map, size_t n, const void* src, void* dst)
+{
+    for (size_t i = 0; i < n; ++i)
+        std::memcpy((char*)dst + size_t(map[i]) * elem_bytes, (const char*)src + i * elem_bytes, elem_bytes);
+    return CSTONE_OK;
+}
+int cstone_hip_fill(cstone_hip_ctx*, int elem_bytes, void* dst, size_t n, const void* value_host)
+{
+    for (size_t i = 0; i < n; ++i)
+        std::memcpy((char*)dst + i * elem_bytes, value_host, elem_bytes);
+    return CSTONE_OK;
+}
+int cstone_hip_count_equal(cstone_hip_ctx*, int elem_bits, const void* data, size_t n, uint64_t value,
+                           uint64_t* count_host)
+{
+    uint64_t c = 0;
+    for (size_t i = 0; i < n; ++i)
+        c += (elem_bits == 32 ? uint64_t(((const uint32_t*)data)[i]) : ((const uint64_t*)data)[i]) == value;
+    *count_host = c;
+    return CSTONE_OK;
+}
+int cstone_hip_exclusive_scan_u32(cstone_hip_ctx*, const uint32_t* in, uint32_t* out, size_t n, uint32_t init)
+{
+    uint32_t run = init;
+    for (size_t i = 0; i < n; ++i)
+    {
+        uint32_t v = in[i];
+        out[i]     = run;
+        run += v;
+    }
+    return CSTONE_OK;
+}
+int cstone_hip_inclusive_scan_u32(cstone_hip_ctx*, const uint32_t* in, uint32_t* out, size_t n)
+{
+    uint32_t run = 0;
+    for (size_t i = 0; i < n; ++i)
+    {
+        run += in[i];
+        out[i] = run;
+    }
+    return CSTONE_OK;
+}
+int cstone_hip_lower_bound(cstone_hip_ctx*, int key_bits, const void* keys, size_t n, const void* values, int num_values,
+                           uint64_t* result)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       auto* a = (const K*)keys;
+                       for (int q = 0; q < num_values; ++q)
+                           result[q] = uint64_t(std::lower_bound(a, a + n, ((const K*)values)[q]) - a);
+                   });
+}
+int cstone_hip_sort_keys(cstone_hip_ctx*, int key_bits, void* keys, size_t n)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       std::sort((K*)keys, (K*)keys + n);
+                   });
+}
+int cstone_hip_gather_ranges(cstone_hip_ctx*, int elem_bytes, int index_bits, const void* range_scan,
+                             const void* range_offsets, int num_ranges, const void* src, void* buffer, size_t buffer_size)
+{
+    if (index_bits != 32) return CSTONE_E_ARG;
+    auto* scan = (const uint32_t*)range_scan;
+    auto* off  = (const uint32_t*)range_offsets;
+    for (size_t i = 0; i < buffer_size; ++i)
+    {
+        int r = int(std::upper_bound(scan, scan + num_ranges, uint32_t(i)) - scan) - 1;
+        std::memcpy((char*)buffer + i * elem_bytes, (const char*)src + size_t(off[r] + uint32_t(i) - scan[r]) * elem_bytes,
+                    elem_bytes);
+    }
+    return CSTONE_OK;
+}
+
+int cstone_hip_compute_node_counts(cstone_hip_ctx*, int key_bits, const void* tree, uint32_t* counts, int num_nodes,
+                                   const void* keys, size_t n, uint32_t max_count)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       nodeCounts<K>((const K*)tree, counts, num_nodes, (const K*)keys, n, max_count);
+                   });
+}
+int cstone_hip_compute_node_ops(cstone_hip_ctx*, int key_bits, const void* tree, int num_nodes, const uint32_t* counts,
+                                uint32_t bucket_size, int32_t* node_ops, int* new_num_nodes_host, int* converged_host)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K         = decltype(k);
+                       *converged_host = rebalanceDecision<K>((const K*)tree, counts, num_nodes, bucket_size, node_ops);
+                       int32_t run     = 0;
+                       for (int i = 0; i <= num_nodes; ++i)
+                       {
+                           int32_t t   = i < num_nodes ? node_ops[i] : 0;
+                           node_ops[i] = run;
+                           run += t;
+                       }
+                       *new_num_nodes_host = node_ops[num_nodes];
+                   });
+}
+int cstone_hip_rebalance_tree(cstone_hip_ctx*, int key_bits, const void* tree, int num_nodes, int new_num_nodes,
+                              const int32_t* node_ops, void* new_tree)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       // processNode, R/tree/csarray.hpp:360-385, with the scanned ops
+                       using K  = decltype(k);
+                       auto* t  = (const K*)tree;
+                       auto* nt = (K*)new_tree;
+                       for (int i = 0; i < num_nodes; ++i)
+                       {
+                           int32_t cnt = node_ops[i + 1] - node_ops[i];
+                           if (cnt == 0) continue;
+                           unsigned level = levelOfSpan<K>(t[i + 1] - t[i]);
+                           unsigned down  = cnt == 1 ? 0 : log8ceil<unsigned>(unsigned(cnt));
+                           K step         = nodeSpan<K>(level + down);
+                           for (int32_t s = 0; s < cnt; ++s)
+                               nt[node_ops[i] + s] = t[i] + K(s) * step;
+                       }
+                       nt[new_num_nodes] = t[num_nodes];
+                   });
+}
+int cstone_hip_build_octree(cstone_hip_ctx*, int key_bits, const void* leaves, int num_leaves, void* prefixes,
+                            int32_t* child_offsets, int32_t* parents, int32_t* level_range, int32_t* internal_to_leaf,
+                            int32_t* leaf_to_internal)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       LinkedOctree<K> o;
+                       buildLinkedOctree<K>((const K*)leaves, num_leaves, o);
+                       std::copy(o.prefixes.begin(), o.prefixes.end(), (K*)prefixes);
+                       std::copy(o.childOffsets.begin(), o.childOffsets.end(), child_offsets);
+                       std::copy(o.parents.begin(), o.parents.end(), parents);
+                       std::copy(o.levelRange.begin(), o.levelRange.end(), level_range);
+                       std::copy(o.internalToLeaf.begin(), o.internalToLeaf.end(), internal_to_leaf);
+                       std::copy(o.leafToInternal.begin(), o.leafToInternal.end(), leaf_to_internal);
+                   });
+}
+int cstone_hip_upsweep_sum(cstone_hip_ctx*, int num_levels_plus2, const int32_t* level_range, const int32_t* child_offsets,
+                           uint32_t* counts)
+{
+    upsweepCounts(level_range, num_levels_plus2, child_offsets, counts);
+    return CSTONE_OK;
+}
+int cstone_hip_node_centers(cstone_hip_ctx*, int curve, int key_bits, int real_bits, const void* prefixes, int num_nodes,
+                            const cstone_box* box_host, void* centers, void* sizes)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    nodeCenters<K, T>(Curve(curve), (const K*)prefixes, num_nodes, mkBox<T>(box_host),
+                                                      (T*)centers, (T*)sizes);
+                                });
+                   });
+}
+int cstone_hip_halo_radii(cstone_hip_ctx*, int h_bits, const void* h, const uint32_t* layout, int first, int last,
+                          int num_leaves, float ext, float* radii)
+{
+    return withReal(h_bits,
+                    [&](auto t)
+                    {
+                        using T = decltype(t);
+                        haloRadii<T>((const T*)h, layout, first, last, num_leaves, ext, radii);
+                    });
+}
+int cstone_hip_find_halos(cstone_hip_ctx*, int curve, int key_bits, int real_bits, const void* prefixes,
+                          const int32_t* child_offsets, const int32_t* internal_to_leaf, const void* leaves,
+                          const float* radii, const cstone_box* box_host, int first, int last, int32_t* flags)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    findHalos<K, T, float>(Curve(curve), (const K*)prefixes, child_offsets,
+                                                           internal_to_leaf, (const K*)leaves, radii, mkBox<T>(box_host),
+                                                           first, last, flags);
+                                });
+                   });
+}
+
+int cstone_hip_rebalance_decision_essential(cstone_hip_ctx*, int key_bits, const void* prefixes,
+                                            const int32_t* child_offsets, const int32_t* parents, const uint32_t* counts,
+                                            const char* macs, uint64_t focus_start, uint64_t focus_end,
+                                            uint32_t bucket_size, int32_t* node_ops, int num_nodes)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       essentialOps<K>((const K*)prefixes, child_offsets, parents, counts, macs, K(focus_start),
+                                       K(focus_end), bucket_size, node_ops, num_nodes);
+                   });
+}
+int cstone_hip_mac_refine_decision(cstone_hip_ctx*, int key_bits, const void* prefixes, const char* macs,
+                                   const int32_t* leaf_to_internal, int num_leaves, int focus_first, int focus_last,
+                                   int32_t* node_ops)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       macRefineOps<K>((const K*)prefixes, macs, leaf_to_internal, num_leaves, focus_first, focus_last,
+                                       node_ops);
+                   });
+}
+int cstone_hip_protect_ancestors(cstone_hip_ctx*, int key_bits, const void* prefixes, const int32_t* parents,
+                                 int32_t* node_ops, int num_nodes, int* converged_host)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K         = decltype(k);
+                       *converged_host = protectAncestors<K>((const K*)prefixes, parents, node_ops, num_nodes) ? 1 : 0;
+                   });
+}
+int cstone_hip_enforce_keys(cstone_hip_ctx*, int key_bits, const void* forced_keys, int num_forced_keys,
+                            const void* prefixes, const int32_t* child_offsets, const int32_t* parents, int32_t* node_ops,
+                            int* status_host)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K      = decltype(k);
+                       *status_host = enforceKeys<K>((const K*)forced_keys, num_forced_keys, (const K*)prefixes,
+                                                     child_offsets, parents, node_ops);
+                   });
+}
+int cstone_hip_range_count(cstone_hip_ctx*, int key_bits, const void* leaves, int num_leaves, const uint32_t* counts,
+                           const void* leaves_focus, const int32_t* leaves_focus_idx, int num_idx, uint32_t* counts_focus)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       rangeCount<K>((const K*)leaves, num_leaves, counts, (const K*)leaves_focus, leaves_focus_idx,
+                                     num_idx, counts_focus);
+                   });
+}
+int cstone_hip_mark_macs(cstone_hip_ctx*, int curve, int key_bits, int real_bits, const void* prefixes,
+                         const int32_t* child_offsets, const void* centers, const cstone_box* box_host,
+                         const void* focus_nodes, int num_focus_nodes, int limit_source, char* markings)
+{
+    if (num_focus_nodes <= 0) return CSTONE_OK;
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    markMacs<K, T>(Curve(curve), (const K*)prefixes, child_offsets, (const T*)centers,
+                                                   mkBox<T>(box_host), (const K*)focus_nodes, num_focus_nodes,
+                                                   limit_source != 0, markings);
+                                });
+                   });
+}
+int cstone_hip_count_sfc_gaps(cstone_hip_ctx*, int key_bits, const void* tree, int num_nodes, int32_t* node_ops)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       // countSfcGapsKernel, R/tree/csarray_gpu.cu:232-240
+                       using K = decltype(k);
+                       auto* t = (const K*)tree;
+                       for (int i = 0; i < num_nodes; ++i)
+                           node_ops[i] = t[i + 1] > t[i] ? spanRange<K>(t[i], t[i + 1], nullptr) : 0;
+                   });
+}
+int cstone_hip_fill_sfc_gaps(cstone_hip_ctx*, int key_bits, const void* tree, int num_nodes, const int32_t* node_ops,
+                             void* new_tree)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       // fillSfcGapsKernel, R/tree/csarray_gpu.cu:243-255
+                       using K  = decltype(k);
+                       auto* t  = (const K*)tree;
+                       auto* nt = (K*)new_tree;
+                       for (int i = 0; i < num_nodes; ++i)
+                           if (t[i + 1] > t[i]) spanRange<K>(t[i], t[i + 1], nt + node_ops[i]);
+                       nt[node_ops[num_nodes]] = t[num_nodes];
+                   });
+}
+int cstone_hip_geo_mac_spheres(cstone_hip_ctx*, int curve, int key_bits, int real_bits, const void* prefixes,
+                               int num_nodes, void* spheres, float inv_theta, const cstone_box* box_host)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    macSpheres<K, T>(Curve(curve), 0, (const K*)prefixes, num_nodes, (T*)spheres,
+                                                     inv_theta, mkBox<T>(box_host));
+                                });
+                   });
+}
+int cstone_hip_find_peers_mac(cstone_hip_ctx*, int curve, int key_bits, int real_bits, const void* prefixes,
+                              const int32_t* child_offsets, const int32_t* level_range, const uint64_t* assignment_host,
+                              int num_ranks, int my_rank, const cstone_box* box_host, float inv_theta_eff,
+                              int32_t* peer_flags_host)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       std::vector<K> a(num_ranks + 1);
+                       for (int r = 0; r <= num_ranks; ++r)
+                           a[r] = K(assignment_host[r]);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    findPeersMac<K, T>(Curve(curve), (const K*)prefixes, child_offsets, level_range,
+                                                       a.data(), num_ranks, my_rank, mkBox<T>(box_host), inv_theta_eff,
+                                                       peer_flags_host);
+                                });
+                   });
+}
+
+// ---- the key-array steps of the treelet exchange and the halo layout (own design of the ABI: plain loops) ---------------
+int cstone_hip_keys_missing(cstone_hip_ctx*, int key_bits, const void* leaves, int num_leaves, const void* keys,
+                            size_t num_keys, uint32_t* flags)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       auto* l = (const K*)leaves;
+                       for (size_t i = 0; i < num_keys; ++i)
+                       {
+                           K key    = ((const K*)keys)[i];
+                           flags[i] = key != l[std::lower_bound(l, l + num_leaves, key) - l];
+                       }
+                   });
+}
+int cstone_hip_partition_keys(cstone_hip_ctx*, int key_bits, const void* keys, const uint32_t* flags, const uint32_t* scan,
+                              size_t num_keys, void* set_out, void* unset_out)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       for (size_t i = 0; i < num_keys; ++i)
+                       {
+                           K key = ((const K*)keys)[i];
+                           if (flags[i])
+                           {
+                               if (set_out) ((K*)set_out)[scan[i]] = key;
+                           }
+                           else if (unset_out) { ((K*)unset_out)[i - scan[i]] = key; }
+                       }
+                   });
+}
+int cstone_hip_zero_ops_at_keys(cstone_hip_ctx*, int key_bits, const void* leaves, int num_leaves, const void* keys,
+                                size_t num_keys, int32_t* node_ops)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       auto* l = (const K*)leaves;
+                       for (size_t i = 0; i < num_keys; ++i)
+                           node_ops[std::lower_bound(l, l + num_leaves + 1, ((const K*)keys)[i]) - l] = 0;
+                   });
+}
+int cstone_hip_locate_nodes(cstone_hip_ctx*, int key_bits, const void* keys, size_t num_keys, const void* prefixes,
+                            const int32_t* level_range, int32_t* idx)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       auto* q = (const K*)keys;
+                       for (size_t i = 0; i + 1 < num_keys; ++i)
+                           idx[i] = locateNode<K>(q[i], q[i + 1], (const K*)prefixes, level_range);
+                   });
+}
+int cstone_hip_node_layout(cstone_hip_ctx*, const uint32_t* counts, const int32_t* flags, int first, int last,
+                           int num_leaves, uint32_t* layout)
+{
+    uint32_t run = 0;
+    for (int i = 0; i < num_leaves; ++i)
+    {
+        bool have = (first <= i && i < last) || flags[i];
+        layout[i] = run;
+        run += have ? counts[i] : 0u;
+    }
+    layout[num_leaves] = run;
+    return CSTONE_OK;
+}
+int cstone_hip_halo_requests(cstone_hip_ctx*, int key_bits, const void* leaves, const int32_t* flags, int num_leaves,
+                             int first, int last, const int32_t* ranges_host, int num_ranks, void* pairs_out,
+                             uint32_t* pair_counts_host, uint32_t* unmatched_host)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       // extractMarkedElements per peer, R/domain/layout.hpp:104-139
+                       using K  = decltype(k);
+                       auto* l  = (const K*)leaves;
+                       auto* o  = (K*)pairs_out;
+                       size_t n = 0;
+                       std::vector<char> owned(num_leaves, 0);
+                       for (int r = 0; r < num_ranks; ++r)
+                       {
+                           int a = ranges_host[2 * r], b = ranges_host[2 * r + 1];
+                           uint32_t pairs = 0;
+                           while (a != b)
+                           {
+                               while (a < b && flags[a] == 0)
+                                   owned[a++] = 1;
+                               if (a != b)
+                               {
+                                   o[n++] = l[a];
+                                   while (a < b && flags[a] == 1)
+                                       owned[a++] = 1;
+                                   o[n++] = l[a];
+                                   ++pairs;
+                               }
+                           }
+                           pair_counts_host[r] = pairs;
+                       }
+                       uint32_t bad = 0;
+                       for (int i = 0; i < num_leaves; ++i)
+                           if (flags[i] && !owned[i] && (i < first || i >= last)) ++bad;
+                       *unmatched_host = bad;
+                   });
+}
+int cstone_hip_ranges_from_keys(cstone_hip_ctx*, int key_bits, const void* leaves, int num_leaves, const uint32_t* layout,
+                                const void* pairs, size_t num_pairs, uint32_t* range_offsets, uint32_t* range_scan)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K      = decltype(k);
+                       auto* l      = (const K*)leaves;
+                       auto* p      = (const K*)pairs;
+                       uint32_t run = 0;
+                       for (size_t r = 0; r < num_pairs; ++r)
+                       {
+                           uint32_t lo = layout[std::lower_bound(l, l + num_leaves + 1, p[2 * r]) - l];
+                           uint32_t hi = layout[std::lower_bound(l, l + num_leaves + 1, p[2 * r + 1]) - l];
+                           range_offsets[r] = lo;
+                           range_scan[r]    = run;
+                           run += hi - lo;
+                       }
+                       range_scan[num_pairs] = run;
+                   });
+}
+
+} // extern "C"

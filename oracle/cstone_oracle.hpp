@@ -1352,4 +1352,106 @@ void binaryTree(const K* codes, NodeIdx numCodes, NodeIdx* child, K* prefix)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// peers of a rank and node lookup (locally essential tree on several ranks), R/traversal/peers.hpp, R/tree/octree.hpp
+// ---------------------------------------------------------------------------------------------------------------------
+
+//! node with key range [start, end): locateNode, R/tree/octree.hpp:216-241; numNodes if there is none
+template<class K>
+inline NodeIdx locateNode(K start, K end, const K* prefixes, const NodeIdx* levelRange)
+{
+    NodeIdx numNodes = levelRange[maxLevel<K>() + 1];
+    int bits         = clz<K>(K(end - start - 1)) - int(KeyInfo<K>::spare);
+    K want           = toPrefix<K>(start, bits);
+    unsigned level   = unsigned(bits) / 3;
+    const K* it = std::lower_bound(prefixes + levelRange[level], prefixes + levelRange[level + 1], want);
+    if (it != prefixes + numNodes && *it == want) return NodeIdx(it - prefixes);
+    return numNodes;
+}
+
+/*! findPeersMac, R/traversal/peers.hpp:63-118: ranks that own a leaf of the (replicated) global tree which fails the
+ *  mutual MAC (minVecMacMutual, R/traversal/macs.hpp:171-194) paired with a leaf of @p myRank's range; dual traversal
+ *  R/traversal/traversal.hpp:135-188 from every node that spans the range.  peerFlags[numRanks] gets 0 / 1. */
+template<class K, class T>
+void findPeersMac(Curve c, const K* prefixes, const NodeIdx* childOffsets, const NodeIdx* levelRange, const K* assignment,
+                  int numRanks, int myRank, const Box<T>& box, float invThetaEff, int* peerFlags)
+{
+    std::fill(peerFlags, peerFlags + numRanks, 0);
+    const K domainStart = assignment[myRank], domainEnd = assignment[myRank + 1];
+    auto isLeaf = [&](NodeIdx n) { return childOffsets[n] == 0; };
+    auto level  = [&](NodeIdx n) { return prefixBits(prefixes[n]) / 3; };
+    auto start  = [&](NodeIdx n) { return fromPrefix(prefixes[n]); };
+    auto end    = [&](NodeIdx n) { return K(fromPrefix(prefixes[n]) + nodeSpan<K>(level(n))); };
+    // minDistance(X, bCenter, bSize, box), R/traversal/boxoverlap.hpp:208-218, squared
+    auto dist2 = [&](const T (&X)[3], const T (&bc)[3], const T (&bs)[3])
+    {
+        T dX[3];
+        for (int d = 0; d < 3; ++d)
+        {
+            T dx = bc[d] - X[d];
+            dx -= T(box.bc[d] == 1) * box.len[d] * std::rint(dx * box.inv[d]);
+            dx = std::abs(dx);
+            dx -= bs[d];
+            dx += std::abs(dx);
+            dx *= T(0.5);
+            dX[d] = dx;
+        }
+        return dX[0] * dX[0] + (dX[1] * dX[1] + dX[2] * dX[2]);
+    };
+    auto follows = [&](NodeIdx a, NodeIdx b)
+    {
+        bool aFocusOverlap = domainStart < end(a) && start(a) < domainEnd;      // overlapTwoRanges
+        bool bInFocus      = start(b) >= domainStart && end(b) <= domainEnd;    // containedIn
+        if (!aFocusOverlap || bInFocus) return false;
+        T ac[3], as[3], bc[3], bs[3];
+        centerAndSize<K, T>(nodeIBox<K>(c, start(a), level(a)), box, ac, as);
+        centerAndSize<K, T>(nodeIBox<K>(c, start(b), level(b)), box, bc, bs);
+        T macA     = std::max(bs[0], std::max(bs[1], bs[2])) * 2 * invThetaEff;
+        bool passA = dist2(bc, ac, as) > macA * macA;
+        T macB     = std::max(as[0], std::max(as[1], as[2])) * 2 * invThetaEff;
+        bool passB = dist2(ac, bc, bs) > macB * macB;
+        return !(passA && passB);
+    };
+    auto mark = [&](NodeIdx b)
+    {
+        int rank = int(std::upper_bound(assignment, assignment + numRanks + 1, start(b)) - assignment) - 1;
+        peerFlags[rank] = 1;
+    };
+    std::vector<K> span(size_t(spanRange<K>(domainStart, domainEnd, nullptr)) + 1);
+    spanRange<K>(domainStart, domainEnd, span.data());
+    span.back() = domainEnd;
+    for (size_t i = 0; i + 1 < span.size(); ++i)
+    {
+        NodeIdx a0 = locateNode<K>(span[i], span[i + 1], prefixes, levelRange);
+        if (isLeaf(a0) && isLeaf(0))
+        {
+            if (follows(a0, 0)) mark(0);
+            continue;
+        }
+        std::vector<std::pair<NodeIdx, NodeIdx>> stack{{a0, 0}};
+        auto interact = [&](NodeIdx a, NodeIdx b)
+        {
+            if (!follows(a, b)) return;
+            if (isLeaf(a) && isLeaf(b)) mark(b);
+            else stack.push_back({a, b});
+        };
+        while (!stack.empty())
+        {
+            auto [target, source] = stack.back();
+            stack.pop_back();
+            if ((level(target) < level(source) && !isLeaf(target)) || isLeaf(source))
+            {
+                if (!isLeaf(target))
+                    for (int oct = 0; oct < 8; ++oct)
+                        interact(childOffsets[target] + oct, source);
+            }
+            else if (!isLeaf(source))
+            {
+                for (int oct = 0; oct < 8; ++oct)
+                    interact(target, childOffsets[source] + oct);
+            }
+        }
+    }
+}
+
 } // namespace orc

@@ -1,0 +1,57 @@
+"""The product's host state machine of the locally essential tree (cornerstone-octree_amd/csrc/let.hpp: plain C++ over
+the C ABI) against the REFERENCE's own FocusedOctree / Halos / findPeersMac, rank by rank under mpiexec
+(oracle/let_check.cpp).  In this CPU suite the C ABI underneath is served by the CPU restatement
+(oracle/cabi_on_oracle.cpp), so the comparison needs no GPU: peers, focus leaves, leaf and node counts, linked octree,
+focus assignment, halo flags, layout, start / end index, buffer size, node centres and the halo particles must all be
+equal after every sync, and the run must have gone through the rarer paths (focus transfer, MAC refinement, key
+injection, rejected treelet keys, counts from the global tree)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "let_check")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists(MPIEXEC)),
+                                reason="oracle/_ref/let_check (reference + MPI build) not present")
+
+
+def run(ranks, *args, timeout=900):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run([MPIEXEC, "-n", str(ranks), EXE] + [str(a) for a in args], capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd="/tmp")
+    out = p.stdout + p.stderr
+    assert p.returncode == 0 and "LET_CHECK OK" in out, out[-3000:]
+    m = re.search(r"LET_PATHS (.*)", out)
+    return {k: int(v) for k, v in (kv.split("=") for kv in m.group(1).split())}
+
+
+# types, particles, syncs, bucket, bucketFocus, boundaries, kind (0 uniform, 1 blobs, 2 drifting blobs), seed
+@pytest.mark.parametrize("ranks,args", [
+    (1, ("k64f64", 12000, 3, 64, 8, 0, 0, 0, 0, 101)),
+    (2, ("k64f64", 12000, 3, 64, 8, 0, 0, 0, 0, 101)),
+    (3, ("k64f64", 15000, 3, 64, 8, 1, 1, 1, 1, 102)),
+    (4, ("k64f64", 16000, 4, 96, 16, 0, 0, 0, 1, 103)),
+    (2, ("k64f32", 10000, 3, 64, 16, 1, 1, 1, 0, 107)),
+])
+def test_let_equals_reference(ranks, args):
+    paths = run(ranks, *args)
+    assert paths["treeUpdates"] >= ranks * args[2]
+
+
+def test_let_equals_reference_when_the_assignment_moves():
+    """drifting blobs: the SFC ranges of the ranks move every sync, parts of the focus trees change owner"""
+    paths = run(5, "k32f32", 12000, 4, 64, 8, 0, 0, 0, 2, 106)
+    assert paths["focusTransfers"] > 0 and paths["keysTransferred"] > 0
+    assert paths["macRefineSteps"] > 0 and paths["keysInjected"] > 0 and paths["keysRejected"] > 0
+    paths = run(3, "k64f32", 10000, 5, 64, 16, 1, 0, 2, 2, 107)
+    assert paths["focusTransfers"] > 0 and paths["macRefineSteps"] > 0
+
+
+def test_let_equals_reference_with_ranks_that_are_no_peers():
+    """12 ranks: far ranks are no peers, their regions get their counts from the global tree"""
+    paths = run(12, "k64f64", 24000, 3, 32, 8, 0, 0, 0, 0, 104)
+    assert paths["leavesFromGlobal"] > 0
