@@ -30,6 +30,7 @@
 #include "ctx.hpp"
 #include "devbuf.hpp"
 #include "device_keys.hpp"
+#include "let.hpp"
 #include "resort.hpp"
 #include "scan.hpp"
 
@@ -309,6 +310,8 @@ struct MrBase
     virtual int exchangeHalos(void* array, int elemBytes)                                = 0;
     virtual int reapplySync(const void* in, size_t n, int elemBytes, void* out)          = 0;
     virtual int octree(cstone_hip_domain_mr_octree* out)                                 = 0;
+    virtual int setHaloMode(int mode)                                                    = 0;
+    virtual int setTheta(float theta)                                                    = 0;
 };
 
 template<class K, class T>
@@ -332,6 +335,24 @@ public:
 
     void setHaloFactor(float f) override { haloExt_ = f; }
 
+    //! before the first sync: how halos are found (CSTONE_MR_HALOS_LET: the reference's way, CSTONE_MR_HALOS_OWNER_SIDE)
+    int setHaloMode(int mode) override
+    {
+        if (!firstCall_) return fail(ctx_, CSTONE_E_ARG, "domain_mr_set_halo_mode: only before the first sync");
+        if (mode != CSTONE_MR_HALOS_LET && mode != CSTONE_MR_HALOS_OWNER_SIDE)
+            return fail(ctx_, CSTONE_E_ARG, "domain_mr_set_halo_mode: unknown mode %d", mode);
+        useLet_ = mode == CSTONE_MR_HALOS_LET;
+        return CSTONE_OK;
+    }
+
+    //! before the first sync: the opening angle of the focus tree's MAC (Domain ctor, R/domain/domain.hpp:95-113)
+    int setTheta(float theta) override
+    {
+        if (!firstCall_ || !(theta > 0.0f)) return fail(ctx_, CSTONE_E_ARG, "domain_mr_set_theta: only before the first sync");
+        theta_ = theta;
+        return CSTONE_OK;
+    }
+
     /*! Domain::exchangeHalos (R/domain/domain.hpp:381-386, R/halos/halos.hpp:224-257): repeats the halo exchange of the
      *  last sync for another field.  array: device, laid out like the result arrays (num_particles_with_halos elements
      *  of 1, 2, 4, 8, 12, 16, 24 or 32 bytes); its assigned range is read, its halo ranges are overwritten. */
@@ -342,6 +363,7 @@ public:
             elemBytes != 24 && elemBytes != 32)
             return fail(ctx_, CSTONE_E_ARG, "exchange_halos: element size %d", elemBytes);
         if (firstCall_) return fail(ctx_, CSTONE_E_ARG, "exchange_halos: no sync yet");
+        if (useLet_) return let_->exchangeHalos(array, elemBytes);
         uint64_t any = 0;
         for (int p = 0; p < P_; ++p)
             any += haloSend_[p] + haloRecv_[p];
@@ -424,6 +446,20 @@ public:
     int octree(cstone_hip_domain_mr_octree* out) override
     {
         if (firstCall_) return fail(ctx_, CSTONE_E_ARG, "domain_mr_octree: no sync yet");
+        if (useLet_)
+        {
+            // Domain::octreeProperties() is the focus tree itself (R/domain/domain.hpp:425-437): leaves whose particles
+            // are not here have empty layout ranges
+            const FocusLet<K, T>& t = *let_;
+            out->num_leaves = t.numLeaves(), out->num_nodes = t.numNodes();
+            out->leaves = t.leaves(), out->leaf_counts = t.leafCounts();
+            out->prefixes = t.prefixes(), out->child_offsets = t.childOffsets();
+            out->parents = t.parents(), out->level_range = t.levelRange();
+            out->internal_to_leaf = t.internalToLeaf(), out->leaf_to_internal = t.leafToInternal();
+            out->layout = t.layout();
+            out->centers = t.geoCenters(), out->sizes = t.geoSizes();
+            return CSTONE_OK;
+        }
         if (nsSync_ != syncs_)
         {
             CS_TRY(buildNsTree());
@@ -544,13 +580,13 @@ public:
             const char* e = std::getenv("CSTONE_MR_RESORT_MIN");
             return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(1) << 25;
         }();
-        const bool tryResort = !firstCall_ && n >= resortMin && n == layoutParticles_ && tileLeaves > 0 && sameBox && fLeaves_ > 0 &&
+        const bool tryResort = !firstCall_ && n >= resortMin && n == layoutParticles_ && tileLeaves > 0 && sameBox && resortLeaves_ > 0 &&
                                resortBackoff_ == 0 && !pending_ && std::getenv("CSTONE_NO_RESORT") == nullptr &&
                                std::getenv("CSTONE_FULL_SORT") == nullptr;
         if (resortBackoff_ > 0) --resortBackoff_;
         if (tryResort)
         {
-            CS_TRY(resort_.prepare(ctx_, fTree_.as<K>(), layout_.as<uint32_t>(), fLeaves_, n, keysAlt_.as<K>(),
+            CS_TRY(resort_.prepare(ctx_, resortTree_, layout_.as<uint32_t>(), resortLeaves_, n, keysAlt_.as<K>(),
                                    lastMovers_ > 100000));
             const ResortArgs<K> ra = resort_.args();
             bool done              = false;
@@ -783,168 +819,211 @@ public:
         }
         tick("4 exchange+merge+place");
 
-        // ---- this rank's finest tree over its assigned particles; its SFC range must end on leaf boundaries
-        CS_TRY(updateFocusTree(keysM, nm));
-        tick("5a focus update");
-        int first = 0, last = 0;
-        CS_TRY(enforceBoundaries(keysM, nm, &first, &last));
-        tick("5b boundaries");
-        CS_TRY(buildFocusOctree());
-        tick("5c linked octree");
-        // the level ranges are only needed by the NEXT sync (how many digits to sort): they travel to a pinned block of
-        // this domain now and are looked at then, behind many later synchronisations of the stream
-        if (!hostLevelRange_)
-            CS_HIP(ctx_, hipHostMalloc(reinterpret_cast<void**>(&hostLevelRange_), 32 * sizeof(NodeIdx), hipHostMallocDefault));
-        CS_HIP(ctx_, hipMemcpyAsync(hostLevelRange_, fLevelRange_.p, (maxLevel<K>() + 2) * sizeof(NodeIdx),
-                                    hipMemcpyDeviceToHost, ctx_->stream));
-        levelRangePending_ = true;
-        const int L = fLeaves_;
-        CS_TRY(layout_.ensure(ctx_, size_t(L + 1) * sizeof(uint32_t)));
-        CS_HIP(ctx_, hipMemsetAsync(layout_.p, 0, sizeof(uint32_t), ctx_->stream));
-        CS_TRY(cstone_hip_inclusive_scan_u32(ctx_, fCounts_.as<uint32_t>(), layout_.as<uint32_t>() + 1, size_t(L)));
-        layoutParticles_ = nm; // the next sync's re-sort starts from this layout: nm particles in this box
-        layoutBox_       = box_;
-        tick("5 focus tree");
-
-        // ---- C4: owner-side halo discovery
         std::vector<uint64_t> hsCounts(P_, 0), hmatrix(size_t(P_) * P_, 0);
         uint64_t numMyBoxes = 0, selTotal = 0;
-        if (P_ > 1)
+        uint64_t nlo = 0, nhi = 0, haloAny = 0; // haloAny: the same on every rank, it decides about the collective
+        std::vector<size_t> hSendBytes(P_, 0), hRecvBytes(P_, 0);
+        if (useLet_)
         {
-            const int nLocal = last - first;
-            CS_TRY(radii_.ensure(ctx_, size_t(L) * sizeof(float)));
-            CS_TRY(boxes_.ensure(ctx_, size_t(std::max(nLocal, 1)) * 32));
-            CS_TRY(boxFlags_.ensure(ctx_, size_t(nLocal + 1) * sizeof(uint32_t)));
-            CS_TRY(cstone_hip_halo_radii(ctx_, rb, o.h.as<T>() + M, layout_.as<uint32_t>() + first, first, last, L, haloExt_,
-                                         radii_.as<float>()));
-            // only boxes that really reach a leaf outside my range are exported (a third to a tenth of those the
-            // enclosing-node test alone lets through: less to gather, fewer targets for every owner's traversal)
-            CS_TRY(cstone_hip_halo_boxes_foreign(ctx_, curve_, kb, rb, fPrefixes_.p, fChild_.as<int32_t>(),
-                                                 fItl_.as<int32_t>(), fTree_.p, radii_.as<float>(), &box_, first, last,
-                                                 boxes_.as<int32_t>()));
-            hipLaunchKernelGGL(boxFlagsKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream, boxes_.as<int32_t>(), nLocal,
-                               boxFlags_.as<uint32_t>());
-            uint32_t* total = scal_.as<uint32_t>() + 16;
-            CS_TRY(exclusiveScanWithTotal(boxFlags_.as<uint32_t>(), nLocal, total));
-            // box counts of everybody straight from the device scalar (one read-back for mine and theirs), then the
-            // boxes themselves padded to the longest list
-            std::vector<uint64_t> boxCounts(P_);
+            // ---- the reference's way (R/domain/domain.hpp:217-237): peers, locally essential tree (focus tree), halo
+            //      discovery on it, key-range requests to the owners -- csrc/let.hpp.  h is in SFC order at o.h + M.
+            if (!let_) let_ = std::make_unique<FocusLet<K, T>>(ctx_, curve_, rank_, P_, bucketFocus_, theta_, comm_);
+            injectFailure("exchange");
+            int rc = let_->update(box_, keysM, size_t(nm), assignment_.data(), gTree_.as<K>(), gCounts_.as<uint32_t>(),
+                                  gLeaves_, o.h.as<T>() + M, haloExt_, pending_ ? rank_ + 1 : 0);
+            if (rc != CSTONE_OK)
             {
-                uint32_t* recv = reinterpret_cast<uint32_t*>(scal_.as<char>() + 4096);
-                injectFailure("exchange");
-                statusW32_ = pending_ ? 1u : 0u; // second word: the status of this rank (a member, see above)
-                CS_HIP(ctx_, hipMemcpyAsync(total + 1, &statusW32_, 4, hipMemcpyHostToDevice, ctx_->stream));
-                CS_TRY(callComm(comm_.all_gather(comm_.user, total, recv, 8), "all_gather (box counts)"));
-                std::vector<uint32_t> c32(size_t(P_) * 2);
-                CS_TRY(toHost(c32.data(), recv, c32.size() * 4));
+                pending_ = 0;
+                if (toggled_) cur_ ^= 1, toggled_ = false;
+                return rc;
+            }
+            if (uint64_t(let_->endIndex() - let_->startIndex()) != nm)
+                return fail(ctx_, CSTONE_E_INTERNAL, "domain_mr_sync: the focus tree counts %u assigned particles, %llu are here",
+                            let_->endIndex() - let_->startIndex(), (unsigned long long)nm);
+            nlo      = let_->startIndex();
+            nhi      = let_->numParticlesWithHalos() - let_->endIndex();
+            haloAny  = 1;
+            selTotal = let_->halosSent();
+            // the leaves of my own range and their offsets among my particles: what the next sync's re-sort starts from
+            const int first = let_->startCell(), last = let_->endCell();
+            fLeaves_        = let_->numLeaves();
+            resortTree_     = let_->leaves() + first;
+            resortLeaves_   = last - first;
+            CS_TRY(layout_.ensure(ctx_, size_t(resortLeaves_ + 1) * sizeof(uint32_t)));
+            CS_TRY(cstone_hip_increment(ctx_, 32, let_->layout() + first, layout_.p, size_t(resortLeaves_) + 1,
+                                        uint64_t(uint32_t(0u - uint32_t(nlo)))));
+            layoutParticles_ = nm;
+            layoutBox_       = box_;
+            if (!hostLevelRange_)
+                CS_HIP(ctx_, hipHostMalloc(reinterpret_cast<void**>(&hostLevelRange_), 32 * sizeof(NodeIdx), hipHostMallocDefault));
+            CS_HIP(ctx_, hipMemcpyAsync(hostLevelRange_, let_->levelRange(), (maxLevel<K>() + 2) * sizeof(NodeIdx),
+                                        hipMemcpyDeviceToHost, ctx_->stream));
+            levelRangePending_ = true;
+            tick("5 focus tree (LET)");
+        }
+        else
+        {
+            // ---- this rank's finest tree over its assigned particles; its SFC range must end on leaf boundaries
+            CS_TRY(updateFocusTree(keysM, nm));
+            tick("5a focus update");
+            int first = 0, last = 0;
+            CS_TRY(enforceBoundaries(keysM, nm, &first, &last));
+            tick("5b boundaries");
+            CS_TRY(buildFocusOctree());
+            tick("5c linked octree");
+            // the level ranges are only needed by the NEXT sync (how many digits to sort): they travel to a pinned block of
+            // this domain now and are looked at then, behind many later synchronisations of the stream
+            if (!hostLevelRange_)
+                CS_HIP(ctx_, hipHostMalloc(reinterpret_cast<void**>(&hostLevelRange_), 32 * sizeof(NodeIdx), hipHostMallocDefault));
+            CS_HIP(ctx_, hipMemcpyAsync(hostLevelRange_, fLevelRange_.p, (maxLevel<K>() + 2) * sizeof(NodeIdx),
+                                        hipMemcpyDeviceToHost, ctx_->stream));
+            levelRangePending_ = true;
+            const int L = fLeaves_;
+            CS_TRY(layout_.ensure(ctx_, size_t(L + 1) * sizeof(uint32_t)));
+            CS_HIP(ctx_, hipMemsetAsync(layout_.p, 0, sizeof(uint32_t), ctx_->stream));
+            CS_TRY(cstone_hip_inclusive_scan_u32(ctx_, fCounts_.as<uint32_t>(), layout_.as<uint32_t>() + 1, size_t(L)));
+            layoutParticles_ = nm; // the next sync's re-sort starts from this layout: nm particles in this box
+            layoutBox_       = box_;
+            resortTree_      = fTree_.as<K>();
+            resortLeaves_    = fLeaves_;
+            tick("5 focus tree");
+
+            // ---- C4: owner-side halo discovery
+            if (P_ > 1)
+            {
+                const int nLocal = last - first;
+                CS_TRY(radii_.ensure(ctx_, size_t(L) * sizeof(float)));
+                CS_TRY(boxes_.ensure(ctx_, size_t(std::max(nLocal, 1)) * 32));
+                CS_TRY(boxFlags_.ensure(ctx_, size_t(nLocal + 1) * sizeof(uint32_t)));
+                CS_TRY(cstone_hip_halo_radii(ctx_, rb, o.h.as<T>() + M, layout_.as<uint32_t>() + first, first, last, L, haloExt_,
+                                             radii_.as<float>()));
+                // only boxes that really reach a leaf outside my range are exported (a third to a tenth of those the
+                // enclosing-node test alone lets through: less to gather, fewer targets for every owner's traversal)
+                CS_TRY(cstone_hip_halo_boxes_foreign(ctx_, curve_, kb, rb, fPrefixes_.p, fChild_.as<int32_t>(),
+                                                     fItl_.as<int32_t>(), fTree_.p, radii_.as<float>(), &box_, first, last,
+                                                     boxes_.as<int32_t>()));
+                hipLaunchKernelGGL(boxFlagsKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream, boxes_.as<int32_t>(), nLocal,
+                                   boxFlags_.as<uint32_t>());
+                uint32_t* total = scal_.as<uint32_t>() + 16;
+                CS_TRY(exclusiveScanWithTotal(boxFlags_.as<uint32_t>(), nLocal, total));
+                // box counts of everybody straight from the device scalar (one read-back for mine and theirs), then the
+                // boxes themselves padded to the longest list
+                std::vector<uint64_t> boxCounts(P_);
+                {
+                    uint32_t* recv = reinterpret_cast<uint32_t*>(scal_.as<char>() + 4096);
+                    injectFailure("exchange");
+                    statusW32_ = pending_ ? 1u : 0u; // second word: the status of this rank (a member, see above)
+                    CS_HIP(ctx_, hipMemcpyAsync(total + 1, &statusW32_, 4, hipMemcpyHostToDevice, ctx_->stream));
+                    CS_TRY(callComm(comm_.all_gather(comm_.user, total, recv, 8), "all_gather (box counts)"));
+                    std::vector<uint32_t> c32(size_t(P_) * 2);
+                    CS_TRY(toHost(c32.data(), recv, c32.size() * 4));
+                    for (int p = 0; p < P_; ++p)
+                    {
+                        if (c32[2 * p + 1] != 0) return agreed(p);
+                        boxCounts[p] = c32[2 * p];
+                    }
+                }
+                const uint32_t nbx = uint32_t(boxCounts[rank_]);
+                numMyBoxes         = nbx;
+                CS_TRY(myBoxes_.ensure(ctx_, size_t(std::max<uint32_t>(nbx, 1)) * 32));
+                hipLaunchKernelGGL(compactBoxesKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream, boxes_.as<int32_t>(),
+                                   boxFlags_.as<uint32_t>(), nLocal, rank_, myBoxes_.as<int32_t>());
+                uint64_t maxBoxes = *std::max_element(boxCounts.begin(), boxCounts.end());
+                if (maxBoxes)
+                {
+                    CS_TRY(myBoxes_.ensure(ctx_, size_t(maxBoxes) * 32, true));
+                    if (maxBoxes > numMyBoxes) // padding records must read "no box"
+                        CS_HIP(ctx_, hipMemsetAsync(myBoxes_.as<char>() + numMyBoxes * 32, 0, (maxBoxes - numMyBoxes) * 32,
+                                                    ctx_->stream));
+                    CS_TRY(allBoxes_.ensure(ctx_, size_t(maxBoxes) * 32 * P_));
+                    CS_TRY(callComm(comm_.all_gather(comm_.user, myBoxes_.p, allBoxes_.p, size_t(maxBoxes) * 32),
+                                    "all_gather (halo boxes)"));
+                }
+                CS_TRY(oflags_.ensure(ctx_, size_t(L) * sizeof(int32_t)));
+                bool haveMatrix = false;
+                if (maxBoxes && P_ <= 32 && !peerLoop_)
+                {
+                    // all peers in one go: the records carry their exporter, find_overlaps sets one bit per exporter
+                    // (two calls: the records before and behind my own); then counts, one scan and one fill for all peers
+                    const int np = P_ - 1;
+                    CS_HIP(ctx_, hipMemsetAsync(oflags_.p, 0, size_t(L) * sizeof(int32_t), ctx_->stream));
+                    if (rank_ > 0)
+                        CS_TRY(cstone_hip_find_overlaps(ctx_, curve_, kb, fPrefixes_.p, fChild_.as<int32_t>(),
+                                                        fItl_.as<int32_t>(), fTree_.p, allBoxes_.as<int32_t>(),
+                                                        int(size_t(rank_) * maxBoxes), first, last, oflags_.as<int32_t>()));
+                    if (rank_ + 1 < P_)
+                        CS_TRY(cstone_hip_find_overlaps(ctx_, curve_, kb, fPrefixes_.p, fChild_.as<int32_t>(),
+                                                        fItl_.as<int32_t>(), fTree_.p,
+                                                        allBoxes_.as<int32_t>() + size_t(rank_ + 1) * maxBoxes * 8,
+                                                        int(size_t(P_ - rank_ - 1) * maxBoxes), first, last,
+                                                        oflags_.as<int32_t>()));
+                    const size_t items = size_t(np) * nLocal;
+                    CS_TRY(cnt_.ensure(ctx_, (items + 1) * sizeof(uint32_t)));
+                    hipLaunchKernelGGL(peerCountsKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream, oflags_.as<int32_t>(),
+                                       layout_.as<uint32_t>(), first, last, P_, rank_, cnt_.as<uint32_t>());
+                    CS_TRY(exclusiveScanWithTotal(cnt_.as<uint32_t>(), int(items), total));
+                    // my row of the count matrix goes from the device into the all-gather of the rows; one read-back
+                    uint64_t* row  = scal_.as<uint64_t>() + 32;
+                    uint64_t* rows = reinterpret_cast<uint64_t*>(scal_.as<char>() + 4096);
+                    hipLaunchKernelGGL(peerTotalsKernel, 1, 64, 0, ctx_->stream, cnt_.as<uint32_t>(), total, nLocal, np,
+                                       rank_, row);
+                    CS_TRY(callComm(comm_.all_gather(comm_.user, row, rows, size_t(P_) * 8), "all_gather (halo counts)"));
+                    hmatrix.assign(size_t(P_) * P_, 0);
+                    CS_TRY(toHost(hmatrix.data(), rows, size_t(P_) * P_ * 8));
+                    haveMatrix = true;
+                    for (int p = 0; p < P_; ++p)
+                    {
+                        hsCounts[p] = hmatrix[size_t(rank_) * P_ + p];
+                        selTotal += hsCounts[p];
+                    }
+                    if (selTotal)
+                    {
+                        CS_TRY(sel_.ensure(ctx_, selTotal * sizeof(uint32_t)));
+                        hipLaunchKernelGGL(peerFillKernel, gridFor(items, 16), 256, 0, ctx_->stream, oflags_.as<int32_t>(),
+                                           layout_.as<uint32_t>(), cnt_.as<uint32_t>(), first, last, P_, rank_,
+                                           sel_.as<uint32_t>());
+                    }
+                }
+                else
+                {
+                CS_TRY(cnt_.ensure(ctx_, size_t(nLocal + 1) * sizeof(uint32_t)));
                 for (int p = 0; p < P_; ++p)
                 {
-                    if (c32[2 * p + 1] != 0) return agreed(p);
-                    boxCounts[p] = c32[2 * p];
-                }
-            }
-            const uint32_t nbx = uint32_t(boxCounts[rank_]);
-            numMyBoxes         = nbx;
-            CS_TRY(myBoxes_.ensure(ctx_, size_t(std::max<uint32_t>(nbx, 1)) * 32));
-            hipLaunchKernelGGL(compactBoxesKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream, boxes_.as<int32_t>(),
-                               boxFlags_.as<uint32_t>(), nLocal, rank_, myBoxes_.as<int32_t>());
-            uint64_t maxBoxes = *std::max_element(boxCounts.begin(), boxCounts.end());
-            if (maxBoxes)
-            {
-                CS_TRY(myBoxes_.ensure(ctx_, size_t(maxBoxes) * 32, true));
-                if (maxBoxes > numMyBoxes) // padding records must read "no box"
-                    CS_HIP(ctx_, hipMemsetAsync(myBoxes_.as<char>() + numMyBoxes * 32, 0, (maxBoxes - numMyBoxes) * 32,
-                                                ctx_->stream));
-                CS_TRY(allBoxes_.ensure(ctx_, size_t(maxBoxes) * 32 * P_));
-                CS_TRY(callComm(comm_.all_gather(comm_.user, myBoxes_.p, allBoxes_.p, size_t(maxBoxes) * 32),
-                                "all_gather (halo boxes)"));
-            }
-            CS_TRY(oflags_.ensure(ctx_, size_t(L) * sizeof(int32_t)));
-            bool haveMatrix = false;
-            if (maxBoxes && P_ <= 32 && !peerLoop_)
-            {
-                // all peers in one go: the records carry their exporter, find_overlaps sets one bit per exporter
-                // (two calls: the records before and behind my own); then counts, one scan and one fill for all peers
-                const int np = P_ - 1;
-                CS_HIP(ctx_, hipMemsetAsync(oflags_.p, 0, size_t(L) * sizeof(int32_t), ctx_->stream));
-                if (rank_ > 0)
-                    CS_TRY(cstone_hip_find_overlaps(ctx_, curve_, kb, fPrefixes_.p, fChild_.as<int32_t>(),
-                                                    fItl_.as<int32_t>(), fTree_.p, allBoxes_.as<int32_t>(),
-                                                    int(size_t(rank_) * maxBoxes), first, last, oflags_.as<int32_t>()));
-                if (rank_ + 1 < P_)
+                    if (p == rank_ || boxCounts[p] == 0) continue;
+                    CS_HIP(ctx_, hipMemsetAsync(oflags_.p, 0, size_t(L) * sizeof(int32_t), ctx_->stream));
                     CS_TRY(cstone_hip_find_overlaps(ctx_, curve_, kb, fPrefixes_.p, fChild_.as<int32_t>(),
                                                     fItl_.as<int32_t>(), fTree_.p,
-                                                    allBoxes_.as<int32_t>() + size_t(rank_ + 1) * maxBoxes * 8,
-                                                    int(size_t(P_ - rank_ - 1) * maxBoxes), first, last,
-                                                    oflags_.as<int32_t>()));
-                const size_t items = size_t(np) * nLocal;
-                CS_TRY(cnt_.ensure(ctx_, (items + 1) * sizeof(uint32_t)));
-                hipLaunchKernelGGL(peerCountsKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream, oflags_.as<int32_t>(),
-                                   layout_.as<uint32_t>(), first, last, P_, rank_, cnt_.as<uint32_t>());
-                CS_TRY(exclusiveScanWithTotal(cnt_.as<uint32_t>(), int(items), total));
-                // my row of the count matrix goes from the device into the all-gather of the rows; one read-back
-                uint64_t* row  = scal_.as<uint64_t>() + 32;
-                uint64_t* rows = reinterpret_cast<uint64_t*>(scal_.as<char>() + 4096);
-                hipLaunchKernelGGL(peerTotalsKernel, 1, 64, 0, ctx_->stream, cnt_.as<uint32_t>(), total, nLocal, np,
-                                   rank_, row);
-                CS_TRY(callComm(comm_.all_gather(comm_.user, row, rows, size_t(P_) * 8), "all_gather (halo counts)"));
-                hmatrix.assign(size_t(P_) * P_, 0);
-                CS_TRY(toHost(hmatrix.data(), rows, size_t(P_) * P_ * 8));
-                haveMatrix = true;
-                for (int p = 0; p < P_; ++p)
-                {
-                    hsCounts[p] = hmatrix[size_t(rank_) * P_ + p];
-                    selTotal += hsCounts[p];
+                                                    allBoxes_.as<int32_t>() + size_t(p) * maxBoxes * 8, int(boxCounts[p]),
+                                                    first, last, oflags_.as<int32_t>()));
+                    hipLaunchKernelGGL(flaggedCountsKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream,
+                                       oflags_.as<int32_t>(), layout_.as<uint32_t>(), first, last, cnt_.as<uint32_t>());
+                    CS_TRY(exclusiveScanWithTotal(cnt_.as<uint32_t>(), nLocal, total));
+                    uint32_t tp = 0;
+                    CS_TRY(toHost(&tp, total, 4));
+                    if (tp)
+                    {
+                        CS_TRY(sel_.ensure(ctx_, (selTotal + tp) * sizeof(uint32_t), true));
+                        hipLaunchKernelGGL(fillIndicesKernel, gridFor(nLocal, 16), 256, 0, ctx_->stream,
+                                           oflags_.as<int32_t>(), layout_.as<uint32_t>(), cnt_.as<uint32_t>(), first, last,
+                                           sel_.as<uint32_t>() + selTotal);
+                    }
+                    hsCounts[p] = tp;
+                    selTotal += tp;
                 }
-                if (selTotal)
-                {
-                    CS_TRY(sel_.ensure(ctx_, selTotal * sizeof(uint32_t)));
-                    hipLaunchKernelGGL(peerFillKernel, gridFor(items, 16), 256, 0, ctx_->stream, oflags_.as<int32_t>(),
-                                       layout_.as<uint32_t>(), cnt_.as<uint32_t>(), first, last, P_, rank_,
-                                       sel_.as<uint32_t>());
                 }
+                if (!haveMatrix) CS_TRY(countMatrix(hsCounts, hmatrix));
             }
-            else
-            {
-            CS_TRY(cnt_.ensure(ctx_, size_t(nLocal + 1) * sizeof(uint32_t)));
+            for (uint64_t v : hmatrix)
+                haloAny += v;
             for (int p = 0; p < P_; ++p)
             {
-                if (p == rank_ || boxCounts[p] == 0) continue;
-                CS_HIP(ctx_, hipMemsetAsync(oflags_.p, 0, size_t(L) * sizeof(int32_t), ctx_->stream));
-                CS_TRY(cstone_hip_find_overlaps(ctx_, curve_, kb, fPrefixes_.p, fChild_.as<int32_t>(),
-                                                fItl_.as<int32_t>(), fTree_.p,
-                                                allBoxes_.as<int32_t>() + size_t(p) * maxBoxes * 8, int(boxCounts[p]),
-                                                first, last, oflags_.as<int32_t>()));
-                hipLaunchKernelGGL(flaggedCountsKernel, gridFor(nLocal, 256), 256, 0, ctx_->stream,
-                                   oflags_.as<int32_t>(), layout_.as<uint32_t>(), first, last, cnt_.as<uint32_t>());
-                CS_TRY(exclusiveScanWithTotal(cnt_.as<uint32_t>(), nLocal, total));
-                uint32_t tp = 0;
-                CS_TRY(toHost(&tp, total, 4));
-                if (tp)
-                {
-                    CS_TRY(sel_.ensure(ctx_, (selTotal + tp) * sizeof(uint32_t), true));
-                    hipLaunchKernelGGL(fillIndicesKernel, gridFor(nLocal, 16), 256, 0, ctx_->stream,
-                                       oflags_.as<int32_t>(), layout_.as<uint32_t>(), cnt_.as<uint32_t>(), first, last,
-                                       sel_.as<uint32_t>() + selTotal);
-                }
-                hsCounts[p] = tp;
-                selTotal += tp;
+                uint64_t r = hmatrix[size_t(p) * P_ + rank_];
+                (p < rank_ ? nlo : nhi) += (p == rank_ ? 0 : r);
+                hSendBytes[p] = hsCounts[p] * 4 * sizeof(T);
+                hRecvBytes[p] = (p == rank_ ? 0 : r) * 4 * sizeof(T);
             }
-            }
-            if (!haveMatrix) CS_TRY(countMatrix(hsCounts, hmatrix));
-        }
-        uint64_t nlo = 0, nhi = 0, haloAny = 0; // haloAny: the same on every rank, it decides about the collective
-        for (uint64_t v : hmatrix)
-            haloAny += v;
-        std::vector<size_t> hSendBytes(P_, 0), hRecvBytes(P_, 0);
-        for (int p = 0; p < P_; ++p)
-        {
-            uint64_t r = hmatrix[size_t(p) * P_ + rank_];
-            (p < rank_ ? nlo : nhi) += (p == rank_ ? 0 : r);
-            hSendBytes[p] = hsCounts[p] * 4 * sizeof(T);
-            hRecvBytes[p] = (p == rank_ ? 0 : r) * 4 * sizeof(T);
-        }
 
+        }
         tick("6 halo discovery");
         // ---- room for the halos on both sides of the assigned block
         const uint64_t total = nlo + nm + nhi;
@@ -974,7 +1053,26 @@ public:
         prevLo_ = nlo, prevHi_ = nhi;
         tick("7 margins");
         // ---- C5: halo exchange
-        if (P_ > 1 && haloAny)
+        if (useLet_ && P_ > 1)
+        {
+            // the particle buffers start at `off`: halos below | assigned | halos above, in the order of the focus tree's
+            // leaves (R/domain/domain.hpp:522-540: exchangeHalos(x, y, z, h), then the keys of the halo particles)
+            for (DevBuf* b : {&o.x, &o.y, &o.z, &o.h})
+                CS_TRY(let_->exchangeHalos(b->as<T>() + off, int(sizeof(T))));
+            if (nlo)
+            {
+                CS_HIP(ctx_, hipMemsetAsync(o.keys.as<K>() + off, 0, nlo * sizeof(K), ctx_->stream));
+                CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, o.x.as<T>() + off, o.y.as<T>() + off,
+                                                   o.z.as<T>() + off, o.keys.as<K>() + off, nlo, &box_));
+            }
+            if (nhi)
+            {
+                CS_HIP(ctx_, hipMemsetAsync(o.keys.as<K>() + A + nm, 0, nhi * sizeof(K), ctx_->stream));
+                CS_TRY(cstone_hip_compute_sfc_keys(ctx_, curve_, kb, rb, o.x.as<T>() + A + nm, o.y.as<T>() + A + nm,
+                                                   o.z.as<T>() + A + nm, o.keys.as<K>() + A + nm, nhi, &box_));
+            }
+        }
+        else if (P_ > 1 && haloAny)
         {
             CS_TRY(sendRows_.ensure(ctx_, std::max<size_t>(selTotal, 1) * 4 * sizeof(T)));
             CS_TRY(recvRows_.ensure(ctx_, std::max<size_t>(nlo + nhi, 1) * 4 * sizeof(T)));
@@ -1033,6 +1131,15 @@ public:
         view_.num_global_leaves = gLeaves_, view_.num_focus_leaves = fLeaves_;
         view_.global_leaves = gTree_.p, view_.global_counts = gCounts_.as<uint32_t>();
         view_.focus_leaves = fTree_.p, view_.focus_leaf_counts = fCounts_.as<uint32_t>();
+        view_.start_cell = 0, view_.end_cell = fLeaves_, view_.num_peers = 0;
+        view_.layout = nullptr, view_.halo_flags = nullptr;
+        if (useLet_)
+        {
+            view_.focus_leaves = let_->leaves(), view_.focus_leaf_counts = let_->leafCounts();
+            view_.start_cell = let_->startCell(), view_.end_cell = let_->endCell();
+            view_.num_peers  = int32_t(let_->peers().size());
+            view_.layout = let_->layout(), view_.halo_flags = let_->haloFlags();
+        }
         view_.range_start = uint64_t(assignment_[rank_]), view_.range_end = uint64_t(assignment_[rank_ + 1]);
         view_.particles_sent      = mSend;
         view_.halos_received      = nlo + nhi;
@@ -1493,6 +1600,11 @@ private:
     cstone_box box_;
     cstone_hip_comm_ops comm_;
     float haloExt_  = 1.0f;
+    float theta_    = 0.5f;
+    bool useLet_    = std::getenv("CSTONE_MR_OWNER_SIDE") == nullptr; // halos through the locally essential tree (default)
+    std::unique_ptr<FocusLet<K, T>> let_;
+    const K* resortTree_ = nullptr; // the leaves of my own key range (and their number) the next sync's re-sort starts from
+    int resortLeaves_    = 0;
     bool firstCall_ = true;
     bool toggled_   = false; // this sync has switched to the other output buffer set already
     int pending_    = 0; // status of this rank inside sync(): 0, or the error code the peers have to learn about
@@ -1653,6 +1765,18 @@ int cstone_hip_domain_mr_reapply_sync(cstone_hip_domain_mr* dom, const void* in,
 {
     if (!dom) return CSTONE_E_ARG;
     return dom->impl->reapplySync(in, n, elem_bytes, out);
+}
+
+int cstone_hip_domain_mr_set_halo_mode(cstone_hip_domain_mr* dom, int mode)
+{
+    if (!dom) return CSTONE_E_ARG;
+    return dom->impl->setHaloMode(mode);
+}
+
+int cstone_hip_domain_mr_set_theta(cstone_hip_domain_mr* dom, float theta)
+{
+    if (!dom) return CSTONE_E_ARG;
+    return dom->impl->setTheta(theta);
 }
 
 int cstone_hip_domain_mr_set_halo_factor(cstone_hip_domain_mr* dom, float factor)

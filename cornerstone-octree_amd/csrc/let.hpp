@@ -134,9 +134,12 @@ public:
     /*! The focus-tree part of Domain::sync (R/domain/domain.hpp:217-237) followed by Halos::discover / computeLayout.
      *  keys: the rank's assigned particles, sorted (device); h: their smoothing lengths in the same order (device);
      *  assignment: numRanks + 1 keys (host); globalLeaves / globalCounts: the replicated global tree (device).
-     *  Collective: every rank calls it. */
+     *  externalFailure != 0: the caller has a failure of its own pending that its peers must learn about -- this rank
+     *  goes through all the collectives, the status word of the last count exchange carries the failure, and every rank
+     *  returns an error from there.  Collective: every rank calls it. */
     int update(const cstone_box& box, const K* keys, size_t numKeys, const K* assignment, const K* globalLeaves,
-               const uint32_t* globalCounts, int numGlobalLeaves, const T* h, float haloSearchExt)
+               const uint32_t* globalCounts, int numGlobalLeaves, const T* h, float haloSearchExt,
+               int externalFailure = 0)
     {
         const float invThetaEff = 1.0f / theta_ + 0.5f; // invThetaMinMac, R/traversal/macs.hpp:44
         LET_TRY(init());
@@ -148,7 +151,7 @@ public:
         LET_TRY(updateTree(assignment, box, &converged));
         LET_TRY(updateCounts(keys, numKeys, globalLeaves, globalCounts, numGlobalLeaves));
         LET_TRY(discoverHalos(box, h, haloSearchExt));
-        LET_TRY(computeLayout());
+        LET_TRY(computeLayout(externalFailure));
         firstCall_ = false;
         return CSTONE_OK;
     }
@@ -947,7 +950,7 @@ private:
      *  R/domain/layout.hpp:150-165), the key ranges I want from every peer (exchangeRequestKeys,
      *  R/domain/exchange_keys.hpp:63-119) and the index ranges the peers want from me, the ranges the halos arrive in
      *  (computeHaloRecvList, layout.hpp:175-190) */
-    int computeLayout()
+    int computeLayout(int externalFailure)
     {
         const int L = L_, first = assignment_[rank_].start, last = assignment_[rank_].end;
         LET_TRY(cstone_hip_node_layout(ctx_, leafCounts_.as<uint32_t>(), flags_.as<int32_t>(), first, last, L,
@@ -966,14 +969,19 @@ private:
         std::vector<uint64_t> row(P_ + 1, 0), matrix;
         for (int p = 0; p < P_; ++p)
             row[p] = 2 * uint64_t(pairCounts[p]);
-        row[P_] = unmatched ? 1 : 0;
+        row[P_] = externalFailure ? 2 : (unmatched ? 1 : 0);
         LET_TRY(gatherRows(row, matrix));
         for (int p = 0; p < P_; ++p)
-            if (matrix[size_t(p) * (P_ + 1) + P_] != 0)
+        {
+            const uint64_t st = matrix[size_t(p) * (P_ + 1) + P_];
+            if (st == 1)
                 return fail(CSTONE_E_INTERNAL,
                             "halo discovery: rank %d found halo cells that belong to none of its peers (the sync was "
                             "abandoned on every rank)",
                             p);
+            if (st != 0)
+                return fail(CSTONE_E_INTERNAL, "rank %d reported a failure (the sync was abandoned on every rank)", p);
+        }
         std::vector<uint64_t> sendCounts(P_, 0), recvCounts(P_, 0);
         uint64_t recvKeys = 0;
         for (int p = 0; p < P_; ++p)

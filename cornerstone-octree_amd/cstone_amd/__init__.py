@@ -46,6 +46,10 @@ EXPORTS = [
     "cstone_hip_move_centers", "cstone_hip_leaf_source_centers", "cstone_hip_upsweep_centers",
     "cstone_hip_comm_rccl_unique_id", "cstone_hip_comm_rccl_create", "cstone_hip_comm_rccl_ops",
     "cstone_hip_comm_rccl_destroy", "cstone_hip_create_binary_tree",
+    # the device work behind the locally essential tree's host state machine (csrc/let.hpp)
+    "cstone_hip_raise", "cstone_hip_find_peers_mac", "cstone_hip_keys_missing", "cstone_hip_partition_keys",
+    "cstone_hip_zero_ops_at_keys", "cstone_hip_locate_nodes", "cstone_hip_node_layout", "cstone_hip_halo_requests",
+    "cstone_hip_ranges_from_keys", "cstone_hip_domain_mr_set_halo_mode", "cstone_hip_domain_mr_set_theta",
 ]
 
 

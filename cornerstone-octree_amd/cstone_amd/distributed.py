@@ -35,7 +35,8 @@ class MrView(C.Structure):
                 ("focus_leaf_counts", C.c_void_p), ("range_start", C.c_uint64), ("range_end", C.c_uint64),
                 ("particles_sent", C.c_uint64), ("halos_received", C.c_uint64), ("halos_sent", C.c_uint64),
                 ("halo_boxes_exported", C.c_uint64), ("props", C.c_void_p * 16),
-                ("resorts", C.c_uint64)]
+                ("resorts", C.c_uint64), ("start_cell", C.c_int32), ("end_cell", C.c_int32),
+                ("num_peers", C.c_int32), ("pad1_", C.c_int32), ("layout", C.c_void_p), ("halo_flags", C.c_void_p)]
 
 
 class MrOctree(C.Structure):
@@ -184,8 +185,10 @@ class RcclCollectives:
 class NativeDistributedDomain:
     """cstone_hip_domain_mr_* (multi-rank Domain::sync inside libcstone_hip) with torch.distributed collectives"""
 
+    HALOS_LET, HALOS_OWNER_SIDE = 0, 1  # CSTONE_MR_HALOS_*
+
     def __init__(self, ctx, curve, key_bits, real_bits, bucket, bucket_focus, box_lim, box_bc=(0, 0, 0), group=None,
-                 coll=None):
+                 coll=None, halo_mode=None, theta=None):
         import cstone_amd
 
         self.ctx, self.kb, self.rb = ctx, key_bits, real_bits
@@ -199,6 +202,11 @@ class NativeDistributedDomain:
                                                      C.c_int(self.coll.size), C.c_uint32(bucket),
                                                      C.c_uint32(bucket_focus), C.byref(box), C.byref(self.coll.ops)),
                  "domain_mr_create")
+        # how halos are found: the reference's locally essential tree (the default) or owner-side discovery
+        if halo_mode is not None:
+            ctx._chk(ctx.lib.cstone_hip_domain_mr_set_halo_mode(self.h, C.c_int(halo_mode)), "domain_mr_set_halo_mode")
+        if theta is not None:
+            ctx._chk(ctx.lib.cstone_hip_domain_mr_set_theta(self.h, C.c_float(theta)), "domain_mr_set_theta")
         self._keep = None
 
     def close(self):

@@ -602,6 +602,12 @@ extern "C"
                                             halo ranges are NOT filled (exchange_halos does that on request) */
         uint64_t resorts;                /* syncs so far whose local particles were ordered by the incremental re-sort
                                             (csrc/resort.hpp) instead of the radix sort; same results either way */
+        /* with CSTONE_MR_HALOS_LET (the default) focus_leaves / focus_leaf_counts are the reference's focusTree():
+         * the locally essential tree over the WHOLE key range, and: */
+        int32_t start_cell, end_cell;    /* Domain::startCell / endCell: this rank's leaves in focus_leaves */
+        int32_t num_peers, pad1_;
+        const uint32_t* layout;          /* Domain::layout(): u32[num_focus_leaves + 1], offsets into the result arrays */
+        const int32_t* halo_flags;       /* i32[num_focus_leaves]: 1 for the leaves whose particles are here as halos */
     } cstone_hip_domain_mr_view;
 
     int cstone_hip_domain_mr_create(cstone_hip_ctx* ctx, cstone_hip_domain_mr** out, int curve, int key_bits,
@@ -639,6 +645,19 @@ extern "C"
     int cstone_hip_domain_mr_reapply_sync(cstone_hip_domain_mr* dom, const void* in, size_t n, int elem_bytes,
                                           void* out);
     int cstone_hip_domain_mr_set_halo_factor(cstone_hip_domain_mr* dom, float factor);
+    /* How the halos of a multi-rank sync are found; to be chosen before the first sync.
+     * CSTONE_MR_HALOS_LET (default): the reference's way, R/domain/domain.hpp:217-237 -- peers from the MAC on the global
+     *   tree, the locally essential (focus) tree with treelet / count exchanges between peers, halo discovery on it and
+     *   key-range requests to the owners (csrc/let.hpp).  Focus tree, layout(), nParticlesWithHalos() and the halo
+     *   particles are the reference's, bit for bit.
+     * CSTONE_MR_HALOS_OWNER_SIDE: every rank exports the dilated boxes of its boundary leaves, the owners answer on
+     *   their own finest trees: fewer exchange steps, the halo set is complete but may differ from
+     *   the reference's by the particles of a few cells; focus_leaves is then this rank's own finest tree. */
+#define CSTONE_MR_HALOS_LET 0
+#define CSTONE_MR_HALOS_OWNER_SIDE 1
+    int cstone_hip_domain_mr_set_halo_mode(cstone_hip_domain_mr* dom, int mode);
+    /* the opening angle theta of the Domain constructor (R/domain/domain.hpp:95-113), default 0.5; before the first sync */
+    int cstone_hip_domain_mr_set_theta(cstone_hip_domain_mr* dom, float theta);
 
     /* Domain::octreeProperties() and Domain::layout() (R/domain/domain.hpp:388-437) for the result arrays of the last
      * sync: a cornerstone tree with bucket_size_focus over ALL local particles, halos included, as an OctreeNsView

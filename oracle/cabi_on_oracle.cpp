@@ -51,12 +51,12 @@ int withReal(int realBits, F&& f)
 extern "C"
 {
 
-int cstone_fake_ctx_create(cstone_hip_ctx** out)
+int cstone_hip_ctx_create(cstone_hip_ctx** out, int, void*, int)
 {
     *out = new cstone_hip_ctx;
     return CSTONE_OK;
 }
-int cstone_fake_ctx_destroy(cstone_hip_ctx* ctx)
+int cstone_hip_ctx_destroy(cstone_hip_ctx* ctx)
 {
     delete ctx;
     return CSTONE_OK;

@@ -5,9 +5,12 @@
 // compiled from the headers where they lie under /root/reference/include), then FocusLet::update gets the same inputs
 // -- box, assigned keys, smoothing lengths, global tree and assignment -- and must arrive at the same peers, focus
 // leaves, leaf and node counts, focus assignment, halo flags, layout, start / end index, buffer size, node centres
-// and, through exchangeHalos, the same halo particles.  In this container the C ABI underneath is
-// oracle/cabi_on_oracle.cpp (CPU restatement on host memory; there is no GPU here); built by oracle/Makefile into
-// oracle/_ref/let_check, run by tests/test_let.py with mpiexec -n 1..5.
+// and, through exchangeHalos, the same halo particles.  The harness only talks to the C ABI (cstone_hip_malloc /
+// memcpy for every array it hands over or looks at), so the same source gives two programs (oracle/Makefile):
+//   oracle/_ref/let_check      the ABI served by oracle/cabi_on_oracle.cpp (CPU restatement on host memory): runs in
+//                              this container, which has no GPU (tests/test_let.py, -m "not gpu")
+//   oracle/_ref/let_check_hip  linked against libcstone_hip.so: the HIP kernels behind the same state machine on the
+//                              MI355X box, the ranks of mpiexec sharing the GPU (tests/test_let.py, -m gpu)
 //
 // usage: let_check <k64f64|k32f32|k64f32> <numParticles> <syncs> <bucket> <bucketFocus> <bcx> <bcy> <bcz> <kind> <seed>
 //        kind: 0 uniform, 1 blobs (imbalanced), 2 drifting blob (the assignment moves every sync)
@@ -36,32 +39,43 @@
 #include "cstone_hip.h"
 #include "../cornerstone-octree_amd/csrc/let.hpp"
 
-extern "C" int cstone_fake_ctx_create(cstone_hip_ctx** out);
-extern "C" int cstone_fake_ctx_destroy(cstone_hip_ctx* ctx);
 
 using namespace cstone;
 
 namespace
 {
 
+//! cstone_hip_comm_ops over MPI: the buffers are DEVICE buffers of the ABI, staged through the host
 struct MpiComm
 {
     int P;
+    cstone_hip_ctx* ctx;
 };
 
-int mpiAllReduce(void*, void* buf, size_t count, int dtype, int op)
+int mpiAllReduce(void* user, void* buf, size_t count, int dtype, int op)
 {
+    auto* c        = static_cast<MpiComm*>(user);
+    const size_t e = dtype == 0 ? 8 : 4;
+    std::vector<char> h(count * e);
+    if (cstone_hip_memcpy_d2h(c->ctx, h.data(), buf, h.size())) return 1;
     MPI_Datatype t = dtype == 0 ? MPI_DOUBLE : MPI_UINT32_T;
     MPI_Op o       = op == 0 ? MPI_SUM : MPI_MIN;
-    return MPI_Allreduce(MPI_IN_PLACE, buf, int(count), t, o, MPI_COMM_WORLD) == MPI_SUCCESS ? 0 : 1;
+    if (MPI_Allreduce(MPI_IN_PLACE, h.data(), int(count), t, o, MPI_COMM_WORLD) != MPI_SUCCESS) return 1;
+    return cstone_hip_memcpy_h2d(c->ctx, buf, h.data(), h.size());
 }
-int mpiAllGather(void*, const void* send, void* recv, size_t bytes)
+int mpiAllGather(void* user, const void* send, void* recv, size_t bytes)
 {
-    return MPI_Allgather(send, int(bytes), MPI_BYTE, recv, int(bytes), MPI_BYTE, MPI_COMM_WORLD) == MPI_SUCCESS ? 0 : 1;
+    auto* c = static_cast<MpiComm*>(user);
+    std::vector<char> s(bytes), r(bytes * c->P);
+    if (cstone_hip_memcpy_d2h(c->ctx, s.data(), send, bytes)) return 1;
+    if (MPI_Allgather(s.data(), int(bytes), MPI_BYTE, r.data(), int(bytes), MPI_BYTE, MPI_COMM_WORLD) != MPI_SUCCESS)
+        return 1;
+    return cstone_hip_memcpy_h2d(c->ctx, recv, r.data(), r.size());
 }
 int mpiAllToAllV(void* user, const void* send, const size_t* sb, void* recv, const size_t* rb)
 {
-    int P = static_cast<MpiComm*>(user)->P;
+    auto* c = static_cast<MpiComm*>(user);
+    int P   = c->P;
     std::vector<int> sc(P), sd(P), rc(P), rd(P);
     int so = 0, ro = 0;
     for (int p = 0; p < P; ++p)
@@ -69,10 +83,40 @@ int mpiAllToAllV(void* user, const void* send, const size_t* sb, void* recv, con
         sc[p] = int(sb[p]), sd[p] = so, so += sc[p];
         rc[p] = int(rb[p]), rd[p] = ro, ro += rc[p];
     }
-    return MPI_Alltoallv(send, sc.data(), sd.data(), MPI_BYTE, recv, rc.data(), rd.data(), MPI_BYTE, MPI_COMM_WORLD) ==
-                   MPI_SUCCESS
-               ? 0
-               : 1;
+    std::vector<char> s(std::max(so, 1)), r(std::max(ro, 1));
+    if (so && cstone_hip_memcpy_d2h(c->ctx, s.data(), send, size_t(so))) return 1;
+    if (MPI_Alltoallv(s.data(), sc.data(), sd.data(), MPI_BYTE, r.data(), rc.data(), rd.data(), MPI_BYTE,
+                      MPI_COMM_WORLD) != MPI_SUCCESS)
+        return 1;
+    if (ro && cstone_hip_memcpy_h2d(c->ctx, recv, r.data(), size_t(ro))) return 1;
+    return 0;
+}
+
+//! a host array on the device of the ABI
+template<class V>
+struct OnDevice
+{
+    cstone_hip_ctx* ctx;
+    void* p = nullptr;
+    OnDevice(cstone_hip_ctx* c, const V* host, size_t n)
+        : ctx(c)
+    {
+        if (cstone_hip_malloc(ctx, &p, std::max<size_t>(n, 1) * sizeof(V)) ||
+            cstone_hip_memcpy_h2d(ctx, p, host, n * sizeof(V)))
+            std::abort();
+    }
+    ~OnDevice() { cstone_hip_free(ctx, p); }
+    const V* get() const { return static_cast<const V*>(p); }
+    V* get() { return static_cast<V*>(p); }
+};
+
+//! a device array of the ABI on the host
+template<class V>
+std::vector<V> fetch(cstone_hip_ctx* ctx, const V* dev, size_t n)
+{
+    std::vector<V> out(n);
+    if (n && cstone_hip_memcpy_d2h(ctx, out.data(), dev, n * sizeof(V))) std::abort();
+    return out;
 }
 
 int failures = 0;
@@ -140,8 +184,12 @@ int run(int rank, int P, char** argv)
     Domain<K, T, CpuTag> dom(rank, P, bucket, bucketFocus, theta, box);
 
     cstone_hip_ctx* ctx = nullptr;
-    cstone_fake_ctx_create(&ctx);
-    MpiComm mc{P};
+    if (cstone_hip_ctx_create(&ctx, 0, nullptr, 1) != 0)
+    {
+        std::fprintf(stderr, "[rank %d] no context: %s\n", rank, cstone_hip_last_error(nullptr));
+        return 1;
+    }
+    MpiComm mc{P, ctx};
     cstone_hip_comm_ops ops{&mc, mpiAllReduce, mpiAllGather, mpiAllToAllV};
     cship::FocusLet<K, T> let(ctx, CSTONE_HILBERT, rank, P, bucketFocus, theta, ops);
 
@@ -163,8 +211,11 @@ int run(int rank, int P, char** argv)
             assignment[r] = ga.assignment()[r];
         auto gl = ga.treeLeaves();
         auto gc = ga.nodeCounts();
-        int rc  = let.update(cb, keys.data() + st, en - st, assignment.data(), gl.data(), gc.data(), int(gl.size()) - 1,
-                             h.data() + st, 1.0f);
+        OnDevice<K> dKeys(ctx, keys.data() + st, en - st), dGl(ctx, gl.data(), gl.size());
+        OnDevice<unsigned> dGc(ctx, gc.data(), gc.size());
+        OnDevice<T> dH(ctx, h.data() + st, en - st);
+        int rc = let.update(cb, dKeys.get(), en - st, assignment.data(), dGl.get(), dGc.get(), int(gl.size()) - 1, dH.get(),
+                            1.0f);
         int rcAll = rc != 0;
         MPI_Allreduce(MPI_IN_PLACE, &rcAll, 1, MPI_INT, MPI_SUM, MPI_COMM_WORLD);
         if (rcAll)
@@ -180,12 +231,15 @@ int run(int rank, int P, char** argv)
         const auto& ft = dom.focusTree_;
         auto fl        = ft.treeLeaves();
         const int L    = let.numLeaves(), M = let.numNodes();
-        expectEqual("focus leaves", s, fl.data(), fl.size(), let.leaves(), size_t(L) + 1);
-        expectEqual("focus leaf counts", s, ft.leafCounts().data(), ft.leafCounts().size(), let.leafCounts(), size_t(L));
-        expectEqual("focus node counts", s, ft.counts_.data(), ft.counts_.size(), let.nodeCounts(), size_t(M));
-        expectEqual("prefixes", s, ft.treeData_.prefixes.data(), size_t(ft.treeData_.numNodes), let.prefixes(), size_t(M));
+        expectEqual("focus leaves", s, fl.data(), fl.size(), fetch(ctx, let.leaves(), size_t(L) + 1).data(), size_t(L) + 1);
+        expectEqual("focus leaf counts", s, ft.leafCounts().data(), ft.leafCounts().size(),
+                    fetch(ctx, let.leafCounts(), size_t(L)).data(), size_t(L));
+        expectEqual("focus node counts", s, ft.counts_.data(), ft.counts_.size(),
+                    fetch(ctx, let.nodeCounts(), size_t(M)).data(), size_t(M));
+        expectEqual("prefixes", s, ft.treeData_.prefixes.data(), size_t(ft.treeData_.numNodes),
+                    fetch(ctx, let.prefixes(), size_t(M)).data(), size_t(M));
         expectEqual("child offsets", s, ft.treeData_.childOffsets.data(), size_t(ft.treeData_.numNodes),
-                    let.childOffsets(), size_t(M));
+                    fetch(ctx, let.childOffsets(), size_t(M)).data(), size_t(M));
         {
             std::vector<int> a, c;
             for (auto pr : ft.assignment())
@@ -195,16 +249,16 @@ int run(int rank, int P, char** argv)
             expectEqual("focus assignment", s, a.data(), a.size(), c.data(), c.size());
         }
         auto hf = dom.halos_.haloFlags();
-        expectEqual("halo flags", s, hf.data(), size_t(L), let.haloFlags(), size_t(L));
+        expectEqual("halo flags", s, hf.data(), size_t(L), fetch(ctx, let.haloFlags(), size_t(L)).data(), size_t(L));
         auto lay = dom.layout();
-        expectEqual("layout", s, lay.data(), lay.size(), let.layout(), size_t(L) + 1);
+        expectEqual("layout", s, lay.data(), lay.size(), fetch(ctx, let.layout(), size_t(L) + 1).data(), size_t(L) + 1);
         const uint32_t idx[3]  = {uint32_t(st), uint32_t(en), uint32_t(dom.nParticlesWithHalos())};
         const uint32_t mine[3] = {let.startIndex(), let.endIndex(), let.numParticlesWithHalos()};
         expectEqual("start / end / size", s, idx, 3, mine, 3);
         expectEqual("node centres", s, reinterpret_cast<const T*>(ft.geoCentersAcc_.data()), ft.geoCentersAcc_.size() * 3,
-                    let.geoCenters(), size_t(M) * 3);
+                    fetch(ctx, let.geoCenters(), size_t(M) * 3).data(), size_t(M) * 3);
         expectEqual("node sizes", s, reinterpret_cast<const T*>(ft.geoSizesAcc_.data()), ft.geoSizesAcc_.size() * 3,
-                    let.geoSizes(), size_t(M) * 3);
+                    fetch(ctx, let.geoSizes(), size_t(M) * 3).data(), size_t(M) * 3);
         // the halo exchange: x with its halo ranges wiped must come back as the reference left it (8-byte elements);
         // a 3-byte field derived from the keys as well
         if (let.numParticlesWithHalos() == x.size())
@@ -212,16 +266,24 @@ int run(int rank, int P, char** argv)
             std::vector<T> xx(x);
             std::fill(xx.begin(), xx.begin() + st, T(-7));
             std::fill(xx.begin() + en, xx.end(), T(-7));
-            if (let.exchangeHalos(xx.data(), int(sizeof(T))) != 0)
             {
-                ++failures;
-                std::fprintf(stderr, "[rank %d sync %d] exchangeHalos failed: %s\n", rank, s, cstone_hip_last_error(ctx));
+                OnDevice<T> dx(ctx, xx.data(), xx.size());
+                if (let.exchangeHalos(dx.get(), int(sizeof(T))) != 0)
+                {
+                    ++failures;
+                    std::fprintf(stderr, "[rank %d sync %d] exchangeHalos failed: %s\n", rank, s, cstone_hip_last_error(ctx));
+                }
+                xx = fetch(ctx, dx.get(), xx.size());
             }
             expectEqual("halo x", s, x.data(), x.size(), xx.data(), xx.size());
             std::vector<uint16_t> tag(x.size()), want(x.size());
             for (size_t i = 0; i < x.size(); ++i)
                 want[i] = uint16_t(keys[i] >> 7), tag[i] = (i >= st && i < en) ? want[i] : uint16_t(0xFFFF);
-            let.exchangeHalos(tag.data(), 2);
+            {
+                OnDevice<uint16_t> dt(ctx, tag.data(), tag.size());
+                let.exchangeHalos(dt.get(), 2);
+                tag = fetch(ctx, dt.get(), tag.size());
+            }
             expectEqual("halo tags", s, want.data(), want.size(), tag.data(), tag.size());
         }
         if (rank == 0)
@@ -254,7 +316,7 @@ int run(int rank, int P, char** argv)
                         (unsigned long long)v[3], (unsigned long long)v[4], (unsigned long long)v[5],
                         (unsigned long long)v[6], (unsigned long long)v[7], (unsigned long long)v[8]);
     }
-    cstone_fake_ctx_destroy(ctx);
+    cstone_hip_ctx_destroy(ctx);
     return failures;
 }
 

@@ -13,7 +13,9 @@
 //           (the box is the unit cube in every fixture)
 //   output <prefix>.rank<r>.bin, per sync: int64 {start, end, withHalos, numGlobalLeaves, P+1}, double lim[6],
 //           K range[2], K globalLeaves[L+1], uint32 zeros[L] (padded to an even count),
-//           K keys[end-start], T x[end-start], h[end-start], T haloX[], haloY[], haloZ[] (withHalos-(end-start) each)
+//           K keys[end-start], T x[end-start], h[end-start], T haloX[], haloY[], haloZ[] (withHalos-(end-start) each),
+//           int64 {Lf, startCell, endCell}, K focusLeaves[Lf+1], uint32 focusCounts[Lf], uint32 layout[Lf+1] (each padded
+//           to an even count), K haloKeys[], T haloH[]
 #include <mpi.h>
 
 #include <cstdio>
@@ -100,6 +102,28 @@ int run(int argc, char** argv, int rank, int P)
         {
             put(out, a->data(), size_t(st));
             put(out, a->data() + en, size_t(wh - en));
+        }
+        // the locally essential (focus) tree and the layout of the particle buffers: int64 {Lf, startCell, endCell},
+        // K focusLeaves[Lf + 1], uint32 leafCounts[Lf], uint32 layout[Lf + 1] (both padded to an even count), then the
+        // keys and smoothing lengths of the halo particles
+        {
+            auto flv      = dom.focusTree().treeLeaves();
+            auto fcv      = dom.focusTree().leafCounts();
+            auto lay      = dom.layout();
+            const long Lf = long(flv.size()) - 1;
+            long finfo[3] = {Lf, long(dom.startCell()), long(dom.endCell())};
+            put(out, finfo, 3);
+            put(out, flv.data(), flv.size());
+            std::vector<unsigned> c(fcv.begin(), fcv.end());
+            if (c.size() & 1) c.push_back(0u);
+            put(out, c.data(), c.size());
+            std::vector<unsigned> l(lay.begin(), lay.begin() + Lf + 1);
+            if (l.size() & 1) l.push_back(0u);
+            put(out, l.data(), l.size());
+            put(out, keys.data(), size_t(st));
+            put(out, keys.data() + en, size_t(wh - en));
+            put(out, h.data(), size_t(st));
+            put(out, h.data() + en, size_t(wh - en));
         }
 
         // the client keeps only its assigned particles and moves them

@@ -2,7 +2,8 @@
 """Generates tests/golden/ref_domain_mpi_P*.npz by running the REFERENCE's cstone::Domain<uint64_t,double,CpuTag> on
 several MPI ranks (oracle/_ref/ref_domain_mpi, built by `make -C oracle refdomain`; needs /root/reference and the MPICH
 under /opt/conda, i.e. it runs in the build container only).  The fixtures hold inputs and, per sync and rank: the box,
-the rank's SFC range, the global tree, and keys / x / h of the assigned particles."""
+the rank's SFC range, the global tree, keys / x / h of the assigned particles, the locally essential (focus) tree with
+its leaf counts, startCell / endCell, layout(), and the halo particles (x, y, z, h, keys in buffer order)."""
 import os
 import struct
 import subprocess
@@ -78,6 +79,16 @@ def run(P, n, syncs, bucket, bucket_focus, bc, kind, seed, key_bits=64, real_bit
                 out[f"s{s}_r{r}_h"] = np.frombuffer(raw, rdt, m, off).copy(); off += rs * m
                 nh = wh - m
                 out[f"s{s}_r{r}_halos"] = np.frombuffer(raw, rdt, 3 * nh, off).reshape(3, nh).copy(); off += 3 * rs * nh
+                # the locally essential (focus) tree, layout() and the halo particles' keys and smoothing lengths
+                finfo = np.frombuffer(raw, np.int64, 3, off); off += 24
+                Lf = int(finfo[0])
+                out[f"s{s}_r{r}_cells"] = finfo[1:].copy()
+                out[f"s{s}_r{r}_focus_leaves"] = np.frombuffer(raw, kdt, Lf + 1, off).copy(); off += ks * (Lf + 1)
+                out[f"s{s}_r{r}_focus_counts"] = np.frombuffer(raw, np.uint32, Lf, off).copy(); off += 4 * (Lf + (Lf & 1))
+                out[f"s{s}_r{r}_layout"] = np.frombuffer(raw, np.uint32, Lf + 1, off).copy()
+                off += 4 * (Lf + 1 + ((Lf + 1) & 1))
+                out[f"s{s}_r{r}_halo_keys"] = np.frombuffer(raw, kdt, nh, off).copy(); off += ks * nh
+                out[f"s{s}_r{r}_halo_h"] = np.frombuffer(raw, rdt, nh, off).copy(); off += rs * nh
                 if r == 0:
                     out[f"s{s}_leaves"] = leaves
             assert off == len(raw)

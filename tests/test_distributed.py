@@ -115,7 +115,7 @@ def test_native_domain_one_traversal_per_peer(monkeypatch):
     """beyond 32 ranks the exporter bit mask does not fit and the halo discovery serves one peer at a time; the path is
     forced here on 3 ranks"""
     monkeypatch.setenv("CSTONE_MR_PEER_LOOP", "1")
-    _launch(3, "hip", 40000, 2, 1, 29648, impl="native")
+    _launch(3, "hip", 40000, 2, 1, 29648, impl="native", extra=["--owner-side", "1"])
 
 
 @pytest.mark.gpu
@@ -176,8 +176,25 @@ def test_gloo_ranks_native_domain(nproc, pbc):
 @pytest.mark.gpu
 @pytest.mark.parametrize("fixture,nproc", GOLDEN_MPI)
 def test_reference_decomposition_native_domain(fixture, nproc):
-    """the C++ multi-rank Domain against the fixtures of the reference Domain under MPI, bit for bit"""
+    """the C++ multi-rank Domain against the fixtures of the reference Domain under MPI, bit for bit: box, SFC ranges,
+    global tree, assigned particles AND the locally essential (focus) tree with its counts, startCell / endCell,
+    layout(), nParticlesWithHalos() and the halo particles in buffer order (csrc/let.hpp)"""
     _launch(nproc, "hip", 0, 0, 0, 29720 + nproc, golden=fixture, impl="native")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,nproc", GOLDEN_MPI[:2])
+def test_reference_decomposition_native_domain_owner_side(fixture, nproc):
+    """the opt-in owner-side halo discovery: same decomposition, halo set complete and within a few cells of the
+    reference's"""
+    _launch(nproc, "hip", 0, 0, 0, 29730 + nproc, golden=fixture, impl="native", extra=["--owner-side", "1"])
+
+
+@pytest.mark.gpu
+def test_gloo_ranks_native_domain_owner_side():
+    r = _launch(3, "hip", 60000, 3, 1, 29707, impl="native", extra=["--owner-side", "1"])
+    for step in (e for e in r["report"] if "step" in e):
+        assert step["neighbors"] == step["found"] and step["neighbors"] > 0
 
 
 @pytest.mark.gpu
@@ -190,9 +207,10 @@ def test_gloo_ranks_morton_32bit_keys(impl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("point", ["start", "assign", "exchange"])
-def test_native_domain_failure_reaches_every_rank(point):
+@pytest.mark.parametrize("point,owner_side", [("start", 0), ("assign", 0), ("exchange", 0), ("exchange", 1)])
+def test_native_domain_failure_reaches_every_rank(point, owner_side):
     """a rank-local failure inside cstone_hip_domain_mr_sync (injected on rank 1: CSTONE_MR_FAIL_AT) travels as a status
     word on the next collective: every rank returns an error from the same point, nobody is left waiting in a
     collective, and the next sync works again"""
-    _launch(3, "hip", 30000, 1, 0, 29670 + len(point), impl="native", extra=["--fail-at", point], timeout=300)
+    _launch(3, "hip", 30000, 1, 0, 29670 + len(point) + owner_side, impl="native",
+            extra=["--fail-at", point, "--owner-side", str(owner_side)], timeout=300)

@@ -13,15 +13,16 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "oracle", "_ref", "let_check")
+EXE_HIP = os.path.join(ROOT, "oracle", "_ref", "let_check_hip")  # the same harness on libcstone_hip.so (GPU box)
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
 pytestmark = pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists(MPIEXEC)),
                                 reason="oracle/_ref/let_check (reference + MPI build) not present")
 
 
-def run(ranks, *args, timeout=900):
+def run(ranks, *args, timeout=900, exe=EXE):
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    p = subprocess.run([MPIEXEC, "-n", str(ranks), EXE] + [str(a) for a in args], capture_output=True, text=True,
+    p = subprocess.run([MPIEXEC, "-n", str(ranks), exe] + [str(a) for a in args], capture_output=True, text=True,
                        timeout=timeout, env=env, cwd="/tmp")
     out = p.stdout + p.stderr
     assert p.returncode == 0 and "LET_CHECK OK" in out, out[-3000:]
@@ -55,3 +56,30 @@ def test_let_equals_reference_with_ranks_that_are_no_peers():
     """12 ranks: far ranks are no peers, their regions get their counts from the global tree"""
     paths = run(12, "k64f64", 24000, 3, 32, 8, 0, 0, 0, 0, 104)
     assert paths["leavesFromGlobal"] > 0
+
+
+# ---- the same comparisons with the HIP kernels underneath (libcstone_hip.so instead of the CPU restatement): the ranks
+#      of mpiexec share the GPU of the box
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,args", [
+    (1, ("k64f64", 12000, 3, 64, 8, 0, 0, 0, 0, 101)),
+    (2, ("k64f64", 12000, 3, 64, 8, 0, 0, 0, 0, 101)),
+    (3, ("k64f64", 15000, 3, 64, 8, 1, 1, 1, 1, 102)),
+    (4, ("k64f64", 40000, 4, 96, 16, 0, 0, 0, 1, 103)),
+    (2, ("k64f32", 10000, 3, 64, 16, 1, 1, 1, 0, 107)),
+    (3, ("k32f32", 30000, 3, 64, 16, 0, 1, 2, 1, 108)),
+])
+def test_hip_let_equals_reference(ranks, args):
+    assert os.path.exists(EXE_HIP), "oracle/_ref/let_check_hip not built (make -C oracle)"
+    paths = run(ranks, *args, exe=EXE_HIP)
+    assert paths["treeUpdates"] >= ranks * args[2]
+
+
+@pytest.mark.gpu
+def test_hip_let_equals_reference_when_the_assignment_moves():
+    assert os.path.exists(EXE_HIP), "oracle/_ref/let_check_hip not built (make -C oracle)"
+    paths = run(5, "k32f32", 12000, 4, 64, 8, 0, 0, 0, 2, 106, exe=EXE_HIP)
+    assert paths["focusTransfers"] > 0 and paths["keysTransferred"] > 0
+    assert paths["macRefineSteps"] > 0 and paths["keysInjected"] > 0 and paths["keysRejected"] > 0
+    paths = run(3, "k64f32", 10000, 5, 64, 16, 1, 0, 2, 2, 107, exe=EXE_HIP)
+    assert paths["focusTransfers"] > 0 and paths["macRefineSteps"] > 0
