@@ -833,7 +833,9 @@ public:
                                   gLeaves_, o.h.as<T>() + M, haloExt_, pending_ ? rank_ + 1 : 0);
             if (rc != CSTONE_OK)
             {
-                pending_ = 0;
+                // (a failure of my own that the status word of the tree's last count exchange has told everybody about:
+                //  reported with its own message)
+                if (pending_) return agreed(rank_);
                 if (toggled_) cur_ ^= 1, toggled_ = false;
                 return rc;
             }

@@ -559,6 +559,158 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
     }
 }
 
+/*! The leaf pass for tiles in which something moved, second formulation (round 3).  Ordering a leaf by counting costs
+ *  (leaf size)^2 comparisons whatever the lanes do; here every element first drops into one of 8 buckets of its leaf
+ *  by the three leading bits of its digest (the octant of the leaf's cell it lies in: one returning LDS atomic), then
+ *  counts the smaller digests among the handful of elements of its own bucket only.  The thread that loaded an element
+ *  keeps its key in registers through both phases and stores it itself: no key is read twice, no key lives in LDS
+ *  (21 KB of LDS: the grouped digests and the bucket tables).  Digests as in leafSortKernel: 24 leading bits of
+ *  (key - first key of the leaf), then the slot in the leaf; two elements of a bucket whose 24 bits agree are placed by
+ *  key and old index proper (global memory, about one in 10^4).  Same result: leaf j's elements at layoutNew[j]... in
+ *  the order of (key, old index). */
+template<class K, int G>
+__global__ __launch_bounds__(256) void leafSortBucketsKernel(
+    const K* __restrict__ keysIn, const uint64_t* __restrict__ mask, const uint32_t* __restrict__ rank,
+    const K* __restrict__ leafLo, const uint32_t* __restrict__ leafPos, const uint32_t* __restrict__ inOffset,
+    const uint32_t* __restrict__ layoutNew, const K* __restrict__ binKeys, const uint32_t* __restrict__ binIdx, uint32_t J,
+    bool alwaysCount, K* __restrict__ keysOut, uint32_t* __restrict__ orderOut)
+{
+    constexpr int ITER = (RESORT_TILE_SLOTS + 255) / 256;
+    constexpr K HOLE   = ~K(0);
+    __shared__ uint32_t sGrp[RESORT_TILE_SLOTS]; // digests, grouped by (leaf, bucket)
+    __shared__ uint32_t posK[G + 1], inK[G + 1], outK[G + 1];
+    __shared__ K loK[G + 1];
+    __shared__ uint8_t cutK[G];
+    __shared__ uint32_t cntK[G * 8], baseK[G * 8];
+
+    const uint32_t j0 = blockIdx.x * uint32_t(G);
+    const uint32_t nl = min(uint32_t(G), J - j0);
+    const uint32_t t  = threadIdx.x;
+    if (t <= nl)
+    {
+        posK[t] = leafPos[j0 + t];
+        inK[t]  = inOffset[j0 + t];
+        outK[t] = layoutNew[j0 + t];
+        loK[t]  = leafLo[j0 + t];
+    }
+    for (uint32_t i = t; i < uint32_t(G) * 8; i += 256)
+        cntK[i] = 0;
+    __syncthreads();
+    if (t < nl)
+    {
+        const K span   = loK[t + 1] - loK[t] - 1;
+        const int bits = span ? int(8 * sizeof(K)) - clzKey(span) : 0;
+        cutK[t]        = uint8_t(bits > 24 ? bits - 24 : 0);
+    }
+    const uint32_t p0 = posK[0], p1 = posK[nl], in0 = inK[0], in1 = inK[nl];
+    const uint32_t nOldAll = p1 - p0, slots = nOldAll + (in1 - in0);
+    if (slots > RESORT_TILE_SLOTS) return; // guarded by checkTilesKernel
+    bool changed = in1 != in0 || alwaysCount;
+    if (t < nl) changed = changed || (outK[t + 1] - outK[t]) != (posK[t + 1] - posK[t]);
+    const bool quiet = !__syncthreads_or(changed) && nOldAll <= RESORT_QUIET_SLOTS;
+    if (quiet) return; // the quiet instantiation of leafSortKernel takes this tile
+
+    // ---- phase 1: every element (old slots, then arrivals) -> leaf, digest, bucket, place inside the bucket
+    K key[ITER];
+    uint32_t dig[ITER], info[ITER]; // info: leaf (8 bits) | place in the bucket (24 bits); ~0u: no element
+#pragma unroll
+    for (int i = 0; i < ITER; ++i)
+    {
+        const uint32_t e = t + 256u * i;
+        info[i]          = ~0u;
+        key[i]           = HOLE;
+        dig[i]           = ~0u;
+        if (e < nOldAll) key[i] = keysIn[p0 + e];
+        else if (e < slots) key[i] = binKeys[in0 + (e - nOldAll)];
+    }
+#pragma unroll
+    for (int i = 0; i < ITER; ++i)
+    {
+        const uint32_t e = t + 256u * i;
+        if (e >= slots || key[i] == HOLE) continue;
+        uint32_t k, slot;
+        if (e < nOldAll)
+        {
+            const uint32_t p = p0 + e;
+            k    = rank[p >> 6] + uint32_t(__popcll(mask[p >> 6] & ((2ull << (p & 63u)) - 1))) - 1u - j0;
+            slot = p - posK[k];
+        }
+        else
+        {
+            const uint32_t m = in0 + (e - nOldAll);
+            uint32_t lo = 0, hi = nl; // leaf of bin entry m: last k with inK[k] <= m
+            while (hi - lo > 1)
+            {
+                uint32_t mid = (lo + hi) / 2;
+                if (inK[mid] <= m) lo = mid;
+                else hi = mid;
+            }
+            k    = lo;
+            slot = (posK[k + 1] - posK[k]) + (m - inK[k]);
+        }
+        const uint32_t d  = (uint32_t((key[i] - loK[k]) >> cutK[k]) << 8) | slot;
+        const uint32_t at = atomicAdd(&cntK[k * 8 + (d >> 29)], 1u);
+        dig[i]  = d;
+        info[i] = (k << 24) | at;
+    }
+    __syncthreads();
+    // ---- bucket starts in the tile's NEW order (leaf k starts at outK[k] - outK[0])
+    if (t < nl)
+    {
+        uint32_t run = outK[t] - outK[0];
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+        {
+            baseK[t * 8 + b] = run;
+            run += cntK[t * 8 + b];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITER; ++i)
+        if (info[i] != ~0u) sGrp[baseK[(info[i] >> 24) * 8 + (dig[i] >> 29)] + (info[i] & 0xFFFFFFu)] = dig[i];
+    __syncthreads();
+
+    // ---- phase 2: rank inside the bucket, store
+    auto placeExact = [&](uint32_t k, K kx, uint32_t ix)
+    {
+        const uint32_t nOld = posK[k + 1] - posK[k], nInc = inK[k + 1] - inK[k];
+        uint32_t less = 0;
+        for (uint32_t q = 0; q < nOld; ++q)
+        {
+            const K kq = keysIn[posK[k] + q]; // (a hole is larger than any key)
+            less += (kq < kx || (kq == kx && posK[k] + q < ix)) ? 1u : 0u;
+        }
+        for (uint32_t q = 0; q < nInc; ++q)
+        {
+            const K kq = binKeys[inK[k] + q];
+            less += (kq < kx || (kq == kx && binIdx[inK[k] + q] < ix)) ? 1u : 0u;
+        }
+        return less;
+    };
+#pragma unroll
+    for (int i = 0; i < ITER; ++i)
+    {
+        if (info[i] == ~0u) continue;
+        const uint32_t e = t + 256u * i;
+        const uint32_t k = info[i] >> 24, d = dig[i], bk = k * 8 + (d >> 29);
+        const uint32_t b0 = baseK[bk], nb = cntK[bk];
+        uint32_t less = 0;
+        bool clash    = false;
+        for (uint32_t q = 0; q < nb; ++q)
+        {
+            const uint32_t v = sGrp[b0 + q];
+            less += v < d;
+            clash = clash || ((v ^ d) >> 8 == 0 && v != d);
+        }
+        const uint32_t ix = e < nOldAll ? p0 + e : binIdx[in0 + (e - nOldAll)];
+        uint32_t at       = outK[0] + b0 + less;
+        if (clash) at = outK[k] + placeExact(k, key[i], ix);
+        keysOut[at]  = key[i];
+        orderOut[at] = ix;
+    }
+}
+
 /*! Positions of the leaf boundaries of ANOTHER tree (the focus tree after its rebalance) in the keys this re-sort has just
  *  ordered: the leaf table knows where every old leaf starts now (layoutNew), so the search for a boundary key only
  *  covers the particles of the one old leaf whose key range holds it -- a few dozen keys instead of all of them. */
@@ -747,23 +899,35 @@ int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, 
     // quiet tiles and tiles in which something moved: one launch each over all tiles (without movers there are none of
     // the second kind)
     const bool someMoved = numMovers > 0 || alwaysCount || largeQuietTiles;
+    // tiles in which something moved: buckets by the leading digest bits, counting inside a bucket (the default), or
+    // counting over the whole leaf (the round-2 formulation, kept for comparison: CSTONE_RESORT_SCAN=1)
+    static const bool scanLeaves = std::getenv("CSTONE_RESORT_SCAN") != nullptr;
+#define CSTONE_LEAF_BUCKETS(G)                                                                                         \
+    hipLaunchKernelGGL((leafSortBucketsKernel<K, G>), grid, 256, 0, ctx->stream, keysIn, mask_.as<uint64_t>(),         \
+                       rank_.as<uint32_t>(), leafLo_.as<K>(), leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(),       \
+                       layoutNew_.as<uint32_t>(), binKeys_.as<K>(), binIdx_.as<uint32_t>(), J, alwaysCount, keysOut,  \
+                       orderOut)
     if (leavesPerTile == 64)
     {
         CSTONE_LEAF_SORT(64, false);
-        if (someMoved) CSTONE_LEAF_SORT(64, true);
+        if (someMoved && scanLeaves) CSTONE_LEAF_SORT(64, true);
+        else if (someMoved) CSTONE_LEAF_BUCKETS(64);
     }
     else if (leavesPerTile == 32)
     {
         CSTONE_LEAF_SORT(32, false);
-        if (someMoved) CSTONE_LEAF_SORT(32, true);
+        if (someMoved && scanLeaves) CSTONE_LEAF_SORT(32, true);
+        else if (someMoved) CSTONE_LEAF_BUCKETS(32);
     }
     else if (leavesPerTile == 16)
     {
         CSTONE_LEAF_SORT(16, false);
-        if (someMoved) CSTONE_LEAF_SORT(16, true);
+        if (someMoved && scanLeaves) CSTONE_LEAF_SORT(16, true);
+        else if (someMoved) CSTONE_LEAF_BUCKETS(16);
     }
     else return fail(ctx, CSTONE_E_INTERNAL, "resort: %d leaves per workgroup not instantiated", leavesPerTile);
 #undef CSTONE_LEAF_SORT
+#undef CSTONE_LEAF_BUCKETS
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <numeric>
 #include <random>
 #include <string>
@@ -191,7 +192,8 @@ int run(int rank, int P, char** argv)
     }
     MpiComm mc{P, ctx};
     cstone_hip_comm_ops ops{&mc, mpiAllReduce, mpiAllGather, mpiAllToAllV};
-    cship::FocusLet<K, T> let(ctx, CSTONE_HILBERT, rank, P, bucketFocus, theta, ops);
+    auto letOwner = std::make_unique<cship::FocusLet<K, T>>(ctx, CSTONE_HILBERT, rank, P, bucketFocus, theta, ops);
+    cship::FocusLet<K, T>& let = *letOwner;
 
     for (int s = 0; s < syncs; ++s)
     {
@@ -316,6 +318,7 @@ int run(int rank, int P, char** argv)
                         (unsigned long long)v[3], (unsigned long long)v[4], (unsigned long long)v[5],
                         (unsigned long long)v[6], (unsigned long long)v[7], (unsigned long long)v[8]);
     }
+    letOwner.reset(); // its buffers go before the context does
     cstone_hip_ctx_destroy(ctx);
     return failures;
 }
