@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- particles/sec through domain.sync (encode + sort + tree + halo) on MI355X.
 
-One "step" = one steady-state `sync` of the hot path over the resident particle set (SURVEY.md section 3.1,
+One "step" = one steady-state `sync` of the hot path over the resident particle set, in a time-stepping loop: before
+every sync EVERY particle is displaced by up to 0.1 h per coordinate (the displacement is the client's work: it runs
+outside the timed intervals, every sync is bracketed on its own); (SURVEY.md section 3.1,
 reference include/cstone/domain/domain.hpp:196-243 with the stages a rank executes):
     bounding box (min/max of x,y,z) -> SFC key encode -> stable radix sort of (key, index) ->
     global-tree rebalance step + node counts -> gather h -> focus-tree rebalance step + counts ->
@@ -84,31 +86,40 @@ class SyncPipeline:
             self.h = torch.full((n,), h0, dtype=rdt, device=dev)
             lim = [0, 1] * 3
         self.keys = torch.zeros(n, dtype=cstone_amd.key_torch_dtype(key_bits), device=dev)
-        self.scratch = torch.empty(n, dtype=rdt, device=dev)
+        # the scratch tuple of the client (R/domain/domain.hpp:196-206: at least three vectors there as well)
+        self.scratch = [torch.empty(n, dtype=rdt, device=dev) for _ in range(int(os.environ.get("CSTONE_BENCH_SCRATCH", "3")))]
         self.dom = Domain(ctx, cv, key_bits, real_bits, bucket, bucket_focus, 0.5, cstone_amd.make_cbox(lim))
         self.f_leaves = self.g_leaves = 0
 
     def step(self):
         """one Domain::sync (domain.hpp:196-243); the first call also converges both trees from the root.  Straight
-        through the C ABI, as a C++ client would call it: five pointers the library may exchange among themselves; the
-        tensors follow their buffers (no particle is removed here, so every array keeps its length)"""
+        through the C ABI, as a C++ client would call it: the particle arrays and a scratch tuple of three buffers (like
+        the reference's sync takes) that the library may exchange among themselves; the tensors follow their buffers (no
+        particle is removed here, so every array keeps its length)"""
         import ctypes as C
 
-        arrays = (self.x, self.y, self.z, self.h, self.scratch)
+        arrays = (self.x, self.y, self.z, self.h, *self.scratch)
+        ns = len(self.scratch)
         if not hasattr(self, "_ptrs"):
             self._keys_ptr = C.c_void_p(self.keys.data_ptr())
-            self._ptrs = [C.c_void_p() for _ in range(5)]
+            self._ptrs = [C.c_void_p() for _ in range(4)]
+            self._sarr = (C.c_void_p * ns)()
             self._n = C.c_size_t(self.x.numel())
             self._none = C.c_void_p(None)
         by_ptr = {}
-        for p, t in zip(self._ptrs, arrays):
+        for p, t in zip(self._ptrs, arrays[:4]):
             p.value = t.data_ptr()
             by_ptr[p.value] = t
-        rc = self.ctx.lib.cstone_hip_domain_sync(self.dom.h, C.byref(self._keys_ptr), C.byref(self._ptrs[0]),
-                                                 C.byref(self._ptrs[1]), C.byref(self._ptrs[2]), C.byref(self._ptrs[3]),
-                                                 self._n, C.byref(self._ptrs[4]), self._none, self._none, C.c_int(0))
+        for q, t in enumerate(self.scratch):
+            self._sarr[q] = t.data_ptr()
+            by_ptr[t.data_ptr()] = t
+        rc = self.ctx.lib.cstone_hip_domain_sync_scratch(self.dom.h, C.byref(self._keys_ptr), C.byref(self._ptrs[0]),
+                                                         C.byref(self._ptrs[1]), C.byref(self._ptrs[2]),
+                                                         C.byref(self._ptrs[3]), self._n, self._sarr, C.c_int(ns),
+                                                         self._none, self._none, C.c_int(0))
         self.ctx._chk(rc, "domain_sync")
-        self.x, self.y, self.z, self.h, self.scratch = [by_ptr[p.value] for p in self._ptrs]
+        self.x, self.y, self.z, self.h = [by_ptr[p.value] for p in self._ptrs]
+        self.scratch = [by_ptr[self._sarr[q]] for q in range(ns)]
 
     def first_sync(self):
         self.step()
@@ -169,8 +180,28 @@ class SyncPipeline:
         ctx._chk(rc, "find_neighbors")
         ctx.sync()
         ms, _ = ctx.profile_get("neighbors")
-        return {"targets": nt, "ngmax": ngmax, "ms": ms, "targets_per_s": nt / (ms * 1e-3) if ms > 0 else None,
-                "mean_neighbors": float(counts.double().mean().item()), "max_neighbors": int(counts.max().item())}
+        out = {"targets": nt, "ngmax": ngmax, "ms": ms, "targets_per_s": nt / (ms * 1e-3) if ms > 0 else None,
+               "mean_neighbors": float(counts.double().mean().item()), "max_neighbors": int(counts.max().item())}
+        if ngmax == 0:
+            # the traversal counters of the reference's NcStats (find_neighbors.cuh:345-369) from one more, untimed run of
+            # the instrumented kernel; rates on the time of the plain kernel above.  11 flop per distance test is the
+            # reference's own accounting (test/performance/neighbor_driver.cu:169)
+            st = (C.c_uint64 * 4)()
+            rc = ctx.lib.cstone_hip_find_neighbors_stats(ctx.h, C.c_int(self.rb), P(self.x), P(self.y), P(self.z),
+                                                         P(self.h), C.c_uint32(first), C.c_uint32(first + nt),
+                                                         C.byref(v.box), C.c_void_p(v.child_offsets),
+                                                         C.c_void_p(v.internal_to_leaf), C.c_void_p(v.layout),
+                                                         C.c_void_p(v.centers), C.c_void_p(v.sizes), C.c_float(1.0),
+                                                         C.c_uint32(0), None, P(counts), st)
+            ctx._chk(rc, "find_neighbors_stats")
+            sec = ms * 1e-3
+            out.update({"p2p_tests": int(st[0]), "p2p_tests_per_target": st[0] / nt, "max_p2p_tests_of_a_target": int(st[1]),
+                        "max_stack": int(st[2]), "p2p_tests_issued": int(st[3]),
+                        "lane_efficiency": st[0] / st[3] if st[3] else None,
+                        "p2p_tests_per_s": st[0] / sec if sec > 0 else None,
+                        "gflops_11_per_test": 11.0 * st[0] / sec / 1e9 if sec > 0 else None,
+                        "gflops_11_per_issued_test": 11.0 * st[3] / sec / 1e9 if sec > 0 else None})
+        return out
 
 
 class DistributedPipeline:
@@ -222,8 +253,15 @@ class DistributedPipeline:
             d = (torch.rand(m, dtype=a.dtype, device=a.device, generator=self.g) - 0.5) * (4 * self.h0)
             a[idx] = (a[idx] + d).clamp_(0.0, 1.0)
 
+    def drift(self, frac=0.1):
+        """displace EVERY assigned particle by up to frac * h per coordinate (the same motion as on one GPU)"""
+        torch = self.torch
+        for a in (self.x, self.y, self.z):
+            d = torch.rand(a.numel(), dtype=a.dtype, device=a.device, generator=self.g)
+            a.add_(d.sub_(0.5).mul_(2 * frac * self.h0)).clamp_(0.0, 1.0)
+            del d
+
     def step(self):
-        self.jiggle()
         r = self.dom.sync(self.x, self.y, self.z, self.h)
         s, e = r["start"], r["end"]
         # the client owns the assigned particles (updated in place); halos are re-discovered by the next sync
@@ -233,7 +271,7 @@ class DistributedPipeline:
         v = self.dom.view()
         self.f_leaves, self.g_leaves = v.num_focus_leaves, v.num_global_leaves
         self.stats = dict(moved=v.particles_sent, halos=v.halos_received, served=v.halos_sent,
-                          halo_boxes=v.halo_boxes_exported)
+                          halo_boxes=v.halo_boxes_exported, peers=v.num_peers)
 
     first_sync = step
 
@@ -257,11 +295,33 @@ class DistributedPipeline:
         return int(t[0].item()) == n_global and int(t[1].item()) == dist.get_world_size()
 
 
+def granted_cores():
+    """the host cores this process may really use: its affinity mask, cut by the cgroup's CPU quota (a lease on a shared
+    host grants a share of the machine's cores; os.cpu_count() reports all of them)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // pr))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline_domain(n_sample, bucket, bucket_focus, min_seconds=10.0):
     """the reference's own cstone::Domain<uint64_t,double,CpuTag>::sync on one MPI rank (oracle/_ref, prebuilt)"""
     import ctypes as C
 
     import numpy as np
+
+    cores = granted_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # before the OpenMP runtime of the library starts
 
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libcstone_ref_domain.so"))
     lib.cstone_refdom_create.restype = C.c_void_p
@@ -280,10 +340,11 @@ def cpu_baseline_domain(n_sample, bucket, bucket_focus, min_seconds=10.0):
         t_total += time.perf_counter() - t0
         done += 1
     lib.cstone_refdom_destroy(d)
-    return {"value": n_sample * done / t_total, "unit": "particles/s", "cores": os.cpu_count(), "kind": "reference",
+    return {"value": n_sample * done / t_total, "unit": "particles/s", "cores": cores, "kind": "reference",
+            "host_cores_total": os.cpu_count(),
             "sample": f"{done} steady-state Domain<uint64_t,double,CpuTag>::sync of {n_sample} uniform particles on 1 MPI rank, "
-                      f"bucket {bucket}, bucketFocus {bucket_focus}, OpenMP over all host cores (the sort inside is a serial "
-                      f"std::stable_sort)"}
+                      f"bucket {bucket}, bucketFocus {bucket_focus}, OMP_NUM_THREADS={cores} = the cores granted to this "
+                      f"process (the sort inside is a serial std::stable_sort)"}
 
 
 def cpu_baseline(n_sample, key_bits, real_bits, curve, bucket_focus, min_seconds=8.0):
@@ -379,23 +440,35 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def run_syncs(count, move):
+        """count syncs, each bracketed on its own by barrier + device synchronisation on both sides; the particles are
+        displaced (by the client: not part of a sync) before each of them; returns the seconds spent inside the syncs"""
+        total = 0.0
+        for _ in range(count):
+            if move:
+                move()
+            barrier()
+            ts = time.perf_counter()
+            pipe.step()
+            barrier()
+            total += time.perf_counter() - ts
+        return total
+
     barrier()
     t_first = time.perf_counter()
     pipe.first_sync()  # converges both trees from the root and moves every particle: reported, not part of `value`
     barrier()
     first_sync_ms = (time.perf_counter() - t_first) * 1e3
-    for _ in range(args.warmup):
-        pipe.step()
+    # the headline workload: a time-stepping loop in which EVERY particle is displaced by up to 0.1 h per coordinate
+    # between two syncs (about 7 % of them leave their leaf, the trees change a little every time)
+    move = pipe.drift
+    run_syncs(args.warmup, move)
     # HIP events around the kernels that move the particle arrays only (roofline): every stage of a sync bracketed costs
-    # 0.1 ms of a 3.3 ms sync in event records; the full stage table comes from further syncs behind the timed region
+    # 0.1 ms of it in event records; the full stage table comes from further syncs behind the timed region
     ctx.profile_enable(0 if args.no_stage_timers else 2)
     ctx.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    stats_before = pipe.dom.stats() if not distributed else None
+    elapsed = run_syncs(args.steps, move)
     if not distributed:
         pipe.note_leaves()
     n_sorted = n_local
@@ -407,12 +480,15 @@ def main():
         n_sorted = pipe.assigned
     timed_stages = {s: ctx.profile_get(s) for s in cstone_amd.STAGES}
     timed_spreads = {s: ctx.profile_spread(s) for s in cstone_amd.STAGES}
+    timed_stats = None
+    if not distributed:
+        after = pipe.dom.stats()
+        timed_stats = {k: after[k] - stats_before[k] for k in ("resorts", "resort_fallbacks", "box_redos",
+                                                                "full_sort_fallbacks")} | {"last_movers": after["last_movers"]}
     # every stage of a sync, on args.steps further syncs of the same kind (not part of `value`)
     ctx.profile_enable(0 if args.no_stage_timers else 1)
     ctx.profile_reset()
-    for _ in range(args.steps):
-        pipe.step()
-    barrier()
+    run_syncs(args.steps, move)
     stage_ms = {s: ctx.profile_get(s)[0] / args.steps for s in cstone_amd.STAGES}
     radix_stats = None
     resorted = timed_stages["resort_leaves"][1] > 0
@@ -449,17 +525,11 @@ def main():
         # the same syncs with the radix sort forced over ALL key digits (what the reference's GPU path does every time;
         # by default Domain::sync sorts the digits above the previous tree's leaf level and finishes the rest in runs)
         def timed_variant(before_step=None):
-            """args.steps syncs with their stage times and what the domain's counters say about them"""
+            """args.steps syncs (the motion before each of them outside the timed intervals) with their stage times and
+            what the domain's counters say about them"""
             ctx.profile_reset()
             st0 = pipe.dom.stats()
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                if before_step:
-                    before_step()
-                pipe.step()
-            barrier()
-            dt = (time.perf_counter() - t1) / args.steps
+            dt = run_syncs(args.steps, before_step) / args.steps
             st1 = pipe.dom.stats()
             nonlocal radix_stats
             if radix_stats is None and ctx.profile_get("sort_pass")[1]:
@@ -471,35 +541,29 @@ def main():
                                           if ctx.profile_get(k)[1]},
                     "syncs": {k: st1[k] - st0[k] for k in st1 if k != "last_movers"} | {"last_movers": st1["last_movers"]}}
 
+        # the same time-stepping loop with the radix sort forced over ALL key digits (what the reference's GPU path does
+        # every time) ...
         os.environ["CSTONE_FULL_SORT"] = "1"
-        pipe.step()
-        extras["all_digits_sorted"] = timed_variant()
+        run_syncs(1, move)
+        extras["all_digits_sorted"] = timed_variant(move)
+        extras["all_digits_sorted"]["note"] = "the headline loop, every sync sorted from scratch over all 8 key digits"
         del os.environ["CSTONE_FULL_SORT"]
-        # the sort of a sync from scratch, as the reference does it every time: radix passes over the digits above the
-        # previous tree's leaf level + run fix-up, no use of the previous order
+        # ... and sorted from scratch the cheaper way: radix passes over the digits above the previous tree's leaf level +
+        # run fix-up, no use of the previous order
         os.environ["CSTONE_NO_RESORT"] = "1"
-        pipe.step()
-        extras["sorted_from_scratch"] = timed_variant()
+        run_syncs(1, move)
+        extras["sorted_from_scratch"] = timed_variant(move)
+        extras["sorted_from_scratch"]["note"] = "the headline loop without the incremental re-sort"
         del os.environ["CSTONE_NO_RESORT"]
-        pipe.step()
-        # and with particles that move between the syncs (the tree changes a little every time; the displacement itself
-        # is inside this timed loop, about 0.1 ms)
-        pipe.jiggle()
-        pipe.step()
+        run_syncs(1, move)
+        # other motions: 1 % of the particles displaced by up to 2h, and none at all (every sync gets back exactly what
+        # the previous one returned: the friendliest input)
+        run_syncs(1, pipe.jiggle)
         extras["moving_particles"] = timed_variant(pipe.jiggle)
         extras["moving_particles"]["note"] = "1% of the particles displaced by <= 2h before every sync"
-        # every particle drifts by up to 0.1 h per coordinate between the syncs (the displacement is timed with it: two
-        # passes over x, y, z, about 1.5 ms)
-        pipe.drift()
-        pipe.step()
-        extras["all_particles_drift"] = timed_variant(pipe.drift)
-        extras["all_particles_drift"]["note"] = ("every particle displaced by <= 0.1 h per coordinate before every sync; "
-                                                 "ms_per_step includes the displacement itself")
-        t3 = time.perf_counter()
-        for _ in range(args.steps):
-            pipe.drift()
-        barrier()
-        extras["all_particles_drift"]["displacement_ms"] = (time.perf_counter() - t3) / args.steps * 1e3
+        run_syncs(2, None)
+        extras["zero_motion"] = timed_variant(None)
+        extras["zero_motion"]["note"] = "no particle moves between the syncs"
     if not distributed and args.neighbor_targets > 0:
         extras["find_neighbors"] = [pipe.find_neighbors(args.neighbor_targets, 0),
                                     pipe.find_neighbors(args.neighbor_targets, 128)]
@@ -569,21 +633,26 @@ def main():
 
     if rank == 0:
         kbytes, rbytes = args.key_bits // 8, args.real_bits // 8
+        n_scratch = len(pipe.scratch) if hasattr(pipe, "scratch") else 1
         # ---- roofline.  Every kernel that moves the particle arrays, with its ALGORITHMIC bytes per launch (DESIGN.md
         # section 3) over its launch time measured live with HIP events on the context's stream (stage timers).  The
         # top-level fields are those of the kernel with the largest total time inside the timed syncs.
         models = [  # (kernel, stage, bytes per particle and launch, what the bytes are)
             ("encodeResortKernel" if stage_ms.get("resort_leaves", 0) > 0 else "encodeHistogramKernel", "encode",
              3 * rbytes + 2 * kbytes, "x, y, z and the old key read, the new key written"),
-            ("leafSortKernel", "resort_leaves", 2 * kbytes + 4, "key read; key + old index written"),
+            ("leafSortKernel + leafSortBucketsKernel", "resort_leaves", 2 * kbytes + 4,
+             "key read; key + old index written (one bracket around the launch for quiet tiles and the one for tiles with movers)"),
             ("onesweepKernel", "sort_pass", 2 * (kbytes + 4), "key + index read and written"),
             ("onesweepKernel (positions generated)", "sort_pass_iota", 2 * kbytes + 4, "key read; key + index written"),
-            ("gatherKernel", "gather", 4 + 2 * rbytes, "index + element read, element written; one launch per array"),
+            (("gatherMultiKernel (x, y, z in one launch)", "gather", 4 + 6 * rbytes,
+              "index read once, three elements read and written") if n_scratch >= 3 else
+             ("gatherKernel", "gather", 4 + 2 * rbytes, "index + element read, element written; one launch per array")),
+            ("gatherHaloRadiiKernel", "gather_h", 4 + 2 * rbytes, "index + h read, h written (+ one radius per leaf)"),
         ]
         tjson = None
-        for tname in ("r02_kernel_hbm_traffic.json",):
+        for tname in ("r03_kernel_hbm_traffic.json", "r02_kernel_hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and tjson is None:
                 tjson = (tname, json.load(open(tpath)))
 
         def pmc_traffic(kernel):
@@ -591,7 +660,7 @@ def main():
             this run's particles per launch; None when the profile does not hold the kernel"""
             if not tjson:
                 return None
-            wanted = {"leafSortKernel": "leafSortKernel/quiet"}.get(kernel.split(" ")[0], kernel.split(" ")[0])
+            wanted = {"leafSortKernel": "leafSortKernel/moved"}.get(kernel.split(" ")[0], kernel.split(" ")[0])
             for row in tjson[1]["kernels"]:
                 if row["kernel"] == wanted:
                     return (row["hbm_read_bytes"] + row["hbm_write_bytes"]) * n_sorted / tjson[1].get("particles", 1e8)
@@ -653,7 +722,8 @@ def main():
                     "sync": {"algorithmic_bytes_per_step": sync_bytes,
                              "achieved": sync_bytes / (elapsed / args.steps) / 1e9,
                              "frac": sync_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
-                             "note": "bytes of the kernels listed here over the wall time of a whole sync"},
+                             "note": "bytes of the kernels listed here (x, y, z, h gathers included) over the wall time of a "
+                                     "whole sync"},
                     "onesweep": onesweep}
         out = {
             "metric": "particles/sec domain.sync (encode+sort+tree+halo), 10^8 uniform, 1/2/4/8 GPU",
@@ -670,14 +740,18 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{n_global:.0e} uniform particles, {args.key_bits}-bit {args.curve} keys, "
                                    f"f{args.real_bits} coordinates, bucketFocus {args.bucket_focus}, "
-                                   f"bucket {bucket_global}, steady-state cstone_hip_domain_sync: the arrays a sync "
-                                   f"returns go into the next one; particles still inside their leaf are ordered leaf by "
-                                   f"leaf, the others are binned (csrc/resort.hpp) -- the same order as sorting all keys; "
-                                   f"extras.sorted_from_scratch / all_digits_sorted: the radix sort instead"
+                                   f"bucket {bucket_global}, time-stepping loop: before every sync EVERY particle is "
+                                   f"displaced by <= 0.1 h per coordinate (outside the timed intervals, each sync is "
+                                   f"bracketed on its own); the arrays a sync returns go into the next one; particles "
+                                   f"still inside their leaf are ordered leaf by leaf, the others are binned "
+                                   f"(csrc/resort.hpp) -- the same order as sorting all keys; extras: the radix sort "
+                                   f"instead (sorted_from_scratch / all_digits_sorted), other motions (moving_particles, "
+                                   f"zero_motion)"
                                    + ("" if not distributed else
-                                      f"; {world} rank(s): SFC domain decomposition, particle + halo exchange with "
-                                      f"all_to_all over RCCL, 1% of the particles displaced by <=2h before every sync"),
+                                      f"; {world} rank(s): SFC domain decomposition, particle exchange, locally essential "
+                                      f"tree and halo exchange with all_to_all over RCCL"),
                        "particles_per_gpu": n_local, "focus_leaves": pipe.f_leaves, "global_leaves": pipe.g_leaves,
+                       **({"syncs_timed": timed_stats} if timed_stats else {}),
                        **({"invariants_ok": invariants_ok, "rank0_assigned": pipe.assigned, "rank0_halos": pipe.halos,
                            "rank0_exchange": dict(pipe.stats),
                            "orchestration": "libcstone_hip (cstone_hip_domain_mr_sync)",

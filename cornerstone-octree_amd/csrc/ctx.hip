@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <cstdio>
 
+#include <cstring>
+
 #include "ctx.hpp"
 #include "hilbert_tables.hpp"
 
@@ -54,7 +56,7 @@ StageTimer::StageTimer(cstone_hip_ctx* c, int stage)
     // microseconds of stream time; a sync has about forty brackets, eight of them around such kernels)
     const bool heavy = stage == CSTONE_STAGE_ENCODE || stage == CSTONE_STAGE_SORT_PASS ||
                        stage == CSTONE_STAGE_SORT_PASS_IOTA || stage == CSTONE_STAGE_GATHER ||
-                       stage == CSTONE_STAGE_RESORT_LEAVES || stage == CSTONE_STAGE_HALOS ||
+                       stage == CSTONE_STAGE_RESORT_LEAVES || stage == CSTONE_STAGE_HALOS || stage == CSTONE_STAGE_GATHER_H ||
                        stage == CSTONE_STAGE_NEIGHBORS;
     if (ctx->profiling == 2 && !heavy) return;
     cstone_hip_ctx::Bracket b{stage, takeEvent(ctx), takeEvent(ctx)};
@@ -159,6 +161,7 @@ int cstone_hip_ctx_destroy(cstone_hip_ctx* ctx)
     if (ctx->devScalars) (void)hipFree(ctx->devScalars);
     if (ctx->hilbertTables) (void)hipFree(ctx->hilbertTables);
     if (ctx->hostScalars) (void)hipHostFree(ctx->hostScalars);
+    if (ctx->uploadStage) (void)hipHostFree(ctx->uploadStage);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CSTONE_OK;
@@ -214,6 +217,30 @@ int cstone_hip_memcpy_h2d(cstone_hip_ctx* ctx, void* dst, const void* src, size_
     if (bytes == 0) return CSTONE_OK;
     CS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // pageable source must stay valid: complete before returning
+    return CSTONE_OK;
+}
+
+int cstone_hip_upload(cstone_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    if (bytes == 0) return CSTONE_OK;
+    constexpr size_t stageBytes = size_t(1) << 20;
+    if (!ctx->uploadStage)
+    {
+        CS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->uploadStage), stageBytes, hipHostMallocDefault));
+        ctx->uploadBytes = stageBytes, ctx->uploadCursor = 0;
+    }
+    if (bytes > ctx->uploadBytes / 4) return cstone_hip_memcpy_h2d(ctx, dst, src, bytes); // large: the plain, synchronising copy
+    size_t off = (ctx->uploadCursor + 63) & ~size_t(63);
+    if (off + bytes > ctx->uploadBytes)
+    {
+        // wrap around: the copies queued from the ring so far must have left it
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        off = 0;
+    }
+    std::memcpy(ctx->uploadStage + off, src, bytes);
+    CS_HIP(ctx, hipMemcpyAsync(dst, ctx->uploadStage + off, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->uploadCursor = off + bytes;
     return CSTONE_OK;
 }
 

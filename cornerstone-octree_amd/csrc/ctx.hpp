@@ -28,6 +28,11 @@ struct cstone_hip_ctx
     int* hostScalars = nullptr; // [64]
     int* devScalars  = nullptr; // [64]
 
+    // pinned staging ring for small host-to-device uploads that must not synchronise the stream (cstone_hip_upload)
+    char* uploadStage    = nullptr;
+    size_t uploadBytes   = 0;
+    size_t uploadCursor  = 0;
+
     // -1 unknown, else result of the one-time LDS atomic ordering probe of the radix sort (sort.hip)
     int ldsOrderOk = -1;
 

@@ -120,8 +120,8 @@ __global__ void initTreeKernel(K* tree, uint32_t* counts, uint32_t c0)
 struct DomainBase
 {
     virtual ~DomainBase() = default;
-    virtual int sync(void** keys, void** x, void** y, void** z, void** h, size_t n, void** scratch, void** props,
-                     const int* propBytes, int numProps) = 0;
+    virtual int sync(void** keys, void** x, void** y, void** z, void** h, size_t n, void** scratch, int numScratch,
+                     void** props, const int* propBytes, int numProps) = 0;
     virtual int view(cstone_hip_domain_view* out)        = 0;
     virtual void setHaloFactor(float factor)             = 0;
     virtual int reapplySync(const void* in, size_t n, int elemBytes, void* out) = 0;
@@ -142,9 +142,10 @@ public:
     {
     }
 
-    int sync(void** keysPP, void** xPP, void** yPP, void** zPP, void** hPP, size_t n, void** scratchPP, void** props,
-             const int* propBytes, int numProps) override
+    int sync(void** keysPP, void** xPP, void** yPP, void** zPP, void** hPP, size_t n, void** scratchAll, int numScratch,
+             void** props, const int* propBytes, int numProps) override
     {
+        void** scratchPP = scratchAll; // the first scratch buffer: the one the single-scratch rotation works with
         if (n == 0) return fail(ctx_, CSTONE_E_ARG, "domain_sync: no particles");
         if (!firstCall_ && n != bufSize_)
             return fail(ctx_, CSTONE_E_ARG, "Domain sync: input array sizes are inconsistent (%zu != %u)", n, bufSize_);
@@ -445,11 +446,25 @@ public:
         // which is the inclusive scan written above shifted by one.
 
         // ---- updateLayout (domain.hpp:542-604): keys already sit at offset 0; gather the unordered arrays
-        void** arrays[3] = {xPP, yPP, zPP};
-        for (auto a : arrays)
+        if (numScratch >= 3)
         {
-            CS_TRY(cstone_hip_gather(ctx_, sizeof(T), order_.as<uint32_t>(), numAssigned, *a, *scratchPP));
-            std::swap(*a, *scratchPP);
+            // three free buffers (the caller's scratch tuple, R/domain/domain.hpp:196-206 has three as well): x, y, z go
+            // to their new order in ONE pass that reads the ordering once
+            const void* src[3] = {*xPP, *yPP, *zPP};
+            void* dst[3]       = {scratchAll[0], scratchAll[1], scratchAll[2]};
+            CS_TRY(cstone_hip_gather_multi(ctx_, sizeof(T), order_.as<uint32_t>(), numAssigned, src, dst, 3));
+            std::swap(*xPP, scratchAll[0]);
+            std::swap(*yPP, scratchAll[1]);
+            std::swap(*zPP, scratchAll[2]);
+        }
+        else
+        {
+            void** arrays[3] = {xPP, yPP, zPP};
+            for (auto a : arrays)
+            {
+                CS_TRY(cstone_hip_gather(ctx_, sizeof(T), order_.as<uint32_t>(), numAssigned, *a, *scratchPP));
+                std::swap(*a, *scratchPP);
+            }
         }
         for (int p = 0; p < numProps; ++p)
         {
@@ -745,7 +760,18 @@ int cstone_hip_domain_sync(cstone_hip_domain* dom, void** keys, void** x, void**
     if (!dom || !keys || !x || !y || !z || !h || !scratch || !*keys || !*x || !*y || !*z || !*h || !*scratch ||
         num_props < 0 || (num_props && (!props || !prop_bytes)))
         return fail(dom ? dom->ctx : nullptr, CSTONE_E_ARG, "domain_sync: bad argument");
-    return dom->impl->sync(keys, x, y, z, h, n, scratch, props, prop_bytes, num_props);
+    return dom->impl->sync(keys, x, y, z, h, n, scratch, 1, props, prop_bytes, num_props);
+}
+
+int cstone_hip_domain_sync_scratch(cstone_hip_domain* dom, void** keys, void** x, void** y, void** z, void** h, size_t n,
+                                   void** scratch, int num_scratch, void** props, const int* prop_bytes, int num_props)
+{
+    if (!dom || !keys || !x || !y || !z || !h || !scratch || !*keys || !*x || !*y || !*z || !*h || num_scratch < 1 ||
+        num_props < 0 || (num_props && (!props || !prop_bytes)))
+        return fail(dom ? dom->ctx : nullptr, CSTONE_E_ARG, "domain_sync: bad argument");
+    for (int q = 0; q < num_scratch; ++q)
+        if (!scratch[q]) return fail(dom->ctx, CSTONE_E_ARG, "domain_sync: null scratch buffer %d", q);
+    return dom->impl->sync(keys, x, y, z, h, n, scratch, num_scratch, props, prop_bytes, num_props);
 }
 
 int cstone_hip_domain_view_get(cstone_hip_domain* dom, cstone_hip_domain_view* out)

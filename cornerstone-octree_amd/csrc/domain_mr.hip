@@ -830,7 +830,7 @@ public:
             if (!let_) let_ = std::make_unique<FocusLet<K, T>>(ctx_, curve_, rank_, P_, bucketFocus_, theta_, comm_);
             injectFailure("exchange");
             int rc = let_->update(box_, keysM, size_t(nm), assignment_.data(), gTree_.as<K>(), gCounts_.as<uint32_t>(),
-                                  gLeaves_, o.h.as<T>() + M, haloExt_, pending_ ? rank_ + 1 : 0);
+                                  gLeaves_, o.h.as<T>() + M, haloExt_, pending_ ? rank_ + 1 : 0, gTreeSame_);
             if (rc != CSTONE_OK)
             {
                 // (a failure of my own that the status word of the tree's last count exchange has told everybody about:
@@ -1328,6 +1328,7 @@ private:
             }
             CS_TRY(rc);
             gLeaves_ = leaves;
+            gTreeSame_ = steps == 0 && !firstCall_ && conv != 0; // the one step of a later sync kept every leaf
             if (P_ > 1)
             {
                 CS_TRY(gLocalCounts_.ensure(ctx_, size_t(leaves) * sizeof(uint32_t)));
@@ -1627,6 +1628,7 @@ private:
     DevBuf keys_, order_, keysAlt_, orderAlt_, sortTmp_;
     DevBuf gTree_, gCounts_, gLocalCounts_;
     int gCap_ = 0, gLeaves_ = 0;
+    bool gTreeSame_ = false; // the global leaf array is that of the previous sync
     DevBuf fTree_, fCounts_, fTmp_;
     int fCap_ = 0, fLeaves_ = 0;
     DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_;

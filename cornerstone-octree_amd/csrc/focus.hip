@@ -15,6 +15,7 @@
 
 #include "ctx.hpp"
 #include "device_keys.hpp"
+#include "scan.hpp"
 
 namespace cship
 {
@@ -823,6 +824,24 @@ int findPeers(cstone_hip_ctx* ctx, int curve, const void* prefixes, const int32_
     return rc;
 }
 
+//! leafOps[i] = opsAll[leafToInternal[i]] for the leaves in leaf order (leafOps[numLeaves] = 0); changed += leaves whose
+//! op is not "keep"
+__global__ __launch_bounds__(256) void leafOpsCountKernel(const NodeIdx* __restrict__ opsAll,
+                                                          const NodeIdx* __restrict__ leafToInternal, NodeIdx numLeaves,
+                                                          uint32_t* __restrict__ leafOps, int* __restrict__ changed)
+{
+    NodeIdx i = blockIdx.x * 256 + threadIdx.x;
+    int op    = 1;
+    if (i < numLeaves)
+    {
+        op         = opsAll[leafToInternal[i]];
+        leafOps[i] = uint32_t(op);
+    }
+    else if (i == numLeaves) { leafOps[i] = 0; }
+    const uint64_t b = __ballot(op != 1);
+    if ((threadIdx.x & 63u) == 0 && b) atomicAdd(changed, int(__popcll(b)));
+}
+
 //! one int from the device scalars to the host (synchronises the stream)
 int readScalar(cstone_hip_ctx* ctx, int slot, int* out)
 {
@@ -927,6 +946,60 @@ int cstone_hip_enforce_keys(cstone_hip_ctx* ctx, int key_bits, const void* force
     }
     CS_HIP(ctx, hipGetLastError());
     return readScalar(ctx, 11, status_host);
+}
+
+int cstone_hip_focus_update_ops(cstone_hip_ctx* ctx, int key_bits, const void* prefixes, const int32_t* child_offsets,
+                                const int32_t* parents, const uint32_t* counts, const char* macs, uint64_t focus_start,
+                                uint64_t focus_end, uint32_t bucket_size, const void* forced_keys, int num_forced_keys,
+                                const int32_t* leaf_to_internal, int num_leaves, int num_nodes, int32_t* node_ops_all,
+                                int32_t* leaf_ops, int* result_host)
+{
+    if (!ctx || badKeyBits(key_bits) || num_leaves < 1 || num_nodes < num_leaves || num_forced_keys < 0 || !prefixes ||
+        !child_offsets || !counts || !macs || !leaf_to_internal || !node_ops_all || !leaf_ops || !result_host ||
+        (num_forced_keys && !forced_keys) || (num_nodes > 1 && !parents))
+        return fail(ctx, CSTONE_E_ARG, "focus_update_ops: bad argument");
+    // devScalars 10: nodes whose protected op is not "keep", 11: status of the enforced keys, 12: leaves that do not
+    // keep, 13: new number of leaves
+    int* sc = ctx->devScalars + 10;
+    CS_HIP(ctx, hipMemsetAsync(sc, 0, 4 * sizeof(int), ctx->stream));
+    int rc = CSTONE_OK;
+    {
+        StageTimer timer(ctx, CSTONE_STAGE_REBALANCE);
+        CSTONE_KEY_SWITCH(key_bits,
+                          hipLaunchKernelGGL(essentialOpsKernel<K>, gridFor(size_t(num_nodes), 256), 256, 0, ctx->stream,
+                                             (const K*)prefixes, child_offsets, parents, counts, macs, K(focus_start),
+                                             K(focus_end), bucket_size, node_ops_all, num_nodes));
+        if (num_forced_keys)
+            CSTONE_KEY_SWITCH(key_bits, hipLaunchKernelGGL(enforceKeysKernel<K>, gridFor(size_t(num_forced_keys), 64), 64,
+                                                           0, ctx->stream, (const K*)forced_keys, num_forced_keys,
+                                                           (const K*)prefixes, child_offsets, parents, node_ops_all,
+                                                           sc + 1));
+        CSTONE_KEY_SWITCH(key_bits, hipLaunchKernelGGL(protectAncestorsKernel<K>, gridFor(size_t(num_nodes), 256), 256, 0,
+                                                       ctx->stream, (const K*)prefixes, parents, node_ops_all, num_nodes,
+                                                       sc));
+        hipLaunchKernelGGL(leafOpsCountKernel, gridFor(size_t(num_leaves) + 1, 256), 256, 0, ctx->stream, node_ops_all,
+                           leaf_to_internal, num_leaves, reinterpret_cast<uint32_t*>(leaf_ops), sc + 2);
+        rc = arenaReserve(ctx, scanArenaBytes(size_t(num_leaves) + 1));
+        if (rc == CSTONE_OK)
+        {
+            rc = scanU32(ctx, reinterpret_cast<uint32_t*>(leaf_ops), reinterpret_cast<uint32_t*>(leaf_ops),
+                         size_t(num_leaves) + 1, 0u, false, reinterpret_cast<uint32_t*>(sc + 3));
+            arenaReset(ctx);
+        }
+    }
+    CS_TRY(rc);
+    CS_HIP(ctx, hipGetLastError());
+    CS_HIP(ctx, hipMemcpyAsync(ctx->hostScalars + 10, sc, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int changedNodes = ctx->hostScalars[10], status = ctx->hostScalars[11], changedLeaves = ctx->hostScalars[12];
+    int converged = changedNodes == 0;                 // protectAncestors (R/focus/rebalance.hpp:171-184)
+    if (status == 1) converged = changedLeaves == 0;   // cancelMerge: every LEAF keeps (R/focus/octree_focus.hpp:114-117)
+    if (status >= 2) converged = 0;                    // rebalance / failed
+    result_host[0] = status;
+    result_host[1] = converged;
+    result_host[2] = changedLeaves == 0;
+    result_host[3] = ctx->hostScalars[13];
+    return CSTONE_OK;
 }
 
 int cstone_hip_range_count(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int num_leaves,

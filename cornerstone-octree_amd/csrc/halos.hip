@@ -348,7 +348,7 @@ int gatherWithHaloRadii(cstone_hip_ctx* ctx, int h_bits, const void* h, const ui
                         const uint32_t* layout, int numLeaves, float ext, float* radii)
 {
     if (numLeaves == 0) return CSTONE_OK;
-    StageTimer timer(ctx, CSTONE_STAGE_HALOS);
+    StageTimer timer(ctx, CSTONE_STAGE_GATHER_H);
     unsigned grid = gridFor(size_t(numLeaves), RADII_LEAVES_PER_BLOCK);
     if (h_bits == 32)
         hipLaunchKernelGGL(gatherHaloRadiiKernel<float>, grid, 256, 0, ctx->stream, (const float*)h, order, (float*)hOut,

@@ -136,14 +136,15 @@ public:
      *  assignment: numRanks + 1 keys (host); globalLeaves / globalCounts: the replicated global tree (device).
      *  externalFailure != 0: the caller has a failure of its own pending that its peers must learn about -- this rank
      *  goes through all the collectives, the status word of the last count exchange carries the failure, and every rank
-     *  returns an error from there.  Collective: every rank calls it. */
+     *  returns an error from there.  globalTreeSame: the caller knows that the global leaf array is the one of the last
+     *  update (then an unchanged assignment and box keep the peers).  Collective: every rank calls it. */
     int update(const cstone_box& box, const K* keys, size_t numKeys, const K* assignment, const K* globalLeaves,
                const uint32_t* globalCounts, int numGlobalLeaves, const T* h, float haloSearchExt,
-               int externalFailure = 0)
+               int externalFailure = 0, bool globalTreeSame = false)
     {
         const float invThetaEff = 1.0f / theta_ + 0.5f; // invThetaMinMac, R/traversal/macs.hpp:44
         LET_TRY(init());
-        LET_TRY(findPeers(assignment, globalLeaves, numGlobalLeaves, box, invThetaEff));
+        LET_TRY(findPeers(assignment, globalLeaves, numGlobalLeaves, box, invThetaEff, globalTreeSame));
         if (firstCall_)
             LET_TRY(converge(box, keys, numKeys, assignment, globalLeaves, globalCounts, numGlobalLeaves, invThetaEff));
         LET_TRY(updateMinMac(assignment, invThetaEff));
@@ -215,7 +216,7 @@ public:
     struct Stats
     {
         uint64_t treeUpdates = 0, treeBuilds = 0, focusTransfers = 0, keysTransferred = 0, macRefineSteps = 0,
-                 keysInjected = 0, keysRejected = 0, leavesFromGlobal = 0, convergeSteps = 0;
+                 keysInjected = 0, keysRejected = 0, leavesFromGlobal = 0, convergeSteps = 0, peerSearchesSkipped = 0;
     };
     const Stats& stats() const { return stats_; }
     uint64_t halosSent() const { return sendTotal_; }
@@ -261,7 +262,7 @@ private:
         LET_TRY(scratchU64_.ensure(m * (sizeof(K) + 8) + 64));
         K* dq        = scratchU64_.as<K>();
         uint64_t* dr = reinterpret_cast<uint64_t*>(scratchU64_.as<char>() + ((m * sizeof(K) + 63) / 64) * 64);
-        LET_TRY(cstone_hip_memcpy_h2d(ctx_, dq, queries.data(), m * sizeof(K)));
+        LET_TRY(cstone_hip_upload(ctx_, dq, queries.data(), m * sizeof(K)));
         LET_TRY(cstone_hip_lower_bound(ctx_, kb, keys, n, dq, int(m), dr));
         std::vector<uint64_t> r(m);
         LET_TRY(cstone_hip_memcpy_d2h(ctx_, r.data(), dr, m * 8));
@@ -290,7 +291,7 @@ private:
         LET_TRY(rowBuf_.ensure(w * 8 * (P_ + 1)));
         uint64_t* send = rowBuf_.as<uint64_t>();
         uint64_t* recv = send + w;
-        LET_TRY(cstone_hip_memcpy_h2d(ctx_, send, mine.data(), w * 8));
+        LET_TRY(cstone_hip_upload(ctx_, send, mine.data(), w * 8));
         LET_TRY(commCall(comm_.all_gather(comm_.user, send, recv, w * 8), "all_gather (counts)"));
         return cstone_hip_memcpy_d2h(ctx_, matrix.data(), recv, w * 8 * P_);
     }
@@ -368,24 +369,37 @@ private:
         if (L_ != 0) return CSTONE_OK;
         const K root[2] = {K(0), endKey()};
         LET_TRY(leaves_.ensure(2 * sizeof(K)));
-        LET_TRY(cstone_hip_memcpy_h2d(ctx_, leaves_.p, root, sizeof root));
+        LET_TRY(cstone_hip_upload(ctx_, leaves_.p, root, sizeof root));
         L_ = 1;
         LET_TRY(buildOctree());
         const uint32_t c0 = bucket_ + 1; // counts_{bucketSize + 1}
         const char m0     = 1;           // macs_{1}
         LET_TRY(counts_.ensure(4));
         LET_TRY(macs_.ensure(1));
-        LET_TRY(cstone_hip_memcpy_h2d(ctx_, counts_.p, &c0, 4));
-        LET_TRY(cstone_hip_memcpy_h2d(ctx_, macs_.p, &m0, 1));
+        LET_TRY(cstone_hip_upload(ctx_, counts_.p, &c0, 4));
+        LET_TRY(cstone_hip_upload(ctx_, macs_.p, &m0, 1));
         haveLeafCounts_ = false;
         return CSTONE_OK;
     }
 
     // ---- peers ---------------------------------------------------------------------------------------------------
-    int findPeers(const K* assignment, const K* globalLeaves, int numGlobalLeaves, const cstone_box& box, float invThetaEff)
+    int findPeers(const K* assignment, const K* globalLeaves, int numGlobalLeaves, const cstone_box& box, float invThetaEff,
+                  bool globalTreeSame)
     {
-        peers_.clear();
         if (P_ == 1) return CSTONE_OK;
+        // the peers are a function of (global tree, assignment, box): a sync that changed none of them keeps its peers
+        bool same = globalTreeSame && peersValid_ && numGlobalLeaves == peersGlobalLeaves_;
+        for (int r = 0; r <= P_ && same; ++r)
+            same = assignment[r] == peersAssignment_[r];
+        for (int k = 0; k < 6 && same; ++k)
+            same = box.lim[k] == peersBox_.lim[k];
+        if (same)
+        {
+            ++stats_.peerSearchesSkipped;
+            return CSTONE_OK;
+        }
+        peers_.clear();
+        peersValid_ = false;
         const int GL = numGlobalLeaves, GM = numNodesOf(GL);
         LET_TRY(gPrefixes_.ensure(size_t(GM) * sizeof(K)));
         LET_TRY(gChild_.ensure(size_t(GM + 1) * 4));
@@ -405,6 +419,10 @@ private:
                                           flags.data()));
         for (int r = 0; r < P_; ++r)
             if (flags[r] && r != rank_) peers_.push_back(r);
+        peersAssignment_.assign(assignment, assignment + P_ + 1);
+        peersBox_          = box;
+        peersGlobalLeaves_ = numGlobalLeaves;
+        peersValid_        = true;
         return CSTONE_OK;
     }
 
@@ -560,50 +578,28 @@ private:
         const int L = L_, M = numNodesOf(L), I = numInternalOf(L);
         LET_TRY(opsAll_.ensure(size_t(M + 1) * 4));
         LET_TRY(ops_.ensure(size_t(L + 2) * 4));
-        LET_TRY(cstone_hip_rebalance_decision_essential(ctx_, kb, prefixes_.p, child_.as<int32_t>(),
-                                                        parents_.as<int32_t>(), counts_.as<uint32_t>(),
-                                                        macs_.as<char>(), uint64_t(focusStart), uint64_t(focusEnd),
-                                                        bucket_, opsAll_.as<int32_t>(), M));
         std::vector<K> all{focusStart, focusEnd};
         all.insert(all.end(), mandatory.begin(), mandatory.end());
         LET_TRY(scratchKeys_.ensure(all.size() * sizeof(K)));
-        LET_TRY(cstone_hip_memcpy_h2d(ctx_, scratchKeys_.p, all.data(), all.size() * sizeof(K)));
-        int status = 0, converged = 0;
-        LET_TRY(cstone_hip_enforce_keys(ctx_, kb, scratchKeys_.p, int(all.size()), prefixes_.p, child_.as<int32_t>(),
-                                        parents_.as<int32_t>(), opsAll_.as<int32_t>(), &status));
-        LET_TRY(cstone_hip_protect_ancestors(ctx_, kb, prefixes_.p, parents_.as<int32_t>(), opsAll_.as<int32_t>(), M,
-                                             &converged));
-        // the leaves' decisions in leaf order
-        LET_TRY(cstone_hip_gather(ctx_, 4, lti_.as<uint32_t>() + I, size_t(L), opsAll_.p, ops_.p));
-        LET_TRY(cstone_hip_memset(ctx_, ops_.as<int32_t>() + L, 0, 4));
-        if (status == 1) // cancelMerge
-        {
-            uint64_t ones = 0;
-            LET_TRY(cstone_hip_count_equal(ctx_, 32, ops_.p, size_t(L), 1, &ones));
-            converged = ones == uint64_t(L);
-        }
-        else if (status == 2) { converged = 0; } // rebalance
-        if (status == 3) converged = 0;          // failed
-
+        LET_TRY(cstone_hip_upload(ctx_, scratchKeys_.p, all.data(), all.size() * sizeof(K)));
+        // decisions from counts and MACs, mandatory keys enforced, ancestors protected, the leaves' ops scanned: one
+        // call, one read-back: {status of the enforced keys, converged, every leaf keeps, new number of leaves}
+        int res[4] = {0, 0, 0, 0};
+        LET_TRY(cstone_hip_focus_update_ops(ctx_, kb, prefixes_.p, child_.as<int32_t>(), parents_.as<int32_t>(),
+                                            counts_.as<uint32_t>(), macs_.as<char>(), uint64_t(focusStart),
+                                            uint64_t(focusEnd), bucket_, scratchKeys_.p, int(all.size()),
+                                            lti_.as<int32_t>() + I, L, M, opsAll_.as<int32_t>(), ops_.as<int32_t>(), res));
+        const int status = res[0], newL = res[3];
         // (every op "keep" and nothing to inject: the leaf array and the linked octree stay what they are; the reference
         //  rebuilds regardless because it parks the ops in the tree's arrays)
-        bool allKeep = status != 3 && converged;
-        if (status == 2)
-        {
-            uint64_t ones = 0;
-            LET_TRY(cstone_hip_count_equal(ctx_, 32, ops_.p, size_t(L), 1, &ones));
-            allKeep = ones == uint64_t(L);
-        }
-        else if (status == 0 && !converged)
-        {
-            // an inner node wants to change although every leaf keeps: nothing happens to the leaf array
-            uint64_t ones = 0;
-            LET_TRY(cstone_hip_count_equal(ctx_, 32, ops_.p, size_t(L), 1, &ones));
-            allKeep = ones == uint64_t(L);
-        }
+        const bool allKeep = status != 3 && res[2] != 0;
         if (!allKeep)
         {
-            LET_TRY(rebalanceFromOps());
+            if (newL < 1) return fail(CSTONE_E_INTERNAL, "focus tree: rebalance produced %d leaves", newL);
+            LET_TRY(leavesNew_.ensure(size_t(newL + 1) * sizeof(K)));
+            LET_TRY(cstone_hip_rebalance_tree(ctx_, kb, leaves_.p, L, newL, ops_.as<int32_t>(), leavesNew_.p));
+            leaves_.swap(leavesNew_);
+            L_ = newL;
             if (status == 3)
             {
                 LET_TRY(injectKeys(all));
@@ -611,7 +607,7 @@ private:
             }
             LET_TRY(buildOctree());
         }
-        *convergedOut = converged != 0;
+        *convergedOut = res[1] != 0;
         return CSTONE_OK;
     }
 
@@ -621,7 +617,7 @@ private:
     {
         const size_t n = size_t(L_) + 1 + keys.size();
         LET_TRY(leaves_.ensure(n * sizeof(K), true));
-        LET_TRY(cstone_hip_memcpy_h2d(ctx_, leaves_.as<K>() + L_ + 1, keys.data(), keys.size() * sizeof(K)));
+        LET_TRY(cstone_hip_upload(ctx_, leaves_.as<K>() + L_ + 1, keys.data(), keys.size() * sizeof(K)));
         LET_TRY(cstone_hip_sort_keys(ctx_, kb, leaves_.p, n));
         LET_TRY(ops_.ensure((n + 1) * 4));
         LET_TRY(cstone_hip_count_sfc_gaps(ctx_, kb, leaves_.p, int(n) - 1, ops_.as<int32_t>()));
@@ -757,7 +753,7 @@ private:
             LET_TRY(scratchIdx_.ensure(size_t(P_ + 1) * 8));
             uint32_t* dmap = scratchIdx_.as<uint32_t>();
             uint32_t* dval = dmap + (P_ + 1);
-            LET_TRY(cstone_hip_memcpy_h2d(ctx_, dmap, map.data(), size_t(P_ + 1) * 4));
+            LET_TRY(cstone_hip_upload(ctx_, dmap, map.data(), size_t(P_ + 1) * 4));
             LET_TRY(cstone_hip_gather(ctx_, 4, dmap, size_t(P_) + 1, tlScan_.p, dval));
             LET_TRY(readBack(dval, at32.data(), size_t(P_) + 1));
             for (int p = 0; p < P_; ++p)
@@ -853,7 +849,7 @@ private:
         if (!fromGlobal.empty())
         {
             LET_TRY(scratchIdx_.ensure(fromGlobal.size() * 4));
-            LET_TRY(cstone_hip_memcpy_h2d(ctx_, scratchIdx_.p, fromGlobal.data(), fromGlobal.size() * 4));
+            LET_TRY(cstone_hip_upload(ctx_, scratchIdx_.p, fromGlobal.data(), fromGlobal.size() * 4));
             LET_TRY(cstone_hip_range_count(ctx_, kb, globalLeaves, numGlobalLeaves, globalCounts, leaves_.p,
                                            scratchIdx_.as<int32_t>(), int(fromGlobal.size()),
                                            leafCounts_.as<uint32_t>()));
@@ -914,7 +910,7 @@ private:
             if (P_ > 1)
             {
                 LET_TRY(rowBuf_.ensure(64));
-                LET_TRY(cstone_hip_memcpy_h2d(ctx_, rowBuf_.p, &sum, 4));
+                LET_TRY(cstone_hip_upload(ctx_, rowBuf_.p, &sum, 4));
                 LET_TRY(commCall(comm_.all_reduce(comm_.user, rowBuf_.p, 1, 1, 0), "all_reduce (converged)"));
                 LET_TRY(readBack(rowBuf_.as<uint32_t>(), &sum));
             }
@@ -1000,54 +996,47 @@ private:
         haloSendCounts_.assign(P_, 0);
         sendTotal_ = 0;
         if (numSendRanges_)
-        {
             LET_TRY(cstone_hip_ranges_from_keys(ctx_, kb, leaves_.p, L, layout_.as<uint32_t>(), recvBuf_.p,
                                                 size_t(numSendRanges_), rangeOffsets_.as<uint32_t>(),
                                                 rangeScan_.as<uint32_t>()));
-            // particles per peer = differences of the range scan at the peers' first ranges
-            std::vector<uint32_t> map(P_ + 1, 0), at32(P_ + 1, 0);
+        // ONE read-back for: particles per peer (differences of the range scan at the peers' first ranges), where the
+        // halos arrive and the extent of the buffers (the layout at the assignment boundaries)
+        {
+            const size_t nA = size_t(P_) + 1, nB = 2 * size_t(P_) + 1;
+            std::vector<uint32_t> map(nA + nB, 0), val(nA + nB, 0);
             for (int p = 0; p < P_; ++p)
                 map[p + 1] = map[p] + uint32_t(recvCounts[p] / 2);
-            LET_TRY(scratchIdx_.ensure(size_t(P_ + 1) * 8));
-            uint32_t* dmap = scratchIdx_.as<uint32_t>();
-            uint32_t* dval = dmap + (P_ + 1);
-            LET_TRY(cstone_hip_memcpy_h2d(ctx_, dmap, map.data(), size_t(P_ + 1) * 4));
-            LET_TRY(cstone_hip_gather(ctx_, 4, dmap, size_t(P_) + 1, rangeScan_.p, dval));
-            LET_TRY(readBack(dval, at32.data(), size_t(P_) + 1));
             for (int p = 0; p < P_; ++p)
             {
-                haloSendCounts_[p] = at32[p + 1] - at32[p];
-                sendTotal_ += haloSendCounts_[p];
+                map[nA + 2 * p]     = uint32_t(assignment_[p].start);
+                map[nA + 2 * p + 1] = uint32_t(assignment_[p].end);
             }
-        }
-        // where the halos arrive and the extent of the buffers: layout at the assignment boundaries
-        {
-            std::vector<uint32_t> map, val;
-            for (int p = 0; p < P_; ++p)
-            {
-                map.push_back(uint32_t(assignment_[p].start));
-                map.push_back(uint32_t(assignment_[p].end));
-            }
-            map.push_back(uint32_t(L));
-            val.resize(map.size());
+            map[nA + 2 * P_] = uint32_t(L);
             LET_TRY(scratchIdx_.ensure(map.size() * 8));
             uint32_t* dmap = scratchIdx_.as<uint32_t>();
             uint32_t* dval = dmap + map.size();
-            LET_TRY(cstone_hip_memcpy_h2d(ctx_, dmap, map.data(), map.size() * 4));
-            LET_TRY(cstone_hip_gather(ctx_, 4, dmap, map.size(), layout_.p, dval));
+            LET_TRY(cstone_hip_upload(ctx_, dmap, map.data(), map.size() * 4));
+            if (numSendRanges_) LET_TRY(cstone_hip_gather(ctx_, 4, dmap, nA, rangeScan_.p, dval));
+            LET_TRY(cstone_hip_gather(ctx_, 4, dmap + nA, nB, layout_.p, dval + nA));
             LET_TRY(readBack(dval, val.data(), val.size()));
+            for (int p = 0; p < P_ && numSendRanges_; ++p)
+            {
+                haloSendCounts_[p] = val[p + 1] - val[p];
+                sendTotal_ += haloSendCounts_[p];
+            }
+            const uint32_t* lay = val.data() + nA;
             haloRecvCounts_.assign(P_, 0);
             haloRecvOffsets_.assign(P_, 0);
             recvTotal_ = 0;
             for (int peer : peers_)
             {
-                haloRecvOffsets_[peer] = val[2 * peer];
-                haloRecvCounts_[peer]  = val[2 * peer + 1] - val[2 * peer];
+                haloRecvOffsets_[peer] = lay[2 * peer];
+                haloRecvCounts_[peer]  = lay[2 * peer + 1] - lay[2 * peer];
                 recvTotal_ += haloRecvCounts_[peer];
             }
-            particleStart_ = val[2 * rank_];
-            particleEnd_   = val[2 * rank_ + 1];
-            particleTotal_ = val.back();
+            particleStart_ = lay[2 * rank_];
+            particleEnd_   = lay[2 * rank_ + 1];
+            particleTotal_ = lay[2 * P_];
         }
         return CSTONE_OK;
     }
@@ -1071,6 +1060,10 @@ private:
     LetBuf gPrefixes_, gChild_, gParents_, gLevelRange_, gItl_, gLti_; // linked octree of the global tree (peer search)
 
     std::vector<int> peers_;
+    std::vector<K> peersAssignment_; // what the peers were computed for
+    cstone_box peersBox_{};
+    int peersGlobalLeaves_ = 0;
+    bool peersValid_       = false;
     std::vector<LetRange> assignment_; // leaf index range of every peer's (and my) key range
     std::vector<K> globAssignment_;    // the key ranges of the last updateTree
 

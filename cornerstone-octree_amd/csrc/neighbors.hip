@@ -52,13 +52,14 @@ __device__ __forceinline__ double readLane(double v, unsigned k)
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
-template<class T, bool GROUPS>
+template<class T, bool GROUPS, bool STATS>
 __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
     const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, const T* __restrict__ h, uint32_t first,
     uint32_t last, const uint32_t* __restrict__ groupStart, const uint32_t* __restrict__ groupEnd, uint32_t numGroups,
     DBox<T> box, const NodeIdx* __restrict__ childOffsets, const NodeIdx* __restrict__ internalToLeaf,
     const uint32_t* __restrict__ layout, const T* __restrict__ centers, const T* __restrict__ sizes, float ext,
-    uint32_t ngmax, uint32_t* __restrict__ neighbors, uint32_t* __restrict__ counts, int* __restrict__ errors)
+    uint32_t ngmax, uint32_t* __restrict__ neighbors, uint32_t* __restrict__ counts, int* __restrict__ errors,
+    unsigned long long* __restrict__ stats)
 {
     __shared__ NodeIdx stackNode[NB_WAVES][NB_STACK];
     __shared__ uint64_t stackMask[NB_WAVES][NB_STACK];
@@ -94,6 +95,10 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
 
     uint32_t* out = neighbors + size_t(tid) * ngmax;
     uint32_t nn   = 0;
+    // STATS (NcStats, R/traversal/find_neighbors.cuh:345-369,494-502): distance tests of THIS target, tests the wave
+    // issued (64 lanes per leaf particle), deepest stack use
+    uint32_t myTests = 0, issued = 0;
+    int maxTop       = 0;
 
     // n is wave-uniform: centers and sizes come through the scalar cache
     auto overlaps = [&](NodeIdx n) -> bool
@@ -119,6 +124,11 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
         NodeIdx leaf      = uniform(internalToLeaf[n]);
         const uint32_t jb = uniform(layout[leaf]), je = uniform(layout[leaf + 1]);
         const bool fold   = __any(mine && usePbc);
+        if (STATS)
+        {
+            issued += je - jb;
+            if (mine) myTests += je - jb;
+        }
         for (uint32_t base = jb; base < je; base += 64)
         {
             const uint32_t cnt = min(64u, je - base);
@@ -198,6 +208,7 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
                             sMask[top] = cm;
                         }
                         ++top;
+                        if (STATS) maxTop = max(maxTop, top);
                     }
                     else if (lane == 0) { atomicOr(errors, 4); }
                 }
@@ -210,6 +221,23 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
         }
     }
     if (valid) counts[tid] = nn;
+    if (STATS)
+    {
+        unsigned long long sum = valid ? myTests : 0u;
+        uint32_t mx            = valid ? myTests : 0u;
+        for (int o = 32; o > 0; o >>= 1)
+        {
+            sum += __shfl_down(sum, o);
+            mx = max(mx, uint32_t(__shfl_down(int(mx), o)));
+        }
+        if (lane == 0)
+        {
+            atomicAdd(&stats[0], sum);
+            atomicMax(&stats[1], (unsigned long long)mx);
+            atomicMax(&stats[2], (unsigned long long)maxTop);
+            atomicAdd(&stats[3], (unsigned long long)issued * 64ull);
+        }
+    }
     chunk += 64;
     } while (GROUPS && chunk < chunkEnd);
 }
@@ -223,12 +251,13 @@ using namespace cship;
 namespace
 {
 
-template<bool GROUPS>
+template<bool GROUPS, bool STATS = false>
 int launchFindNeighbors(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y, const void* z, const void* h,
                         uint32_t first, uint32_t last, const uint32_t* groupStart, const uint32_t* groupEnd,
                         uint32_t numGroups, const cstone_box* box_host, const int32_t* child_offsets,
                         const int32_t* internal_to_leaf, const uint32_t* layout, const void* centers, const void* sizes,
-                        float ext, uint32_t ngmax, uint32_t* neighbors, uint32_t* counts)
+                        float ext, uint32_t ngmax, uint32_t* neighbors, uint32_t* counts,
+                        unsigned long long* statsDev = nullptr)
 {
     if (!ctx || !x || !y || !z || !h || !box_host || !child_offsets || !internal_to_leaf || !layout || !centers ||
         !sizes || !counts || (ngmax && !neighbors) || last < first || (GROUPS && numGroups && (!groupStart || !groupEnd)))
@@ -240,15 +269,17 @@ int launchFindNeighbors(cstone_hip_ctx* ctx, int real_bits, const void* x, const
         StageTimer timer(ctx, CSTONE_STAGE_NEIGHBORS);
         unsigned grid = GROUPS ? gridFor(numGroups, NB_WAVES) : gridFor(size_t(last - first), NB_BLOCK);
         if (real_bits == 32)
-            hipLaunchKernelGGL((findNeighborsKernel<float, GROUPS>), grid, NB_BLOCK, 0, ctx->stream, (const float*)x,
+            hipLaunchKernelGGL((findNeighborsKernel<float, GROUPS, STATS>), grid, NB_BLOCK, 0, ctx->stream, (const float*)x,
                                (const float*)y, (const float*)z, (const float*)h, first, last, groupStart, groupEnd,
                                numGroups, makeDBox<float>(*box_host), child_offsets, internal_to_leaf, layout,
-                               (const float*)centers, (const float*)sizes, ext, ngmax, neighbors, counts, errors);
+                               (const float*)centers, (const float*)sizes, ext, ngmax, neighbors, counts, errors,
+                               statsDev);
         else
-            hipLaunchKernelGGL((findNeighborsKernel<double, GROUPS>), grid, NB_BLOCK, 0, ctx->stream, (const double*)x,
-                               (const double*)y, (const double*)z, (const double*)h, first, last, groupStart, groupEnd,
-                               numGroups, makeDBox<double>(*box_host), child_offsets, internal_to_leaf, layout,
-                               (const double*)centers, (const double*)sizes, ext, ngmax, neighbors, counts, errors);
+            hipLaunchKernelGGL((findNeighborsKernel<double, GROUPS, STATS>), grid, NB_BLOCK, 0, ctx->stream,
+                               (const double*)x, (const double*)y, (const double*)z, (const double*)h, first, last,
+                               groupStart, groupEnd, numGroups, makeDBox<double>(*box_host), child_offsets,
+                               internal_to_leaf, layout, (const double*)centers, (const double*)sizes, ext, ngmax,
+                               neighbors, counts, errors, statsDev);
     }
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
@@ -279,4 +310,32 @@ extern "C" int cstone_hip_find_neighbors_groups(cstone_hip_ctx* ctx, int real_bi
     return launchFindNeighbors<true>(ctx, real_bits, x, y, z, h, first, last, group_start, group_end, num_groups,
                                      box_host, child_offsets, internal_to_leaf, layout, centers, sizes, ext, ngmax,
                                      neighbors, counts);
+}
+
+/* findNeighbors with the traversal counters of the reference's NcStats (R/traversal/find_neighbors.cuh:345-369,494-502) */
+extern "C" int cstone_hip_find_neighbors_stats(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y,
+                                               const void* z, const void* h, uint32_t first, uint32_t last,
+                                               const cstone_box* box_host, const int32_t* child_offsets,
+                                               const int32_t* internal_to_leaf, const uint32_t* layout,
+                                               const void* centers, const void* sizes, float ext, uint32_t ngmax,
+                                               uint32_t* neighbors, uint32_t* counts, uint64_t* stats_host)
+{
+    if (!ctx || !stats_host) return fail(ctx, CSTONE_E_ARG, "find_neighbors_stats: bad argument");
+    CS_TRY(arenaReserve(ctx, 256));
+    auto* dev = static_cast<unsigned long long*>(arenaTake(ctx, 4 * sizeof(unsigned long long)));
+    int rc    = CSTONE_OK;
+    if (hipMemsetAsync(dev, 0, 4 * sizeof(unsigned long long), ctx->stream) != hipSuccess)
+        rc = fail(ctx, CSTONE_E_HIP, "find_neighbors_stats: memset failed");
+    if (rc == CSTONE_OK)
+        rc = launchFindNeighbors<false, true>(ctx, real_bits, x, y, z, h, first, last, nullptr, nullptr, 0, box_host,
+                                              child_offsets, internal_to_leaf, layout, centers, sizes, ext, ngmax,
+                                              neighbors, counts, dev);
+    if (rc == CSTONE_OK)
+    {
+        hipError_t e = hipMemcpyAsync(stats_host, dev, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, CSTONE_E_HIP, "find_neighbors_stats: %s", hipGetErrorString(e));
+    }
+    arenaReset(ctx);
+    return rc;
 }

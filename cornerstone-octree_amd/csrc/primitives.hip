@@ -159,6 +159,51 @@ __global__ __launch_bounds__(256) void mergePositionsKernel(const K* __restrict_
     }
 }
 
+//! dst[a][i] = src[a][map[i]] for NUM arrays of equal element size: the map is read ONCE for all of them (4 + 2 E NUM
+//! bytes per element instead of NUM (4 + 2 E)), all loads of a thread are in flight before the first store
+template<class E, int PER, int NUM>
+__global__ __launch_bounds__(256) void gatherMultiKernel(const uint32_t* __restrict__ map, size_t n,
+                                                         const E* __restrict__ s0, const E* __restrict__ s1,
+                                                         const E* __restrict__ s2, const E* __restrict__ s3,
+                                                         E* __restrict__ d0, E* __restrict__ d1, E* __restrict__ d2,
+                                                         E* __restrict__ d3)
+{
+    size_t base = size_t(blockIdx.x) * (256 * PER) + threadIdx.x;
+    uint32_t in[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+    {
+        size_t i = base + size_t(k) * 256;
+        in[k]    = i < n ? map[i] : 0u;
+    }
+    const E* src[4] = {s0, s1, s2, s3};
+    E* dst[4]       = {d0, d1, d2, d3};
+    E v[NUM][PER];
+#pragma unroll
+    for (int a = 0; a < NUM; ++a)
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (base + size_t(k) * 256 < n) v[a][k] = src[a][in[k]];
+#pragma unroll
+    for (int a = 0; a < NUM; ++a)
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (base + size_t(k) * 256 < n) dst[a][base + size_t(k) * 256] = v[a][k];
+}
+
+template<int B, int NUM>
+void launchGatherMulti(cstone_hip_ctx* ctx, const uint32_t* map, size_t n, const void* const* src, void* const* dst)
+{
+    constexpr int PER = 4;
+    using E           = Elem<B>;
+    const E* s[4]     = {nullptr, nullptr, nullptr, nullptr};
+    E* d[4]           = {nullptr, nullptr, nullptr, nullptr};
+    for (int a = 0; a < NUM; ++a)
+        s[a] = (const E*)src[a], d[a] = (E*)dst[a];
+    hipLaunchKernelGGL((gatherMultiKernel<E, PER, NUM>), gridFor(n, 256, PER), 256, 0, ctx->stream, map, n, s[0], s[1],
+                       s[2], s[3], d[0], d[1], d[2], d[3]);
+}
+
 template<bool GATHER, int B>
 void launchPermute(cstone_hip_ctx* ctx, const uint32_t* map, size_t n, const void* src, void* dst)
 {
@@ -396,6 +441,39 @@ extern "C"
 int cstone_hip_gather(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map, size_t n, const void* src, void* dst)
 {
     return permute<true>(ctx, elem_bytes, map, n, src, dst);
+}
+
+int cstone_hip_gather_multi(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map, size_t n, const void* const* src,
+                            void* const* dst, int num_arrays)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    if (num_arrays < 1 || num_arrays > 4 || !src || !dst) return fail(ctx, CSTONE_E_ARG, "gather_multi: 1..4 arrays");
+    if (n == 0) return CSTONE_OK;
+    if (num_arrays == 1) return cstone_hip_gather(ctx, elem_bytes, map, n, src[0], dst[0]);
+    if (!map) return fail(ctx, CSTONE_E_ARG, "gather_multi: null map");
+    if (elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16)
+        return fail(ctx, CSTONE_E_ARG, "gather_multi: elements of 4, 8 or 16 bytes");
+    for (int a = 0; a < num_arrays; ++a)
+    {
+        if (!src[a] || !dst[a] || (uintptr_t(src[a]) % elem_bytes) || (uintptr_t(dst[a]) % elem_bytes))
+            return fail(ctx, CSTONE_E_ARG, "gather_multi: null or misaligned array %d", a);
+        for (int b = 0; b < num_arrays; ++b)
+            if (dst[a] == src[b]) return fail(ctx, CSTONE_E_ARG, "gather_multi: a destination aliases a source");
+    }
+    StageTimer timer(ctx, CSTONE_STAGE_GATHER);
+#define CSTONE_GM(B)                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (num_arrays == 2) launchGatherMulti<B, 2>(ctx, map, n, src, dst);                                           \
+        else if (num_arrays == 3) launchGatherMulti<B, 3>(ctx, map, n, src, dst);                                      \
+        else launchGatherMulti<B, 4>(ctx, map, n, src, dst);                                                           \
+    } while (0)
+    if (elem_bytes == 4) CSTONE_GM(4);
+    else if (elem_bytes == 8) CSTONE_GM(8);
+    else CSTONE_GM(16);
+#undef CSTONE_GM
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
 }
 
 int cstone_hip_scatter(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map, size_t n, const void* src, void* dst)

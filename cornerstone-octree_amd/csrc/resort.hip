@@ -564,24 +564,33 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
  *  by the three leading bits of its digest (the octant of the leaf's cell it lies in: one returning LDS atomic), then
  *  counts the smaller digests among the handful of elements of its own bucket only.  The thread that loaded an element
  *  keeps its key in registers through both phases and stores it itself: no key is read twice, no key lives in LDS
- *  (21 KB of LDS: the grouped digests and the bucket tables).  Digests as in leafSortKernel: 24 leading bits of
- *  (key - first key of the leaf), then the slot in the leaf; two elements of a bucket whose 24 bits agree are placed by
- *  key and old index proper (global memory, about one in 10^4).  Same result: leaf j's elements at layoutNew[j]... in
- *  the order of (key, old index). */
+ *  (21 KB of LDS: the grouped digests and the bucket tables).
+ *  The kernel is a chain of LDS round trips per element (leaf search, atomic, bucket scan): written element by
+ *  element, a thread's 17 elements wait for each other's LDS latencies one after the other (that form took the same
+ *  0.9 ms as counting over the whole leaf).  So every step is written ACROSS a batch of the thread's elements, branch
+ *  free: one search step / one atomic / one scan step for all of them, then the next -- nine independent LDS accesses in
+ *  flight per wait.
+ *  Digests as in leafSortKernel: 24 leading bits of (key - first key of the leaf), then the slot in the leaf; two
+ *  elements of a bucket whose 24 bits agree are placed by key and old index proper (global memory, about one in 10^4).
+ *  Same result: leaf j's elements at layoutNew[j]... in the order of (key, old index). */
 template<class K, int G>
-__global__ __launch_bounds__(256) void leafSortBucketsKernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void leafSortBucketsKernel(
     const K* __restrict__ keysIn, const uint64_t* __restrict__ mask, const uint32_t* __restrict__ rank,
     const K* __restrict__ leafLo, const uint32_t* __restrict__ leafPos, const uint32_t* __restrict__ inOffset,
     const uint32_t* __restrict__ layoutNew, const K* __restrict__ binKeys, const uint32_t* __restrict__ binIdx, uint32_t J,
     bool alwaysCount, K* __restrict__ keysOut, uint32_t* __restrict__ orderOut)
 {
-    constexpr int ITER = (RESORT_TILE_SLOTS + 255) / 256;
-    constexpr K HOLE   = ~K(0);
+    constexpr int ITER  = (RESORT_TILE_SLOTS + 255) / 256;
+    constexpr int BATCH = 6;
+    constexpr K HOLE    = ~K(0);
     __shared__ uint32_t sGrp[RESORT_TILE_SLOTS]; // digests, grouped by (leaf, bucket)
-    __shared__ uint32_t posK[G + 1], inK[G + 1], outK[G + 1];
+    __shared__ uint32_t pinK[2 * (G + 1)];       // first old position | first bin entry of every leaf
+    __shared__ uint32_t outK[G + 1];
     __shared__ K loK[G + 1];
     __shared__ uint8_t cutK[G];
-    __shared__ uint32_t cntK[G * 8], baseK[G * 8];
+    __shared__ uint32_t cntK[G * 8 + 1], baseK[G * 8 + 1]; // (the last entry: where elements that are none count)
+    uint32_t* const posK = pinK;
+    uint32_t* const inK  = pinK + (G + 1);
 
     const uint32_t j0 = blockIdx.x * uint32_t(G);
     const uint32_t nl = min(uint32_t(G), J - j0);
@@ -593,8 +602,8 @@ __global__ __launch_bounds__(256) void leafSortBucketsKernel(
         outK[t] = layoutNew[j0 + t];
         loK[t]  = leafLo[j0 + t];
     }
-    for (uint32_t i = t; i < uint32_t(G) * 8; i += 256)
-        cntK[i] = 0;
+    for (uint32_t i = t; i < uint32_t(G) * 8 + 1; i += 256)
+        cntK[i] = 0, baseK[i] = 0;
     __syncthreads();
     if (t < nl)
     {
@@ -617,41 +626,52 @@ __global__ __launch_bounds__(256) void leafSortBucketsKernel(
     for (int i = 0; i < ITER; ++i)
     {
         const uint32_t e = t + 256u * i;
-        info[i]          = ~0u;
         key[i]           = HOLE;
-        dig[i]           = ~0u;
         if (e < nOldAll) key[i] = keysIn[p0 + e];
         else if (e < slots) key[i] = binKeys[in0 + (e - nOldAll)];
     }
 #pragma unroll
-    for (int i = 0; i < ITER; ++i)
+    for (int bs = 0; bs < ITER; bs += BATCH)
     {
-        const uint32_t e = t + 256u * i;
-        if (e >= slots || key[i] == HOLE) continue;
-        uint32_t k, slot;
-        if (e < nOldAll)
+        uint32_t val[BATCH], lo[BATCH], off[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
         {
-            const uint32_t p = p0 + e;
-            k    = rank[p >> 6] + uint32_t(__popcll(mask[p >> 6] & ((2ull << (p & 63u)) - 1))) - 1u - j0;
-            slot = p - posK[k];
+            const int i      = bs + j < ITER ? bs + j : ITER - 1;
+            const uint32_t e = t + 256u * i;
+            const bool isOld = e < nOldAll, any = e < slots;
+            // what is searched for: the old position among the leaves' first positions, or the bin entry among the leaves'
+            // first entries (an element that is none searches for the tile's first position: in range, result unused)
+            val[j] = !any ? p0 : (isOld ? p0 + e : in0 + (e - nOldAll));
+            off[j] = (any && !isOld) ? uint32_t(G + 1) : 0u;
+            lo[j]  = 0;
         }
-        else
+        // last leaf k of the tile with pinK[off + k] <= val, all elements of the batch one search step at a time
+        for (uint32_t n = nl; n > 1;)
         {
-            const uint32_t m = in0 + (e - nOldAll);
-            uint32_t lo = 0, hi = nl; // leaf of bin entry m: last k with inK[k] <= m
-            while (hi - lo > 1)
+            const uint32_t half = n >> 1;
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j)
             {
-                uint32_t mid = (lo + hi) / 2;
-                if (inK[mid] <= m) lo = mid;
-                else hi = mid;
+                const uint32_t probe = pinK[off[j] + lo[j] + half];
+                lo[j]                = probe <= val[j] ? lo[j] + half : lo[j];
             }
-            k    = lo;
-            slot = (posK[k + 1] - posK[k]) + (m - inK[k]);
+            n -= half;
         }
-        const uint32_t d  = (uint32_t((key[i] - loK[k]) >> cutK[k]) << 8) | slot;
-        const uint32_t at = atomicAdd(&cntK[k * 8 + (d >> 29)], 1u);
-        dig[i]  = d;
-        info[i] = (k << 24) | at;
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+        {
+            if (bs + j >= ITER) continue; // (compile time)
+            const int i      = bs + j;
+            const uint32_t e = t + 256u * i;
+            const bool ok    = e < slots && key[i] != HOLE;
+            const uint32_t k = lo[j];
+            const uint32_t slot = off[j] ? (posK[k + 1] - posK[k]) + (val[j] - inK[k]) : val[j] - posK[k];
+            const uint32_t d    = (uint32_t((key[i] - loK[k]) >> cutK[k]) << 8) | (slot & 0xFFu);
+            const uint32_t at   = atomicAdd(&cntK[ok ? k * 8 + (d >> 29) : uint32_t(G) * 8], 1u);
+            dig[i]  = ok ? d : ~0u;
+            info[i] = ok ? (k << 24) | at : ~0u;
+        }
     }
     __syncthreads();
     // ---- bucket starts in the tile's NEW order (leaf k starts at outK[k] - outK[0])
@@ -689,25 +709,48 @@ __global__ __launch_bounds__(256) void leafSortBucketsKernel(
         return less;
     };
 #pragma unroll
-    for (int i = 0; i < ITER; ++i)
+    for (int bs = 0; bs < ITER; bs += BATCH)
     {
-        if (info[i] == ~0u) continue;
-        const uint32_t e = t + 256u * i;
-        const uint32_t k = info[i] >> 24, d = dig[i], bk = k * 8 + (d >> 29);
-        const uint32_t b0 = baseK[bk], nb = cntK[bk];
-        uint32_t less = 0;
-        bool clash    = false;
-        for (uint32_t q = 0; q < nb; ++q)
+        uint32_t bb[BATCH], nb[BATCH], less[BATCH], same[BATCH];
+        uint32_t maxNb = 0;
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
         {
-            const uint32_t v = sGrp[b0 + q];
-            less += v < d;
-            clash = clash || ((v ^ d) >> 8 == 0 && v != d);
+            const int i       = bs + j < ITER ? bs + j : ITER - 1;
+            const bool ok     = bs + j < ITER && info[i] != ~0u;
+            const uint32_t bk = ok ? (info[i] >> 24) * 8 + (dig[i] >> 29) : uint32_t(G) * 8;
+            bb[j]   = baseK[bk];
+            nb[j]   = ok ? cntK[bk] : 0u;
+            less[j] = 0, same[j] = 0;
+            maxNb   = max(maxNb, nb[j]);
         }
-        const uint32_t ix = e < nOldAll ? p0 + e : binIdx[in0 + (e - nOldAll)];
-        uint32_t at       = outK[0] + b0 + less;
-        if (clash) at = outK[k] + placeExact(k, key[i], ix);
-        keysOut[at]  = key[i];
-        orderOut[at] = ix;
+        // the buckets of all elements of the batch, one entry at a time
+        for (uint32_t q = 0; q < maxNb; ++q)
+        {
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j)
+            {
+                const int i      = bs + j < ITER ? bs + j : ITER - 1;
+                const bool in    = q < nb[j];
+                const uint32_t v = sGrp[bb[j] + (in ? q : 0u)];
+                less[j] += (in && v < dig[i]) ? 1u : 0u;
+                same[j] += (in && ((v ^ dig[i]) >> 8) == 0) ? 1u : 0u; // (itself included)
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+        {
+            if (bs + j >= ITER) continue; // (compile time)
+            const int i = bs + j;
+            if (info[i] == ~0u) continue;
+            const uint32_t e  = t + 256u * i;
+            const uint32_t k  = info[i] >> 24;
+            const uint32_t ix = e < nOldAll ? p0 + e : binIdx[in0 + (e - nOldAll)];
+            uint32_t at       = outK[0] + bb[j] + less[j];
+            if (same[j] > 1) at = outK[k] + placeExact(k, key[i], ix);
+            keysOut[at]  = key[i];
+            orderOut[at] = ix;
+        }
     }
 }
 

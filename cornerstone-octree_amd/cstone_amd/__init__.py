@@ -19,7 +19,7 @@ MORTON, HILBERT = 0, 1
 
 STAGES = {
     "encode": 0, "sort_hist": 1, "sort_pass": 2, "gather": 3, "node_counts": 4, "rebalance": 5, "link_octree": 6,
-    "halos": 7, "neighbors": 8, "minmax": 9, "sort_pass_iota": 10, "resort_bins": 11, "resort_leaves": 12,
+    "halos": 7, "neighbors": 8, "minmax": 9, "sort_pass_iota": 10, "resort_bins": 11, "resort_leaves": 12, "gather_h": 13,
 }
 
 EXPORTS = [
@@ -50,6 +50,8 @@ EXPORTS = [
     "cstone_hip_raise", "cstone_hip_find_peers_mac", "cstone_hip_keys_missing", "cstone_hip_partition_keys",
     "cstone_hip_zero_ops_at_keys", "cstone_hip_locate_nodes", "cstone_hip_node_layout", "cstone_hip_halo_requests",
     "cstone_hip_ranges_from_keys", "cstone_hip_domain_mr_set_halo_mode", "cstone_hip_domain_mr_set_theta",
+    "cstone_hip_upload", "cstone_hip_focus_update_ops", "cstone_hip_find_neighbors_stats",
+    "cstone_hip_gather_multi", "cstone_hip_domain_sync_scratch",
 ]
 
 

@@ -53,23 +53,34 @@ class Domain:
             pass
 
     def sync(self, keys, x, y, z, h, scratch, props=()):
-        """returns (keys, x, y, z, h, scratch, props) as tensors after the buffer exchange, truncated to the new size"""
-        tensors = [x, y, z, h, scratch] + list(props)
+        """returns (keys, x, y, z, h, scratch, props) as tensors after the buffer exchange, truncated to the new size;
+        scratch: one tensor, or a list of tensors (cstone_hip_domain_sync_scratch: from three on x, y, z are gathered in
+        one pass) -- a list comes back as a list"""
+        many = isinstance(scratch, (list, tuple))
+        scr = list(scratch) if many else [scratch]
+        tensors = [x, y, z, h] + scr + list(props)
         by_ptr = {t.data_ptr(): t for t in tensors}
         n = x.numel()
         pk = C.c_void_p(keys.data_ptr())
-        ptrs = [C.c_void_p(t.data_ptr()) for t in (x, y, z, h, scratch)]
+        ptrs = [C.c_void_p(t.data_ptr()) for t in (x, y, z, h)]
+        sarr = (C.c_void_p * len(scr))(*[t.data_ptr() for t in scr])
         parr = (C.c_void_p * max(1, len(props)))(*[t.data_ptr() for t in props])
         pbytes = (C.c_int * max(1, len(props)))(*[t.element_size() for t in props])
-        rc = self.ctx.lib.cstone_hip_domain_sync(self.h, C.byref(pk), C.byref(ptrs[0]), C.byref(ptrs[1]),
-                                                 C.byref(ptrs[2]), C.byref(ptrs[3]), C.c_size_t(n), C.byref(ptrs[4]),
-                                                 parr, pbytes, C.c_int(len(props)))
+        if many:
+            rc = self.ctx.lib.cstone_hip_domain_sync_scratch(self.h, C.byref(pk), C.byref(ptrs[0]), C.byref(ptrs[1]),
+                                                             C.byref(ptrs[2]), C.byref(ptrs[3]), C.c_size_t(n), sarr,
+                                                             C.c_int(len(scr)), parr, pbytes, C.c_int(len(props)))
+        else:
+            rc = self.ctx.lib.cstone_hip_domain_sync(self.h, C.byref(pk), C.byref(ptrs[0]), C.byref(ptrs[1]),
+                                                     C.byref(ptrs[2]), C.byref(ptrs[3]), C.c_size_t(n), sarr,
+                                                     parr, pbytes, C.c_int(len(props)))
         self.ctx._chk(rc, "domain_sync")
         v = self.view()
         m = v.num_particles_with_halos
         out = [by_ptr[p.value] for p in ptrs]
+        sout = [by_ptr[sarr[i]] for i in range(len(scr))]
         pout = [by_ptr[parr[i]] for i in range(len(props))]
-        return keys[:m], out[0][:m], out[1][:m], out[2][:m], out[3][:m], out[4], [t[:m] for t in pout]
+        return keys[:m], out[0][:m], out[1][:m], out[2][:m], out[3][:m], (sout if many else sout[0]), [t[:m] for t in pout]
 
     def reapply_sync(self, field):
         """Domain::reapplySync: field (n rows of the last sync's input, 1..32 bytes each) in the order of the result"""

@@ -91,8 +91,9 @@ extern "C"
 #define CSTONE_STAGE_SORT_PASS_IOTA 10 /* a digit pass that produces the positions instead of reading values: K + (K+4) B/pair */
 #define CSTONE_STAGE_RESORT_BINS 11   /* incremental re-sort of Domain::sync: leaf table, mover bins (csrc/resort.hpp) */
 #define CSTONE_STAGE_RESORT_LEAVES 12 /* ... its pass over the leaves: K read, K + 4 written per particle */
+#define CSTONE_STAGE_GATHER_H 13      /* gather of h fused with the halo radii of Domain::sync: 4 + 2 T bytes per particle */
 #define CSTONE_NUM_STAGES 16
-    /* on: 0 off, 1 every stage, 2 only ENCODE, SORT_PASS(_IOTA), RESORT_LEAVES, GATHER, HALOS, NEIGHBORS (the kernels that
+    /* on: 0 off, 1 every stage, 2 only ENCODE, SORT_PASS(_IOTA), RESORT_LEAVES, GATHER(_H), HALOS, NEIGHBORS (the kernels that
      * move the particle arrays: eight brackets per sync instead of forty) */
     int cstone_hip_profile_enable(cstone_hip_ctx* ctx, int on);
     int cstone_hip_profile_reset(cstone_hip_ctx* ctx);
@@ -141,6 +142,11 @@ extern "C"
                           void* dst);
     int cstone_hip_scatter(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map, size_t n, const void* src,
                            void* dst);
+    /* gather of 1..4 arrays of equal element size (4, 8 or 16 bytes) through the SAME map, which is read once:
+     * dst[a][i] = src[a][map[i]] (what gatherArrays, R/domain/layout.hpp:203-239, does array after array); no
+     * destination may be one of the sources */
+    int cstone_hip_gather_multi(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map, size_t n,
+                                const void* const* src, void* const* dst, int num_arrays);
 
     /* gatherScatter (R/primitives/gather.hpp:120-131): dst[map_out[i]] = src[map_in[i]], element sizes as gather */
     int cstone_hip_gather_scatter(cstone_hip_ctx* ctx, int elem_bytes, const uint32_t* map_in, const uint32_t* map_out,
@@ -408,6 +414,22 @@ extern "C"
      *                 range_scan[num_pairs + 1] = exclusive scan of the lengths (what gather_ranges takes)
      * ------------------------------------------------------------------------------------------- */
     int cstone_hip_raise(cstone_hip_ctx* ctx, int code, const char* message);
+    /* upload : a SMALL host array to the device without synchronising the stream: the bytes are copied to a pinned
+     *          staging ring first, so src_host may be reused as soon as the call returns; ordered on the context's stream
+     *          like any other work (arrays beyond a quarter of the ring, 256 KiB, go the way of memcpy_h2d) */
+    int cstone_hip_upload(cstone_hip_ctx* ctx, void* dst, const void* src_host, size_t bytes);
+    /* focus_update_ops : the decision part of CombinedUpdate::updateFocus (R/focus/octree_focus.hpp:97-122) in one call
+     *          and ONE read-back: rebalance_decision_essential, enforce_keys (num_forced_keys device keys),
+     *          protect_ancestors on node_ops_all[num_nodes], then the leaves' ops in leaf order (leaf_to_internal: the
+     *          leaf part of the tree's map, num_leaves entries), scanned exclusively into leaf_ops[num_leaves + 1] (what
+     *          rebalance_tree takes).  result_host = {status of the enforced keys, converged as updateFocus reports it,
+     *          1 if every leaf keeps, new number of leaves} */
+    int cstone_hip_focus_update_ops(cstone_hip_ctx* ctx, int key_bits, const void* prefixes,
+                                    const int32_t* child_offsets, const int32_t* parents, const uint32_t* counts,
+                                    const char* macs, uint64_t focus_start, uint64_t focus_end, uint32_t bucket_size,
+                                    const void* forced_keys, int num_forced_keys, const int32_t* leaf_to_internal,
+                                    int num_leaves, int num_nodes, int32_t* node_ops_all, int32_t* leaf_ops,
+                                    int* result_host);
     int cstone_hip_find_peers_mac(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* prefixes,
                                   const int32_t* child_offsets, const int32_t* level_range,
                                   const uint64_t* assignment_host, int num_ranks, int my_rank,
@@ -441,6 +463,21 @@ extern "C"
                                   const int32_t* child_offsets, const int32_t* internal_to_leaf,
                                   const uint32_t* layout, const void* centers, const void* sizes, float ext,
                                   uint32_t ngmax, uint32_t* neighbors, uint32_t* counts);
+
+    /* the same search with the traversal counters of the reference's NcStats (R/traversal/find_neighbors.cuh:345-369,
+     * 494-502; what its neighbor_driver prints, test/performance/neighbor_driver.cu:159-170):
+     * stats_host[0] = sumP2P  : distance tests, summed over the targets (a target is tested against every particle of
+     *                           every leaf its own walk reaches)
+     * stats_host[1] = maxP2P  : most distance tests of one target
+     * stats_host[2] = maxStack: deepest use of the traversal stack (entries; one stack per wave of 64 targets)
+     * stats_host[3]           : tests the SIMDs issued: a wave tests every particle of a leaf in all 64 lanes, also for
+     *                           the lanes whose own walk did not reach that leaf (>= sumP2P; their ratio is the lane
+     *                           efficiency of sharing one traversal among 64 targets) */
+    int cstone_hip_find_neighbors_stats(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y, const void* z,
+                                        const void* h, uint32_t first, uint32_t last, const cstone_box* box_host,
+                                        const int32_t* child_offsets, const int32_t* internal_to_leaf,
+                                        const uint32_t* layout, const void* centers, const void* sizes, float ext,
+                                        uint32_t ngmax, uint32_t* neighbors, uint32_t* counts, uint64_t* stats_host);
 
     /* ---------------------------------------------------------------------------------------------
      * target particle groups: replace computeFixedGroups (R/traversal/groups_gpu.h:46, groups_gpu.cu:41-71) and
@@ -523,6 +560,15 @@ extern "C"
     int cstone_hip_domain_destroy(cstone_hip_domain* dom);
     int cstone_hip_domain_sync(cstone_hip_domain* dom, void** keys, void** x, void** y, void** z, void** h, size_t n,
                                void** scratch, void** props, const int* prop_bytes, int num_props);
+    /* the same with num_scratch >= 1 scratch buffers of n elements each (scratch: array of num_scratch device
+     * pointers), like the scratch TUPLE of the reference's sync (R/domain/domain.hpp:196-206).  From three buffers on
+     * x, y and z are brought into SFC order by ONE kernel that reads the ordering once (cstone_hip_gather_multi: 52
+     * instead of 60 bytes per particle for f64); with fewer the arrays rotate through scratch[0] one after the other.
+     * All buffers take part in the pointer exchange: on return *x, *y, *z, *h, props[i] and scratch[q] are a
+     * permutation of the buffers passed in.  Same results whatever num_scratch is. */
+    int cstone_hip_domain_sync_scratch(cstone_hip_domain* dom, void** keys, void** x, void** y, void** z, void** h,
+                                       size_t n, void** scratch, int num_scratch, void** props, const int* prop_bytes,
+                                       int num_props);
     int cstone_hip_domain_view_get(cstone_hip_domain* dom, cstone_hip_domain_view* out);
     /* Domain::setHaloFactor (R/domain/domain.hpp:412): extra search factor of the halo discovery (default 1.0), lets a
      * client take several integration steps between syncs */

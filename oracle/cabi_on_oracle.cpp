@@ -86,6 +86,11 @@ int cstone_hip_memcpy_h2d(cstone_hip_ctx*, void* dst, const void* src, size_t by
     if (bytes) std::memcpy(dst, src, bytes);
     return CSTONE_OK;
 }
+int cstone_hip_upload(cstone_hip_ctx*, void* dst, const void* src, size_t bytes)
+{
+    if (bytes) std::memcpy(dst, src, bytes);
+    return CSTONE_OK;
+}
 int cstone_hip_memcpy_d2h(cstone_hip_ctx*, void* dst, const void* src, size_t bytes)
 {
     if (bytes) std::memcpy(dst, src, bytes);
@@ -351,6 +356,41 @@ int cstone_hip_enforce_keys(cstone_hip_ctx*, int key_bits, const void* forced_ke
                        using K      = decltype(k);
                        *status_host = enforceKeys<K>((const K*)forced_keys, num_forced_keys, (const K*)prefixes,
                                                      child_offsets, parents, node_ops);
+                   });
+}
+int cstone_hip_focus_update_ops(cstone_hip_ctx*, int key_bits, const void* prefixes, const int32_t* child_offsets,
+                                const int32_t* parents, const uint32_t* counts, const char* macs, uint64_t focus_start,
+                                uint64_t focus_end, uint32_t bucket_size, const void* forced_keys, int num_forced_keys,
+                                const int32_t* leaf_to_internal, int num_leaves, int num_nodes, int32_t* node_ops_all,
+                                int32_t* leaf_ops, int* result_host)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       // CombinedUpdate::updateFocus, R/focus/octree_focus.hpp:97-122
+                       using K = decltype(k);
+                       essentialOps<K>((const K*)prefixes, child_offsets, parents, counts, macs, K(focus_start),
+                                       K(focus_end), bucket_size, node_ops_all, num_nodes);
+                       int status    = enforceKeys<K>((const K*)forced_keys, num_forced_keys, (const K*)prefixes,
+                                                      child_offsets, parents, node_ops_all);
+                       int converged = protectAncestors<K>((const K*)prefixes, parents, node_ops_all, num_nodes) ? 1 : 0;
+                       int keep      = 1;
+                       for (int i = 0; i < num_leaves; ++i)
+                       {
+                           leaf_ops[i] = node_ops_all[leaf_to_internal[i]];
+                           if (leaf_ops[i] != 1) keep = 0;
+                       }
+                       if (status == 1) converged = keep;
+                       if (status >= 2) converged = 0;
+                       int32_t run = 0;
+                       for (int i = 0; i <= num_leaves; ++i)
+                       {
+                           int32_t t   = i < num_leaves ? leaf_ops[i] : 0;
+                           leaf_ops[i] = run;
+                           run += t;
+                       }
+                       result_host[0] = status, result_host[1] = converged, result_host[2] = keep;
+                       result_host[3] = leaf_ops[num_leaves];
                    });
 }
 int cstone_hip_range_count(cstone_hip_ctx*, int key_bits, const void* leaves, int num_leaves, const uint32_t* counts,

@@ -13,9 +13,10 @@ GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "gold
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("full_sort", [False, True], ids=["partial-digit-sort", "all-digits-sorted"])
+@pytest.mark.parametrize("full_sort,num_scratch", [(False, 1), (True, 1), (False, 3)],
+                         ids=["partial-digit-sort", "all-digits-sorted", "three-scratch-buffers"])
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
-def test_domain_sync_matches_reference(hip, path, full_sort, monkeypatch):
+def test_domain_sync_matches_reference(hip, path, full_sort, num_scratch, monkeypatch):
     import torch
 
     if full_sort:  # the radix passes over ALL key digits instead of the digits above the previous tree's leaf level
@@ -36,7 +37,9 @@ def test_domain_sync_matches_reference(hip, path, full_sort, monkeypatch):
         n = x.numel()
         kin = d[f"in{s}_keys"] if f"in{s}_keys" in d else np.zeros(n, kdt)
         keys = torch.from_numpy(kin.view(ksigned).copy()).cuda()
-        scratch = torch.empty_like(x)
+        # one scratch buffer, or the scratch tuple of the reference's sync (cstone_hip_domain_sync_scratch: x, y, z are then
+        # gathered by one kernel)
+        scratch = torch.empty_like(x) if num_scratch == 1 else [torch.empty_like(x) for _ in range(num_scratch)]
         # a conserved property travelling along (not wider than the coordinates: it shares their scratch buffer)
         tag = torch.arange(n, dtype=torch.float64 if rb == 64 else torch.float32, device="cuda")
         late = [torch.stack([x, y, z], dim=1).to(torch.float32).contiguous(), (h * 1e3).to(torch.int16)]

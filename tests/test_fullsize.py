@@ -280,3 +280,78 @@ def test_encode_sort_tree_1e7_against_reference_digests(hip, oracle):
     hip.sync()
     assert sha(cstone_amd.keys_to_numpy(k2, 64)) == want["sorted_keys_sha256"]
     assert sha(o2.cpu().numpy().view(np.uint32)) == want["order_sha256"]
+
+
+def test_resort_full_size_drift(hip):
+    """The mover path of the incremental re-sort (csrc/resort.hpp) at BASELINE's full size: 10^8 uniform particles through
+    the bench's time-stepping loop -- three steps in which EVERY particle drifts by up to 0.1 h per coordinate (7 % of
+    them leave their leaf) and one in which 1 % jump by up to 2h -- once through a domain that may re-sort and once through
+    one that may not (CSTONE_NO_RESORT): keys, coordinates, h, the particle identities, layout and leaf array are equal
+    after every sync, the keys are the encode of the coordinates next to them, and all four syncs were re-sorted."""
+    import torch
+
+    import cstone_amd
+    from cstone_amd.domain import Domain
+
+    n, bucket_focus = 100_000_000, 64
+    h0 = 0.6 * (3.0 * 100 / (4 * np.pi * n)) ** (1.0 / 3.0)
+
+    def fresh():
+        g = torch.Generator(device="cuda").manual_seed(77)
+        x, y, z = [torch.rand(n, dtype=torch.float64, device="cuda", generator=g) for _ in range(3)]
+        h = torch.full((n,), h0, dtype=torch.float64, device="cuda")
+        ident = torch.arange(n, dtype=torch.float64, device="cuda")
+        dom = Domain(hip, cstone_amd.HILBERT, 64, 64, n // 100, bucket_focus, 0.5, cstone_amd.make_cbox([0, 1] * 3))
+        return dict(dom=dom, k=torch.zeros(n, dtype=torch.int64, device="cuda"), x=x, y=y, z=z, h=h, id=ident,
+                    s=torch.empty_like(x))
+
+    def sync(d, allow):
+        if allow:
+            os.environ.pop("CSTONE_NO_RESORT", None)
+        else:
+            os.environ["CSTONE_NO_RESORT"] = "1"
+        try:
+            d["k"], d["x"], d["y"], d["z"], d["h"], d["s"], (d["id"],) = d["dom"].sync(d["k"], d["x"], d["y"], d["z"],
+                                                                                     d["h"], d["s"], [d["id"]])
+        finally:
+            os.environ.pop("CSTONE_NO_RESORT", None)
+        hip.sync()
+
+    def move(d, kind, seed):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        if kind == "drift":
+            for a in (d["x"], d["y"], d["z"]):
+                t = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+                a.add_(t.sub_(0.5).mul_(0.2 * h0)).clamp_(0.0, 1.0)
+                del t
+        else:
+            # (distinct indices: an indexed assignment with repeated indices keeps an arbitrary one of the writes, the two
+            #  domains of this test would drift apart)
+            idx = torch.unique(torch.randint(0, n, (n // 100,), device="cuda", generator=g))
+            m = idx.numel()
+            for a in (d["x"], d["y"], d["z"]):
+                t = (torch.rand(m, dtype=torch.float64, device="cuda", generator=g) - 0.5) * (4 * h0)
+                a[idx] = (a[idx] + t).clamp_(0.0, 1.0)
+
+    a, b = fresh(), fresh()
+    sync(a, True), sync(b, False)
+    for step, kind in enumerate(["drift", "drift", "jump", "drift"]):
+        move(a, kind, 100 + step), move(b, kind, 100 + step)
+        sync(a, True), sync(b, False)
+        va, vb = a["dom"].view(), b["dom"].view()
+        assert (va.end_index, va.num_focus_leaves) == (vb.end_index, vb.num_focus_leaves) == (n, va.num_focus_leaves), step
+        for f in ("k", "x", "y", "z", "h", "id"):
+            assert bool(torch.equal(a[f], b[f])), (step, kind, f)
+        L = va.num_focus_leaves
+        assert np.array_equal(a["dom"].fetch(va.layout, L + 1, np.uint32), b["dom"].fetch(vb.layout, L + 1, np.uint32)), step
+        assert np.array_equal(a["dom"].fetch(va.focus_leaves, L + 1, np.uint64),
+                              b["dom"].fetch(vb.focus_leaves, L + 1, np.uint64)), step
+        again = hip.compute_sfc_keys(cstone_amd.HILBERT, 64, a["x"], a["y"], a["z"], va.box)
+        assert bool((again == a["k"]).all()) and bool((a["k"][1:] >= a["k"][:-1]).all()), (step, kind)
+        del again
+    sa, sb = a["dom"].stats(), b["dom"].stats()
+    # (the first drift step moves the outermost particles: the open box follows once, that sync encodes again and sorts
+    #  from scratch; every other sync is re-sorted)
+    assert sa["resorts"] + sa["box_redos"] == 4 and sa["resorts"] >= 3 and sa["resort_fallbacks"] == 0, sa
+    assert sb["resorts"] == 0, sb
+    assert sa["last_movers"] > n // 50, sa  # the drift step: several per cent of the particles changed their leaf

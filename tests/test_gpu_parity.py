@@ -620,3 +620,78 @@ def test_sort_with_ballot_ranking(hip, kb, monkeypatch):
     monkeypatch.setenv("CSTONE_SORT_BALLOT_RANK", "1")
     test_sort_adversarial_digit_patterns_large_tiles(hip, kb)
     test_sort_pairs_fuzz_sizes(hip, kb)
+
+
+@pytest.mark.parametrize("elem_dtype,num", [("float32", 2), ("float64", 3), ("float64", 4), ("complex128", 3)])
+def test_gather_multi(hip, elem_dtype, num):
+    """cstone_hip_gather_multi: several arrays through one map (gatherArrays, R/domain/layout.hpp:203-239, array after
+    array in the reference) against torch indexing, sizes around the kernel's 1024-element blocks"""
+    import ctypes as C
+
+    import torch
+
+    dt = getattr(torch, elem_dtype)
+    for n in (1, 255, 1024, 1025, 70001):
+        g = torch.Generator(device="cuda").manual_seed(n)
+        perm = torch.randperm(n, device="cuda", generator=g).to(torch.int32)
+        src = [torch.randn(n, device="cuda", generator=g, dtype=torch.float64).to(dt) + a for a in range(num)]
+        dst = [torch.zeros_like(t) for t in src]
+        sp = (C.c_void_p * num)(*[t.data_ptr() for t in src])
+        dp = (C.c_void_p * num)(*[t.data_ptr() for t in dst])
+        rc = hip.lib.cstone_hip_gather_multi(hip.h, C.c_int(src[0].element_size()), C.c_void_p(perm.data_ptr()),
+                                             C.c_size_t(n), sp, dp, C.c_int(num))
+        hip._chk(rc, "gather_multi")
+        hip.sync()
+        for a in range(num):
+            assert torch.equal(dst[a], src[a][perm.long()]), (n, a)
+    # a destination that is also a source is refused
+    sp = (C.c_void_p * 2)(src[0].data_ptr(), src[1].data_ptr())
+    dp = (C.c_void_p * 2)(src[1].data_ptr(), dst[0].data_ptr())
+    assert hip.lib.cstone_hip_gather_multi(hip.h, C.c_int(src[0].element_size()), C.c_void_p(perm.data_ptr()),
+                                           C.c_size_t(n), sp, dp, C.c_int(2)) != 0
+
+
+def test_find_neighbors_stats(hip):
+    """cstone_hip_find_neighbors_stats: the counters of the reference's NcStats (find_neighbors.cuh:345-369).  On a tree
+    that is one leaf every target is tested against every particle: sumP2P = targets * n exactly, nothing on the stack; on
+    a real tree the counters bracket the neighbour counts"""
+    import ctypes as C
+
+    import torch
+
+    import cstone_amd
+
+    n = 20000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x, y, z = [torch.rand(n, dtype=torch.float64, device="cuda", generator=g) for _ in range(3)]
+    h = torch.full((n,), 0.02, dtype=torch.float64, device="cuda")
+    cb = cstone_amd.make_cbox([0, 1] * 3)
+    keys = hip.compute_sfc_keys(cstone_amd.HILBERT, 64, x, y, z, cb)
+    order = torch.arange(n, dtype=torch.int32, device="cuda")
+    hip.sort_pairs(keys, order)
+    x, y, z = [a[order.long()].contiguous() for a in (x, y, z)]
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    def run(bucket, first, last):
+        tree, counts, _ = hip.compute_octree(keys, bucket)
+        o = hip.build_octree(tree)
+        layout = torch.cat([torch.zeros(1, dtype=torch.int32, device="cuda"), counts.cumsum(0).to(torch.int32)])
+        cen, siz = hip.node_centers(cstone_amd.HILBERT, o["prefixes"], cb, 64)
+        nc = torch.zeros(last - first, dtype=torch.int32, device="cuda")
+        st = (C.c_uint64 * 4)()
+        rc = hip.lib.cstone_hip_find_neighbors_stats(hip.h, C.c_int(64), P(x), P(y), P(z), P(h), C.c_uint32(first),
+                                                     C.c_uint32(last), C.byref(cb), P(o["child_offsets"]),
+                                                     P(o["internal_to_leaf"]), P(layout), P(cen), P(siz), C.c_float(1.0),
+                                                     C.c_uint32(0), None, P(nc), st)
+        hip._chk(rc, "find_neighbors_stats")
+        _, nc_plain = hip.find_neighbors(x, y, z, h, first, last, cb, o, layout, cen, siz, 0)
+        hip.sync()
+        assert torch.equal(nc, nc_plain)  # the instrumented kernel finds the same neighbours
+        return [int(v) for v in st], nc
+
+    st, nc = run(n + 1, 100, 1124)  # the root is the only leaf
+    assert st[0] == 1024 * n and st[1] == n and st[2] == 0 and st[3] == 1024 * n
+    st, nc = run(64, 0, n)
+    total = int(nc.long().sum().item())
+    assert total + n <= st[0] <= st[3] and st[1] <= st[0] and 0 < st[2] <= 160
+    assert st[1] >= int(nc.max().item()) + 1

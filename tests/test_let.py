@@ -14,6 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "oracle", "_ref", "let_check")
 EXE_HIP = os.path.join(ROOT, "oracle", "_ref", "let_check_hip")  # the same harness on libcstone_hip.so (GPU box)
+EXE_ASAN = os.path.join(ROOT, "oracle", "_ref", "let_check_asan")  # ... built with -fsanitize=address,undefined
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
 pytestmark = pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists(MPIEXEC)),
@@ -21,7 +22,7 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists(MPIE
 
 
 def run(ranks, *args, timeout=900, exe=EXE):
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", ASAN_OPTIONS="detect_leaks=0")  # (MPICH keeps its own allocations)
     p = subprocess.run([MPIEXEC, "-n", str(ranks), exe] + [str(a) for a in args], capture_output=True, text=True,
                        timeout=timeout, env=env, cwd="/tmp")
     out = p.stdout + p.stderr
@@ -83,3 +84,13 @@ def test_hip_let_equals_reference_when_the_assignment_moves():
     assert paths["macRefineSteps"] > 0 and paths["keysInjected"] > 0 and paths["keysRejected"] > 0
     paths = run(3, "k64f32", 10000, 5, 64, 16, 1, 0, 2, 2, 107, exe=EXE_HIP)
     assert paths["focusTransfers"] > 0 and paths["macRefineSteps"] > 0
+
+
+@pytest.mark.skipif(not os.path.exists(EXE_ASAN), reason="oracle/_ref/let_check_asan not built")
+def test_let_under_address_and_ub_sanitizers():
+    """SURVEY.md section 5 (sanitizers on the CPU side): the host state machine, the CPU restatement behind the ABI and the
+    reference's headers in one program instrumented with ASan + UBSan (-fno-sanitize-recover): a moving assignment on 3
+    ranks takes it through the transfer / refine / inject / reject paths; any report aborts the run"""
+    paths = run(3, "k64f32", 6000, 4, 64, 16, 1, 0, 2, 2, 107, exe=EXE_ASAN, timeout=1200)
+    assert paths["focusTransfers"] > 0 and paths["keysRejected"] > 0
+    run(2, "k32f32", 5000, 3, 64, 8, 0, 0, 0, 1, 3, exe=EXE_ASAN, timeout=1200)
