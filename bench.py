@@ -640,8 +640,9 @@ def main():
         models = [  # (kernel, stage, bytes per particle and launch, what the bytes are)
             ("encodeResortKernel" if stage_ms.get("resort_leaves", 0) > 0 else "encodeHistogramKernel", "encode",
              3 * rbytes + 2 * kbytes, "x, y, z and the old key read, the new key written"),
-            ("leafSortKernel + leafSortBucketsKernel", "resort_leaves", 2 * kbytes + 4,
-             "key read; key + old index written (one bracket around the launch for quiet tiles and the one for tiles with movers)"),
+            ("leafSortWaveKernel", "resort_leaves", 2 * kbytes + 4,
+             "key read; key + old index written (one wave per leaf; with fewer movers than tiles a launch of leafSortKernel "
+             "for the quiet tiles comes first, inside the same bracket)"),
             ("onesweepKernel", "sort_pass", 2 * (kbytes + 4), "key + index read and written"),
             ("onesweepKernel (positions generated)", "sort_pass_iota", 2 * kbytes + 4, "key read; key + index written"),
             (("gatherMultiKernel (x, y, z in one launch)", "gather", 4 + 6 * rbytes,
@@ -660,7 +661,7 @@ def main():
             this run's particles per launch; None when the profile does not hold the kernel"""
             if not tjson:
                 return None
-            wanted = {"leafSortKernel": "leafSortKernel/moved"}.get(kernel.split(" ")[0], kernel.split(" ")[0])
+            wanted = kernel.split(" ")[0]
             for row in tjson[1]["kernels"]:
                 if row["kernel"] == wanted:
                     return (row["hbm_read_bytes"] + row["hbm_write_bytes"]) * n_sorted / tjson[1].get("particles", 1e8)

@@ -3,6 +3,7 @@
 // (sortByKeyGpu, R/primitives/primitives_gpu.cu:305-353).  gfx950: wave64, 160 KB LDS per CU.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "device_keys.hpp"
 #include "resort.hpp"
@@ -10,6 +11,16 @@
 
 namespace cship
 {
+// CSTONE_RESORT_TRACE (tuning builds only, tools/leafpass_trace.py): thread 0 of every workgroup of the leaf pass for
+// tiles with movers records wall-clock stamps (100 MHz) at its phase boundaries
+#ifdef CSTONE_RESORT_TRACE
+constexpr int RESORT_TRACE_SLOTS = 12;
+__device__ uint64_t* g_resortTrace;
+#define RESORT_TRACE(slot)                                                                                             \
+    if (g_resortTrace && threadIdx.x == 0) g_resortTrace[size_t(blockIdx.x) * RESORT_TRACE_SLOTS + (slot)] = wall_clock64();
+#else
+#define RESORT_TRACE(slot)
+#endif
 namespace
 {
 
@@ -559,38 +570,163 @@ __global__ __launch_bounds__(256) void leafSortKernel(const K* __restrict__ keys
     }
 }
 
-/*! The leaf pass for tiles in which something moved, second formulation (round 3).  Ordering a leaf by counting costs
- *  (leaf size)^2 comparisons whatever the lanes do; here every element first drops into one of 8 buckets of its leaf
- *  by the three leading bits of its digest (the octant of the leaf's cell it lies in: one returning LDS atomic), then
- *  counts the smaller digests among the handful of elements of its own bucket only.  The thread that loaded an element
- *  keeps its key in registers through both phases and stores it itself: no key is read twice, no key lives in LDS
- *  (21 KB of LDS: the grouped digests and the bucket tables).
- *  The kernel is a chain of LDS round trips per element (leaf search, atomic, bucket scan): written element by
- *  element, a thread's 17 elements wait for each other's LDS latencies one after the other (that form took the same
- *  0.9 ms as counting over the whole leaf).  So every step is written ACROSS a batch of the thread's elements, branch
- *  free: one search step / one atomic / one scan step for all of them, then the next -- nine independent LDS accesses in
- *  flight per wait.
- *  Digests as in leafSortKernel: 24 leading bits of (key - first key of the leaf), then the slot in the leaf; two
- *  elements of a bucket whose 24 bits agree are placed by key and old index proper (global memory, about one in 10^4).
- *  Same result: leaf j's elements at layoutNew[j]... in the order of (key, old index). */
-template<class K, int G>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void leafSortBucketsKernel(
-    const K* __restrict__ keysIn, const uint64_t* __restrict__ mask, const uint32_t* __restrict__ rank,
-    const K* __restrict__ leafLo, const uint32_t* __restrict__ leafPos, const uint32_t* __restrict__ inOffset,
-    const uint32_t* __restrict__ layoutNew, const K* __restrict__ binKeys, const uint32_t* __restrict__ binIdx, uint32_t J,
-    bool alwaysCount, K* __restrict__ keysOut, uint32_t* __restrict__ orderOut)
+// ---------------------------------------------------------------------------------------------------------------------
+// The leaf pass for tiles in which something moved (round 3): ONE WAVE PER LEAF, sorted in registers.
+//
+// What the phase trace of the earlier formulations showed (tools/leafpass_trace.py, CSTONE_RESORT_TRACE): 25-30 us of a
+// tile's 32 us went into its LDS phases -- every element looked its leaf up (six dependent, bank-conflicting reads), took
+// a place by a returning atomic, scanned its bucket (or its whole leaf) entry by entry; the LDS pipe of a CU serves four
+// such tiles at a time and is what those kernels waited for, whatever the arithmetic around it (counting over the leaf
+// 0.97-1.07 ms at 10^8 particles, eight buckets per leaf 0.90-0.95 ms, the same with batched accesses 0.99-1.05 ms, with
+// stores staged through LDS 1.03-1.10 ms).
+// A leaf of the focus tree holds at most a bucket of particles and a wave has 64 lanes.  So: lane s of a wave loads slot
+// s of the leaf (old slots, then the arrivals; coalesced) and builds the 32-bit digest (24 leading bits of key - first
+// key of the leaf, then the slot number); the wave sorts the digests with a bitonic network in registers (21
+// compare-exchange steps for 64 elements, no search: the leaf is the wave's).  The partners come through DPP inside a
+// row of 16 lanes and v_permlane16_swap / v_permlane32_swap across rows, all on the VALU: the same network over
+// ds_bpermute was bound by the LDS pipe again (0.95 ms).  The place of every slot in the new order goes back to the lane
+// that loaded it through a 16-bit table per wave in LDS (two LDS accesses per element), and that lane stores its key and
+// old index at layoutNew[leaf] + place: every key is read once and never leaves its register.  Holes (digest ~0) sort
+// last.  Leaves with 65..255 slots take two or four elements per lane.  Two sorted neighbours with equal leading bits
+// (equal keys among them; about one leaf in 10^4) send the leaf to the exact path: every element counts the elements
+// in front of it by (key, old index) proper.  A leaf nothing arrived in and whose remaining keys are still in order goes
+// out as it came in, without the network.
+// The loop over the wave's leaves is ROLLED (see below), and the wave number is deliberately NOT declared wave-uniform:
+// with readfirstlane on it the leaf's table entries travel through scalar registers and every leaf starts with a chain of
+// LDS read -> s_waitcnt -> v_readfirstlane -> scalar ALU before the first load can be issued (0.74 / 0.83 ms against
+// 0.66 / 0.75 ms, 1 % movers / everything drifting).
+// ---------------------------------------------------------------------------------------------------------------------
+// ---- cross-lane partners on the VALU (no LDS pipe): DPP within a row of 16 lanes, v_permlane16/32_swap (gfx950) across
+//      rows; lane mappings verified with tools/dpp_probe.hip on the hardware
+template<int CTRL, int BANK>
+__device__ __forceinline__ uint32_t dppMov(uint32_t old, uint32_t v)
 {
-    constexpr int ITER  = (RESORT_TILE_SLOTS + 255) / 256;
-    constexpr int BATCH = 6;
-    constexpr K HOLE    = ~K(0);
-    __shared__ uint32_t sGrp[RESORT_TILE_SLOTS]; // digests, grouped by (leaf, bucket)
-    __shared__ uint32_t pinK[2 * (G + 1)];       // first old position | first bin entry of every leaf
-    __shared__ uint32_t outK[G + 1];
+    return uint32_t(__builtin_amdgcn_update_dpp(int(old), int(v), CTRL, 0xF, BANK, false));
+}
+//! a permutation inside the row in which every lane has a source: written so that the compiler may fold it into the
+//! operation that consumes it (v_min_u32_dpp / v_max_u32_dpp)
+template<int CTRL>
+__device__ __forceinline__ uint32_t dppAll(uint32_t v)
+{
+    return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, 0xF, 0xF, true));
+}
+//! value of lane ^ X
+template<int X>
+__device__ __forceinline__ uint32_t laneXor(uint32_t v, unsigned lane)
+{
+    if constexpr (X == 1) return dppAll<0xB1>(v);        // quad_perm [1,0,3,2]
+    else if constexpr (X == 2) return dppAll<0x4E>(v);   // quad_perm [2,3,0,1]
+    else if constexpr (X == 3) return dppAll<0x1B>(v);   // quad_perm [3,2,1,0]
+    else if constexpr (X == 7) return dppAll<0x141>(v);  // row_half_mirror
+    else if constexpr (X == 15) return dppAll<0x140>(v); // row_mirror
+    else if constexpr (X == 4)
+    {
+        const uint32_t t = dppMov<0x104, 0x5>(v, v); // row_shl:4 into banks 0 and 2 (lane reads lane + 4)
+        return dppMov<0x114, 0xA>(t, v);             // row_shr:4 into banks 1 and 3 (lane reads lane - 4)
+    }
+    else if constexpr (X == 8)
+    {
+        const uint32_t t = dppMov<0x108, 0x3>(v, v);
+        return dppMov<0x118, 0xC>(t, v);
+    }
+    else if constexpr (X == 16)
+    {
+        auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false); // [0]: rows 0,0,2,2   [1]: rows 1,1,3,3
+        return (lane & 16u) ? p[0] : p[1];
+    }
+    else if constexpr (X == 32)
+    {
+        auto p = __builtin_amdgcn_permlane32_swap(v, v, false, false); // [0]: lower half twice   [1]: upper half twice
+        return (lane & 32u) ? p[0] : p[1];
+    }
+    else if constexpr (X == 31) return laneXor<15>(laneXor<16>(v, lane), lane);
+    else
+    {
+        static_assert(X == 63, "partner not implemented");
+        return laneXor<15>(laneXor<16>(laneXor<32>(v, lane), lane), lane);
+    }
+}
+
+//! compare-exchange with the lane at distance X, for N independent registers at once (one step of N sorts: their
+//! instructions interleave, which fills the wait states between a VALU write and a DPP read); the lane whose bit LOWBIT
+//! is clear is the lower one and keeps the minimum
+template<int X, unsigned LOWBIT, int N>
+__device__ __forceinline__ void cmpExchange(uint32_t (&v)[N], unsigned lane)
+{
+    const bool upper = (lane & LOWBIT) != 0;
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+    {
+        const uint32_t o = laneXor<X>(v[n], lane);
+        v[n]             = upper ? max(v[n], o) : min(v[n], o);
+    }
+}
+
+//! the half-cleaners behind a merge step: distances J, J/2, ... 1
+template<int J, int N>
+__device__ __forceinline__ void halfClean(uint32_t (&v)[N], unsigned lane)
+{
+    if constexpr (J >= 1)
+    {
+        cmpExchange<J, unsigned(J), N>(v, lane);
+        halfClean<J / 2, N>(v, lane);
+    }
+}
+
+/*! N independent ascending sorts of 64 values each (register n of every lane: one sort): bitonic network without
+ *  direction flags -- every merge of two sorted blocks starts with a compare-exchange against the MIRRORED position
+ *  (distance k - 1), followed by half-cleaners at distances k/4 ... 1, the lower lane always keeps the minimum. */
+template<int N>
+__device__ __forceinline__ void waveSort64(uint32_t (&v)[N], unsigned lane)
+{
+    cmpExchange<1, 1u, N>(v, lane);                              // blocks of 2
+    cmpExchange<3, 2u, N>(v, lane), halfClean<1, N>(v, lane);    // 4
+    cmpExchange<7, 4u, N>(v, lane), halfClean<2, N>(v, lane);    // 8
+    cmpExchange<15, 8u, N>(v, lane), halfClean<4, N>(v, lane);   // 16
+    cmpExchange<31, 16u, N>(v, lane), halfClean<8, N>(v, lane);  // 32
+    cmpExchange<63, 32u, N>(v, lane), halfClean<16, N>(v, lane); // 64
+}
+
+//! ascending sort of the 64 R values d[r] (element 64 r + lane) of a wave
+template<int R>
+__device__ __forceinline__ void waveBitonicSort(uint32_t (&d)[R], unsigned lane)
+{
+    waveSort64<R>(d, lane);
+    if constexpr (R >= 2)
+    {
+        // blocks of 128: element (r, lane) against (r ^ 1, 63 - lane)
+#pragma unroll
+        for (int r = 0; r < R; r += 2)
+        {
+            const uint32_t a = d[r], b = d[r + 1];
+            d[r]     = min(a, laneXor<63>(b, lane));
+            d[r + 1] = max(b, laneXor<63>(a, lane));
+        }
+        halfClean<32, R>(d, lane);
+    }
+    if constexpr (R == 4)
+    {
+        // blocks of 256: (r, lane) against (3 - r, 63 - lane), then distance 64 (registers r, r ^ 1), then within registers
+        const uint32_t a0 = d[0], a1 = d[1], a2 = d[2], a3 = d[3];
+        d[0] = min(a0, laneXor<63>(a3, lane)), d[3] = max(a3, laneXor<63>(a0, lane));
+        d[1] = min(a1, laneXor<63>(a2, lane)), d[2] = max(a2, laneXor<63>(a1, lane));
+        const uint32_t b0 = d[0], b1 = d[1], b2 = d[2], b3 = d[3];
+        d[0] = min(b0, b1), d[1] = max(b0, b1), d[2] = min(b2, b3), d[3] = max(b2, b3);
+        halfClean<32, R>(d, lane);
+    }
+}
+
+template<class K, int G>
+__global__ __launch_bounds__(256) void leafSortWaveKernel(
+    const K* __restrict__ keysIn, const K* __restrict__ leafLo, const uint32_t* __restrict__ leafPos,
+    const uint32_t* __restrict__ inOffset, const uint32_t* __restrict__ layoutNew, const K* __restrict__ binKeys,
+    const uint32_t* __restrict__ binIdx, uint32_t J, bool alwaysCount, bool allTiles, K* __restrict__ keysOut,
+    uint32_t* __restrict__ orderOut)
+{
+    constexpr K HOLE = ~K(0);
+    __shared__ uint32_t posK[G + 1], inK[G + 1], outK[G + 1];
     __shared__ K loK[G + 1];
-    __shared__ uint8_t cutK[G];
-    __shared__ uint32_t cntK[G * 8 + 1], baseK[G * 8 + 1]; // (the last entry: where elements that are none count)
-    uint32_t* const posK = pinK;
-    uint32_t* const inK  = pinK + (G + 1);
+    __shared__ uint16_t sPlace[4][256];
 
     const uint32_t j0 = blockIdx.x * uint32_t(G);
     const uint32_t nl = min(uint32_t(G), J - j0);
@@ -602,155 +738,168 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         outK[t] = layoutNew[j0 + t];
         loK[t]  = leafLo[j0 + t];
     }
-    for (uint32_t i = t; i < uint32_t(G) * 8 + 1; i += 256)
-        cntK[i] = 0, baseK[i] = 0;
     __syncthreads();
-    if (t < nl)
-    {
-        const K span   = loK[t + 1] - loK[t] - 1;
-        const int bits = span ? int(8 * sizeof(K)) - clzKey(span) : 0;
-        cutK[t]        = uint8_t(bits > 24 ? bits - 24 : 0);
-    }
     const uint32_t p0 = posK[0], p1 = posK[nl], in0 = inK[0], in1 = inK[nl];
-    const uint32_t nOldAll = p1 - p0, slots = nOldAll + (in1 - in0);
-    if (slots > RESORT_TILE_SLOTS) return; // guarded by checkTilesKernel
-    bool changed = in1 != in0 || alwaysCount;
-    if (t < nl) changed = changed || (outK[t + 1] - outK[t]) != (posK[t + 1] - posK[t]);
-    const bool quiet = !__syncthreads_or(changed) && nOldAll <= RESORT_QUIET_SLOTS;
-    if (quiet) return; // the quiet instantiation of leafSortKernel takes this tile
+    if (!allTiles)
+    {
+        // the quiet instantiation of leafSortKernel takes the tiles in which nothing moved (same vote as there)
+        const uint32_t nOldAll = p1 - p0;
+        bool changed           = in1 != in0 || alwaysCount;
+        if (t < nl) changed = changed || (outK[t + 1] - outK[t]) != (posK[t + 1] - posK[t]);
+        const bool quiet = !__syncthreads_or(changed) && nOldAll <= RESORT_QUIET_SLOTS;
+        if (quiet) return;
+    }
+    const unsigned lane = t & 63u;
+    const unsigned wave = t >> 6;
 
-    // ---- phase 1: every element (old slots, then arrivals) -> leaf, digest, bucket, place inside the bucket
-    K key[ITER];
-    uint32_t dig[ITER], info[ITER]; // info: leaf (8 bits) | place in the bucket (24 bits); ~0u: no element
-#pragma unroll
-    for (int i = 0; i < ITER; ++i)
+    //! what the loop needs to know about leaf k
+    struct Leaf
     {
-        const uint32_t e = t + 256u * i;
-        key[i]           = HOLE;
-        if (e < nOldAll) key[i] = keysIn[p0 + e];
-        else if (e < slots) key[i] = binKeys[in0 + (e - nOldAll)];
-    }
-#pragma unroll
-    for (int bs = 0; bs < ITER; bs += BATCH)
-    {
-        uint32_t val[BATCH], lo[BATCH], off[BATCH];
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j)
-        {
-            const int i      = bs + j < ITER ? bs + j : ITER - 1;
-            const uint32_t e = t + 256u * i;
-            const bool isOld = e < nOldAll, any = e < slots;
-            // what is searched for: the old position among the leaves' first positions, or the bin entry among the leaves'
-            // first entries (an element that is none searches for the tile's first position: in range, result unused)
-            val[j] = !any ? p0 : (isOld ? p0 + e : in0 + (e - nOldAll));
-            off[j] = (any && !isOld) ? uint32_t(G + 1) : 0u;
-            lo[j]  = 0;
-        }
-        // last leaf k of the tile with pinK[off + k] <= val, all elements of the batch one search step at a time
-        for (uint32_t n = nl; n > 1;)
-        {
-            const uint32_t half = n >> 1;
-#pragma unroll
-            for (int j = 0; j < BATCH; ++j)
-            {
-                const uint32_t probe = pinK[off[j] + lo[j] + half];
-                lo[j]                = probe <= val[j] ? lo[j] + half : lo[j];
-            }
-            n -= half;
-        }
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j)
-        {
-            if (bs + j >= ITER) continue; // (compile time)
-            const int i      = bs + j;
-            const uint32_t e = t + 256u * i;
-            const bool ok    = e < slots && key[i] != HOLE;
-            const uint32_t k = lo[j];
-            const uint32_t slot = off[j] ? (posK[k + 1] - posK[k]) + (val[j] - inK[k]) : val[j] - posK[k];
-            const uint32_t d    = (uint32_t((key[i] - loK[k]) >> cutK[k]) << 8) | (slot & 0xFFu);
-            const uint32_t at   = atomicAdd(&cntK[ok ? k * 8 + (d >> 29) : uint32_t(G) * 8], 1u);
-            dig[i]  = ok ? d : ~0u;
-            info[i] = ok ? (k << 24) | at : ~0u;
-        }
-    }
-    __syncthreads();
-    // ---- bucket starts in the tile's NEW order (leaf k starts at outK[k] - outK[0])
-    if (t < nl)
-    {
-        uint32_t run = outK[t] - outK[0];
-#pragma unroll
-        for (int b = 0; b < 8; ++b)
-        {
-            baseK[t * 8 + b] = run;
-            run += cntK[t * 8 + b];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < ITER; ++i)
-        if (info[i] != ~0u) sGrp[baseK[(info[i] >> 24) * 8 + (dig[i] >> 29)] + (info[i] & 0xFFFFFFu)] = dig[i];
-    __syncthreads();
-
-    // ---- phase 2: rank inside the bucket, store
-    auto placeExact = [&](uint32_t k, K kx, uint32_t ix)
-    {
-        const uint32_t nOld = posK[k + 1] - posK[k], nInc = inK[k + 1] - inK[k];
-        uint32_t less = 0;
-        for (uint32_t q = 0; q < nOld; ++q)
-        {
-            const K kq = keysIn[posK[k] + q]; // (a hole is larger than any key)
-            less += (kq < kx || (kq == kx && posK[k] + q < ix)) ? 1u : 0u;
-        }
-        for (uint32_t q = 0; q < nInc; ++q)
-        {
-            const K kq = binKeys[inK[k] + q];
-            less += (kq < kx || (kq == kx && binIdx[inK[k] + q] < ix)) ? 1u : 0u;
-        }
-        return less;
+        uint32_t pk, nOld, ik, nInc, ok, nNew, slots;
+        K lo;
+        unsigned cut;
     };
-#pragma unroll
-    for (int bs = 0; bs < ITER; bs += BATCH)
+    auto leafOf = [&](uint32_t k)
     {
-        uint32_t bb[BATCH], nb[BATCH], less[BATCH], same[BATCH];
-        uint32_t maxNb = 0;
+        Leaf f;
+        f.pk = posK[k], f.nOld = posK[k + 1] - f.pk;
+        f.ik = inK[k], f.nInc = inK[k + 1] - f.ik;
+        f.ok = outK[k], f.nNew = outK[k + 1] - f.ok;
+        f.slots        = f.nOld + f.nInc;
+        f.lo           = loK[k];
+        const K span   = loK[k + 1] - f.lo - 1;
+        const int bits = span ? int(8 * sizeof(K)) - clzKey(span) : 0;
+        f.cut          = bits > 24 ? unsigned(bits - 24) : 0u;
+        return f;
+    };
+    // slot s of a leaf: an old position or an arrival
+    auto loadSlot = [&](const Leaf& f, uint32_t s, K& key, uint32_t& idx)
+    {
+        key = HOLE, idx = 0;
+        if (s < f.nOld) key = keysIn[f.pk + s], idx = f.pk + s;
+        else if (s < f.slots) key = binKeys[f.ik + (s - f.nOld)], idx = binIdx[f.ik + (s - f.nOld)];
+    };
+    auto digestOf = [&](const Leaf& f, K key, uint32_t slot) -> uint32_t
+    { return key == HOLE ? ~0u : ((uint32_t((key - f.lo) >> f.cut) << 8) | slot); };
+
+    // the sorted digests of a leaf -> its new content: the place of every slot in the new order goes back to the lane that
+    // loaded the slot (and still holds its key) through a 16-bit table per wave in LDS, two LDS accesses per element; that
+    // lane stores key and old index at layoutNew[leaf] + place.  false: two neighbours in the new order have equal leading
+    // key bits (the caller then places the leaf by keys and old indices proper)
+    auto finishLeaf = [&](const Leaf& f, auto rTag, const K* key, const uint32_t* idx, uint32_t* d) -> bool
+    {
+        constexpr int R = decltype(rTag)::value;
+        bool clash      = false;
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j)
+        for (int r = 0; r < R; ++r)
         {
-            const int i       = bs + j < ITER ? bs + j : ITER - 1;
-            const bool ok     = bs + j < ITER && info[i] != ~0u;
-            const uint32_t bk = ok ? (info[i] >> 24) * 8 + (dig[i] >> 29) : uint32_t(G) * 8;
-            bb[j]   = baseK[bk];
-            nb[j]   = ok ? cntK[bk] : 0u;
-            less[j] = 0, same[j] = 0;
-            maxNb   = max(maxNb, nb[j]);
+            // the element in front: the lane below, for lane 0 the last lane of the register before (all lanes shuffle)
+            const uint32_t below = uint32_t(__shfl_up(int(d[r]), 1));
+            const uint32_t last  = R > 1 ? uint32_t(__shfl(int(d[r > 0 ? r - 1 : 0]), 63)) : ~0u;
+            const uint32_t prev  = lane != 0 ? below : (r > 0 ? last : ~0u);
+            clash = clash || (d[r] != ~0u && prev != ~0u && (d[r] >> 8) == (prev >> 8));
         }
-        // the buckets of all elements of the batch, one entry at a time
-        for (uint32_t q = 0; q < maxNb; ++q)
-        {
+        if (__any(clash)) return false;
+        uint16_t* place = sPlace[wave];
 #pragma unroll
-            for (int j = 0; j < BATCH; ++j)
+        for (int r = 0; r < R; ++r)
+            if (d[r] != ~0u) place[d[r] & 0xFFu] = uint16_t(lane + 64u * r);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+        {
+            if (key[r] == HOLE) continue;
+            const uint32_t at = place[lane + 64u * r];
+            if (at < f.nNew)
             {
-                const int i      = bs + j < ITER ? bs + j : ITER - 1;
-                const bool in    = q < nb[j];
-                const uint32_t v = sGrp[bb[j] + (in ? q : 0u)];
-                less[j] += (in && v < dig[i]) ? 1u : 0u;
-                same[j] += (in && ((v ^ dig[i]) >> 8) == 0) ? 1u : 0u; // (itself included)
+                keysOut[f.ok + at]  = key[r];
+                orderOut[f.ok + at] = idx[r];
             }
         }
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j)
+        __builtin_amdgcn_wave_barrier();
+        return true;
+    };
+    // exact path: every loaded element counts the elements of its leaf in front of it by (key, old index)
+    auto exactLeaf = [&](const Leaf& f, int R, const K* key, const uint32_t* idx)
+    {
+        for (int r = 0; r < R; ++r)
         {
-            if (bs + j >= ITER) continue; // (compile time)
-            const int i = bs + j;
-            if (info[i] == ~0u) continue;
-            const uint32_t e  = t + 256u * i;
-            const uint32_t k  = info[i] >> 24;
-            const uint32_t ix = e < nOldAll ? p0 + e : binIdx[in0 + (e - nOldAll)];
-            uint32_t at       = outK[0] + bb[j] + less[j];
-            if (same[j] > 1) at = outK[k] + placeExact(k, key[i], ix);
-            keysOut[at]  = key[i];
-            orderOut[at] = ix;
+            if (key[r] == HOLE) continue;
+            uint32_t less = 0;
+            for (uint32_t q = 0; q < f.nOld; ++q)
+            {
+                const K kq = keysIn[f.pk + q]; // (a hole is larger than any key)
+                less += (kq < key[r] || (kq == key[r] && f.pk + q < idx[r])) ? 1u : 0u;
+            }
+            for (uint32_t q = 0; q < f.nInc; ++q)
+            {
+                const K kq = binKeys[f.ik + q];
+                less += (kq < key[r] || (kq == key[r] && binIdx[f.ik + q] < idx[r])) ? 1u : 0u;
+            }
+            keysOut[f.ok + less]  = key[r];
+            orderOut[f.ok + less] = idx[r];
         }
+    };
+    auto bigLeaf = [&](const Leaf& f, auto rTag)
+    {
+        constexpr int R = decltype(rTag)::value;
+        K key[R];
+        uint32_t idx[R], d[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+        {
+            loadSlot(f, lane + 64u * r, key[r], idx[r]);
+            d[r] = digestOf(f, key[r], lane + 64u * r);
+        }
+        waveBitonicSort<R>(d, lane);
+        if (!finishLeaf(f, rTag, key, idx, d)) exactLeaf(f, R, key, idx);
+    };
+
+    // The leaves of this wave: wave, wave + 4, ...  A ROLLED loop: the body (load, 64-element network, store) is a few
+    // hundred instructions and stays in the instruction cache; unrolled over the wave's 16 leaves the kernel was
+    // 24-41 thousand instructions (190-330 KB of code streaming through the instruction cache) and took 0.7-0.9 ms
+    // whatever the network cost.  The key of the NEXT leaf is requested before the current one is sorted.
+    if (wave >= nl) return;
+    Leaf cur = leafOf(wave);
+    K keyN        = HOLE;
+    uint32_t idxN = 0;
+    if (cur.slots <= 64) loadSlot(cur, lane, keyN, idxN);
+#pragma unroll 1
+    for (uint32_t k = wave; k < nl; k += 4)
+    {
+        const Leaf f     = cur;
+        K key1[1]        = {keyN};
+        uint32_t idx1[1] = {idxN};
+        keyN = HOLE, idxN = 0;
+        if (k + 4 < nl)
+        {
+            cur = leafOf(k + 4);
+            if (cur.slots <= 64) loadSlot(cur, lane, keyN, idxN);
+        }
+        if (f.slots == 0) continue;
+        if (f.slots <= 64)
+        {
+            // nothing arrived and what stayed is still in order (a departure leaves the largest key behind, so only
+            // departures from the end of the leaf pass): the content goes out as it came in
+            {
+                const K below     = K(__shfl_up((unsigned long long)key1[0], 1));
+                const bool behind = lane != 0 && key1[0] < below;
+                if (f.nInc == 0 && !__any(behind))
+                {
+                    if (lane < f.nNew)
+                    {
+                        keysOut[f.ok + lane]  = key1[0];
+                        orderOut[f.ok + lane] = idx1[0];
+                    }
+                    continue;
+                }
+            }
+            uint32_t d[1] = {digestOf(f, key1[0], lane)};
+            waveBitonicSort<1>(d, lane);
+            if (!finishLeaf(f, std::integral_constant<int, 1>{}, key1, idx1, d)) exactLeaf(f, 1, key1, idx1);
+        }
+        else if (f.slots <= 128) { bigLeaf(f, std::integral_constant<int, 2>{}); }
+        else { bigLeaf(f, std::integral_constant<int, 4>{}); }
     }
 }
 
@@ -942,35 +1091,38 @@ int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, 
     // quiet tiles and tiles in which something moved: one launch each over all tiles (without movers there are none of
     // the second kind)
     const bool someMoved = numMovers > 0 || alwaysCount || largeQuietTiles;
-    // tiles in which something moved: buckets by the leading digest bits, counting inside a bucket (the default), or
-    // counting over the whole leaf (the round-2 formulation, kept for comparison: CSTONE_RESORT_SCAN=1)
-    static const bool scanLeaves = std::getenv("CSTONE_RESORT_SCAN") != nullptr;
-#define CSTONE_LEAF_BUCKETS(G)                                                                                         \
-    hipLaunchKernelGGL((leafSortBucketsKernel<K, G>), grid, 256, 0, ctx->stream, keysIn, mask_.as<uint64_t>(),         \
-                       rank_.as<uint32_t>(), leafLo_.as<K>(), leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(),       \
-                       layoutNew_.as<uint32_t>(), binKeys_.as<K>(), binIdx_.as<uint32_t>(), J, alwaysCount, keysOut,  \
-                       orderOut)
+    // tiles in which something moved: one wave per leaf (the default), or counting over the whole leaf (the round-2
+    // formulation, kept for comparison: CSTONE_RESORT_SCAN=1).  With at least one mover per tile on average hardly a
+    // tile is quiet: the wave kernel then takes all tiles and the launch for quiet tiles is left out (at 10^8 particles
+    // 0.56 / 0.72 ms instead of 0.59 / 0.77 ms; CSTONE_RESORT_WAVE_ALL=0/1 forces either)
+    static const bool scanLeaves  = std::getenv("CSTONE_RESORT_SCAN") != nullptr;
+    static const char* waveAllEnv = std::getenv("CSTONE_RESORT_WAVE_ALL");
+    const bool waveAll = !scanLeaves && !alwaysCount && (waveAllEnv ? waveAllEnv[0] == '1' : numMovers >= grid);
+#define CSTONE_LEAF_WAVE(G)                                                                                            \
+    hipLaunchKernelGGL((leafSortWaveKernel<K, G>), grid, 256, 0, ctx->stream, keysIn, leafLo_.as<K>(),                 \
+                       leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), layoutNew_.as<uint32_t>(), binKeys_.as<K>(), \
+                       binIdx_.as<uint32_t>(), J, alwaysCount, waveAll, keysOut, orderOut)
     if (leavesPerTile == 64)
     {
-        CSTONE_LEAF_SORT(64, false);
+        if (!waveAll) CSTONE_LEAF_SORT(64, false);
         if (someMoved && scanLeaves) CSTONE_LEAF_SORT(64, true);
-        else if (someMoved) CSTONE_LEAF_BUCKETS(64);
+        else if (someMoved || waveAll) CSTONE_LEAF_WAVE(64);
     }
     else if (leavesPerTile == 32)
     {
-        CSTONE_LEAF_SORT(32, false);
+        if (!waveAll) CSTONE_LEAF_SORT(32, false);
         if (someMoved && scanLeaves) CSTONE_LEAF_SORT(32, true);
-        else if (someMoved) CSTONE_LEAF_BUCKETS(32);
+        else if (someMoved || waveAll) CSTONE_LEAF_WAVE(32);
     }
     else if (leavesPerTile == 16)
     {
-        CSTONE_LEAF_SORT(16, false);
+        if (!waveAll) CSTONE_LEAF_SORT(16, false);
         if (someMoved && scanLeaves) CSTONE_LEAF_SORT(16, true);
-        else if (someMoved) CSTONE_LEAF_BUCKETS(16);
+        else if (someMoved || waveAll) CSTONE_LEAF_WAVE(16);
     }
     else return fail(ctx, CSTONE_E_INTERNAL, "resort: %d leaves per workgroup not instantiated", leavesPerTile);
 #undef CSTONE_LEAF_SORT
-#undef CSTONE_LEAF_BUCKETS
+#undef CSTONE_LEAF_WAVE
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }
@@ -995,5 +1147,14 @@ int LeafResort<K>::countLeaves(cstone_hip_ctx* ctx, const K* tree, int numNodes,
 
 template class LeafResort<uint32_t>;
 template class LeafResort<uint64_t>;
+
+#ifdef CSTONE_RESORT_TRACE
+//! tuning builds: device buffer of RESORT_TRACE_SLOTS stamps per workgroup (nullptr: off)
+extern "C" int cstone_hip_resort_trace_set(void* buffer)
+{
+    uint64_t* p = static_cast<uint64_t*>(buffer);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_resortTrace), &p, sizeof p) == hipSuccess ? 0 : 1;
+}
+#endif
 
 } // namespace cship

@@ -230,6 +230,22 @@ public:
     BoundaryType boundaryZ() const { return BoundaryType(pod_.bc[2]); }
     const cstone_box& pod() const { return pod_; }
 
+    /*! R/sfc/box.hpp:168-176: the box through the client's I/O layer.  Archive: anything with
+     *  stepAttribute(name, pointer, count) like the reference's (SPH-EXA's IFileReader / IFileWriter); a reading archive
+     *  overwrites the limits and boundary types, a writing one stores them */
+    template<class Archive>
+    void loadOrStore(Archive* ar)
+    {
+        T lim[6] = {xmin(), xmax(), ymin(), ymax(), zmin(), zmax()};
+        ar->stepAttribute("box", lim, 6);
+        char bnd[3] = {char(pod_.bc[0]), char(pod_.bc[1]), char(pod_.bc[2])};
+        ar->stepAttribute("boundaryType", bnd, 3);
+        for (int k = 0; k < 6; ++k)
+            pod_.lim[k] = double(lim[k]);
+        for (int d = 0; d < 3; ++d)
+            pod_.bc[d] = int(bnd[d]);
+    }
+
 private:
     cstone_box pod_;
 };
@@ -701,13 +717,19 @@ template<class KeyType, class T>
 class MultiRankDomain
 {
 public:
+    /*! theta: the opening angle of the focus tree's MAC (Domain ctor, R/domain/domain.hpp:95-113); ownerSideHalos:
+     *  CSTONE_MR_HALOS_OWNER_SIDE instead of the reference's locally essential tree (cstone_hip.h) */
     MultiRankDomain(int rank, int nRanks, unsigned bucketSize, unsigned bucketSizeFocus, const Box<T>& box,
-                    const cstone_hip_comm_ops& comm, Curve curve = Curve::hilbert)
+                    const cstone_hip_comm_ops& comm, Curve curve = Curve::hilbert, float theta = 0.5f,
+                    bool ownerSideHalos = false)
     {
         int rc = cstone_hip_domain_mr_create(Context::get(), &dom_, int(curve), detail::keyBits<KeyType>(),
                                              detail::realBits<T>(), rank, nRanks, bucketSize, bucketSizeFocus,
                                              &box.pod(), &comm);
         Context::check(rc, "MultiRankDomain");
+        Context::check(cstone_hip_domain_mr_set_theta(dom_, theta), "MultiRankDomain (theta)");
+        if (ownerSideHalos)
+            Context::check(cstone_hip_domain_mr_set_halo_mode(dom_, CSTONE_MR_HALOS_OWNER_SIDE), "MultiRankDomain (halos)");
     }
     MultiRankDomain(const MultiRankDomain&)            = delete;
     MultiRankDomain& operator=(const MultiRankDomain&) = delete;
@@ -834,9 +856,10 @@ public:
      *  to nParticlesWithHalos() with the assigned range [startIndex(), endIndex()) and the halos of x, y, z, h filled --
      *  at the price of one device copy per array out of the domain-owned result buffers; MultiRankDomain is the
      *  zero-copy interface underneath. */
-    Domain(int rank, int nRanks, unsigned bucketSize, unsigned bucketSizeFocus, float /*theta*/, const Box<T>& box,
+    Domain(int rank, int nRanks, unsigned bucketSize, unsigned bucketSizeFocus, float theta, const Box<T>& box,
            const cstone_hip_comm_ops& comm, Curve curve = Curve::hilbert)
-        : mr_(std::make_unique<MultiRankDomain<KeyType, T>>(rank, nRanks, bucketSize, bucketSizeFocus, box, comm, curve))
+        : mr_(std::make_unique<MultiRankDomain<KeyType, T>>(rank, nRanks, bucketSize, bucketSizeFocus, box, comm, curve,
+                                                            theta))
     {
         if (bucketSize < bucketSizeFocus)
             throw std::runtime_error("The bucket size of the global tree must not be smaller than the bucket size"
@@ -978,8 +1001,12 @@ public:
     LocalIndex nParticles() const { return endIndex() - startIndex(); }
     LocalIndex nParticlesWithHalos() const { return mr_ ? mr_->nParticlesWithHalos() : view().num_particles_with_halos; }
     Box<T> box() const { return mr_ ? mr_->box() : Box<T>(view().box); }
-    TreeNodeIndex startCell() const { return 0; }
-    TreeNodeIndex endCell() const { return view().num_focus_leaves; }
+    //! the rank's own cells in focusTree() (R/domain/domain.hpp:403-405)
+    TreeNodeIndex startCell() const { return mr_ ? mr_->view().start_cell : 0; }
+    TreeNodeIndex endCell() const { return mr_ ? mr_->view().end_cell : view().num_focus_leaves; }
+    /*! R/domain/domain.hpp:393: the client has appended particles behind the assigned range of its arrays; the next sync
+     *  takes [startIndex(), i) as this rank's present particles */
+    void setEndIndex(std::size_t i) { endOverride_ = LocalIndex(i), haveEndOverride_ = true; }
     //! particle offsets of each focus tree leaf cell, device pointer (Domain::layout)
     std::span<const LocalIndex> layout() const
     {
@@ -1066,7 +1093,11 @@ private:
     {
         const std::size_t n = x.size();
         // first call: everything passed is assigned; later: the previous layout with its assigned range
-        const LocalIndex first = synced_ ? mr_->startIndex() : 0, last = synced_ ? mr_->endIndex() : LocalIndex(n);
+        const LocalIndex first = synced_ ? mr_->startIndex() : 0;
+        LocalIndex last        = synced_ ? mr_->endIndex() : LocalIndex(n);
+        if (haveEndOverride_ && synced_) last = endOverride_; // setEndIndex(): particles appended behind the assigned range
+        haveEndOverride_ = false;
+        if (last < first || last > n) throw std::runtime_error("Domain sync: end index outside the arrays\n");
         if (synced_ && n != mr_->nParticlesWithHalos())
             throw std::runtime_error("Domain sync: input array sizes are inconsistent\n");
         bool sizesOk = true;
@@ -1098,6 +1129,8 @@ private:
     cstone_hip_domain* dom_{nullptr};
     std::unique_ptr<MultiRankDomain<KeyType, T>> mr_;
     bool synced_{false};
+    LocalIndex endOverride_{0};
+    bool haveEndOverride_{false};
     std::size_t prevSize_{0};
     LocalIndex prevStart_{0}, prevEnd_{0};
 };

@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--lopsided", type=int, default=0, help="1: the last rank starts without particles")
     ap.add_argument("--impl", default="python", choices=["python", "native"],
                     help="python: tests/py_domain.DistributedDomain; native: cstone_hip_domain_mr_* (hip only)")
+    ap.add_argument("--contract", type=int, default=0,
+                    help="native only: this many more syncs in which the cloud contracts by 3.5 % (the trees deepen)")
     ap.add_argument("--owner-side", type=int, default=0,
                     help="native only: 1 = owner-side halo discovery instead of the locally essential tree")
     ap.add_argument("--fail-at", default="", help="native only: after one good sync, rank 1 is made to fail at this point "
@@ -358,6 +360,31 @@ def main():
             x, y, z = x.clamp(0.0, top), y.clamp(0.0, top), z.clamp(0.0, top)
         tag64 = x * 3.0 + y * 5.0 + z * 7.0 + h
         tag32 = (x + 2.0 * y).to(torch.float32)
+    if a.impl == "native" and a.contract:
+        # the cloud contracts towards the box centre, a few per cent per sync, over many RE-SORTED syncs: the rank's tree
+        # deepens by a level every few syncs (across the 5 -> 6 boundary of the node-key sort's digit passes as well);
+        # neighbour completeness after every sync shows that the linked octree behind the halo search stayed right
+        for extra in range(a.contract):
+            x, y, z = [(0.5 + (v_ - 0.5) * 0.965).clamp_(0.0, top) for v_ in (x, y, z)]
+            h = h * 0.965
+            r = dom.sync(x, y, z, h)
+            st, en = r["start"], r["end"]
+            tot = torch.tensor([en - st], dtype=torch.int64)
+            dist.all_reduce(tot)
+            ok &= int(tot.item()) == N
+            lx, ly, lz, lh = [r[k].cpu().numpy() for k in "xyzh"]
+            tsum = torch.tensor([neighbor_sum(o, lx, ly, lz, lh, st, en, r["lim"], bc)], dtype=torch.int64)
+            dist.all_reduce(tsum)
+            parts = [None] * P
+            dist.all_gather_object(parts, np.stack([lx[st:en], ly[st:en], lz[st:en], lh[st:en]]))
+            if rank == 0:
+                allp = np.concatenate(parts, axis=1)
+                ref = neighbor_sum(o, allp[0].copy(), allp[1].copy(), allp[2].copy(), allp[3].copy(), 0, allp.shape[1],
+                                   r["lim"], bc)
+                ok &= ref == int(tsum.item())
+                report.append(dict(contract_step=extra, neighbors=ref, found=int(tsum.item()),
+                                   focus_leaves=dom.view().num_focus_leaves, resorts=dom.view().resorts))
+            x, y, z, h = [r[k][st:en].clone() for k in "xyzh"]
     if a.impl == "native":
         # a quiet stretch: the particles barely move any more, so the local order of a sync can be repaired from the
         # previous one (the incremental re-sort, csrc/resort.hpp; the first syncs behind the large moves above give up and

@@ -214,3 +214,17 @@ def test_native_domain_failure_reaches_every_rank(point, owner_side):
     collective, and the next sync works again"""
     _launch(3, "hip", 30000, 1, 0, 29670 + len(point) + owner_side, impl="native",
             extra=["--fail-at", point, "--owner-side", str(owner_side)], timeout=300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("owner_side", [1, 0])
+def test_native_domain_tree_deepens_over_resorted_syncs(owner_side):
+    """the bound on the digit passes of the node-key sort follows the previous sync's tree on EVERY
+    sync, also the re-sorted ones.  A periodic cloud (the box never changes) contracts by 3.5 % per sync for 14 syncs on 2
+    ranks with the re-sort forced on (CSTONE_MR_RESORT_MIN=1): the trees deepen across a level boundary of the digit
+    passes; the neighbour counts found with local + halo particles stay those of the undistributed cloud"""
+    r = _launch(2, "hip", 40000, 2, 1, 29750 + owner_side, impl="native",
+                extra=["--contract", "14", "--owner-side", str(owner_side)], timeout=1200)
+    steps = [e for e in r["report"] if "contract_step" in e]
+    assert len(steps) == 14 and all(e["neighbors"] == e["found"] for e in steps)
+    assert steps[-1]["focus_leaves"] != steps[0]["focus_leaves"]
