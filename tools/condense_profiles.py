@@ -12,6 +12,7 @@ import os
 import shutil
 import sys
 from collections import defaultdict
+from statistics import median
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof_r1"
@@ -31,6 +32,35 @@ for trace in glob.glob(os.path.join(src, "bench", "**", "*kernel_trace.csv"), re
                 "max_us": max(v) / 1e3} for g, v in sorted(groups.items())]
     json.dump({"kernel": "onesweepKernel", "source": "rocprofv3 --kernel-trace of `python bench.py --steps 5 --warmup 1`",
                "by_grid": summary}, open(f"profiles/{tag}_onesweep_launches.json", "w"), indent=1)
+# every kernel of the library: the --stats average mixes a kernel's launches over the full particle set with its small
+# ones (tree-sized sorts, launches of the leaf pass that find no tile of their kind); here the launches whose grid is
+# within 10 % of the kernel's largest one are averaged on their own -- the number bench.py's live stage timers must match
+for trace in glob.glob(os.path.join(src, "bench", "**", "*kernel_trace.csv"), recursive=True):
+    groups = defaultdict(list)
+    for row in csv.DictReader(open(trace)):
+        name = row["Kernel_Name"]
+        if "cship" not in name:
+            continue
+        m = re.search(r"(\w+Kernel)\b", name)
+        if not m:
+            continue
+        short = m.group(1)
+        if short == "leafSortKernel":
+            short += "/counting" if ", true>" in name else "/quiet"
+        groups[short].append((int(row["Grid_Size_X"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+    out = []
+    for short, v in sorted(groups.items()):
+        top = max(g for g, _ in v)
+        full = [ns for g, ns in v if g >= 0.9 * top]
+        if short.startswith("leafSortKernel"):  # launches that find no tile of their kind return at once
+            full = [ns for ns in full if ns >= 0.5 * max(full)]
+        out.append({"kernel": short, "grid_threads": top, "launches_total": len(v), "launches_full_size": len(full),
+                    "avg_us_full_size": sum(full) / len(full) / 1e3, "median_us_full_size": median(full) / 1e3, "min_us": min(full) / 1e3, "max_us": max(full) / 1e3,
+                    "total_ms_all_launches": sum(ns for _, ns in v) / 1e6})
+    out.sort(key=lambda e: -e["total_ms_all_launches"])
+    json.dump({"source": "rocprofv3 --kernel-trace of `python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-plummer` "
+                         "(headline loop and the extras' loops), launches over the full particle set of every kernel",
+               "kernels": out}, open(f"profiles/{tag}_bench_kernel_launches.json", "w"), indent=1)
 means = defaultdict(dict)
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     acc = defaultdict(lambda: [0.0, 0])
@@ -69,10 +99,23 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             short = m.group(1)
             if short == "leafSortKernel":
                 # two instantiations share every grid: the one of the quiet tiles and the one of the tiles with movers
-                short += "/moved" if re.search(r"true>\(", name) or name.rstrip().endswith("true>") or ", true>" in name else "/quiet"
+                short += "/counting" if ", true>" in name else "/quiet"
             key = (short, int(row["Grid_Size"]))
             perk[key][c].append(float(row["Counter_Value"]))
             perk[key]["ns"].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+# tools/gather_calib.py under the same counters: three launches each through the identity, a permutation inside blocks of
+# 64 elements, a random permutation of everything
+calib = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(os.path.join(src, f"gather_calib_{c}", "**", "*counter_collection.csv"), recursive=True):
+        rows = sorted((r for r in csv.DictReader(open(f)) if "gatherMultiKernel" in r["Kernel_Name"]),
+                      key=lambda r: int(r["Start_Timestamp"]))
+        for i, name in enumerate(("identity", "inside_blocks_of_64", "random")):
+            part = rows[3 * i:3 * i + 3]
+            if part:
+                e = calib.setdefault(name, {"elements": 1e8, "algorithmic_read_bytes": 28e8, "algorithmic_write_bytes": 24e8})
+                e[c + "_raw_bytes"] = 1024 * median([float(r["Counter_Value"]) for r in part])
+                e["us_" + c] = median([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in part]) / 1e3
 if perk:
     # the full-size launches of a kernel: grids within 10 % of its largest one (the grids of the leaf kernels follow the
     # number of leaves, which differs a little from sync to sync and from run to run)
@@ -95,14 +138,19 @@ if perk:
         idle = short.startswith("leafSortKernel")
         fs = [x for x in v["FETCH_SIZE"] if not idle or x >= 0.5 * max(v["FETCH_SIZE"])]
         ws = [x for x in v["WRITE_SIZE"] if not idle or x >= 0.5 * max(v["WRITE_SIZE"])]
-        fetch = 2.0 * 1024 * sum(fs) / len(fs)
-        write = 1024 * sum(ws) / len(ws)
-        us = sum(v["ns"]) / len(v["ns"]) / 1e3
-        table.append({"kernel": short, "grid_threads": grid, "launches": len(v["ns"]) // 2, "avg_us_under_pmc": us,
+        # medians: the first sync of a run sorts a random cloud from scratch and its gathers follow a random permutation
+        # (14 x the fetched bytes of a steady-state launch, tools/gather_calib.py); the steady state is what is reported
+        fetch = 2.0 * 1024 * median(fs)
+        write = 1024 * median(ws)
+        us = median(v["ns"]) / 1e3
+        table.append({"kernel": short, "grid_threads": grid, "launches": len(v["ns"]) // 2, "median_us_under_pmc": us,
                       "hbm_read_bytes": fetch, "hbm_write_bytes": write,
                       "hbm_GBps": (fetch + write) / (us * 1e-6) / 1e9 if us > 0 else None})
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python bench.py --steps 3` (N = 1e8), the full-size "
-                         "launches of every kernel; FETCH_SIZE doubled (gfx950); durations are those of the counter runs",
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python bench.py --steps 3` (N = 1e8), medians over "
+                         "the full-size launches of every kernel; FETCH_SIZE doubled (gfx950: checked for the gathers' "
+                         "8-byte accesses on known byte counts, gather_calibration below); durations are those of the "
+                         "counter runs",
+               "particles": 1e8, "gather_calibration": calib,
                "kernels": table}, open(f"profiles/{tag}_kernel_hbm_traffic.json", "w"), indent=1)
 # the multi-rank sync at the per-GPU size of the 8-GPU point (tools/mr_bench.py --rccl --particles 1.25e7): kernels per
 # sync, averaged over the last 10 syncs of the trace (a sync starts with its one encodeHistogramKernel launch)
@@ -126,8 +174,8 @@ for trace in glob.glob(os.path.join(src, "mr", "**", "*kernel_trace.csv"), recur
     kernels = sorted(({"name": k, "launches_per_sync": v[0] / n, "us_per_sync": round(v[1] / n, 2)} for k, v in per.items()),
                      key=lambda e: -e["us_per_sync"])
     json.dump({"source": "rocprofv3 --kernel-trace of tools/mr_bench.py --rccl --particles 1.25e7 (cstone_hip_domain_mr_sync, "
-                         "one rank, RCCL collectives from inside the library, 1 % of the particles displaced before every "
-                         "sync), averages over the last 10 syncs",
+                         "one rank, RCCL collectives from inside the library, every particle displaced by <= 0.1 h before "
+                         "every sync), averages over the last 10 syncs",
                "launches_per_sync": sum(e["launches_per_sync"] for e in kernels),
                "kernel_time_ms_per_sync": sum(e["us_per_sync"] for e in kernels) / 1e3,
                "wall_ms_per_sync_under_profiler": wall / n, "kernels": kernels},

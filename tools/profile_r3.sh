@@ -16,3 +16,8 @@ done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/mr -o mr --output-format csv -- python3 $R/tools/mr_bench.py --rccl --particles 1.25e7 --syncs 14 > $O/mr_stdout.log 2>&1
 echo "mr trace done" >> $O/progress.log
 ls $O
+# what the counters say for the gathers' access pattern on known byte counts (tools/gather_calib.py)
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c -d $O/gather_calib_$c -o p --output-format csv -- python3 $R/tools/gather_calib.py > $O/gather_calib_$c.log 2>&1
+done
+echo "gather calibration done" >> $O/progress.log
