@@ -858,8 +858,8 @@ public:
             layoutBox_       = box_;
             if (!hostLevelRange_)
                 CS_HIP(ctx_, hipHostMalloc(reinterpret_cast<void**>(&hostLevelRange_), 32 * sizeof(NodeIdx), hipHostMallocDefault));
-            CS_HIP(ctx_, hipMemcpyAsync(hostLevelRange_, let_->levelRange(), (maxLevel<K>() + 2) * sizeof(NodeIdx),
-                                        hipMemcpyDeviceToHost, ctx_->stream));
+            // (the level ranges came back with the layout: no copy of their own)
+            std::copy(let_->levelRangeHost().begin(), let_->levelRangeHost().end(), hostLevelRange_);
             levelRangePending_ = true;
             tick("5 focus tree (LET)");
         }
@@ -1059,8 +1059,9 @@ public:
         {
             // the particle buffers start at `off`: halos below | assigned | halos above, in the order of the focus tree's
             // leaves (R/domain/domain.hpp:522-540: exchangeHalos(x, y, z, h), then the keys of the halo particles)
-            for (DevBuf* b : {&o.x, &o.y, &o.z, &o.h})
-                CS_TRY(let_->exchangeHalos(b->as<T>() + off, int(sizeof(T))));
+            // (x, y, z and h travel together: one message per peer instead of four)
+            void* xyzh[4] = {o.x.as<T>() + off, o.y.as<T>() + off, o.z.as<T>() + off, o.h.as<T>() + off};
+            CS_TRY(let_->exchangeHalosRows(xyzh, 4, int(sizeof(T))));
             if (nlo)
             {
                 CS_HIP(ctx_, hipMemsetAsync(o.keys.as<K>() + off, 0, nlo * sizeof(K), ctx_->stream));

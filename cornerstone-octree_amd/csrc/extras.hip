@@ -139,6 +139,45 @@ __global__ __launch_bounds__(256) void gatherRangesKernel(const I* __restrict__ 
     buffer[i]   = src[offsets[r] + I(i) - scan[r]];
 }
 
+//! gatherRanges for up to four equally laid out arrays at once, as rows: rows[i * NUM + a] = src[a][offsets[r] + i -
+//! scan[r]] (one message per peer carries all arrays of a halo exchange instead of one message per array)
+template<class E, int NUM>
+__global__ __launch_bounds__(256) void gatherRangesRowsKernel(const uint32_t* __restrict__ scan,
+                                                              const uint32_t* __restrict__ offsets, int numRanges,
+                                                              const E* __restrict__ s0, const E* __restrict__ s1,
+                                                              const E* __restrict__ s2, const E* __restrict__ s3,
+                                                              E* __restrict__ rows, size_t numRows)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= numRows) return;
+    int lo = 0, len = numRanges;
+    while (len > 0)
+    {
+        int half = len >> 1;
+        if (!(uint32_t(i) < scan[lo + half])) { lo += half + 1, len -= half + 1; }
+        else { len = half; }
+    }
+    const int r      = lo - 1;
+    const size_t j   = size_t(offsets[r]) + (i - scan[r]);
+    const E* src[4]  = {s0, s1, s2, s3};
+#pragma unroll
+    for (int a = 0; a < NUM; ++a)
+        rows[i * NUM + a] = src[a][j];
+}
+
+//! the receiving side: dst[a][i] = rows[i * NUM + a]
+template<class E, int NUM>
+__global__ __launch_bounds__(256) void scatterRowsKernel(const E* __restrict__ rows, size_t numRows, E* __restrict__ d0,
+                                                         E* __restrict__ d1, E* __restrict__ d2, E* __restrict__ d3)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= numRows) return;
+    E* dst[4] = {d0, d1, d2, d3};
+#pragma unroll
+    for (int a = 0; a < NUM; ++a)
+        dst[a][i] = rows[i * NUM + a];
+}
+
 //! index of the first element >= value in a sorted device array, one thread (the arrays are small or the call is rare)
 template<class T>
 __global__ void lowerBoundOneKernel(const T* __restrict__ data, size_t n, T value, unsigned long long* out)
@@ -365,6 +404,75 @@ int cstone_hip_gather_ranges(cstone_hip_ctx* ctx, int elem_bytes, int index_bits
         default: return fail(ctx, CSTONE_E_ARG, "gather_ranges: element size %d unsupported", elem_bytes);
     }
 #undef CSTONE_GR_CASE
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int cstone_hip_gather_ranges_rows(cstone_hip_ctx* ctx, int elem_bytes, int num_arrays, const uint32_t* range_scan,
+                                  const uint32_t* range_offsets, int num_ranges, const void* const* src, void* rows,
+                                  size_t num_rows)
+{
+    if (!ctx || num_arrays < 1 || num_arrays > 4 || (elem_bytes != 4 && elem_bytes != 8) || num_ranges < 0 ||
+        (num_rows && (!range_scan || !range_offsets || !src || !rows || num_ranges == 0)))
+        return fail(ctx, CSTONE_E_ARG, "gather_ranges_rows: bad argument");
+    if (num_rows == 0) return CSTONE_OK;
+    if (num_rows >= (size_t(1) << 32)) return fail(ctx, CSTONE_E_ARG, "gather_ranges_rows: too many rows");
+    const void* s[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int a = 0; a < num_arrays; ++a)
+    {
+        if (!src[a]) return fail(ctx, CSTONE_E_ARG, "gather_ranges_rows: null array");
+        s[a] = src[a];
+    }
+    StageTimer timer(ctx, CSTONE_STAGE_GATHER);
+    unsigned grid = gridFor(num_rows, 256);
+#define CSTONE_GRR(E, NUM)                                                                                             \
+    hipLaunchKernelGGL((gatherRangesRowsKernel<E, NUM>), grid, 256, 0, ctx->stream, range_scan, range_offsets,         \
+                       num_ranges, (const E*)s[0], (const E*)s[1], (const E*)s[2], (const E*)s[3], (E*)rows, num_rows)
+#define CSTONE_GRR_NUM(E)                                                                                              \
+    switch (num_arrays)                                                                                                \
+    {                                                                                                                  \
+        case 1: CSTONE_GRR(E, 1); break;                                                                               \
+        case 2: CSTONE_GRR(E, 2); break;                                                                               \
+        case 3: CSTONE_GRR(E, 3); break;                                                                               \
+        default: CSTONE_GRR(E, 4); break;                                                                              \
+    }
+    if (elem_bytes == 4) { CSTONE_GRR_NUM(uint32_t) }
+    else { CSTONE_GRR_NUM(uint64_t) }
+#undef CSTONE_GRR_NUM
+#undef CSTONE_GRR
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int cstone_hip_scatter_rows(cstone_hip_ctx* ctx, int elem_bytes, int num_arrays, const void* rows, size_t num_rows,
+                            void* const* dst, size_t dst_offset)
+{
+    if (!ctx || num_arrays < 1 || num_arrays > 4 || (elem_bytes != 4 && elem_bytes != 8) || (num_rows && (!rows || !dst)))
+        return fail(ctx, CSTONE_E_ARG, "scatter_rows: bad argument");
+    if (num_rows == 0) return CSTONE_OK;
+    char* d[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int a = 0; a < num_arrays; ++a)
+    {
+        if (!dst[a]) return fail(ctx, CSTONE_E_ARG, "scatter_rows: null array");
+        d[a] = static_cast<char*>(dst[a]) + dst_offset * size_t(elem_bytes);
+    }
+    StageTimer timer(ctx, CSTONE_STAGE_GATHER);
+    unsigned grid = gridFor(num_rows, 256);
+#define CSTONE_SR(E, NUM)                                                                                              \
+    hipLaunchKernelGGL((scatterRowsKernel<E, NUM>), grid, 256, 0, ctx->stream, (const E*)rows, num_rows, (E*)d[0],     \
+                       (E*)d[1], (E*)d[2], (E*)d[3])
+#define CSTONE_SR_NUM(E)                                                                                               \
+    switch (num_arrays)                                                                                                \
+    {                                                                                                                  \
+        case 1: CSTONE_SR(E, 1); break;                                                                                \
+        case 2: CSTONE_SR(E, 2); break;                                                                                \
+        case 3: CSTONE_SR(E, 3); break;                                                                                \
+        default: CSTONE_SR(E, 4); break;                                                                               \
+    }
+    if (elem_bytes == 4) { CSTONE_SR_NUM(uint32_t) }
+    else { CSTONE_SR_NUM(uint64_t) }
+#undef CSTONE_SR_NUM
+#undef CSTONE_SR
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

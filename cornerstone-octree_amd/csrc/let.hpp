@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "cstone_hip.h"
@@ -188,7 +189,44 @@ public:
         return CSTONE_OK;
     }
 
+    /*! The same for up to four arrays of equal element size (4 or 8 bytes) in ONE message per peer: the arrays travel
+     *  as rows (cstone_hip_gather_ranges_rows / cstone_hip_scatter_rows).  What arrives from the ranks below me is one
+     *  block in front of my particles and what arrives from the ranks above one block behind them, both in rank order
+     *  like the receive buffer (R/domain/layout.hpp:175-190), so two launches take the rows apart. */
+    int exchangeHalosRows(void* const* arrays, int numArrays, int elemBytes)
+    {
+        if (P_ == 1) return CSTONE_OK;
+        if (numArrays < 1 || numArrays > 4 || (elemBytes != 4 && elemBytes != 8))
+            return fail(CSTONE_E_ARG, "exchangeHalosRows: %d arrays of %d-byte elements", numArrays, elemBytes);
+        const size_t e = size_t(elemBytes) * size_t(numArrays);
+        LET_TRY(haloSend_.ensure(std::max<uint64_t>(sendTotal_, 1) * e));
+        LET_TRY(haloRecv_.ensure(std::max<uint64_t>(recvTotal_, 1) * e));
+        if (numSendRanges_)
+            LET_TRY(cstone_hip_gather_ranges_rows(ctx_, elemBytes, numArrays, rangeScan_.as<uint32_t>(),
+                                                  rangeOffsets_.as<uint32_t>(), numSendRanges_, arrays, haloSend_.p,
+                                                  size_t(sendTotal_)));
+        std::vector<size_t> sb(P_), rbv(P_);
+        uint64_t below = 0, above = 0;
+        for (int p = 0; p < P_; ++p)
+        {
+            sb[p] = size_t(haloSendCounts_[p]) * e, rbv[p] = size_t(haloRecvCounts_[p]) * e;
+            (p < rank_ ? below : above) += haloRecvCounts_[p];
+        }
+        LET_TRY(commCall(comm_.all_to_all_v(comm_.user, haloSend_.p, sb.data(), haloRecv_.p, rbv.data()),
+                         "all_to_all_v (halos)"));
+        if (below != particleStart_ || above != particleTotal_ - particleEnd_)
+            return fail(CSTONE_E_INTERNAL, "halo exchange: %llu + %llu incoming particles, the layout has room for %u + %u",
+                        (unsigned long long)below, (unsigned long long)above, particleStart_,
+                        particleTotal_ - particleEnd_);
+        LET_TRY(cstone_hip_scatter_rows(ctx_, elemBytes, numArrays, haloRecv_.p, size_t(below), arrays, 0));
+        LET_TRY(cstone_hip_scatter_rows(ctx_, elemBytes, numArrays, haloRecv_.template as<char>() + below * e, size_t(above),
+                                        arrays, size_t(particleEnd_)));
+        return CSTONE_OK;
+    }
+
     // ---- results of the last update ------------------------------------------------------------------------------
+    //! level ranges of the focus tree on the host (from the last update's one read-back of the layout)
+    const std::vector<int32_t>& levelRangeHost() const { return levelRangeHost_; }
     int numLeaves() const { return L_; }
     int numNodes() const { return numNodesOf(L_); }
     const K* leaves() const { return leaves_.as<K>(); }
@@ -259,6 +297,23 @@ private:
         const size_t m = queries.size();
         result.assign(m, 0);
         if (m == 0) return CSTONE_OK;
+        // searches in the leaf array are remembered until it changes: the same few keys (the assignment) are looked up
+        // before, during and after an update of the tree, each time a round trip to the device
+        const bool inLeaves = keys == leaves_.template as<K>();
+        if (inLeaves)
+        {
+            if (memoVersion_ != treeVersion_) memo_.clear(), memoVersion_ = treeVersion_;
+            bool all = true;
+            for (size_t i = 0; i < m && all; ++i)
+            {
+                // a search over the first n' keys remembered as (n', v): over n <= n' keys the answer is min(v, n), over
+                // more keys it is v if v was found inside the first n'
+                auto it = memo_.find(queries[i]);
+                all     = it != memo_.end() && (n <= it->second.first || it->second.second < int64_t(it->second.first));
+                if (all) result[i] = std::min<int64_t>(it->second.second, int64_t(n));
+            }
+            if (all) return CSTONE_OK;
+        }
         LET_TRY(scratchU64_.ensure(m * (sizeof(K) + 8) + 64));
         K* dq        = scratchU64_.as<K>();
         uint64_t* dr = reinterpret_cast<uint64_t*>(scratchU64_.as<char>() + ((m * sizeof(K) + 63) / 64) * 64);
@@ -267,7 +322,10 @@ private:
         std::vector<uint64_t> r(m);
         LET_TRY(cstone_hip_memcpy_d2h(ctx_, r.data(), dr, m * 8));
         for (size_t i = 0; i < m; ++i)
+        {
             result[i] = int64_t(r[i]);
+            if (inLeaves) memo_[queries[i]] = {n, result[i]};
+        }
         return CSTONE_OK;
     }
 
@@ -340,8 +398,29 @@ private:
         LET_TRY(itl_.ensure(size_t(M) * 4));
         LET_TRY(lti_.ensure(size_t(M) * 4));
         ++stats_.treeBuilds;
-        return cstone_hip_build_octree(ctx_, kb, leaves_.p, L, prefixes_.p, child_.as<int32_t>(), parents_.as<int32_t>(),
-                                       levelRange_.as<int32_t>(), itl_.as<int32_t>(), lti_.as<int32_t>());
+        return cstone_hip_build_octree_bounded(ctx_, kb, leaves_.p, L, prefixes_.p, child_.as<int32_t>(),
+                                               parents_.as<int32_t>(), levelRange_.as<int32_t>(), itl_.as<int32_t>(),
+                                               lti_.as<int32_t>(), levelBound_);
+    }
+
+    /*! The leaf array changed.  levelBound_ bounds the level of its deepest leaf from above without a look at the
+     *  device: a rebalance step splits a leaf by one level (deeper = true), keys that join the array bring their own
+     *  level along, and the exact depth comes back with the read-back at the end of every update (computeLayout).  The
+     *  linked octree then sorts its node keys over the digits that can be set only and the upsweeps launch the levels
+     *  that can exist only. */
+    void treeChanged(bool deeper)
+    {
+        ++treeVersion_;
+        if (deeper) levelBound_ = std::min(levelBound_ + 1, maxLevel);
+    }
+    //! level of the coarsest octree node that can start at key
+    static int levelOfKey(K key)
+    {
+        if (key == 0) return 0;
+        int tz = 0;
+        while (((key >> tz) & 1) == 0)
+            ++tz;
+        return std::max(0, maxLevel - tz / 3);
     }
 
     //! the leaf-order part of leafToInternal (leafToInternal(tree) of R/tree/octree.hpp:366-375)
@@ -360,6 +439,7 @@ private:
         LET_TRY(cstone_hip_rebalance_tree(ctx_, kb, leaves_.p, L, newL, ops_.as<int32_t>(), leavesNew_.p));
         leaves_.swap(leavesNew_);
         L_ = newL;
+        treeChanged(true);
         return CSTONE_OK;
     }
 
@@ -371,6 +451,8 @@ private:
         LET_TRY(leaves_.ensure(2 * sizeof(K)));
         LET_TRY(cstone_hip_upload(ctx_, leaves_.p, root, sizeof root));
         L_ = 1;
+        levelBound_ = 0;
+        treeChanged(false);
         LET_TRY(buildOctree());
         const uint32_t c0 = bucket_ + 1; // counts_{bucketSize + 1}
         const char m0     = 1;           // macs_{1}
@@ -478,7 +560,7 @@ private:
         LET_TRY(translateAssignment(assignment));
         LET_TRY(syncTreelets());
         LET_TRY(indexTreelets());
-        LET_TRY(translateAssignment(assignment));
+        LET_TRY(translateAssignment(assignment)); // (answered from memory unless keys were rejected: lowerBounds)
         std::copy(assignment, assignment + P_ + 1, globAssignment_.begin());
 
         box_            = box;
@@ -600,6 +682,7 @@ private:
             LET_TRY(cstone_hip_rebalance_tree(ctx_, kb, leaves_.p, L, newL, ops_.as<int32_t>(), leavesNew_.p));
             leaves_.swap(leavesNew_);
             L_ = newL;
+            treeChanged(true);
             if (status == 3)
             {
                 LET_TRY(injectKeys(all));
@@ -630,6 +713,9 @@ private:
         LET_TRY(cstone_hip_fill_sfc_gaps(ctx_, kb, leaves_.p, int(n) - 1, ops_.as<int32_t>(), leavesNew_.p));
         leaves_.swap(leavesNew_);
         L_ = numGap;
+        for (K key : keys)
+            levelBound_ = std::max(levelBound_, levelOfKey(key));
+        treeChanged(false);
         return CSTONE_OK;
     }
 
@@ -857,8 +943,8 @@ private:
         // first upsweep with local and global data
         LET_TRY(counts_.ensure(size_t(M) * 4));
         LET_TRY(cstone_hip_scatter(ctx_, 4, lti_.as<uint32_t>() + I, size_t(L), leafCounts_.p, counts_.p));
-        LET_TRY(cstone_hip_upsweep_sum(ctx_, maxLevel + 2, levelRange_.as<int32_t>(), child_.as<int32_t>(),
-                                       counts_.as<uint32_t>()));
+        LET_TRY(cstone_hip_upsweep_sum_bounded(ctx_, maxLevel + 2, levelRange_.as<int32_t>(), child_.as<int32_t>(),
+                                               counts_.as<uint32_t>(), levelBound_));
         // counts of the peers' regions from their owners (peerExchange -> exchangeTreeletGeneral, exchange_focus.hpp:289-344)
         if (P_ > 1)
         {
@@ -1012,13 +1098,24 @@ private:
                 map[nA + 2 * p + 1] = uint32_t(assignment_[p].end);
             }
             map[nA + 2 * P_] = uint32_t(L);
-            LET_TRY(scratchIdx_.ensure(map.size() * 8));
+            LET_TRY(scratchIdx_.ensure(map.size() * 8 + (size_t(maxLevel) + 2) * 4));
             uint32_t* dmap = scratchIdx_.as<uint32_t>();
             uint32_t* dval = dmap + map.size();
             LET_TRY(cstone_hip_upload(ctx_, dmap, map.data(), map.size() * 4));
             if (numSendRanges_) LET_TRY(cstone_hip_gather(ctx_, 4, dmap, nA, rangeScan_.p, dval));
             LET_TRY(cstone_hip_gather(ctx_, 4, dmap + nA, nB, layout_.p, dval + nA));
+            // ... and the level ranges of the tree: the exact depth for the bounds of the next update (treeChanged)
+            const size_t nC = size_t(maxLevel) + 2;
+            LET_TRY(cstone_hip_memcpy_d2d(ctx_, dval + nA + nB, levelRange_.p, nC * 4));
+            val.resize(nA + nB + nC);
             LET_TRY(readBack(dval, val.data(), val.size()));
+            levelRangeHost_.assign(val.begin() + nA + nB, val.end());
+            int deepest = 0;
+            for (int l = 0; l <= maxLevel; ++l)
+                if (levelRangeHost_[l + 1] > levelRangeHost_[l]) deepest = l;
+            if (deepest > levelBound_)
+                return fail(CSTONE_E_INTERNAL, "focus tree: level %d exists, the bound was %d", deepest, levelBound_);
+            levelBound_ = deepest;
             for (int p = 0; p < P_ && numSendRanges_; ++p)
             {
                 haloSendCounts_[p] = val[p + 1] - val[p];
@@ -1054,6 +1151,10 @@ private:
     Stats stats_;
 
     int L_ = 0; // leaves of the focus tree
+    int levelBound_ = maxLevel;          // no leaf is deeper than this (treeChanged)
+    uint64_t treeVersion_ = 0, memoVersion_ = 0;
+    std::map<K, std::pair<size_t, int64_t>> memo_; // lowerBounds in the current leaf array: key -> (keys searched, index)
+    std::vector<int32_t> levelRangeHost_;
     LetBuf leaves_, leavesNew_, prefixes_, child_, parents_, levelRange_, itl_, lti_;
     LetBuf counts_, leafCounts_, macs_, centers_, geoCenters_, geoSizes_;
     LetBuf opsAll_, ops_, scratchKeys_, scratchKeys2_, scratchIdx_, scratchIdx2_, scratchU64_;

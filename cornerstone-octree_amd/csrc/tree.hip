@@ -589,6 +589,33 @@ int cstone_hip_upsweep_sum(cstone_hip_ctx* ctx, int num_levels_plus2, const int3
     return CSTONE_OK;
 }
 
+int cstone_hip_build_octree_bounded(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int num_leaves, void* prefixes,
+                                    int32_t* child_offsets, int32_t* parents, int32_t* level_range,
+                                    int32_t* internal_to_leaf, int32_t* leaf_to_internal, int deepest_level)
+{
+    if (!ctx || !leaves || !prefixes || !child_offsets || !parents || !level_range || !internal_to_leaf ||
+        !leaf_to_internal || deepest_level < 0)
+        return fail(ctx, CSTONE_E_ARG, "build_octree_bounded: bad argument");
+    CS_KEY_DISPATCH(key_bits,
+                    buildOctree<uint32_t>(ctx, (const uint32_t*)leaves, num_leaves, (uint32_t*)prefixes, child_offsets,
+                                          parents, level_range, internal_to_leaf, leaf_to_internal, deepest_level),
+                    buildOctree<uint64_t>(ctx, (const uint64_t*)leaves, num_leaves, (uint64_t*)prefixes, child_offsets,
+                                          parents, level_range, internal_to_leaf, leaf_to_internal, deepest_level));
+}
+
+int cstone_hip_upsweep_sum_bounded(cstone_hip_ctx* ctx, int num_levels_plus2, const int32_t* level_range,
+                                   const int32_t* child_offsets, uint32_t* counts, int deepest_level)
+{
+    if (!ctx || !level_range || !child_offsets || !counts || num_levels_plus2 < 2 || deepest_level < 0)
+        return fail(ctx, CSTONE_E_ARG, "upsweep_sum_bounded: bad argument");
+    unsigned grid = unsigned(ctx->numCu) * 4;
+    // (the nodes of the deepest level are leaves: the first level with anything to sum is the one above)
+    for (int level = std::min(num_levels_plus2 - 2, deepest_level - 1); level >= 0; --level)
+        hipLaunchKernelGGL(upsweepLevelKernel, grid, 256, 0, ctx->stream, level, level_range, child_offsets, counts);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
 int cstone_hip_node_centers(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* prefixes,
                             int num_nodes, const cstone_box* box_host, void* centers, void* sizes)
 {

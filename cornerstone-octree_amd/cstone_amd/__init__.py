@@ -51,7 +51,8 @@ EXPORTS = [
     "cstone_hip_zero_ops_at_keys", "cstone_hip_locate_nodes", "cstone_hip_node_layout", "cstone_hip_halo_requests",
     "cstone_hip_ranges_from_keys", "cstone_hip_domain_mr_set_halo_mode", "cstone_hip_domain_mr_set_theta",
     "cstone_hip_upload", "cstone_hip_focus_update_ops", "cstone_hip_find_neighbors_stats",
-    "cstone_hip_gather_multi", "cstone_hip_domain_sync_scratch",
+    "cstone_hip_gather_multi", "cstone_hip_domain_sync_scratch", "cstone_hip_gather_ranges_rows",
+    "cstone_hip_scatter_rows", "cstone_hip_build_octree_bounded", "cstone_hip_upsweep_sum_bounded",
 ]
 
 

@@ -207,6 +207,15 @@ extern "C"
     int cstone_hip_gather_ranges(cstone_hip_ctx* ctx, int elem_bytes, int index_bits, const void* range_scan,
                                  const void* range_offsets, int num_ranges, const void* src, void* buffer,
                                  size_t buffer_size);
+    /* gatherRanges (R/halos/gather_halos_gpu.cu:26-40) of up to four equally laid out arrays of 4- or 8-byte elements
+     * into ROWS, rows[i * num_arrays + a] = src[a][range_offsets[r] + i - range_scan[r]], and the receiving side,
+     * dst[a][dst_offset + i] = rows[i * num_arrays + a]: one message per peer for all arrays of a halo exchange
+     * (the reference sends one message per array and peer, R/halos/exchange_halos_gpu.cuh:71-115) */
+    int cstone_hip_gather_ranges_rows(cstone_hip_ctx* ctx, int elem_bytes, int num_arrays, const uint32_t* range_scan,
+                                      const uint32_t* range_offsets, int num_ranges, const void* const* src, void* rows,
+                                      size_t num_rows);
+    int cstone_hip_scatter_rows(cstone_hip_ctx* ctx, int elem_bytes, int num_arrays, const void* rows, size_t num_rows,
+                                void* const* dst, size_t dst_offset);
     int cstone_hip_lower_bound_value(cstone_hip_ctx* ctx, int kind, const void* data, size_t n, const void* value_host,
                                      uint64_t* index_host);
     int cstone_hip_sort_keys(cstone_hip_ctx* ctx, int key_bits, void* keys, size_t n);
@@ -262,6 +271,14 @@ extern "C"
                                 int32_t* internal_to_leaf, int32_t* leaf_to_internal);
     int cstone_hip_upsweep_sum(cstone_hip_ctx* ctx, int num_levels_plus2, const int32_t* level_range,
                                const int32_t* child_offsets, uint32_t* counts);
+    /* the same two with a bound the caller has on the level of the deepest leaf (e.g. the deepest level of the tree
+     * this one was rebalanced from, plus one): the node keys are sorted over 3 * deepest_level + 1 bits only and the
+     * levels below the bound are not launched.  A bound that is too small is an error of the caller (undetected). */
+    int cstone_hip_build_octree_bounded(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int num_leaves,
+                                        void* prefixes, int32_t* child_offsets, int32_t* parents, int32_t* level_range,
+                                        int32_t* internal_to_leaf, int32_t* leaf_to_internal, int deepest_level);
+    int cstone_hip_upsweep_sum_bounded(cstone_hip_ctx* ctx, int num_levels_plus2, const int32_t* level_range,
+                                       const int32_t* child_offsets, uint32_t* counts, int deepest_level);
     /* computeGeoCentersGpu (R/focus/source_center_gpu.h): centers/sizes [M][3] reals */
     int cstone_hip_node_centers(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* prefixes,
                                 int num_nodes, const cstone_box* box_host, void* centers, void* sizes);

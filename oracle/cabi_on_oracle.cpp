@@ -7,6 +7,8 @@
 // Never linked into libcstone_hip.so, never shipped.
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -191,6 +193,28 @@ int cstone_hip_gather_ranges(cstone_hip_ctx*, int elem_bytes, int index_bits, co
     return CSTONE_OK;
 }
 
+int cstone_hip_gather_ranges_rows(cstone_hip_ctx*, int elem_bytes, int num_arrays, const uint32_t* scan, const uint32_t* off,
+                                  int num_ranges, const void* const* src, void* rows, size_t num_rows)
+{
+    for (size_t i = 0; i < num_rows; ++i)
+    {
+        int r = int(std::upper_bound(scan, scan + num_ranges, uint32_t(i)) - scan) - 1;
+        for (int a = 0; a < num_arrays; ++a)
+            std::memcpy((char*)rows + (i * num_arrays + a) * elem_bytes,
+                        (const char*)src[a] + size_t(off[r] + uint32_t(i) - scan[r]) * elem_bytes, elem_bytes);
+    }
+    return CSTONE_OK;
+}
+int cstone_hip_scatter_rows(cstone_hip_ctx*, int elem_bytes, int num_arrays, const void* rows, size_t num_rows,
+                            void* const* dst, size_t dst_offset)
+{
+    for (size_t i = 0; i < num_rows; ++i)
+        for (int a = 0; a < num_arrays; ++a)
+            std::memcpy((char*)dst[a] + (dst_offset + i) * elem_bytes, (const char*)rows + (i * num_arrays + a) * elem_bytes,
+                        elem_bytes);
+    return CSTONE_OK;
+}
+
 int cstone_hip_compute_node_counts(cstone_hip_ctx*, int key_bits, const void* tree, uint32_t* counts, int num_nodes,
                                    const void* keys, size_t n, uint32_t max_count)
 {
@@ -265,6 +289,32 @@ int cstone_hip_upsweep_sum(cstone_hip_ctx*, int num_levels_plus2, const int32_t*
 {
     upsweepCounts(level_range, num_levels_plus2, child_offsets, counts);
     return CSTONE_OK;
+}
+//! the bounded forms: the bound is CHECKED here (the device versions rely on it), so the harness that links this file
+//! proves the callers' bookkeeping on every path it takes
+static void checkLevelBound(const int32_t* level_range, int num_levels_plus2, int deepest_level, const char* who)
+{
+    for (int l = deepest_level + 1; l + 1 < num_levels_plus2; ++l)
+        if (level_range[l + 1] > level_range[l])
+        {
+            std::fprintf(stderr, "%s: level %d exists, the caller's bound is %d\n", who, l, deepest_level);
+            std::abort();
+        }
+}
+int cstone_hip_build_octree_bounded(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int num_leaves, void* prefixes,
+                                    int32_t* child_offsets, int32_t* parents, int32_t* level_range,
+                                    int32_t* internal_to_leaf, int32_t* leaf_to_internal, int deepest_level)
+{
+    int rc = cstone_hip_build_octree(ctx, key_bits, leaves, num_leaves, prefixes, child_offsets, parents, level_range,
+                                     internal_to_leaf, leaf_to_internal);
+    checkLevelBound(level_range, (key_bits == 32 ? 10 : 21) + 2, deepest_level, "build_octree_bounded");
+    return rc;
+}
+int cstone_hip_upsweep_sum_bounded(cstone_hip_ctx* ctx, int num_levels_plus2, const int32_t* level_range,
+                                   const int32_t* child_offsets, uint32_t* counts, int deepest_level)
+{
+    checkLevelBound(level_range, num_levels_plus2, deepest_level, "upsweep_sum_bounded");
+    return cstone_hip_upsweep_sum(ctx, num_levels_plus2, level_range, child_offsets, counts);
 }
 int cstone_hip_node_centers(cstone_hip_ctx*, int curve, int key_bits, int real_bits, const void* prefixes, int num_nodes,
                             const cstone_box* box_host, void* centers, void* sizes)

@@ -287,6 +287,27 @@ int run(int rank, int P, char** argv)
                 tag = fetch(ctx, dt.get(), tag.size());
             }
             expectEqual("halo tags", s, want.data(), want.size(), tag.data(), tag.size());
+            // x, y, z in one message per peer (exchangeHalosRows): the same particles
+            {
+                std::vector<T> cx(x), cy(y), cz(z);
+                for (auto* v : {&cx, &cy, &cz})
+                {
+                    std::fill(v->begin(), v->begin() + st, T(-7));
+                    std::fill(v->begin() + en, v->end(), T(-7));
+                }
+                OnDevice<T> dx(ctx, cx.data(), cx.size()), dy(ctx, cy.data(), cy.size()), dz(ctx, cz.data(), cz.size());
+                void* arrays[3] = {dx.get(), dy.get(), dz.get()};
+                if (let.exchangeHalosRows(arrays, 3, int(sizeof(T))) != 0)
+                {
+                    ++failures;
+                    std::fprintf(stderr, "[rank %d sync %d] exchangeHalosRows failed: %s\n", rank, s,
+                                 cstone_hip_last_error(ctx));
+                }
+                cx = fetch(ctx, dx.get(), cx.size()), cy = fetch(ctx, dy.get(), cy.size()), cz = fetch(ctx, dz.get(), cz.size());
+                expectEqual("halo rows x", s, x.data(), x.size(), cx.data(), cx.size());
+                expectEqual("halo rows y", s, y.data(), y.size(), cy.data(), cy.size());
+                expectEqual("halo rows z", s, z.data(), z.size(), cz.data(), cz.size());
+            }
         }
         if (rank == 0)
             std::printf("sync %d: leaves %d, peers %zu, halos in %u, assigned %u\n", s, L, peers.size(),
