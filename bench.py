@@ -156,6 +156,19 @@ class SyncPipeline:
             a.add_(d.sub_(0.5).mul_(2 * frac * h0)).clamp_(0.0, 1.0)
             del d
 
+    def drift_unclamped(self, frac=0.1):
+        """the same displacement without keeping the particles inside [0, 1]: the outermost particles of the open box
+        move, so the box of the reference's limitBoxShrinking rule changes with every sync"""
+        import torch
+
+        if not hasattr(self, "g"):
+            self.g = torch.Generator(device=self.x.device).manual_seed(1234)
+        h0 = float(self.h[0])
+        for a in (self.x, self.y, self.z):
+            d = torch.rand(a.numel(), dtype=a.dtype, device=a.device, generator=self.g)
+            a.add_(d.sub_(0.5).mul_(2 * frac * h0))
+            del d
+
     def find_neighbors(self, targets, ngmax):
         """cstone_hip_find_neighbors on the synced domain's own tree view (NOT part of the timed metric)"""
         import ctypes as C
@@ -564,6 +577,14 @@ def main():
         run_syncs(2, None)
         extras["zero_motion"] = timed_variant(None)
         extras["zero_motion"]["note"] = "no particle moves between the syncs"
+        # the case the speculative box does not like: open boundaries whose outermost particles move, so the global box
+        # changes with every sync, every key with it, and nothing of the previous order can be used
+        run_syncs(2, pipe.drift_unclamped)
+        extras["open_box_moving_extremes"] = timed_variant(pipe.drift_unclamped)
+        extras["open_box_moving_extremes"]["note"] = (
+            "every particle displaced by <= 0.1 h and NOT kept inside [0, 1]: the box changes with every sync (syncs.box_redos "
+            "= speculative encodes thrown away; after one of them the extents are measured first), all keys change, the "
+            "radix path sorts")
     if not distributed and args.neighbor_targets > 0:
         extras["find_neighbors"] = [pipe.find_neighbors(args.neighbor_targets, 0),
                                     pipe.find_neighbors(args.neighbor_targets, 128)]

@@ -290,3 +290,45 @@ def test_full_leaves_everywhere(hip, oracle):
             counts = st_.dom.fetch(a["view"].focus_leaf_counts, a["view"].num_focus_leaves, np.uint32)
             assert counts.min() == 64 and counts.max() == 64  # the premise of this test
     assert st_.dom.stats()["resorts"] >= 3, st_.dom.stats()
+
+
+@pytest.mark.gpu
+def test_open_box_whose_outermost_particles_move(hip, oracle, monkeypatch):
+    """open boundaries, the outermost particles move with every step: the box of limitBoxShrinking (R/sfc/box.hpp:415-431)
+    changes with every sync, keys computed with the previous box are worthless.  After ONE such sync the domain measures
+    the extents before it encodes (no second speculative encode is thrown away) and goes back to speculating after a sync
+    whose box stayed; the results equal those of a domain that never speculates (CSTONE_NO_SPECULATIVE_BOX) and the
+    oracle's keys under the domain's box"""
+    from oracle.oracle import Box
+
+    kb, rb, bucket_focus, curve, bc, n = 64, 64, 64, 1, (0, 0, 0), 150_000
+    sa_, sb_ = (_Stepper(hip, kb, rb, bucket_focus, curve, bc, n, 31, True) for _ in range(2))
+    script = ["none", "expand", "expand", "expand", "none", "none", "expand", "none", "jitter", "none"]
+    boxes = []
+    for step, kind in enumerate(script):
+        for s_ in (sa_, sb_):
+            if kind == "expand":  # everybody drifts outwards a little: all six extents move
+                for a in (s_.x, s_.y, s_.z):
+                    a.sub_(0.5).mul_(1.001).add_(0.5)
+            elif step:
+                s_.move(kind, np.random.default_rng(2000 + step))
+        a = sa_.sync()
+        monkeypatch.setenv("CSTONE_NO_SPECULATIVE_BOX", "1")
+        b = sb_.sync()
+        monkeypatch.delenv("CSTONE_NO_SPECULATIVE_BOX")
+        va, vb = a["view"], b["view"]
+        assert list(va.box.lim) == list(vb.box.lim), (step, kind)
+        for f in ("keys", "x", "y", "z", "h", "ident"):
+            assert np.array_equal(a[f], b[f]), (step, kind, f)
+        L = va.num_focus_leaves
+        assert L == vb.num_focus_leaves
+        assert np.array_equal(sa_.dom.fetch(va.layout, L + 1, np.uint32), sb_.dom.fetch(vb.layout, L + 1, np.uint32)), step
+        want = oracle.compute_sfc_keys(curve, kb, a["x"], a["y"], a["z"], Box(list(va.box.lim), bc))
+        assert np.array_equal(a["keys"].view(np.uint64), want), (step, kind)
+        boxes.append(list(va.box.lim))
+    assert boxes[1] != boxes[0] and boxes[2] != boxes[1] and boxes[5] == boxes[4]
+    sa, sb = sa_.dom.stats(), sb_.dom.stats()
+    # speculative encodes thrown away: the first expanding step and the one after the quiet stretch, not every one of the four
+    assert sb["box_redos"] == 0 and 1 <= sa["box_redos"] <= 2, (sa, sb)
+    # the quiet steps behind an unchanged box are re-sorted again in both domains
+    assert sa["resorts"] >= 2 and sb["resorts"] >= 2, (sa, sb)
