@@ -167,7 +167,7 @@ for trace in glob.glob(os.path.join(src, "mr", "**", "*kernel_trace.csv"), recur
         for r in rows[a:b]:
             name = re.sub(r"^void |cship::\(anonymous namespace\)::|cship::", "", r["Kernel_Name"]).split("(")[0]
             if "at::native" in name or "elementwise" in name or "Cijk" in name:
-                name = "torch kernels of the particle displacement (bench jiggle)"
+                name = "torch kernels of the particle displacement (between the syncs, not part of them)"
             per[name][0] += 1
             per[name][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     n = len(use) - 1
@@ -176,10 +176,16 @@ for trace in glob.glob(os.path.join(src, "mr", "**", "*kernel_trace.csv"), recur
     json.dump({"source": "rocprofv3 --kernel-trace of tools/mr_bench.py --rccl --particles 1.25e7 (cstone_hip_domain_mr_sync, "
                          "one rank, RCCL collectives from inside the library, every particle displaced by <= 0.1 h before "
                          "every sync), averages over the last 10 syncs",
-               "launches_per_sync": sum(e["launches_per_sync"] for e in kernels),
-               "kernel_time_ms_per_sync": sum(e["us_per_sync"] for e in kernels) / 1e3,
+               "launches_per_sync": sum(e["launches_per_sync"] for e in kernels if not e["name"].startswith("torch kernels")),
+               "kernel_time_ms_per_sync": sum(e["us_per_sync"] for e in kernels if not e["name"].startswith("torch kernels")) / 1e3,
+               "note": "the sums leave out the torch kernels of the particle displacement between the syncs; the wall time is from the start of one sync to the start of the next, displacement included",
                "wall_ms_per_sync_under_profiler": wall / n, "kernels": kernels},
               open(f"profiles/{tag}_mr_sync_kernels.json", "w"), indent=1)
+if glob.glob(os.path.join(src, "mr_api", "*hip_api_trace.csv")):
+    import subprocess
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "mr_trace.py"),
+                    os.path.join(src, "mr_api"), "--json", f"profiles/{tag}_mr_sync_api_sequence.json"],
+                   check=True, stdout=subprocess.DEVNULL)
 print("wrote", sorted(os.listdir("profiles")))
 
 # the JSON line bench.py printed under the profiler (its live roofline number belongs next to the kernel stats)

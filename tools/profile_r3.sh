@@ -21,3 +21,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c -d $O/gather_calib_$c -o p --output-format csv -- python3 $R/tools/gather_calib.py > $O/gather_calib_$c.log 2>&1
 done
 echo "gather calibration done" >> $O/progress.log
+# the same multi-rank sync as a sequence of HIP API calls with their kernels (tools/mr_trace.py)
+timeout -k 10 300 rocprofv3 --hip-trace --kernel-trace -d $O/mr_api -o mr --output-format csv -- python3 $R/tools/mr_bench.py --rccl --particles 1.25e7 --syncs 8 > $O/mr_api_stdout.log 2>&1
+echo "mr api trace done" >> $O/progress.log
