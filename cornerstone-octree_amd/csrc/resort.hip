@@ -676,15 +676,16 @@ __device__ __forceinline__ void halfClean(uint32_t (&v)[N], unsigned lane)
 /*! N independent ascending sorts of 64 values each (register n of every lane: one sort): bitonic network without
  *  direction flags -- every merge of two sorted blocks starts with a compare-exchange against the MIRRORED position
  *  (distance k - 1), followed by half-cleaners at distances k/4 ... 1, the lower lane always keeps the minimum. */
-template<int N>
+template<int N, int S = 64>
 __device__ __forceinline__ void waveSort64(uint32_t (&v)[N], unsigned lane)
 {
-    cmpExchange<1, 1u, N>(v, lane);                              // blocks of 2
-    cmpExchange<3, 2u, N>(v, lane), halfClean<1, N>(v, lane);    // 4
-    cmpExchange<7, 4u, N>(v, lane), halfClean<2, N>(v, lane);    // 8
-    cmpExchange<15, 8u, N>(v, lane), halfClean<4, N>(v, lane);   // 16
-    cmpExchange<31, 16u, N>(v, lane), halfClean<8, N>(v, lane);  // 32
-    cmpExchange<63, 32u, N>(v, lane), halfClean<16, N>(v, lane); // 64
+    cmpExchange<1, 1u, N>(v, lane);                            // blocks of 2
+    cmpExchange<3, 2u, N>(v, lane), halfClean<1, N>(v, lane);  // 4
+    cmpExchange<7, 4u, N>(v, lane), halfClean<2, N>(v, lane);  // 8
+    cmpExchange<15, 8u, N>(v, lane), halfClean<4, N>(v, lane); // 16
+    // S < 64: the wave holds 64 / S independent sorts of S values in consecutive lanes (several small leaves at once)
+    if constexpr (S >= 32) { cmpExchange<31, 16u, N>(v, lane), halfClean<8, N>(v, lane); }
+    if constexpr (S >= 64) { cmpExchange<63, 32u, N>(v, lane), halfClean<16, N>(v, lane); }
 }
 
 //! ascending sort of the 64 R values d[r] (element 64 r + lane) of a wave
@@ -716,8 +717,13 @@ __device__ __forceinline__ void waveBitonicSort(uint32_t (&d)[R], unsigned lane)
     }
 }
 
-template<class K, int G>
-__global__ __launch_bounds__(256) void leafSortWaveKernel(
+#ifdef CSTONE_WAVE_OCC4
+#define CSTONE_WAVE_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define CSTONE_WAVE_OCC
+#endif
+template<class K, int G, bool PACK>
+__global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
     const K* __restrict__ keysIn, const K* __restrict__ leafLo, const uint32_t* __restrict__ leafPos,
     const uint32_t* __restrict__ inOffset, const uint32_t* __restrict__ layoutNew, const K* __restrict__ binKeys,
     const uint32_t* __restrict__ binIdx, uint32_t J, bool alwaysCount, bool allTiles, K* __restrict__ keysOut,
@@ -726,8 +732,10 @@ __global__ __launch_bounds__(256) void leafSortWaveKernel(
     constexpr K HOLE = ~K(0);
     __shared__ uint32_t posK[G + 1], inK[G + 1], outK[G + 1];
     __shared__ K loK[G + 1];
+    __shared__ uint32_t slotsK[G + 4]; // old slots + arrivals of every leaf, zeros behind the last one
     __shared__ uint16_t sPlace[4][256];
 
+    RESORT_TRACE(0)
     const uint32_t j0 = blockIdx.x * uint32_t(G);
     const uint32_t nl = min(uint32_t(G), J - j0);
     const uint32_t t  = threadIdx.x;
@@ -739,6 +747,7 @@ __global__ __launch_bounds__(256) void leafSortWaveKernel(
         loK[t]  = leafLo[j0 + t];
     }
     __syncthreads();
+    if (t < uint32_t(G) + 4u) slotsK[t] = t < nl ? (posK[t + 1] - posK[t]) + (inK[t + 1] - inK[t]) : 0u;
     const uint32_t p0 = posK[0], p1 = posK[nl], in0 = inK[0], in1 = inK[nl];
     if (!allTiles)
     {
@@ -855,52 +864,193 @@ __global__ __launch_bounds__(256) void leafSortWaveKernel(
         if (!finishLeaf(f, rTag, key, idx, d)) exactLeaf(f, R, key, idx);
     };
 
-    // The leaves of this wave: wave, wave + 4, ...  A ROLLED loop: the body (load, 64-element network, store) is a few
-    // hundred instructions and stays in the instruction cache; unrolled over the wave's 16 leaves the kernel was
+    if constexpr (!PACK)
+    {
+        // The leaves of this wave: wave, wave + 4, ...  A ROLLED loop: the body (load, 64-element network, store) is a few
+        // hundred instructions and stays in the instruction cache; unrolled over the wave's 16 leaves the kernel was
+        // 24-41 thousand instructions (190-330 KB of code streaming through the instruction cache) and took 0.7-0.9 ms
+        // whatever the network cost.  The key of the NEXT leaf is requested before the current one is sorted.
+        if (wave >= nl) return;
+        Leaf cur = leafOf(wave);
+        K keyN        = HOLE;
+        uint32_t idxN = 0;
+        if (cur.slots <= 64) loadSlot(cur, lane, keyN, idxN);
+    #pragma unroll 1
+        for (uint32_t k = wave; k < nl; k += 4)
+        {
+            const Leaf f     = cur;
+            K key1[1]        = {keyN};
+            uint32_t idx1[1] = {idxN};
+            keyN = HOLE, idxN = 0;
+            if (k + 4 < nl)
+            {
+                cur = leafOf(k + 4);
+                if (cur.slots <= 64) loadSlot(cur, lane, keyN, idxN);
+            }
+            if (f.slots == 0) continue;
+            if (f.slots <= 64)
+            {
+                // nothing arrived and what stayed is still in order (a departure leaves the largest key behind, so only
+                // departures from the end of the leaf pass): the content goes out as it came in
+                {
+                    const K below     = K(__shfl_up((unsigned long long)key1[0], 1));
+                    const bool behind = lane != 0 && key1[0] < below;
+                    if (f.nInc == 0 && !__any(behind))
+                    {
+                        if (lane < f.nNew)
+                        {
+                            keysOut[f.ok + lane]  = key1[0];
+                            orderOut[f.ok + lane] = idx1[0];
+                        }
+                        continue;
+                    }
+                }
+                uint32_t d[1] = {digestOf(f, key1[0], lane)};
+                waveBitonicSort<1>(d, lane);
+                if (!finishLeaf(f, std::integral_constant<int, 1>{}, key1, idx1, d)) exactLeaf(f, 1, key1, idx1);
+            }
+            else if (f.slots <= 128) { bigLeaf(f, std::integral_constant<int, 2>{}); }
+            else { bigLeaf(f, std::integral_constant<int, 4>{}); }
+        }
+        return;
+    }
+    // ---- The leaves of this wave: a contiguous quarter of the tile, in a ROLLED loop: the body (load, network, store) is
+    // a few hundred instructions and stays in the instruction cache; unrolled over the wave's 16 leaves the kernel was
     // 24-41 thousand instructions (190-330 KB of code streaming through the instruction cache) and took 0.7-0.9 ms
-    // whatever the network cost.  The key of the NEXT leaf is requested before the current one is sorted.
-    if (wave >= nl) return;
-    Leaf cur = leafOf(wave);
+    // whatever the network cost.  The keys of the NEXT step are requested before the current one is sorted.
+    // The kernel is bound by instruction issue, i.e. by the number of STEPS, and a leaf of a uniform cloud holds anything
+    // between an eighth of a bucket and a bucket: a step therefore takes FOUR consecutive leaves when none of them has more
+    // than 16 slots (each in a segment of 16 lanes, the network stops at blocks of 16), TWO when both have at most 32,
+    // ONE otherwise.  Everything that describes "the leaf" below is per lane.
+    __syncthreads();
+#ifdef CSTONE_RESORT_TRACE
+    RESORT_TRACE(1)
+    long long trSteps = 0, trIssue = 0, trWait = 0, trSort = 0, trFinish = 0, trT = clock64();
+#define WAVE_TRACE(acc)                                                                                                \
+    {                                                                                                                  \
+        const long long now_ = clock64();                                                                              \
+        acc += now_ - trT;                                                                                             \
+        trT = now_;                                                                                                    \
+    }
+#else
+#define WAVE_TRACE(acc)
+#endif
+    const uint32_t per    = (nl + 3u) / 4u;
+    const uint32_t kBegin = min(nl, wave * per), kEnd = min(nl, kBegin + per);
+    if (kBegin >= kEnd) return;
+    // log2 of the segment size for the step that starts at leaf q (leaves of the next wave's quarter are not mine)
+    auto segmentBits = [&](uint32_t q) -> unsigned
+    {
+        const uint32_t s0 = slotsK[q];
+        const uint32_t s1 = q + 1 < kEnd ? slotsK[q + 1] : 0u;
+        const uint32_t s2 = q + 2 < kEnd ? slotsK[q + 2] : 0u;
+        const uint32_t s3 = q + 3 < kEnd ? slotsK[q + 3] : 0u;
+        const uint32_t m2 = max(s0, s1), m4 = max(m2, max(s2, s3));
+#ifdef CSTONE_WAVE_NO_PACKING
+        return 6u;
+#endif
+        return m4 <= 16u ? 4u : (m2 <= 32u ? 5u : 6u);
+    };
+    auto leafAt = [&](uint32_t q, unsigned bits)
+    {
+        const uint32_t kk = q + (lane >> bits);
+        const bool mine   = kk < kEnd;
+        Leaf f            = leafOf(mine ? kk : q);
+        if (!mine) f.nOld = f.nInc = f.nNew = f.slots = 0;
+        return f;
+    };
+    // one element per lane, sorted within segments of (1 << bits) lanes: the new content of the segments' leaves
+    auto finishSegments = [&](const Leaf& f, unsigned bits, uint32_t slot, K key, uint32_t idx, uint32_t d)
+    {
+        const uint32_t below   = uint32_t(__shfl_up(int(d), 1));
+        const bool clash       = slot != 0 && d != ~0u && below != ~0u && (d >> 8) == (below >> 8);
+        const uint64_t clashes = __ballot(clash);
+        const unsigned base    = lane - slot; // first lane of my segment
+        const uint64_t segment = bits == 6 ? ~0ull : (((1ull << (1u << bits)) - 1ull) << base);
+        const bool exact       = (clashes & segment) != 0; // equal leading bits somewhere in MY leaf
+        uint16_t* place        = sPlace[wave];
+        if (d != ~0u) place[base + (d & 0xFFu)] = uint16_t(slot); // the sorted element in this lane: slot -> place
+        __builtin_amdgcn_wave_barrier();
+        if (key != HOLE && !exact)
+        {
+            const uint32_t at = place[lane];
+            if (at < f.nNew)
+            {
+                keysOut[f.ok + at]  = key;
+                orderOut[f.ok + at] = idx;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (exact) exactLeaf(f, 1, &key, &idx);
+    };
+
+    uint32_t k    = kBegin;
+    unsigned bits = segmentBits(k);
+    Leaf cur      = leafAt(k, bits);
     K keyN        = HOLE;
     uint32_t idxN = 0;
-    if (cur.slots <= 64) loadSlot(cur, lane, keyN, idxN);
+    if (cur.slots <= 64) loadSlot(cur, lane & ((1u << bits) - 1u), keyN, idxN);
 #pragma unroll 1
-    for (uint32_t k = wave; k < nl; k += 4)
+    while (k < kEnd)
     {
-        const Leaf f     = cur;
-        K key1[1]        = {keyN};
-        uint32_t idx1[1] = {idxN};
+        const Leaf f        = cur;
+        const unsigned b    = bits;
+        const K key         = keyN;
+        const uint32_t idx  = idxN;
+        const uint32_t slot = lane & ((1u << b) - 1u);
+        k += 64u >> b;
         keyN = HOLE, idxN = 0;
-        if (k + 4 < nl)
+        if (k < kEnd)
         {
-            cur = leafOf(k + 4);
-            if (cur.slots <= 64) loadSlot(cur, lane, keyN, idxN);
+            bits = segmentBits(k);
+            cur  = leafAt(k, bits);
+            if (cur.slots <= 64) loadSlot(cur, lane & ((1u << bits) - 1u), keyN, idxN);
         }
-        if (f.slots == 0) continue;
-        if (f.slots <= 64)
+#ifdef CSTONE_RESORT_TRACE
+        ++trSteps;
+        WAVE_TRACE(trIssue)
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // (the keys of this step: all but the two loads just issued)
+        WAVE_TRACE(trWait)
+#endif
+        if (!__any(f.slots != 0)) continue;
+        if (f.slots > 64) // (only with one leaf for the whole wave)
         {
-            // nothing arrived and what stayed is still in order (a departure leaves the largest key behind, so only
-            // departures from the end of the leaf pass): the content goes out as it came in
+            if (f.slots <= 128) { bigLeaf(f, std::integral_constant<int, 2>{}); }
+            else { bigLeaf(f, std::integral_constant<int, 4>{}); }
+            continue;
+        }
+        // nothing arrived and what stayed is still in order (a departure leaves the largest key behind, so only
+        // departures from the end of a leaf pass): the content goes out as it came in
+        const K below     = K(__shfl_up((unsigned long long)key, 1));
+        const bool behind = slot != 0 && key < below;
+        if (!__any(f.nInc != 0 || behind))
+        {
+            if (slot < f.nNew)
             {
-                const K below     = K(__shfl_up((unsigned long long)key1[0], 1));
-                const bool behind = lane != 0 && key1[0] < below;
-                if (f.nInc == 0 && !__any(behind))
-                {
-                    if (lane < f.nNew)
-                    {
-                        keysOut[f.ok + lane]  = key1[0];
-                        orderOut[f.ok + lane] = idx1[0];
-                    }
-                    continue;
-                }
+                keysOut[f.ok + slot]  = key;
+                orderOut[f.ok + slot] = idx;
             }
-            uint32_t d[1] = {digestOf(f, key1[0], lane)};
-            waveBitonicSort<1>(d, lane);
-            if (!finishLeaf(f, std::integral_constant<int, 1>{}, key1, idx1, d)) exactLeaf(f, 1, key1, idx1);
+            continue;
         }
-        else if (f.slots <= 128) { bigLeaf(f, std::integral_constant<int, 2>{}); }
-        else { bigLeaf(f, std::integral_constant<int, 4>{}); }
+        uint32_t d[1] = {digestOf(f, key, slot)};
+        if (b == 6) waveSort64<1, 64>(d, lane);
+        else if (b == 5) waveSort64<1, 32>(d, lane);
+        else waveSort64<1, 16>(d, lane);
+        WAVE_TRACE(trSort)
+        finishSegments(f, b, slot, key, idx, d[0]);
+        WAVE_TRACE(trFinish)
     }
+#ifdef CSTONE_RESORT_TRACE
+    if (g_resortTrace && threadIdx.x == 0)
+    {
+        uint64_t* tr = g_resortTrace + size_t(blockIdx.x) * RESORT_TRACE_SLOTS;
+        tr[2] = wall_clock64(), tr[3] = uint64_t(trSteps), tr[4] = uint64_t(trIssue), tr[5] = uint64_t(trWait),
+        tr[6] = uint64_t(trSort), tr[7] = uint64_t(trFinish);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr[8] = wall_clock64();
+    }
+#endif
+#undef WAVE_TRACE
 }
 
 /*! Positions of the leaf boundaries of ANOTHER tree (the focus tree after its rebalance) in the keys this re-sort has just
@@ -1098,27 +1248,36 @@ int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, 
     static const bool scanLeaves  = std::getenv("CSTONE_RESORT_SCAN") != nullptr;
     static const char* waveAllEnv = std::getenv("CSTONE_RESORT_WAVE_ALL");
     const bool waveAll = !scanLeaves && !alwaysCount && (waveAllEnv ? waveAllEnv[0] == '1' : numMovers >= grid);
+    // leaves that are less than half full on average: several of them per wave step (the kernel's PACK flavour; with
+    // fuller leaves there is rarely a pair to take and its bookkeeping costs 12-24 %; CSTONE_RESORT_PACK=0/1 forces either)
+    static const char* packEnv = std::getenv("CSTONE_RESORT_PACK");
+    const bool pack            = packEnv ? packEnv[0] == '1' : n_ < size_t(J) * 32u;
 #define CSTONE_LEAF_WAVE(G)                                                                                            \
-    hipLaunchKernelGGL((leafSortWaveKernel<K, G>), grid, 256, 0, ctx->stream, keysIn, leafLo_.as<K>(),                 \
-                       leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), layoutNew_.as<uint32_t>(), binKeys_.as<K>(), \
-                       binIdx_.as<uint32_t>(), J, alwaysCount, waveAll, keysOut, orderOut)
+    if (pack)                                                                                                          \
+        hipLaunchKernelGGL((leafSortWaveKernel<K, G, true>), grid, 256, 0, ctx->stream, keysIn, leafLo_.as<K>(),       \
+                           leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), layoutNew_.as<uint32_t>(),               \
+                           binKeys_.as<K>(), binIdx_.as<uint32_t>(), J, alwaysCount, waveAll, keysOut, orderOut);      \
+    else                                                                                                               \
+        hipLaunchKernelGGL((leafSortWaveKernel<K, G, false>), grid, 256, 0, ctx->stream, keysIn, leafLo_.as<K>(),      \
+                           leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), layoutNew_.as<uint32_t>(),               \
+                           binKeys_.as<K>(), binIdx_.as<uint32_t>(), J, alwaysCount, waveAll, keysOut, orderOut)
     if (leavesPerTile == 64)
     {
         if (!waveAll) CSTONE_LEAF_SORT(64, false);
         if (someMoved && scanLeaves) CSTONE_LEAF_SORT(64, true);
-        else if (someMoved || waveAll) CSTONE_LEAF_WAVE(64);
+        else if (someMoved || waveAll) { CSTONE_LEAF_WAVE(64); }
     }
     else if (leavesPerTile == 32)
     {
         if (!waveAll) CSTONE_LEAF_SORT(32, false);
         if (someMoved && scanLeaves) CSTONE_LEAF_SORT(32, true);
-        else if (someMoved || waveAll) CSTONE_LEAF_WAVE(32);
+        else if (someMoved || waveAll) { CSTONE_LEAF_WAVE(32); }
     }
     else if (leavesPerTile == 16)
     {
         if (!waveAll) CSTONE_LEAF_SORT(16, false);
         if (someMoved && scanLeaves) CSTONE_LEAF_SORT(16, true);
-        else if (someMoved || waveAll) CSTONE_LEAF_WAVE(16);
+        else if (someMoved || waveAll) { CSTONE_LEAF_WAVE(16); }
     }
     else return fail(ctx, CSTONE_E_INTERNAL, "resort: %d leaves per workgroup not instantiated", leavesPerTile);
 #undef CSTONE_LEAF_SORT
