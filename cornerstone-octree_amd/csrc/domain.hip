@@ -124,6 +124,8 @@ struct DomainBase
                      void** props, const int* propBytes, int numProps) = 0;
     virtual int view(cstone_hip_domain_view* out)        = 0;
     virtual void setHaloFactor(float factor)             = 0;
+    virtual void setSortMode(int mode)                   = 0;
+    virtual void setSpeculativeBox(bool on)              = 0;
     virtual int reapplySync(const void* in, size_t n, int elemBytes, void* out) = 0;
     virtual void stats(cstone_hip_domain_stats* out)     = 0;
 };
@@ -177,7 +179,7 @@ public:
         const bool anyOpen = box_.bc[0] != 1 || box_.bc[1] != 1 || box_.bc[2] != 1;
         // (adaptive: a sync whose speculation failed -- the outermost particles of an open box move -- makes the following
         //  syncs measure first, until one of them finds the box unchanged again)
-        bool speculate     = anyOpen && !firstCall_ && !measureFirst_ && std::getenv("CSTONE_NO_SPECULATIVE_BOX") == nullptr;
+        bool speculate     = anyOpen && !firstCall_ && !measureFirst_ && maySpeculate();
         bool boxMoved      = false; // measured first and found a new box: every key changes, nothing to re-sort from
         if (anyOpen && !speculate)
         {
@@ -213,7 +215,7 @@ public:
         // and are ordered by a fix-up pass instead (sort.hip, fixupRunsKernel).  If a run turns out longer (the
         // particles have clustered since), the flag read back below triggers a regular sort of the rest.
         int startPass = 0;
-        if (!firstCall_ && !levelRangeHost_.empty() && std::getenv("CSTONE_FULL_SORT") == nullptr)
+        if (!firstCall_ && !levelRangeHost_.empty() && !allDigits())
         {
             int lmax = 0;
             for (int l = 0; l <= int(maxLevel<K>()); ++l)
@@ -258,8 +260,7 @@ public:
         const int tileLeaves = LeafResort<K>::leavesPerTile(bucketFocus_);
         bool sorted          = false;
         const bool tryResort = !firstCall_ && tileLeaves > 0 && layoutLeaves_ == fLeaves_ && fLeaves_ > 0 &&
-                               resortBackoff_ == 0 && !boxMoved && std::getenv("CSTONE_NO_RESORT") == nullptr &&
-                               std::getenv("CSTONE_FULL_SORT") == nullptr;
+                               resortBackoff_ == 0 && !boxMoved && mayResort();
         if (resortBackoff_ > 0) --resortBackoff_;
         if (tryResort)
         {
@@ -482,11 +483,24 @@ public:
         firstCall_  = false;
         // the sticky device-side error word (look-back spin bail-out of the sort, traversal stack overflow ...): a sync
         // that tripped one of those checks must not report success (tests: CSTONE_FORCE_DEVICE_ERROR raises it)
+#ifdef CSTONE_TEST_HOOKS
         if (std::getenv("CSTONE_FORCE_DEVICE_ERROR")) CS_HIP(ctx_, hipMemsetAsync(ctx_->devScalars + 63, 1, 1, ctx_->stream));
+#endif
         return cstone_hip_ctx_sync(ctx_);
     }
 
     void setHaloFactor(float factor) override { haloSearchExt_ = factor; }
+    void setSortMode(int mode) override { sortMode_ = mode; }
+    void setSpeculativeBox(bool on) override { speculativeBox_ = on; }
+    // what the client chose (cstone_hip_domain_set_sort_mode / _set_speculative_box); the environment variables of the
+    // experiments override it
+    bool mayResort() const
+    {
+        return sortMode_ == CSTONE_SORT_INCREMENTAL && std::getenv("CSTONE_NO_RESORT") == nullptr &&
+               std::getenv("CSTONE_FULL_SORT") == nullptr;
+    }
+    bool allDigits() const { return sortMode_ == CSTONE_SORT_ALL_DIGITS || std::getenv("CSTONE_FULL_SORT") != nullptr; }
+    bool maySpeculate() const { return speculativeBox_ && std::getenv("CSTONE_NO_SPECULATIVE_BOX") == nullptr; }
 
     int view(cstone_hip_domain_view* v) override
     {
@@ -542,6 +556,8 @@ private:
     size_t lastN_ = 0; // input size of the last sync
     int boxRedos_ = 0; // syncs whose speculative keys had to be recomputed because the box changed
     bool measureFirst_ = false; // the last box was not the one before it: measure the extents before encoding
+    int sortMode_        = CSTONE_SORT_INCREMENTAL;
+    bool speculativeBox_ = true;
     int ensureTree(DevBuf& tree, DevBuf& counts, int& cap, int need)
     {
         if (need <= cap) return CSTONE_OK;
@@ -798,6 +814,29 @@ int cstone_hip_domain_set_halo_factor(cstone_hip_domain* dom, float factor)
     if (!dom || !(factor > 0.0f)) return CSTONE_E_ARG;
     dom->impl->setHaloFactor(factor);
     return CSTONE_OK;
+}
+
+int cstone_hip_domain_set_sort_mode(cstone_hip_domain* dom, int mode)
+{
+    if (!dom || mode < CSTONE_SORT_INCREMENTAL || mode > CSTONE_SORT_ALL_DIGITS) return CSTONE_E_ARG;
+    dom->impl->setSortMode(mode);
+    return CSTONE_OK;
+}
+
+int cstone_hip_domain_set_speculative_box(cstone_hip_domain* dom, int on)
+{
+    if (!dom) return CSTONE_E_ARG;
+    dom->impl->setSpeculativeBox(on != 0);
+    return CSTONE_OK;
+}
+
+int cstone_hip_test_hooks(void)
+{
+#ifdef CSTONE_TEST_HOOKS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 } // extern "C"

@@ -312,6 +312,7 @@ struct MrBase
     virtual int octree(cstone_hip_domain_mr_octree* out)                                 = 0;
     virtual int setHaloMode(int mode)                                                    = 0;
     virtual int setTheta(float theta)                                                    = 0;
+    virtual void setSortMode(int mode)                                                   = 0;
 };
 
 template<class K, class T>
@@ -334,6 +335,13 @@ public:
     }
 
     void setHaloFactor(float f) override { haloExt_ = f; }
+    void setSortMode(int mode) override { sortMode_ = mode; }
+    bool mayResort() const
+    {
+        return sortMode_ == CSTONE_SORT_INCREMENTAL && std::getenv("CSTONE_NO_RESORT") == nullptr &&
+               std::getenv("CSTONE_FULL_SORT") == nullptr;
+    }
+    bool allDigits() const { return sortMode_ == CSTONE_SORT_ALL_DIGITS || std::getenv("CSTONE_FULL_SORT") != nullptr; }
 
     //! before the first sync: how halos are found (CSTONE_MR_HALOS_LET: the reference's way, CSTONE_MR_HALOS_OWNER_SIDE)
     int setHaloMode(int mode) override
@@ -581,8 +589,7 @@ public:
             return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(1) << 25;
         }();
         const bool tryResort = !firstCall_ && n >= resortMin && n == layoutParticles_ && tileLeaves > 0 && sameBox && resortLeaves_ > 0 &&
-                               resortBackoff_ == 0 && !pending_ && std::getenv("CSTONE_NO_RESORT") == nullptr &&
-                               std::getenv("CSTONE_FULL_SORT") == nullptr;
+                               resortBackoff_ == 0 && !pending_ && mayResort();
         if (resortBackoff_ > 0) --resortBackoff_;
         if (tryResort)
         {
@@ -613,7 +620,7 @@ public:
             // radix passes only over the digits above the leaf level (+1) of the previous tree, runs of equal high digits
             // are finished by a fix-up pass; a run that is too long raises a flag and the regular sort completes the job
             int startPass = 0;
-            if (!firstCall_ && prevMaxLeafLevel_ >= 0 && std::getenv("CSTONE_FULL_SORT") == nullptr)
+            if (!firstCall_ && prevMaxLeafLevel_ >= 0 && !allDigits())
                 startPass = std::max(0, (3 * int(maxLevel<K>()) -
                                          3 * (prevMaxLeafLevel_ + 1 + (bucketFocus_ > 128) + (bucketFocus_ > 1024))) / 8) & ~1;
             int* tooLong = reinterpret_cast<int*>(scal_.as<char>() + 128);
@@ -1180,10 +1187,14 @@ private:
     //! tests: CSTONE_MR_FAIL_AT="<rank>:<point>" makes that rank fail at the named point of sync()
     void injectFailure(const char* point)
     {
+#ifdef CSTONE_TEST_HOOKS // (the product library carries no fault injection: lib/libcstone_hip_hooks.so is the tests' build)
         const char* e = std::getenv("CSTONE_MR_FAIL_AT");
         if (!e) return;
         const std::string want = std::to_string(rank_) + ":" + point;
         if (want == e) setPending(CSTONE_E_INTERNAL, "domain_mr_sync: failure injected at '%s'", point);
+#else
+        (void)point;
+#endif
     }
 
     //! every rank has seen that rank `culprit` failed: all of them return an error from the same point of the sync
@@ -1605,6 +1616,7 @@ private:
     cstone_hip_comm_ops comm_;
     float haloExt_  = 1.0f;
     float theta_    = 0.5f;
+    int sortMode_   = CSTONE_SORT_INCREMENTAL;
     bool useLet_    = std::getenv("CSTONE_MR_OWNER_SIDE") == nullptr; // halos through the locally essential tree (default)
     std::unique_ptr<FocusLet<K, T>> let_;
     const K* resortTree_ = nullptr; // the leaves of my own key range (and their number) the next sync's re-sort starts from
@@ -1782,6 +1794,13 @@ int cstone_hip_domain_mr_set_theta(cstone_hip_domain_mr* dom, float theta)
 {
     if (!dom) return CSTONE_E_ARG;
     return dom->impl->setTheta(theta);
+}
+
+int cstone_hip_domain_mr_set_sort_mode(cstone_hip_domain_mr* dom, int mode)
+{
+    if (!dom || mode < CSTONE_SORT_INCREMENTAL || mode > CSTONE_SORT_ALL_DIGITS) return CSTONE_E_ARG;
+    dom->impl->setSortMode(mode);
+    return CSTONE_OK;
 }
 
 int cstone_hip_domain_mr_set_halo_factor(cstone_hip_domain_mr* dom, float factor)

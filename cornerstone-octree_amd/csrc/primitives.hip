@@ -30,10 +30,10 @@ struct alignas(8) Elem<24>
 };
 
 // result[q] = index of the first key >= values[q] (unsigned comparison), one lane per query
-template<class K>
+template<class K, class I = uint64_t>
 __global__ __launch_bounds__(256) void lowerBoundKernel(const K* __restrict__ keys, size_t n,
                                                         const K* __restrict__ values, int numValues,
-                                                        uint64_t* __restrict__ result)
+                                                        I* __restrict__ result)
 {
     int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= numValues) return;
@@ -49,7 +49,90 @@ __global__ __launch_bounds__(256) void lowerBoundKernel(const K* __restrict__ ke
         }
         else { len = half; }
     }
-    result[q] = lo;
+    result[q] = I(lo);
+}
+
+//! out[i] = init + i (64-bit flavour of sequenceGpu)
+__global__ __launch_bounds__(256) void sequence64Kernel(uint64_t* __restrict__ out, size_t n, uint64_t init)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) out[i] = init + i;
+}
+
+// ---- prefix sums of 32-bit values in 64 bits (exclusiveScanGpu<unsigned, uint64_t> of the reference's list): the same
+//      three launches as csrc/scan.hip with 64-bit partial sums
+constexpr int SCAN64_ITEMS = 8;
+__device__ __forceinline__ uint64_t blockExclusiveScan256u64(uint64_t v, uint64_t* waveSums /*LDS[4]*/, uint64_t* total)
+{
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+    {
+        const uint64_t t = uint64_t(__shfl_up((unsigned long long)inc, o));
+        if (lane >= unsigned(o)) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) waveSums[w] = inc;
+    __syncthreads();
+    uint64_t off = 0, tot = 0;
+#pragma unroll
+    for (unsigned i = 0; i < 4; ++i)
+    {
+        const uint64_t s = waveSums[i];
+        if (i < w) off += s;
+        tot += s;
+    }
+    if (total) *total = tot;
+    return off + inc - v;
+}
+__global__ __launch_bounds__(256) void blockSum64Kernel(const uint32_t* __restrict__ in, size_t n, uint64_t* __restrict__ sums)
+{
+    __shared__ uint64_t ws[4];
+    const size_t base = (size_t(blockIdx.x) * 256 + threadIdx.x) * SCAN64_ITEMS;
+    uint64_t s        = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN64_ITEMS; ++k)
+        if (base + k < n) s += in[base + k];
+    uint64_t total;
+    blockExclusiveScan256u64(s, ws, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void scanSums64Kernel(uint64_t* __restrict__ sums, unsigned m, uint64_t init)
+{
+    __shared__ uint64_t ws[4];
+    uint64_t carry = init;
+    for (unsigned base = 0; base < m; base += 256)
+    {
+        const unsigned i = base + threadIdx.x;
+        const uint64_t v = i < m ? sums[i] : 0;
+        uint64_t total;
+        const uint64_t ex = blockExclusiveScan256u64(v, ws, &total);
+        if (i < m) sums[i] = carry + ex;
+        carry += total;
+    }
+}
+__global__ __launch_bounds__(256) void blockScan64Kernel(const uint32_t* __restrict__ in, size_t n,
+                                                         const uint64_t* __restrict__ sums, uint64_t* __restrict__ out,
+                                                         bool inclusive)
+{
+    __shared__ uint64_t ws[4];
+    const size_t base = (size_t(blockIdx.x) * 256 + threadIdx.x) * SCAN64_ITEMS;
+    uint32_t v[SCAN64_ITEMS];
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN64_ITEMS; ++k)
+    {
+        v[k] = base + k < n ? in[base + k] : 0u;
+        s += v[k];
+    }
+    uint64_t run = sums[blockIdx.x] + blockExclusiveScan256u64(s, ws, nullptr);
+#pragma unroll
+    for (int k = 0; k < SCAN64_ITEMS; ++k)
+    {
+        if (base + k < n) out[base + k] = inclusive ? run + v[k] : run;
+        run += v[k];
+    }
 }
 
 // dst[i] = src[map[i]]: map and dst are streamed, src is a random read (4 + 2E bytes per element)
@@ -581,6 +664,51 @@ int cstone_hip_lower_bound(cstone_hip_ctx* ctx, int key_bits, const void* keys, 
     else
         hipLaunchKernelGGL(lowerBoundKernel<uint64_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint64_t*)keys, n,
                            (const uint64_t*)values, num_values, result);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int cstone_hip_lower_bound_u32(cstone_hip_ctx* ctx, int key_bits, const void* keys, size_t n, const void* values,
+                               int num_values, uint32_t* result)
+{
+    if (!ctx || (key_bits != 32 && key_bits != 64) || num_values < 0 || n >= (size_t(1) << 32) ||
+        (num_values && (!values || !result)) || (n && !keys))
+        return fail(ctx, CSTONE_E_ARG, "lower_bound_u32: bad argument");
+    if (num_values == 0) return CSTONE_OK;
+    unsigned grid = (unsigned(num_values) + 255) / 256;
+    if (key_bits == 32)
+        hipLaunchKernelGGL((lowerBoundKernel<uint32_t, uint32_t>), dim3(grid), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)keys, n, (const uint32_t*)values, num_values, result);
+    else
+        hipLaunchKernelGGL((lowerBoundKernel<uint64_t, uint32_t>), dim3(grid), dim3(256), 0, ctx->stream,
+                           (const uint64_t*)keys, n, (const uint64_t*)values, num_values, result);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int cstone_hip_sequence_u64(cstone_hip_ctx* ctx, uint64_t* out, size_t n, uint64_t init)
+{
+    if (!ctx || (n && !out)) return fail(ctx, CSTONE_E_ARG, "sequence_u64: bad argument");
+    if (n == 0) return CSTONE_OK;
+    hipLaunchKernelGGL(sequence64Kernel, gridFor(n, 256), 256, 0, ctx->stream, out, n, init);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int cstone_hip_scan_u32_to_u64(cstone_hip_ctx* ctx, const uint32_t* in, uint64_t* out, size_t n, uint64_t init,
+                               int inclusive)
+{
+    if (!ctx || (n && (!in || !out))) return fail(ctx, CSTONE_E_ARG, "scan_u32_to_u64: bad argument");
+    if (n == 0) return CSTONE_OK;
+    if (static_cast<const void*>(in) == static_cast<const void*>(out))
+        return fail(ctx, CSTONE_E_ARG, "scan_u32_to_u64: in place is not possible (the elements grow)");
+    const unsigned blocks = unsigned((n + 256 * SCAN64_ITEMS - 1) / (256 * SCAN64_ITEMS));
+    CS_TRY(arenaReserve(ctx, alignUp(size_t(blocks) * 8) + 256));
+    auto* sums = (uint64_t*)arenaTake(ctx, size_t(blocks) * 8);
+    hipLaunchKernelGGL(blockSum64Kernel, blocks, 256, 0, ctx->stream, in, n, sums);
+    hipLaunchKernelGGL(scanSums64Kernel, 1, 256, 0, ctx->stream, sums, blocks, init);
+    hipLaunchKernelGGL(blockScan64Kernel, blocks, 256, 0, ctx->stream, in, n, sums, out, inclusive != 0);
+    arenaReset(ctx);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

@@ -53,6 +53,9 @@ EXPORTS = [
     "cstone_hip_upload", "cstone_hip_focus_update_ops", "cstone_hip_find_neighbors_stats",
     "cstone_hip_gather_multi", "cstone_hip_domain_sync_scratch", "cstone_hip_gather_ranges_rows",
     "cstone_hip_scatter_rows", "cstone_hip_build_octree_bounded", "cstone_hip_upsweep_sum_bounded",
+    "cstone_hip_lower_bound_u32", "cstone_hip_sequence_u64", "cstone_hip_scan_u32_to_u64",
+    "cstone_hip_domain_set_sort_mode", "cstone_hip_domain_set_speculative_box", "cstone_hip_test_hooks",
+    "cstone_hip_domain_mr_set_sort_mode",
 ]
 
 

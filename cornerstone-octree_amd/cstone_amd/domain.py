@@ -99,6 +99,17 @@ class Domain:
         self.ctx._chk(self.ctx.lib.cstone_hip_domain_view_get(self.h, C.byref(v)), "domain_view_get")
         return v
 
+    SORT_INCREMENTAL, SORT_FROM_SCRATCH, SORT_ALL_DIGITS = 0, 1, 2
+
+    def set_sort_mode(self, mode):
+        """how a sync orders the particles (identical results): incremental re-sort (default), radix sort of the digits
+        above the previous leaf level, radix sort of all digits (cstone_hip_domain_set_sort_mode)"""
+        self.ctx._chk(self.ctx.lib.cstone_hip_domain_set_sort_mode(self.h, C.c_int(mode)), "domain_set_sort_mode")
+
+    def set_speculative_box(self, on):
+        self.ctx._chk(self.ctx.lib.cstone_hip_domain_set_speculative_box(self.h, C.c_int(1 if on else 0)),
+                      "domain_set_speculative_box")
+
     def stats(self):
         """counters of the syncs so far (cstone_hip_domain_stats) as a dict"""
         st = DomainStats()

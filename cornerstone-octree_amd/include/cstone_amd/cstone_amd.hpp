@@ -786,6 +786,11 @@ public:
     {
         Context::check(cstone_hip_domain_mr_set_halo_factor(dom_, factor), "MultiRankDomain::setHaloFactor");
     }
+    //! CSTONE_SORT_INCREMENTAL (default) / _FROM_SCRATCH / _ALL_DIGITS: how a sync orders the particles (same results)
+    void setSortMode(int mode)
+    {
+        Context::check(cstone_hip_domain_mr_set_sort_mode(dom_, mode), "MultiRankDomain::setSortMode");
+    }
     //! Domain::exchangeHalos for one more field (device array of nParticlesWithHalos elements of 1..32 bytes)
     template<class V>
     void exchangeHalos(V* field) const
@@ -1018,6 +1023,17 @@ public:
     {
         if (mr_) { mr_->setHaloFactor(factor); }
         else { Context::check(cstone_hip_domain_set_halo_factor(dom_, factor), "Domain::setHaloFactor"); }
+    }
+    //! CSTONE_SORT_INCREMENTAL (default) / _FROM_SCRATCH / _ALL_DIGITS: how a sync orders the particles (same results)
+    void setSortMode(int mode)
+    {
+        if (mr_) { mr_->setSortMode(mode); }
+        else { Context::check(cstone_hip_domain_set_sort_mode(dom_, mode), "Domain::setSortMode"); }
+    }
+    //! false: the extents of an open box are measured before the keys are computed, every sync (single-rank domain)
+    void setSpeculativeBox(bool on)
+    {
+        if (!mr_) Context::check(cstone_hip_domain_set_speculative_box(dom_, on ? 1 : 0), "Domain::setSpeculativeBox");
     }
     //! kept for source compatibility: the flag has no reader in the reference either (domain.hpp:411,661)
     void setTreeConv(bool) {}

@@ -446,15 +446,8 @@ void lowerBoundGpu(const T* first, const T* last, const T* valueFirst, const T* 
     }
     else
     {
-        // the library answers in 64 bits; narrow on the way out
-        uint64_t* wide = nullptr;
-        check(cstone_hip_malloc(hipCtx(), (void**)&wide, size_t(numValues) * sizeof(uint64_t)));
-        check(cstone_hip_lower_bound(hipCtx(), bitsOf<T>, first, size_t(last - first), valueFirst, numValues, wide));
-        std::vector<uint64_t> host(numValues);
-        check(cstone_hip_memcpy_d2h(hipCtx(), host.data(), wide, host.size() * sizeof(uint64_t)));
-        std::vector<IndexType> narrow(host.begin(), host.end());
-        check(cstone_hip_memcpy_h2d(hipCtx(), result, narrow.data(), narrow.size() * sizeof(IndexType)));
-        check(cstone_hip_free(hipCtx(), wide));
+        check(cstone_hip_lower_bound_u32(hipCtx(), bitsOf<T>, first, size_t(last - first), valueFirst, numValues,
+                                         reinterpret_cast<uint32_t*>(result)));
     }
 }
 template void lowerBoundGpu(const unsigned*, const unsigned*, const unsigned*, const unsigned*, unsigned*);
@@ -492,10 +485,7 @@ void sequenceGpu(IndexType* input, size_t numElements, IndexType init)
     }
     else
     {
-        std::vector<IndexType> host(numElements);
-        for (size_t i = 0; i < numElements; ++i)
-            host[i] = init + IndexType(i);
-        if (numElements) check(cstone_hip_memcpy_h2d(hipCtx(), input, host.data(), numElements * sizeof(IndexType)));
+        check(cstone_hip_sequence_u64(hipCtx(), reinterpret_cast<uint64_t*>(input), numElements, uint64_t(init)));
     }
 }
 template void sequenceGpu(int*, size_t, int);
@@ -544,7 +534,7 @@ SORT_BY_KEY_GPU(uint64_t, int);
 
 namespace
 {
-//! scans over 32-bit integers go straight to the library; the 64-bit sums of the reference's list run on the host
+//! scans over 32-bit integers with 32- or 64-bit sums, all on the device
 template<class IndexType, class SumType>
 void scanGpu(const IndexType* first, const IndexType* last, SumType* output, SumType init, bool inclusive)
 {
@@ -559,17 +549,9 @@ void scanGpu(const IndexType* first, const IndexType* last, SumType* output, Sum
     }
     else
     {
-        std::vector<IndexType> host(n);
-        check(cstone_hip_memcpy_d2h(hipCtx(), host.data(), first, n * sizeof(IndexType)));
-        std::vector<SumType> sums(n);
-        SumType run = init;
-        for (size_t i = 0; i < n; ++i)
-        {
-            if (inclusive) run += SumType(host[i]);
-            sums[i] = run;
-            if (!inclusive) run += SumType(host[i]);
-        }
-        check(cstone_hip_memcpy_h2d(hipCtx(), output, sums.data(), n * sizeof(SumType)));
+        static_assert(sizeof(IndexType) == 4 && sizeof(SumType) == 8, "scan: 32-bit values, 32- or 64-bit sums");
+        check(cstone_hip_scan_u32_to_u64(hipCtx(), reinterpret_cast<const uint32_t*>(first),
+                                         reinterpret_cast<uint64_t*>(output), n, uint64_t(init), inclusive ? 1 : 0));
     }
 }
 } // namespace

@@ -219,6 +219,14 @@ extern "C"
     int cstone_hip_lower_bound_value(cstone_hip_ctx* ctx, int kind, const void* data, size_t n, const void* value_host,
                                      uint64_t* index_host);
     int cstone_hip_sort_keys(cstone_hip_ctx* ctx, int key_bits, void* keys, size_t n);
+    /* the remaining instantiations of the reference's list (R/primitives/primitives_gpu.cu:214-238,395-437,88-103) on
+     * the device: lowerBoundGpu with 32-bit results, sequenceGpu<uint64_t>, exclusive/inclusiveScanGpu with 64-bit sums
+     * of 32-bit values (not in place) */
+    int cstone_hip_lower_bound_u32(cstone_hip_ctx* ctx, int key_bits, const void* keys, size_t n, const void* values,
+                                   int num_values, uint32_t* result);
+    int cstone_hip_sequence_u64(cstone_hip_ctx* ctx, uint64_t* out, size_t n, uint64_t init);
+    int cstone_hip_scan_u32_to_u64(cstone_hip_ctx* ctx, const uint32_t* in, uint64_t* out, size_t n, uint64_t init,
+                                   int inclusive);
 
     /* ---------------------------------------------------------------------------------------------
      * cornerstone leaf array (R/tree/csarray_gpu.h:56-88, R/tree/update_gpu.cuh:59-82)
@@ -590,6 +598,19 @@ extern "C"
     /* Domain::setHaloFactor (R/domain/domain.hpp:412): extra search factor of the halo discovery (default 1.0), lets a
      * client take several integration steps between syncs */
     int cstone_hip_domain_set_halo_factor(cstone_hip_domain* dom, float factor);
+    /* How a sync orders the particles (results are identical in all modes): INCREMENTAL (default) repairs the order of
+     * the previous sync leaf by leaf where it can, FROM_SCRATCH radix-sorts the digits above the previous
+     * tree's leaf level and finishes the runs, ALL_DIGITS radix-sorts all key digits like the reference's GPU path.
+     * set_speculative_box(0): the extents of an open box are always measured before the keys are computed.
+     * The environment variables CSTONE_NO_RESORT / CSTONE_FULL_SORT / CSTONE_NO_SPECULATIVE_BOX override these. */
+#define CSTONE_SORT_INCREMENTAL 0
+#define CSTONE_SORT_FROM_SCRATCH 1
+#define CSTONE_SORT_ALL_DIGITS 2
+    int cstone_hip_domain_set_sort_mode(cstone_hip_domain* dom, int mode);
+    int cstone_hip_domain_set_speculative_box(cstone_hip_domain* dom, int on);
+    /* 1 when the library was built with -DCSTONE_TEST_HOOKS (lib/libcstone_hip_hooks.so: fault injection through
+     * CSTONE_MR_FAIL_AT / CSTONE_FORCE_DEVICE_ERROR for the tests), 0 for the product build */
+    int cstone_hip_test_hooks(void);
     /* Domain::reapplySync (R/domain/domain.hpp:334-378) on one rank: out[i] = in[sfc_order[i]] for the end_index
      * particles the last sync kept; in has the n elements (elem_bytes in {1,2,4,8,12,16,24,32}) of that call's arrays,
      * out must not alias in */
@@ -721,6 +742,7 @@ extern "C"
     int cstone_hip_domain_mr_set_halo_mode(cstone_hip_domain_mr* dom, int mode);
     /* the opening angle theta of the Domain constructor (R/domain/domain.hpp:95-113), default 0.5; before the first sync */
     int cstone_hip_domain_mr_set_theta(cstone_hip_domain_mr* dom, float theta);
+    int cstone_hip_domain_mr_set_sort_mode(cstone_hip_domain_mr* dom, int mode);
 
     /* Domain::octreeProperties() and Domain::layout() (R/domain/domain.hpp:388-437) for the result arrays of the last
      * sync: a cornerstone tree with bucket_size_focus over ALL local particles, halos included, as an OctreeNsView

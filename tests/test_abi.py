@@ -31,6 +31,18 @@ def test_library_exports_every_declared_symbol():
     assert set(declared_symbols()) == set(cstone_amd.EXPORTS), set(declared_symbols()) ^ set(cstone_amd.EXPORTS)
 
 
+def test_fault_injection_is_compiled_into_the_tests_build_only(monkeypatch):
+    """the product library is built without -DCSTONE_TEST_HOOKS; lib/libcstone_hip_hooks.so (same sources, the two objects
+    with hooks recompiled) is what the failure tests load"""
+    import cstone_amd
+
+    assert cstone_amd.load_library().cstone_hip_test_hooks() == 0
+    monkeypatch.setenv("CSTONE_HIP_LIB", cstone_amd.LIBPATH.replace("libcstone_hip.so", "libcstone_hip_hooks.so"))
+    hooked = cstone_amd.load_library()
+    assert hooked.cstone_hip_test_hooks() == 1
+    assert not [s for s in declared_symbols() if not hasattr(hooked, s)]
+
+
 def test_box_pod_layout_matches_header():
     import cstone_amd
 

@@ -49,6 +49,8 @@ def _launch(nproc, backend, particles, syncs, pbc, port, timeout=900, golden="",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"),
            "--backend", backend, "--particles", str(particles), "--syncs", str(syncs), "--pbc", str(pbc)]
     cmd += ["--impl", impl] + list(extra)
+    if "--fail-at" in extra:  # fault injection lives in the tests' build of the library only (-DCSTONE_TEST_HOOKS)
+        env["CSTONE_HIP_LIB"] = os.path.join(ROOT, "cornerstone-octree_amd", "lib", "libcstone_hip_hooks.so")
     if golden:
         cmd += ["--golden", os.path.join(ROOT, "tests", "golden", golden)]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)

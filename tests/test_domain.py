@@ -98,9 +98,18 @@ def test_sync_reports_the_device_side_error_word(hip, monkeypatch):
     x, y, z = [torch.from_numpy(rng.uniform(0, 1, n)).cuda() for _ in range(3)]
     h = torch.full((n,), 0.01, dtype=torch.float64, device="cuda")
     keys = torch.zeros(n, dtype=torch.int64, device="cuda")
+    # the product library carries no fault injection: the hook lives in the tests' build of the same sources
+    monkeypatch.setenv("CSTONE_HIP_LIB", cstone_amd.LIBPATH.replace("libcstone_hip.so", "libcstone_hip_hooks.so"))
+    hooked = cstone_amd.Context(0)
+    monkeypatch.delenv("CSTONE_HIP_LIB")
+    assert hooked.lib.cstone_hip_test_hooks() == 1 and hip.lib.cstone_hip_test_hooks() == 0
+    dom_h = Domain(hooked, cstone_amd.HILBERT, 64, 64, 64, 16, 0.5, cb)
     monkeypatch.setenv("CSTONE_FORCE_DEVICE_ERROR", "1")
     with pytest.raises(cstone_amd.CstoneError, match="device-side check failed"):
-        dom.sync(keys, x.clone(), y.clone(), z.clone(), h.clone(), torch.empty_like(x))
+        dom_h.sync(keys, x.clone(), y.clone(), z.clone(), h.clone(), torch.empty_like(x))
+    # (the product build ignores the variable)
+    dom.sync(keys.clone(), x.clone(), y.clone(), z.clone(), h.clone(), torch.empty_like(x))
+    hip.sync()
     monkeypatch.delenv("CSTONE_FORCE_DEVICE_ERROR")
     dom2 = Domain(hip, cstone_amd.HILBERT, 64, 64, 64, 16, 0.5, cb)
     out = dom2.sync(keys, x.clone(), y.clone(), z.clone(), h.clone(), torch.empty_like(x))

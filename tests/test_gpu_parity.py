@@ -695,3 +695,43 @@ def test_find_neighbors_stats(hip):
     total = int(nc.long().sum().item())
     assert total + n <= st[0] <= st[3] and st[1] <= st[0] and 0 < st[2] <= 160
     assert st[1] >= int(nc.max().item()) + 1
+
+
+@pytest.mark.gpu
+def test_wide_and_narrow_flavours_of_the_primitives(hip):
+    """the instantiations of the reference's list that the shim used to stage through the host
+    (R/primitives/primitives_gpu.cu: lowerBoundGpu with 32-bit results :214-238, sequenceGpu<uint64_t> :88-103,
+    exclusive / inclusiveScanGpu of 32-bit values with 64-bit sums :395-437) against numpy"""
+    import ctypes as C
+
+    import torch
+
+    rng = np.random.default_rng(11)
+    for kb, kdt, tdt in ((32, np.uint32, torch.int32), (64, np.uint64, torch.int64)):
+        keys = np.sort(rng.integers(0, 1 << (kb - 2), 50_001).astype(kdt))
+        vals = rng.integers(0, 1 << (kb - 2), 3_333).astype(kdt)
+        vals[:3] = (0, keys[-1], keys[-1] + 1)
+        dk = torch.from_numpy(keys.view(np.int32 if kb == 32 else np.int64)).cuda()
+        dv = torch.from_numpy(vals.view(np.int32 if kb == 32 else np.int64)).cuda()
+        out = torch.zeros(vals.size, dtype=torch.int32, device="cuda")
+        hip._chk(hip.lib.cstone_hip_lower_bound_u32(hip.h, C.c_int(kb), C.c_void_p(dk.data_ptr()), C.c_size_t(keys.size),
+                                                    C.c_void_p(dv.data_ptr()), C.c_int(vals.size),
+                                                    C.c_void_p(out.data_ptr())), "lower_bound_u32")
+        hip.sync()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), np.searchsorted(keys, vals, side="left").astype(np.uint32))
+    for n in (1, 255, 2048, 2049, 1_000_003):
+        seq = torch.zeros(n, dtype=torch.int64, device="cuda")
+        init = (1 << 40) + 5
+        hip._chk(hip.lib.cstone_hip_sequence_u64(hip.h, C.c_void_p(seq.data_ptr()), C.c_size_t(n), C.c_uint64(init)), "seq")
+        vals = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)  # sums beyond 32 bits from a few elements on
+        din = torch.from_numpy(vals.view(np.int32)).cuda()
+        for inclusive in (0, 1):
+            dout = torch.zeros(n, dtype=torch.int64, device="cuda")
+            hip._chk(hip.lib.cstone_hip_scan_u32_to_u64(hip.h, C.c_void_p(din.data_ptr()), C.c_void_p(dout.data_ptr()),
+                                                        C.c_size_t(n), C.c_uint64(7), C.c_int(inclusive)), "scan64")
+            hip.sync()
+            c = np.cumsum(vals.astype(np.uint64)) + np.uint64(7)
+            want = c if inclusive else np.concatenate(([np.uint64(7)], c[:-1]))
+            assert np.array_equal(dout.cpu().numpy().view(np.uint64), want), (n, inclusive)
+        hip.sync()
+        assert np.array_equal(seq.cpu().numpy().view(np.uint64), np.arange(n, dtype=np.uint64) + np.uint64(init))

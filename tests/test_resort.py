@@ -332,3 +332,25 @@ def test_open_box_whose_outermost_particles_move(hip, oracle, monkeypatch):
     assert sb["box_redos"] == 0 and 1 <= sa["box_redos"] <= 2, (sa, sb)
     # the quiet steps behind an unchanged box are re-sorted again in both domains
     assert sa["resorts"] >= 2 and sb["resorts"] >= 2, (sa, sb)
+
+
+@pytest.mark.gpu
+def test_sort_mode_setters_give_the_same_result(hip, oracle):
+    """cstone_hip_domain_set_sort_mode / _set_speculative_box: the client-side switches behind the environment variables
+    of the experiments.  Three domains walk the same loop -- incremental (default), from scratch, all digits without box
+    speculation -- and agree bit for bit; only the first one re-sorts"""
+    doms = [_Stepper(hip, 64, 64, 64, 1, (0, 0, 0), 90_000, 5, True) for _ in range(3)]
+    doms[1].dom.set_sort_mode(doms[1].dom.SORT_FROM_SCRATCH)
+    doms[2].dom.set_sort_mode(doms[2].dom.SORT_ALL_DIGITS)
+    doms[2].dom.set_speculative_box(False)
+    for step, kind in enumerate(["none", "jitter", "few", "none", "jitter"]):
+        outs = []
+        for d in doms:
+            if step:
+                d.move(kind, np.random.default_rng(300 + step))
+            outs.append(d.sync())
+        for o in outs[1:]:
+            for f in ("keys", "x", "y", "z", "h", "ident"):
+                assert np.array_equal(outs[0][f], o[f]), (step, kind, f)
+    st = [d.dom.stats() for d in doms]
+    assert st[0]["resorts"] >= 3 and st[1]["resorts"] == 0 and st[2]["resorts"] == 0, st
