@@ -424,7 +424,8 @@ class _CpuImpl:
 
 class Oracle(_CpuImpl):
     prefix = "cstone_oracle_"
-    libpath = os.path.join(HERE, "libcstone_oracle.so")
+    # (CSTONE_ORACLE_LIB: the sanitizer build of `make -C oracle asan`)
+    libpath = os.environ.get("CSTONE_ORACLE_LIB", os.path.join(HERE, "libcstone_oracle.so"))
 
     def random_uniform(self, n, box, seed=42, real_bits=64):
         """the reference's RandomCoordinates cloud (std::mt19937(seed); all x, then all y, then all z)"""
