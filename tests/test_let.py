@@ -94,3 +94,16 @@ def test_let_under_address_and_ub_sanitizers():
     paths = run(3, "k64f32", 6000, 4, 64, 16, 1, 0, 2, 2, 107, exe=EXE_ASAN, timeout=1200)
     assert paths["focusTransfers"] > 0 and paths["keysRejected"] > 0
     run(2, "k32f32", 5000, 3, 64, 8, 0, 0, 0, 1, 3, exe=EXE_ASAN, timeout=1200)
+
+
+def test_oracle_suite_under_sanitizers():
+    """`make -C oracle asan`: the oracle's CPU tests (known answers, golden fixtures, focus-tree functions, groups, oracle
+    vs reference) once more with the oracle built under AddressSanitizer + UndefinedBehaviorSanitizer"""
+    import shutil
+
+    if not shutil.which("g++") or not os.path.exists(subprocess.run(
+            ["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()):
+        pytest.skip("no sanitizer runtime on this machine")
+    p = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0 and " passed" in p.stdout and "ERROR: AddressSanitizer" not in p.stdout + p.stderr, \
+        (p.stdout + p.stderr)[-3000:]
