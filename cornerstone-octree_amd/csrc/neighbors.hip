@@ -59,7 +59,7 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
     DBox<T> box, const NodeIdx* __restrict__ childOffsets, const NodeIdx* __restrict__ internalToLeaf,
     const uint32_t* __restrict__ layout, const T* __restrict__ centers, const T* __restrict__ sizes, float ext,
     uint32_t ngmax, uint32_t* __restrict__ neighbors, uint32_t* __restrict__ counts, int* __restrict__ errors,
-    unsigned long long* __restrict__ stats)
+    unsigned long long* __restrict__ stats, bool interleaved)
 {
     __shared__ NodeIdx stackNode[NB_WAVES][NB_STACK];
     __shared__ uint64_t stackMask[NB_WAVES][NB_STACK];
@@ -93,7 +93,11 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
                   (yi + s <= box.hi[1]) && (zi + s <= box.hi[2]);
     const bool usePbc = (px || py || pz) && !inside;
 
-    uint32_t* out = neighbors + size_t(tid) * ngmax;
+    // neighbour k of target t: neighbors[t * ngmax + k] (the CPU findNeighbors, R/findneighbors.hpp:96-188), or in blocks
+    // of 64 targets neighbors[((t / 64) * ngmax + k) * 64 + t % 64] (the warp-interleaved lists of traverseNeighbors,
+    // R/traversal/find_neighbors.cuh:116, with targetSize = 64: a wave's stores of one k are one contiguous line)
+    const uint32_t outStride = interleaved ? 64u : 1u;
+    uint32_t* out = interleaved ? neighbors + size_t(tid >> 6) * ngmax * 64u + (tid & 63u) : neighbors + size_t(tid) * ngmax;
     uint32_t nn   = 0;
     // STATS (NcStats, R/traversal/find_neighbors.cuh:345-369,494-502): distance tests of THIS target, tests the wave
     // issued (64 lanes per leaf particle), deepest stack use
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(NB_BLOCK) void findNeighborsKernel(
                 const bool hit = mine && j != i && dx * dx + dy * dy + dz * dz < radSq;
                 if (hit)
                 {
-                    if (nn < ngmax) out[nn] = j;
+                    if (nn < ngmax) out[size_t(nn) * outStride] = j;
                     ++nn;
                 }
             };
@@ -257,7 +261,7 @@ int launchFindNeighbors(cstone_hip_ctx* ctx, int real_bits, const void* x, const
                         uint32_t numGroups, const cstone_box* box_host, const int32_t* child_offsets,
                         const int32_t* internal_to_leaf, const uint32_t* layout, const void* centers, const void* sizes,
                         float ext, uint32_t ngmax, uint32_t* neighbors, uint32_t* counts,
-                        unsigned long long* statsDev = nullptr)
+                        unsigned long long* statsDev = nullptr, bool interleaved = false)
 {
     if (!ctx || !x || !y || !z || !h || !box_host || !child_offsets || !internal_to_leaf || !layout || !centers ||
         !sizes || !counts || (ngmax && !neighbors) || last < first || (GROUPS && numGroups && (!groupStart || !groupEnd)))
@@ -273,13 +277,13 @@ int launchFindNeighbors(cstone_hip_ctx* ctx, int real_bits, const void* x, const
                                (const float*)y, (const float*)z, (const float*)h, first, last, groupStart, groupEnd,
                                numGroups, makeDBox<float>(*box_host), child_offsets, internal_to_leaf, layout,
                                (const float*)centers, (const float*)sizes, ext, ngmax, neighbors, counts, errors,
-                               statsDev);
+                               statsDev, interleaved);
         else
             hipLaunchKernelGGL((findNeighborsKernel<double, GROUPS, STATS>), grid, NB_BLOCK, 0, ctx->stream,
                                (const double*)x, (const double*)y, (const double*)z, (const double*)h, first, last,
                                groupStart, groupEnd, numGroups, makeDBox<double>(*box_host), child_offsets,
                                internal_to_leaf, layout, (const double*)centers, (const double*)sizes, ext, ngmax,
-                               neighbors, counts, errors, statsDev);
+                               neighbors, counts, errors, statsDev, interleaved);
     }
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
@@ -297,6 +301,18 @@ extern "C" int cstone_hip_find_neighbors(cstone_hip_ctx* ctx, int real_bits, con
     return launchFindNeighbors<false>(ctx, real_bits, x, y, z, h, first, last, nullptr, nullptr, 0, box_host,
                                       child_offsets, internal_to_leaf, layout, centers, sizes, ext, ngmax, neighbors,
                                       counts);
+}
+
+extern "C" int cstone_hip_find_neighbors_interleaved(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y,
+                                                     const void* z, const void* h, uint32_t first, uint32_t last,
+                                                     const cstone_box* box_host, const int32_t* child_offsets,
+                                                     const int32_t* internal_to_leaf, const uint32_t* layout,
+                                                     const void* centers, const void* sizes, float ext, uint32_t ngmax,
+                                                     uint32_t* neighbors, uint32_t* counts)
+{
+    return launchFindNeighbors<false>(ctx, real_bits, x, y, z, h, first, last, nullptr, nullptr, 0, box_host,
+                                      child_offsets, internal_to_leaf, layout, centers, sizes, ext, ngmax, neighbors,
+                                      counts, nullptr, true);
 }
 
 extern "C" int cstone_hip_find_neighbors_groups(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y,

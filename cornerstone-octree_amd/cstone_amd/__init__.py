@@ -55,7 +55,7 @@ EXPORTS = [
     "cstone_hip_scatter_rows", "cstone_hip_build_octree_bounded", "cstone_hip_upsweep_sum_bounded",
     "cstone_hip_lower_bound_u32", "cstone_hip_sequence_u64", "cstone_hip_scan_u32_to_u64",
     "cstone_hip_domain_set_sort_mode", "cstone_hip_domain_set_speculative_box", "cstone_hip_test_hooks",
-    "cstone_hip_domain_mr_set_sort_mode",
+    "cstone_hip_domain_mr_set_sort_mode", "cstone_hip_find_neighbors_interleaved",
 ]
 
 

@@ -31,6 +31,7 @@
 #include "cstone/primitives/primitives_gpu.h"
 #include "cstone/sfc/sfc_gpu.h"
 #include "cstone/traversal/collisions_gpu.h"
+#include "cstone/traversal/groups_gpu.h"
 #include "cstone/tree/csarray_gpu.h"
 #include "cstone/tree/octree_gpu.h"
 
@@ -916,5 +917,45 @@ void moveCenters(const Vec3<T>* src, TreeNodeIndex numNodes, Vec4<T>* dest)
 }
 template void moveCenters(const Vec3<double>*, TreeNodeIndex, Vec4<double>*);
 template void moveCenters(const Vec3<float>*, TreeNodeIndex, Vec4<float>*);
+
+// ---- target particle groups, traversal/groups_gpu.h:46-86 (definitions in traversal/groups_gpu.cu:57-151) --------------
+void computeFixedGroups(LocalIndex first, LocalIndex last, unsigned groupSize, GroupData<GpuTag>& groups)
+{
+    const LocalIndex numBodies = last - first;
+    const LocalIndex numGroups = (numBodies + groupSize - 1) / groupSize;
+    groups.data.resize(numGroups + 1);
+    uint32_t made = 0;
+    check(cstone_hip_compute_fixed_groups(hipCtx(), first, last, groupSize, rawPtr(groups.data), &made));
+    groups.firstBody  = first;
+    groups.lastBody   = last;
+    groups.numGroups  = numGroups;
+    groups.groupStart = rawPtr(groups.data);
+    groups.groupEnd   = rawPtr(groups.data) + 1;
+}
+
+template<class Tc, class T, class KeyType>
+void computeGroupSplits(LocalIndex first, LocalIndex last, const Tc* x, const Tc* y, const Tc* z, const T* /*h*/,
+                        const KeyType* leaves, TreeNodeIndex numLeaves, const LocalIndex* layout, const Box<Tc> box,
+                        unsigned groupSize, float tolFactor, DeviceVector<LocalIndex>& /*numSplitsPerGroup*/,
+                        DeviceVector<LocalIndex>& groups)
+{
+    if (groupSize != 64 && groupSize != 128) throw std::runtime_error("Unsupported spatial group size\n");
+    // (the reference sizes its output after a first pass over split counts; one particle per group is the upper bound)
+    groups.resize(size_t(last - first) + 1);
+    cstone_box b   = podBox(box);
+    uint32_t found = 0;
+    check(cstone_hip_compute_group_splits(hipCtx(), bitsOf<KeyType>, bitsOf<Tc>, first, last, x, y, z, leaves, numLeaves,
+                                          layout, &b, groupSize, tolFactor, rawPtr(groups), groups.size(), &found));
+    groups.resize(size_t(found) + 1);
+}
+template void computeGroupSplits(LocalIndex, LocalIndex, const double*, const double*, const double*, const double*,
+                                 const uint64_t*, TreeNodeIndex, const LocalIndex*, const Box<double>, unsigned, float,
+                                 DeviceVector<LocalIndex>&, DeviceVector<LocalIndex>&);
+template void computeGroupSplits(LocalIndex, LocalIndex, const double*, const double*, const double*, const float*,
+                                 const uint64_t*, TreeNodeIndex, const LocalIndex*, const Box<double>, unsigned, float,
+                                 DeviceVector<LocalIndex>&, DeviceVector<LocalIndex>&);
+template void computeGroupSplits(LocalIndex, LocalIndex, const float*, const float*, const float*, const float*,
+                                 const uint64_t*, TreeNodeIndex, const LocalIndex*, const Box<float>, unsigned, float,
+                                 DeviceVector<LocalIndex>&, DeviceVector<LocalIndex>&);
 
 } // namespace cstone

@@ -530,6 +530,15 @@ extern "C"
                                         int num_leaves, const uint32_t* layout, const cstone_box* box_host,
                                         uint32_t group_size, float tol_factor, uint32_t* groups, size_t capacity,
                                         uint32_t* num_groups);
+    /* the same search with the lists laid out like the warp-interleaved lists of traverseNeighbors
+     * (R/traversal/find_neighbors.cuh:116, targetSize = 64): neighbour k of target t (counted from first) is
+     * neighbors[((t / 64) * ngmax + k) * 64 + t % 64]; neighbors holds ceil((last - first) / 64) * 64 * ngmax entries */
+    int cstone_hip_find_neighbors_interleaved(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y,
+                                              const void* z, const void* h, uint32_t first, uint32_t last,
+                                              const cstone_box* box_host, const int32_t* child_offsets,
+                                              const int32_t* internal_to_leaf, const uint32_t* layout,
+                                              const void* centers, const void* sizes, float ext, uint32_t ngmax,
+                                              uint32_t* neighbors, uint32_t* counts);
     int cstone_hip_find_neighbors_groups(cstone_hip_ctx* ctx, int real_bits, const void* x, const void* y,
                                          const void* z, const void* h, uint32_t first, uint32_t last,
                                          const uint32_t* group_start, const uint32_t* group_end, uint32_t num_groups,

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "cstone/domain/domain.hpp"
+#include "cstone/traversal/groups_gpu.h"
 #include "cstone/util/reallocate.hpp"
 
 using namespace cstone;
@@ -217,6 +218,44 @@ static void run(int rank, int numRanks, LocalIndex numParticles, int numSyncs, c
             if (keys.size() == gkeys.size() && gx.size() == x.size())
                 expectEqual("exchangeHalos field", permuted(f, canonicalOrder(keys, x, y, z)),
                             permuted(download(d_f), canonicalOrder(gkeys, gx, gy, gz)), sync);
+        }
+
+        // target groups through the reference's own entry points (traversal/groups_gpu.h:46-86) on the GPU domain's arrays:
+        // fixed groups are the arithmetic sequence; the spatially split groups refine them -- every fixed boundary is a
+        // boundary, no group is longer than 64, a tolerance nobody meets gives one particle per group
+        if constexpr (std::is_same_v<KeyType, uint64_t>)
+        {
+            const LocalIndex first = gpu.startIndex(), last = gpu.endIndex();
+            GroupData<GpuTag> fixed;
+            computeFixedGroups(first, last, 64, fixed);
+            auto fg = download(fixed.data);
+            bool ok = fg.size() == size_t(fixed.numGroups) + 1 && fixed.groupEnd == fixed.groupStart + 1 &&
+                      fixed.firstBody == first && fixed.lastBody == last && fg.back() == last;
+            for (size_t i = 0; ok && i + 1 < fg.size(); ++i)
+                ok = fg[i] == first + LocalIndex(64 * i);
+            auto leaves = gpu.focusTree().treeLeavesAcc();
+            auto lay    = gpu.layout();
+            DeviceVector<LocalIndex> scratch, groups, singles;
+            computeGroupSplits(first, last, rawPtr(d_x), rawPtr(d_y), rawPtr(d_z), rawPtr(d_h), leaves.data(),
+                               TreeNodeIndex(leaves.size()) - 1, lay.data(), gpu.box(), 64, 1.0f, scratch, groups);
+            auto sg = download(groups);
+            ok      = ok && sg.size() >= fg.size() && sg.front() == first && sg.back() == last;
+            size_t at = 0;
+            for (size_t i = 0; ok && i + 1 < sg.size(); ++i)
+            {
+                ok = sg[i] < sg[i + 1] && sg[i + 1] - sg[i] <= 64;
+                if (at < fg.size() && sg[i] == fg[at]) ++at;
+            }
+            ok = ok && at + 1 == fg.size(); // every fixed boundary (but the last, checked above) was met in order
+            computeGroupSplits(first, last, rawPtr(d_x), rawPtr(d_y), rawPtr(d_z), rawPtr(d_h), leaves.data(),
+                               TreeNodeIndex(leaves.size()) - 1, lay.data(), gpu.box(), 64, 1e-9f, scratch, singles);
+            ok = ok && singles.size() == size_t(last - first) + 1;
+            if (!ok)
+            {
+                ++g_failures;
+                std::printf("[rank %d] sync %d: target groups through the shim are not what they should be "
+                            "(%zu fixed, %zu split, %zu single)\n", rank, sync, fg.size(), sg.size(), singles.size());
+            }
         }
 
         {

@@ -735,3 +735,49 @@ def test_wide_and_narrow_flavours_of_the_primitives(hip):
             assert np.array_equal(dout.cpu().numpy().view(np.uint64), want), (n, inclusive)
         hip.sync()
         assert np.array_equal(seq.cpu().numpy().view(np.uint64), np.arange(n, dtype=np.uint64) + np.uint64(init))
+
+
+@pytest.mark.gpu
+def test_find_neighbors_interleaved_lists(hip):
+    """cstone_hip_find_neighbors_interleaved: the same neighbours in the layout of the reference's warp-interleaved lists
+    (traverseNeighbors, R/traversal/find_neighbors.cuh:116 with targetSize = 64): entry ((t / 64) * ngmax + k) * 64 + t % 64
+    equals entry t * ngmax + k of the row-major lists, for a range that neither starts nor ends on a multiple of 64"""
+    import ctypes as C
+
+    import torch
+
+    import cstone_amd
+
+    n, ngmax = 30000, 48
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x, y, z = [torch.rand(n, dtype=torch.float64, device="cuda", generator=g) for _ in range(3)]
+    h = torch.full((n,), 0.02, dtype=torch.float64, device="cuda")
+    cb = cstone_amd.make_cbox([0, 1] * 3, [1, 0, 1])
+    keys = hip.compute_sfc_keys(cstone_amd.HILBERT, 64, x, y, z, cb)
+    order = torch.arange(n, dtype=torch.int32, device="cuda")
+    hip.sort_pairs(keys, order)
+    x, y, z = [a[order.long()].contiguous() for a in (x, y, z)]
+    tree, counts, _ = hip.compute_octree(keys, 64)
+    o = hip.build_octree(tree)
+    layout = torch.cat([torch.zeros(1, dtype=torch.int32, device="cuda"), counts.cumsum(0).to(torch.int32)])
+    cen, siz = hip.node_centers(cstone_amd.HILBERT, o["prefixes"], cb, 64)
+    first, last = 37, n - 11
+    nt = last - first
+    rows, nc = hip.find_neighbors(x, y, z, h, first, last, cb, o, layout, cen, siz, ngmax)
+    blocks = (nt + 63) // 64
+    inter = torch.full((blocks * 64 * ngmax,), -1, dtype=torch.int32, device="cuda")
+    nc2 = torch.zeros(nt, dtype=torch.int32, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    rc = hip.lib.cstone_hip_find_neighbors_interleaved(hip.h, C.c_int(64), P(x), P(y), P(z), P(h), C.c_uint32(first),
+                                                       C.c_uint32(last), C.byref(cb), P(o["child_offsets"]),
+                                                       P(o["internal_to_leaf"]), P(layout), P(cen), P(siz), C.c_float(1.0),
+                                                       C.c_uint32(ngmax), P(inter), P(nc2))
+    hip._chk(rc, "find_neighbors_interleaved")
+    hip.sync()
+    assert torch.equal(nc, nc2)
+    rows = rows.reshape(nt, ngmax).cpu().numpy()
+    got = inter.reshape(blocks, ngmax, 64).permute(0, 2, 1).reshape(blocks * 64, ngmax)[:nt].cpu().numpy()
+    cnt = np.minimum(nc.cpu().numpy(), ngmax)
+    valid = np.arange(ngmax)[None, :] < cnt[:, None]
+    assert valid.sum() > 5 * nt and np.array_equal(rows[valid], got[valid])
+    assert (got[~valid] == -1).all()  # nothing is written beyond a target's count
