@@ -56,7 +56,7 @@ StageTimer::StageTimer(cstone_hip_ctx* c, int stage)
     // microseconds of stream time; a sync has about forty brackets, eight of them around such kernels)
     const bool heavy = stage == CSTONE_STAGE_ENCODE || stage == CSTONE_STAGE_SORT_PASS ||
                        stage == CSTONE_STAGE_SORT_PASS_IOTA || stage == CSTONE_STAGE_GATHER ||
-                       stage == CSTONE_STAGE_RESORT_LEAVES || stage == CSTONE_STAGE_HALOS || stage == CSTONE_STAGE_GATHER_H ||
+                       stage == CSTONE_STAGE_RESORT_LEAVES || stage == CSTONE_STAGE_HALOS || stage == CSTONE_STAGE_GATHER_H || stage == CSTONE_STAGE_PLACE ||
                        stage == CSTONE_STAGE_NEIGHBORS;
     if (ctx->profiling == 2 && !heavy) return;
     cstone_hip_ctx::Bracket b{stage, takeEvent(ctx), takeEvent(ctx)};

@@ -807,9 +807,12 @@ public:
         {
             T* dst[4] = {o.x.as<T>() + M, o.y.as<T>() + M, o.z.as<T>() + M, o.h.as<T>() + M};
             if (na)
+            {
+                StageTimer timer(ctx_, CSTONE_STAGE_PLACE);
                 hipLaunchKernelGGL((placeColumnsKernel<K, T>), gridFor(na, 256), 256, 0, ctx_->stream, keptO,
                                    nb ? posA_.as<uint32_t>() : nullptr, size_t(na), keptKeys, x, y, z, h, keysM, dst[0],
                                    dst[1], dst[2], dst[3]);
+            }
             for (int c = 0; c < 4 && nb; ++c)
                 CS_TRY(cstone_hip_scatter(ctx_, sizeof(T), posB_.as<uint32_t>(), nb, recvSorted[c], dst[c]));
         }

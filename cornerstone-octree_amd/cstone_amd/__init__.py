@@ -19,7 +19,7 @@ MORTON, HILBERT = 0, 1
 
 STAGES = {
     "encode": 0, "sort_hist": 1, "sort_pass": 2, "gather": 3, "node_counts": 4, "rebalance": 5, "link_octree": 6,
-    "halos": 7, "neighbors": 8, "minmax": 9, "sort_pass_iota": 10, "resort_bins": 11, "resort_leaves": 12, "gather_h": 13,
+    "halos": 7, "neighbors": 8, "minmax": 9, "sort_pass_iota": 10, "resort_bins": 11, "resort_leaves": 12, "gather_h": 13, "place": 14,
 }
 
 EXPORTS = [

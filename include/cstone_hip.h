@@ -92,6 +92,8 @@ extern "C"
 #define CSTONE_STAGE_RESORT_BINS 11   /* incremental re-sort of Domain::sync: leaf table, mover bins (csrc/resort.hpp) */
 #define CSTONE_STAGE_RESORT_LEAVES 12 /* ... its pass over the leaves: K read, K + 4 written per particle */
 #define CSTONE_STAGE_GATHER_H 13      /* gather of h fused with the halo radii of Domain::sync: 4 + 2 T bytes per particle */
+#define CSTONE_STAGE_PLACE 14         /* multi-rank sync: keys, x, y, z, h of the kept particles to their final slots in one
+                                        pass (placeColumnsKernel): 4 + 2 K + 8 T bytes per particle (+ 4 with a merge) */
 #define CSTONE_NUM_STAGES 16
     /* on: 0 off, 1 every stage, 2 only ENCODE, SORT_PASS(_IOTA), RESORT_LEAVES, GATHER(_H), HALOS, NEIGHBORS (the kernels that
      * move the particle arrays: eight brackets per sync instead of forty) */
