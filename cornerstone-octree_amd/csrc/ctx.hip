@@ -135,7 +135,9 @@ int cstone_hip_ctx_create(cstone_hip_ctx** out, int device, void* stream, int pr
     e = hipMemset(ctx->devScalars, 0, 64 * sizeof(int));
     if (e != hipSuccess) return giveUp("hipMemset of the device scalars", e);
     {
-        HilbertTables t = makeHilbertTables();
+        int numStates     = 0;
+        HilbertTables t   = makeHilbertTables(&numStates);
+        if (numStates != HILBERT_STATES) return giveUp("Hilbert transducer: unexpected number of states", hipErrorUnknown);
         e = hipMalloc(&ctx->hilbertTables, sizeof t);
         if (e != hipSuccess) return giveUp("hipMalloc of the Hilbert tables", e);
         e = hipMemcpy(ctx->hilbertTables, &t, sizeof t, hipMemcpyHostToDevice);

@@ -157,10 +157,15 @@ __device__ __forceinline__ void mortonDecode(K key, unsigned& ix, unsigned& iy, 
 // per level instead of ~25 data-dependent bit operations.
 // Entry layout: bits 0..2 digit, bits 3..8 next state.
 // ---------------------------------------------------------------------------------------------------
+constexpr int HILBERT_STATES = 24; // reachable states of the transducer (checked when the tables are built)
+
 struct HilbertTables
 {
     uint16_t enc[48 * 8]; // [state][morton octant]   -> digit | next<<3
     uint16_t dec[48 * 8]; // [state][hilbert digit]   -> morton octant | next<<3
+    // two levels per lookup, straight from the grid coordinates (24 states are reachable):
+    // [state][xx | yy << 2 | zz << 4], xx = the coordinate's bits of the two levels -> two digits | next << 6
+    uint16_t enc2[HILBERT_STATES * 64];
 };
 
 template<class K>
@@ -177,6 +182,47 @@ __host__ __device__ __forceinline__ K hilbertFromMorton(K morton, const uint16_t
         state        = e >> 3;
     }
     return key;
+}
+
+/*! Hilbert keys of VEC grid cells, two levels per table lookup (enc2, in LDS) and straight from the cell coordinates: no
+ *  bit interleave, no 64-bit shifts -- the one-level form above costs about ten vector instructions per level and key on
+ *  64-bit keys, which made the encode kernels VALU-bound (85 % VALU issue at 60 % of the HBM peak); this one five per two
+ *  levels.  The VEC chains are independent and interleave.  Same keys as iHilbert (R/sfc/hilbert.hpp:58-107). */
+template<class K, int VEC>
+__device__ __forceinline__ void hilbertFromGrid(const unsigned (&ix)[VEC], const unsigned (&iy)[VEC],
+                                                const unsigned (&iz)[VEC], const uint16_t* enc2, K (&keys)[VEC])
+{
+    constexpr int L = int(maxLevel<K>());
+    uint32_t acc[VEC][2];
+    unsigned st[VEC]; // next state, already multiplied by 64
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+        acc[v][0] = acc[v][1] = 0, st[v] = 0;
+#pragma unroll
+    for (int p = 0; p < L / 2; ++p)
+    {
+        const int s = L - 2 - 2 * p; // the lower of the two levels
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+        {
+            const unsigned idx = ((ix[v] >> s) & 3u) | (((iy[v] >> s) & 3u) << 2) | (((iz[v] >> s) & 3u) << 4);
+            const unsigned e   = enc2[st[v] | idx];
+            acc[v][p / 5]      = (acc[v][p / 5] << 6) | (e & 63u);
+            st[v]              = e & 0x7C0u;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+    {
+        if constexpr (L & 1)
+        {
+            // the last level on its own: as the upper level of a pair whose lower level is not looked at
+            const unsigned idx = ((ix[v] & 1u) << 1) | ((iy[v] & 1u) << 3) | ((iz[v] & 1u) << 5);
+            const unsigned e   = enc2[st[v] | idx];
+            keys[v]            = (K(acc[v][0]) << 33) | (K(acc[v][1]) << 3) | K((e >> 3) & 7u);
+        }
+        else { keys[v] = K(acc[v][0]); }
+    }
 }
 
 template<class K>

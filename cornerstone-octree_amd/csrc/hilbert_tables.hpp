@@ -76,6 +76,19 @@ inline HilbertTables makeHilbertTables(int* numStatesOut = nullptr)
             t.dec[si * 8 + digit] = uint16_t(oct | (next << 3));
         }
     }
+    // two levels per lookup: index = xx | yy << 2 | zz << 4 (the two bits of a coordinate: upper level, lower level)
+    for (size_t si = 0; si < states.size() && si < size_t(HILBERT_STATES); ++si)
+    {
+        for (unsigned idx = 0; idx < 64; ++idx)
+        {
+            const unsigned xx = idx & 3u, yy = (idx >> 2) & 3u, zz = (idx >> 4) & 3u;
+            const unsigned octHi = ((xx >> 1) << 2) | ((yy >> 1) << 1) | (zz >> 1);
+            const unsigned octLo = ((xx & 1u) << 2) | ((yy & 1u) << 1) | (zz & 1u);
+            const unsigned e1 = t.enc[si * 8 + octHi];
+            const unsigned e2 = t.enc[(e1 >> 3) * 8 + octLo];
+            t.enc2[si * 64 + idx] = uint16_t(((e1 & 7u) << 3) | (e2 & 7u) | ((e2 >> 3) << 6));
+        }
+    }
     if (numStatesOut) *numStatesOut = int(states.size());
     return t;
 }

@@ -19,15 +19,48 @@
 namespace cship
 {
 
+//! the integer cell of a position (R/sfc/sfc.hpp:188-194), without the interleave
 template<class K, class T>
-__device__ __forceinline__ K gridMorton(T x, T y, T z, T mx, T my, T mz, T sx, T sy, T sz)
+__device__ __forceinline__ void gridCell(T x, T y, T z, T mx, T my, T mz, T sx, T sy, T sz, unsigned& ix, unsigned& iy,
+                                         unsigned& iz)
 {
     constexpr int top = (1u << maxLevel<K>()) - 1;
-    int ix = int(floor(x * mx) - sx);
-    int iy = int(floor(y * my) - sy);
-    int iz = int(floor(z * mz) - sz);
-    ix = min(ix, top), iy = min(iy, top), iz = min(iz, top);
-    return mortonEncode<K>(unsigned(ix), unsigned(iy), unsigned(iz));
+    ix = unsigned(min(int(floor(x * mx) - sx), top));
+    iy = unsigned(min(int(floor(y * my) - sy), top));
+    iz = unsigned(min(int(floor(z * mz) - sz), top));
+}
+
+//! keys of VEC positions; enc2: the two-level Hilbert table in LDS (HilbertTables::enc2, unused for Morton keys)
+template<class K, class T, int VEC, bool HILBERT>
+__device__ __forceinline__ void keysOfPositions(const T (&vx)[VEC], const T (&vy)[VEC], const T (&vz)[VEC], T mx, T my,
+                                                T mz, T sx, T sy, T sz, const uint16_t* enc2, K (&out)[VEC])
+{
+    unsigned ix[VEC], iy[VEC], iz[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+        gridCell<K, T>(vx[v], vy[v], vz[v], mx, my, mz, sx, sy, sz, ix[v], iy[v], iz[v]);
+    if constexpr (HILBERT) { hilbertFromGrid<K, VEC>(ix, iy, iz, enc2, out); }
+    else
+    {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            out[v] = mortonEncode<K>(ix[v], iy[v], iz[v]);
+    }
+}
+template<class K, class T, bool HILBERT>
+__device__ __forceinline__ K keyOfPosition(T x, T y, T z, T mx, T my, T mz, T sx, T sy, T sz, const uint16_t* enc2)
+{
+    const T ax[1] = {x}, ay[1] = {y}, az[1] = {z};
+    K out[1];
+    keysOfPositions<K, T, 1, HILBERT>(ax, ay, az, mx, my, mz, sx, sy, sz, enc2, out);
+    return out[0];
+}
+//! the table into LDS (all 256 threads of the workgroup; the caller synchronises)
+__device__ __forceinline__ void loadHilbertPairs(uint16_t* enc2, const uint16_t* __restrict__ tables)
+{
+    const uint16_t* src = tables + 2 * 48 * 8; // HilbertTables::enc2 follows enc and dec
+    for (unsigned i = threadIdx.x; i < HILBERT_STATES * 64; i += 256)
+        enc2[i] = src[i];
 }
 
 template<class K, class T, int VEC, bool HILBERT>
@@ -35,10 +68,10 @@ __global__ __launch_bounds__(256) void encodeKernel(const T* __restrict__ x, con
                                                     const T* __restrict__ z, K* __restrict__ keys, size_t n,
                                                     DBox<T> box, const uint16_t* __restrict__ encTable)
 {
-    __shared__ uint16_t enc[24 * 8];
+    __shared__ uint16_t enc2[HILBERT ? HILBERT_STATES * 64 : 1];
     if (HILBERT)
     {
-        if (threadIdx.x < 24 * 8) enc[threadIdx.x] = encTable[threadIdx.x];
+        loadHilbertPairs(enc2, encTable);
         __syncthreads();
     }
     constexpr unsigned g = 1u << maxLevel<K>();
@@ -57,32 +90,7 @@ __global__ __launch_bounds__(256) void encodeKernel(const T* __restrict__ x, con
         __builtin_memcpy(vz, __builtin_assume_aligned(z + base, sizeof(T) * VEC), sizeof vz);
         __builtin_memcpy(vk, __builtin_assume_aligned(keys + base, sizeof(K) * VEC), sizeof vk);
         K out[VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v)
-            out[v] = gridMorton<K, T>(vx[v], vy[v], vz[v], mx, my, mz, sx, sy, sz);
-        if (HILBERT)
-        {
-            // VEC interleaved transducer chains
-            K h[VEC];
-            unsigned st[VEC];
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-                h[v] = 0, st[v] = 0;
-#pragma unroll
-            for (int level = int(maxLevel<K>()) - 1; level >= 0; --level)
-            {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                {
-                    unsigned e = enc[st[v] * 8 + (unsigned(out[v] >> (3 * level)) & 7u)];
-                    h[v]       = (h[v] << 3) | K(e & 7u);
-                    st[v]      = e >> 3;
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-                out[v] = h[v];
-        }
+        keysOfPositions<K, T, VEC, HILBERT>(vx, vy, vz, mx, my, mz, sx, sy, sz, enc2, out);
 #pragma unroll
         for (int v = 0; v < VEC; ++v)
             if (vk[v] == endKey<K>()) out[v] = vk[v]; // particles flagged for removal keep their marker
@@ -93,8 +101,7 @@ __global__ __launch_bounds__(256) void encodeKernel(const T* __restrict__ x, con
         for (size_t i = base; i < min(base + size_t(VEC), n); ++i)
         {
             K old = keys[i];
-            K m   = gridMorton<K, T>(x[i], y[i], z[i], mx, my, mz, sx, sy, sz);
-            if (HILBERT) m = hilbertFromMorton<K>(m, enc);
+            K m   = keyOfPosition<K, T, HILBERT>(x[i], y[i], z[i], mx, my, mz, sx, sy, sz, enc2);
             if (old != endKey<K>()) keys[i] = m;
         }
     }
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict
                                                              bool honourMarkers, T* __restrict__ extentPartials)
 {
     constexpr int P = int(sizeof(K));
-    __shared__ uint16_t enc[24 * 8];
+    __shared__ uint16_t enc2[HILBERT ? HILBERT_STATES * 64 : 1];
     __shared__ uint32_t lh[P * 256];
     // extentPartials != nullptr: the coordinates' extents are measured on the way (Domain::sync encodes with the box of
     // the previous sync and checks afterwards that the box has not changed: no separate pass over x, y, z)
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict
         ext[2] = yv < ext[2] ? yv : ext[2], ext[3] = yv > ext[3] ? yv : ext[3];
         ext[4] = zv < ext[4] ? zv : ext[4], ext[5] = zv > ext[5] ? zv : ext[5];
     };
-    if (threadIdx.x < 24 * 8) enc[threadIdx.x] = encTable[threadIdx.x];
+    if (HILBERT) loadHilbertPairs(enc2, encTable);
     for (int i = threadIdx.x; i < P * 256; i += 256)
         lh[i] = 0;
     __syncthreads();
@@ -186,8 +193,7 @@ __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict
     };
     auto encodeOne = [&](T xv, T yv, T zv, K old) -> K
     {
-        K m = gridMorton<K, T>(xv, yv, zv, mx, my, mz, sx, sy, sz);
-        if (HILBERT) m = hilbertFromMorton<K>(m, enc);
+        K m = keyOfPosition<K, T, HILBERT>(xv, yv, zv, mx, my, mz, sx, sy, sz, enc2);
         return old == endKey<K>() ? old : m;
     };
 
@@ -218,36 +224,12 @@ __global__ __launch_bounds__(256) void encodeHistogramKernel(const T* __restrict
                 for (int v = 0; v < VEC; ++v)
                     vk[v] = 0;
             }
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-                out[v] = gridMorton<K, T>(vx[v], vy[v], vz[v], mx, my, mz, sx, sy, sz);
+            keysOfPositions<K, T, VEC, HILBERT>(vx, vy, vz, mx, my, mz, sx, sy, sz, enc2, out);
             if (extentPartials)
             {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v)
                     widen(vx[v], vy[v], vz[v]);
-            }
-            if (HILBERT)
-            {
-                K h[VEC];
-                unsigned st[VEC];
-#pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                    h[v] = 0, st[v] = 0;
-#pragma unroll
-                for (int level = int(maxLevel<K>()) - 1; level >= 0; --level)
-                {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v)
-                    {
-                        unsigned e = enc[st[v] * 8 + (unsigned(out[v] >> (3 * level)) & 7u)];
-                        h[v]       = (h[v] << 3) | K(e & 7u);
-                        st[v]      = e >> 3;
-                    }
-                }
-#pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                    out[v] = h[v];
             }
 #pragma unroll
             for (int v = 0; v < VEC; ++v)
@@ -330,7 +312,7 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
     // (a wave flushes at half of this, one iteration adds at most 64 * VEC; larger stages -- fewer atomics on the list's
     //  counter -- cost more in residency than they save: 4x the stage +0.04 ms, 8x +0.24 ms at 1e8 particles)
     constexpr unsigned STAGE = 64 * VEC * 2;
-    __shared__ uint16_t enc[24 * 8];
+    __shared__ uint16_t enc2[HILBERT ? HILBERT_STATES * 64 : 1];
     __shared__ K stageKey[4][STAGE];
     __shared__ uint32_t stageIdx[4][STAGE];
     T ext[6] = {std::numeric_limits<T>::infinity(),  -std::numeric_limits<T>::infinity(),
@@ -342,7 +324,7 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
         ext[2] = yv < ext[2] ? yv : ext[2], ext[3] = yv > ext[3] ? yv : ext[3];
         ext[4] = zv < ext[4] ? zv : ext[4], ext[5] = zv > ext[5] ? zv : ext[5];
     };
-    if (threadIdx.x < 24 * 8) enc[threadIdx.x] = encTable[threadIdx.x];
+    if (HILBERT) loadHilbertPairs(enc2, encTable);
     __syncthreads();
     constexpr unsigned g = 1u << maxLevel<K>();
     const T mx = g * box.inv[0], my = g * box.inv[1], mz = g * box.inv[2]; // R/sfc/sfc.hpp:188-194
@@ -397,67 +379,63 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
     const size_t stride = size_t(gridDim.x) * 256;
     const size_t iters  = (nVec + stride - 1) / stride;
     size_t vi           = size_t(blockIdx.x) * 256 + threadIdx.x;
+    // what an iteration reads: requested one iteration ahead, so that a wave computes the keys of one vector while
+    // the loads of the next are in flight.  (Worth 1-2 % only: four fifths of this kernel's traffic are reads, and
+    // read-dominated streams top out near 4.7 TB/s on this machine -- the pure read of minMaxPartialKernel runs at 4.6 --
+    // whatever the arithmetic costs; halving the VALU and LDS work with the two-level Hilbert table did not move it.)
+    struct In
+    {
+        T x[VEC], y[VEC], z[VEC];
+        K k[VEC];
+        uint64_t word;
+        uint32_t rank;
+    };
+    auto fetch = [&](size_t at, In& in)
+    {
+        const size_t base = at * VEC;
+        __builtin_memcpy(in.x, __builtin_assume_aligned(x + base, sizeof(T) * VEC), sizeof in.x);
+        __builtin_memcpy(in.y, __builtin_assume_aligned(y + base, sizeof(T) * VEC), sizeof in.y);
+        __builtin_memcpy(in.z, __builtin_assume_aligned(z + base, sizeof(T) * VEC), sizeof in.z);
+        // keysIn == nullptr: the caller has no key array, i.e. no remove markers
+        if (keysIn) { __builtin_memcpy(in.k, __builtin_assume_aligned(keysIn + base, sizeof(K) * VEC), sizeof in.k); }
+        else
+        {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                in.k[v] = 0;
+        }
+        // the VEC positions of a lane lie in one 64-position word of the leaf table (base is a multiple of VEC)
+        in.word = ra.leafStart[base >> 6];
+        in.rank = ra.leafRank[base >> 6];
+    };
+    In next{};
+    if (vi < nVec) fetch(vi, next);
     for (size_t it = 0; it < iters; ++it, vi += stride)
     {
-        const bool valid = vi < nVec;
+        const bool valid  = vi < nVec;
         const size_t base = vi * VEC;
+        const In in       = next;
+        if (vi + stride < nVec) fetch(vi + stride, next);
         K out[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v)
             out[v] = 0;
         if (valid)
         {
-            T vx[VEC], vy[VEC], vz[VEC];
-            K vk[VEC];
-            __builtin_memcpy(vx, __builtin_assume_aligned(x + base, sizeof(T) * VEC), sizeof vx);
-            __builtin_memcpy(vy, __builtin_assume_aligned(y + base, sizeof(T) * VEC), sizeof vy);
-            __builtin_memcpy(vz, __builtin_assume_aligned(z + base, sizeof(T) * VEC), sizeof vz);
-            // keysIn == nullptr: the caller has no key array, i.e. no remove markers
-            if (keysIn) { __builtin_memcpy(vk, __builtin_assume_aligned(keysIn + base, sizeof(K) * VEC), sizeof vk); }
-            else
+            keysOfPositions<K, T, VEC, HILBERT>(in.x, in.y, in.z, mx, my, mz, sx, sy, sz, enc2, out);
+            if (extentPartials)
             {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v)
-                    vk[v] = 0;
+                    widen(in.x[v], in.y[v], in.z[v]);
             }
 #pragma unroll
             for (int v = 0; v < VEC; ++v)
-            {
-                out[v] = gridMorton<K, T>(vx[v], vy[v], vz[v], mx, my, mz, sx, sy, sz);
-                if (extentPartials) widen(vx[v], vy[v], vz[v]);
-            }
-            if (HILBERT)
-            {
-                K h[VEC];
-                unsigned st[VEC];
-#pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                    h[v] = 0, st[v] = 0;
-#pragma unroll
-                for (int level = int(maxLevel<K>()) - 1; level >= 0; --level)
-                {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v)
-                    {
-                        unsigned e = enc[st[v] * 8 + (unsigned(out[v] >> (3 * level)) & 7u)];
-                        h[v]       = (h[v] << 3) | K(e & 7u);
-                        st[v]      = e >> 3;
-                    }
-                }
-#pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                    out[v] = h[v];
-            }
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-                if (vk[v] == endKey<K>()) out[v] = vk[v]; // particles flagged for removal keep their marker
+                if (in.k[v] == endKey<K>()) out[v] = in.k[v]; // particles flagged for removal keep their marker
         }
-        // the VEC positions of a lane lie in one 64-position word of the leaf table (base is a multiple of VEC)
-        const uint64_t word = valid ? ra.leafStart[base >> 6] : 0;
-        const uint32_t rank = valid ? ra.leafRank[base >> 6] : 0;
 #pragma unroll
         for (int v = 0; v < VEC; ++v)
-            out[v] = classify(out[v], base + v, valid, word, rank);
+            out[v] = classify(out[v], base + v, valid, valid ? in.word : 0, valid ? in.rank : 0);
         if (valid) __builtin_memcpy(__builtin_assume_aligned(ra.keysOut + base, sizeof(K) * VEC), out, sizeof out);
         if (staged >= STAGE / 2) flush();
     }
@@ -469,8 +447,7 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
         K key      = 0;
         if (valid)
         {
-            K m = gridMorton<K, T>(x[i], y[i], z[i], mx, my, mz, sx, sy, sz);
-            if (HILBERT) m = hilbertFromMorton<K>(m, enc);
+            K m = keyOfPosition<K, T, HILBERT>(x[i], y[i], z[i], mx, my, mz, sx, sy, sz, enc2);
             key = (keysIn && keysIn[i] == endKey<K>()) ? endKey<K>() : m;
             if (extentPartials) widen(x[i], y[i], z[i]);
         }
