@@ -144,6 +144,10 @@ public:
         , box_(box)
     {
     }
+    ~DomainImpl() override
+    {
+        if (pinnedLevels_) (void)hipHostFree(pinnedLevels_);
+    }
 
     int sync(void** keysPP, void** xPP, void** yPP, void** zPP, void** hPP, size_t n, void** scratchAll, int numScratch,
              void** props, const int* propBytes, int numProps) override
@@ -154,6 +158,21 @@ public:
             return fail(ctx_, CSTONE_E_ARG, "Domain sync: input array sizes are inconsistent (%zu != %u)", n, bufSize_);
         K* keys = static_cast<K*>(*keysPP);
         const int kb = 8 * sizeof(K), rb = 8 * sizeof(T);
+        // the level ranges of the linked octree the last sync (re)built travelled to a pinned block behind its last
+        // kernels; that sync ended with a synchronisation of the stream, so they are here now
+        if (levelsPending_)
+        {
+            CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream)); // (idle unless the last sync failed half way)
+            levelRangeHost_.assign(pinnedLevels_, pinnedLevels_ + maxLevel<K>() + 2);
+            int deepest = 0;
+            for (int l = 0; l <= int(maxLevel<K>()); ++l)
+                if (levelRangeHost_[l + 1] > levelRangeHost_[l]) deepest = l;
+            if (deepest > deepestBound_)
+                return fail(ctx_, CSTONE_E_INTERNAL, "domain_sync: the focus tree has level %d, the bound was %d", deepest,
+                            deepestBound_);
+            deepestBound_  = deepest;
+            levelsPending_ = false;
+        }
 
         // ---- GlobalAssignment::assign (assignment.hpp:57-103): box, keys, sort, one global-tree step
         // The box of a sync follows from the extents of x, y, z (makeGlobalBox + limitBoxShrinking).  After the first call
@@ -598,23 +617,19 @@ private:
         CS_TRY(fItl_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
         CS_TRY(fLti_.ensure(ctx_, size_t(M) * sizeof(NodeIdx)));
         // a focus update refines by one level at most: the leaves of the new tree are no deeper than the deepest of the
-        // tree before + 1 (levelRangeHost_ still describes that one)
-        int deepest = int(maxLevel<K>());
-        if (!levelRangeHost_.empty())
-        {
-            int prev = 0;
-            for (int l = 0; l <= int(maxLevel<K>()); ++l)
-                if (levelRangeHost_[l + 1] > levelRangeHost_[l]) prev = l;
-            deepest = std::min(deepest, prev + 1);
-        }
+        // tree before + 1.  deepestBound_ is exact at the start of a sync (above) and grows by one per rebuild inside it.
+        const int deepest = std::min(int(maxLevel<K>()), deepestBound_ + 1);
         CS_TRY(buildLinkedOctree(ctx_, 8 * sizeof(K), fTree_.p, L, fPrefixes_.p, fChild_.as<int32_t>(),
                                  fParents_.as<int32_t>(), fLevelRange_.as<int32_t>(), fItl_.as<int32_t>(),
                                  fLti_.as<int32_t>(), deepest));
-        // the level ranges also on the host (the tree is rebuilt rarely): the upsweep then launches existing levels only
-        levelRangeHost_.resize(maxLevel<K>() + 2);
-        CS_HIP(ctx_, hipMemcpyAsync(levelRangeHost_.data(), fLevelRange_.p, levelRangeHost_.size() * sizeof(NodeIdx),
+        deepestBound_ = deepest;
+        // the exact level ranges go to a pinned block WITHOUT waiting for them: the upsweep of this sync launches the
+        // levels up to the bound (one of them may be empty), the next sync reads the block
+        if (!pinnedLevels_)
+            CS_HIP(ctx_, hipHostMalloc(reinterpret_cast<void**>(&pinnedLevels_), 32 * sizeof(NodeIdx), hipHostMallocDefault));
+        CS_HIP(ctx_, hipMemcpyAsync(pinnedLevels_, fLevelRange_.p, (maxLevel<K>() + 2) * sizeof(NodeIdx),
                                     hipMemcpyDeviceToHost, ctx_->stream));
-        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
+        levelsPending_ = true;
         return CSTONE_OK;
     }
 
@@ -675,8 +690,8 @@ private:
         CS_TRY(fCounts_.ensure(ctx_, size_t(newM) * sizeof(uint32_t)));
         hipLaunchKernelGGL(scatterLeafCountsKernel, gridFor(newL, 256), 256, 0, ctx_->stream,
                            fLeafCounts_.as<uint32_t>(), fLti_.as<NodeIdx>(), newI, newL, fCounts_.as<uint32_t>());
-        CS_TRY(upsweepSumLevels(ctx_, int(maxLevel<K>()) + 2, levelRangeHost_.data(), fLevelRange_.as<int32_t>(),
-                                fChild_.as<int32_t>(), fCounts_.as<uint32_t>()));
+        CS_TRY(cstone_hip_upsweep_sum_bounded(ctx_, int(maxLevel<K>()) + 2, fLevelRange_.as<int32_t>(),
+                                              fChild_.as<int32_t>(), fCounts_.as<uint32_t>(), deepestBound_));
         // updateGeoCenters: the geometry of the nodes follows from the tree and the box alone -- nothing to do for an
         // unchanged tree inside an unchanged box (the reference recomputes it in every sync, octree_focus_mpi.hpp:259-273)
         bool sameBox = centersNodes_ == newM;
@@ -714,7 +729,10 @@ private:
     int layoutLeaves_ = -1; // number of leaves layout_ was computed for
     cstone_box centersBox_{}; // box and node count fCenters_ / fSizes_ were computed for
     NodeIdx centersNodes_ = -1;
-    std::vector<NodeIdx> levelRangeHost_;
+    std::vector<NodeIdx> levelRangeHost_; // of the tree the LAST sync left behind (exact)
+    NodeIdx* pinnedLevels_ = nullptr;     // where the level ranges of a rebuilt tree arrive
+    bool levelsPending_    = false;
+    int deepestBound_      = int(maxLevel<K>()); // no leaf of the current focus tree is deeper
     int fullSortFallbacks_ = 0;
     DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_, fCenters_, fSizes_;
     DevBuf ops_, ops2_, leafOps_, layout_, radii_, flags_;
