@@ -653,6 +653,33 @@ __device__ __forceinline__ uint32_t laneXor(uint32_t v, unsigned lane)
 template<int X, unsigned LOWBIT, int N>
 __device__ __forceinline__ void cmpExchange(uint32_t (&v)[N], unsigned lane)
 {
+    if constexpr ((X == 4 || X == 8) && LOWBIT == unsigned(X))
+    {
+        // the lower lanes of such a step are whole DPP banks (four lanes each): the minimum goes to them through a masked
+        // row_shl, the maximum to the upper banks through a masked row_shr of the ORIGINAL values; lanes outside a mask
+        // keep their operand (old), so no select is needed -- four instructions (two when the moves fold) instead of five
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+        {
+            const uint32_t a = v[n];
+            uint32_t r       = a;
+            // (written as instructions: the compiler does not fold a masked DPP move into its consumer.  s_nop 1: a DPP
+            //  operand written by the instruction before needs two wait states, and the assembler text hides the DPP
+            //  from the compiler's hazard pass)
+            if constexpr (X == 4)
+            {
+                asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %1, %0 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(r) : "v"(a));
+                asm volatile("v_max_u32_dpp %0, %1, %0 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(r) : "v"(a));
+            }
+            else
+            {
+                asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %1, %0 row_shl:8 row_mask:0xf bank_mask:0x3" : "+v"(r) : "v"(a));
+                asm volatile("v_max_u32_dpp %0, %1, %0 row_shr:8 row_mask:0xf bank_mask:0xc" : "+v"(r) : "v"(a));
+            }
+            v[n] = r;
+        }
+        return;
+    }
     const bool upper = (lane & LOWBIT) != 0;
 #pragma unroll
     for (int n = 0; n < N; ++n)
