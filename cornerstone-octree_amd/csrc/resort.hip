@@ -760,6 +760,7 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
     __shared__ uint32_t posK[G + 1], inK[G + 1], outK[G + 1];
     __shared__ K loK[G + 1];
     __shared__ uint32_t slotsK[G + 4]; // old slots + arrivals of every leaf, zeros behind the last one
+    __shared__ uint8_t cutK[G];
     __shared__ uint16_t sPlace[4][256];
 
     RESORT_TRACE(0)
@@ -775,6 +776,13 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
     }
     __syncthreads();
     if (t < uint32_t(G) + 4u) slotsK[t] = t < nl ? (posK[t + 1] - posK[t]) + (inK[t + 1] - inK[t]) : 0u;
+    if (t < nl)
+    {
+        // how far a leaf's keys are shifted for the 24 leading bits of the digest: once per leaf here, not once per step
+        const K span   = loK[t + 1] - loK[t] - 1;
+        const int bits = span ? int(8 * sizeof(K)) - clzKey(span) : 0;
+        cutK[t]        = uint8_t(bits > 24 ? bits - 24 : 0);
+    }
     const uint32_t p0 = posK[0], p1 = posK[nl], in0 = inK[0], in1 = inK[nl];
     if (!allTiles)
     {
@@ -785,6 +793,7 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
         const bool quiet = !__syncthreads_or(changed) && nOldAll <= RESORT_QUIET_SLOTS;
         if (quiet) return;
     }
+    __syncthreads(); // (slotsK, cutK)
     const unsigned lane = t & 63u;
     const unsigned wave = t >> 6;
 
@@ -801,11 +810,9 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
         f.pk = posK[k], f.nOld = posK[k + 1] - f.pk;
         f.ik = inK[k], f.nInc = inK[k + 1] - f.ik;
         f.ok = outK[k], f.nNew = outK[k + 1] - f.ok;
-        f.slots        = f.nOld + f.nInc;
-        f.lo           = loK[k];
-        const K span   = loK[k + 1] - f.lo - 1;
-        const int bits = span ? int(8 * sizeof(K)) - clzKey(span) : 0;
-        f.cut          = bits > 24 ? unsigned(bits - 24) : 0u;
+        f.slots = f.nOld + f.nInc;
+        f.lo    = loK[k];
+        f.cut   = cutK[k];
         return f;
     };
     // slot s of a leaf: an old position or an arrival
@@ -949,7 +956,6 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
     // between an eighth of a bucket and a bucket: a step therefore takes FOUR consecutive leaves when none of them has more
     // than 16 slots (each in a segment of 16 lanes, the network stops at blocks of 16), TWO when both have at most 32,
     // ONE otherwise.  Everything that describes "the leaf" below is per lane.
-    __syncthreads();
 #ifdef CSTONE_RESORT_TRACE
     RESORT_TRACE(1)
     long long trSteps = 0, trIssue = 0, trWait = 0, trSort = 0, trFinish = 0, trT = clock64();
