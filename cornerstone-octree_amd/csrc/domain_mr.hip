@@ -580,13 +580,14 @@ public:
         bool sameBox          = true;
         for (int k = 0; k < 6; ++k)
             sameBox = sameBox && box_.lim[k] == layoutBox_.lim[k];
-        // (below some 3e7 particles per rank the chain of small launches of the re-sort and its read-back cost what the
-        //  four digit passes cost: measured, with 1 % movers, 1.35 against 1.25 ms per sync at 1.25e7, 2.16 against
-        //  2.19 ms at 2.5e7, 3.20 against 3.43 ms at 5e7)
+        // (below some 6e6 particles per rank the chain of small launches of the re-sort and its read-back cost more than
+        //  the digit passes they replace: measured in round 3, every particle drifting, re-sorted against radix-sorted:
+        //  0.73 / 0.60 ms per sync at 1e6, 0.91 / 0.90 at 3e6, 0.90 / 0.95 at 6e6, 1.49 / 1.53 at 1.25e7, 2.62 / 2.66 at
+        //  2.5e7, 3.36 / 3.7 at 5e7; tools/mr_bench.py --rccl)
         static const size_t resortMin = []
         {
             const char* e = std::getenv("CSTONE_MR_RESORT_MIN");
-            return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(1) << 25;
+            return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(6) << 20;
         }();
         const bool tryResort = !firstCall_ && n >= resortMin && n == layoutParticles_ && tileLeaves > 0 && sameBox && resortLeaves_ > 0 &&
                                resortBackoff_ == 0 && !pending_ && mayResort();
