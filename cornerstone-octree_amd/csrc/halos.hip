@@ -273,11 +273,18 @@ __global__ __launch_bounds__(256) void haloRadiiKernel(const Th* __restrict__ h,
     float out = 0.0f;
     if (b > a)
     {
+        // four slots per lane at a time (a leaf holds at most a bucket): the loads of a leaf go out together
         Th m = h[a];
-        for (uint32_t i = a + sub; i < b; i += 16)
+        for (uint32_t i = a + sub; i < b; i += 64)
         {
-            Th v = h[i];
-            m    = v > m ? v : m;
+            const uint32_t i1 = i + 16, i2 = i + 32, i3 = i + 48;
+            const Th v0 = h[i];
+            const Th v1 = i1 < b ? h[i1] : v0;
+            const Th v2 = i2 < b ? h[i2] : v0;
+            const Th v3 = i3 < b ? h[i3] : v0;
+            const Th m01 = v0 > v1 ? v0 : v1, m23 = v2 > v3 ? v2 : v3;
+            const Th m4  = m01 > m23 ? m01 : m23;
+            m            = m4 > m ? m4 : m;
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1)
