@@ -104,6 +104,8 @@ int minMaxCoordinates(cstone_hip_ctx* ctx, int real_bits, const void* const* xs,
 //! the same without the read-back: devOut[2 d] = min, devOut[2 d + 1] = -max as doubles on the device (primitives.hip)
 int minMaxCoordinatesDev(cstone_hip_ctx* ctx, int real_bits, const void* const* xs, int numArrays, size_t n,
                          double* devOut);
+//! {min, max} per axis as T on the device -> (min, -max) as doubles: the operand of the box all-reduce
+int extentsToReduceOperand(cstone_hip_ctx* ctx, int real_bits, const void* extents, double* devOut);
 
 //! encode + the sort's digit histograms in one kernel (sfc.hip); *fused = false: hist untouched (unaligned input)
 //! extentsOut (device, 6 reals {xmin, xmax, ymin, ...}, or nullptr): the extents of x, y, z measured by the same pass;

@@ -548,7 +548,30 @@ public:
         ++syncs_;
         tick(nullptr);
 
-        CS_TRY(updateBox(x, y, z, n));
+        // ---- the box.  Measuring it costs a pass over x, y, z and a round trip before the first key can be computed.
+        //      A sync that is going to re-sort (below) computes its keys with the box of the previous sync instead and
+        //      measures the extents in the same pass; the all-reduce of the extents follows the encode, the result comes
+        //      back with the re-sort's counters, and only a box that really changed costs a second encode (with the
+        //      radix path, as every key changes then).  After such a sync the extents are measured first again until a
+        //      sync finds the box unchanged (an open box whose outermost particles move changes every time).
+        //      The box all-reduce stays the first collective of the sync on every rank either way.
+        const bool anyOpen = !(box_.bc[0] == 1 && box_.bc[1] == 1 && box_.bc[2] == 1);
+        bool boxSame       = true;
+        for (int k = 0; k < 6; ++k)
+            boxSame = boxSame && box_.lim[k] == layoutBox_.lim[k];
+        const int tileLeavesSpec = LeafResort<K>::leavesPerTile(bucketFocus_);
+        bool speculate = anyOpen && !firstCall_ && !measureFirst_ && !pending_ && boxSame && n >= resortMinParticles() &&
+                         n == layoutParticles_ && tileLeavesSpec > 0 && resortLeaves_ > 0 && resortBackoff_ == 0 &&
+                         mayResort() && speculativeBox_;
+        if (!speculate)
+        {
+            const cstone_box before = box_;
+            CS_TRY(updateBox(x, y, z, n));
+            bool moved = false;
+            for (int k = 0; k < 6; ++k)
+                moved = moved || box_.lim[k] != before.lim[k];
+            if (!firstCall_ && anyOpen) measureFirst_ = moved;
+        }
         tick("1 box");
 
         // ---- keys + SFC ordering of the present particles
@@ -576,19 +599,12 @@ public:
         //      the previous sync handed out, ordered by the leaves of this rank's tree (layout_); particles still inside
         //      their leaf are ordered leaf by leaf, the others are binned.  Rank-local: no collective depends on it.
         bool resorted         = false;
+        bool boxChecked       = false;
         const int tileLeaves  = LeafResort<K>::leavesPerTile(bucketFocus_);
         bool sameBox          = true;
         for (int k = 0; k < 6; ++k)
             sameBox = sameBox && box_.lim[k] == layoutBox_.lim[k];
-        // (below some 6e6 particles per rank the chain of small launches of the re-sort and its read-back cost more than
-        //  the digit passes they replace: measured in round 3, every particle drifting, re-sorted against radix-sorted:
-        //  0.73 / 0.60 ms per sync at 1e6, 0.91 / 0.90 at 3e6, 0.90 / 0.95 at 6e6, 1.49 / 1.53 at 1.25e7, 2.62 / 2.66 at
-        //  2.5e7, 3.36 / 3.7 at 5e7; tools/mr_bench.py --rccl)
-        static const size_t resortMin = []
-        {
-            const char* e = std::getenv("CSTONE_MR_RESORT_MIN");
-            return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(6) << 20;
-        }();
+        const size_t resortMin = resortMinParticles();
         const bool tryResort = !firstCall_ && n >= resortMin && n == layoutParticles_ && tileLeaves > 0 && sameBox && resortLeaves_ > 0 &&
                                resortBackoff_ == 0 && !pending_ && mayResort();
         if (resortBackoff_ > 0) --resortBackoff_;
@@ -598,10 +614,36 @@ public:
                                    lastMovers_ > 100000));
             const ResortArgs<K> ra = resort_.args();
             bool done              = false;
-            CS_TRY(computeKeysResort(ctx_, curve_, kb, rb, x, y, z, keysIn ? keys_.p : nullptr, n, box_, &ra, nullptr, &done));
-            if (done)
+            T* extentsDev = reinterpret_cast<T*>(scal_.as<char>() + 256); // {min, max} per axis, measured by the encode
+            CS_TRY(computeKeysResort(ctx_, curve_, kb, rb, x, y, z, keysIn ? keys_.p : nullptr, n, box_, &ra,
+                                     speculate ? extentsDev : nullptr, &done));
+            bool boxHolds = true;
+            if (speculate)
             {
-                CS_TRY(resort_.binMovers(ctx_, tileLeaves));
+                boxChecked = true;
+                // (the keys above were computed with the box of the previous sync: was it still the box?)
+                double* dev = scal_.as<double>();
+                if (done) { CS_TRY(extentsToReduceOperand(ctx_, rb, extentsDev, dev)); }
+                else
+                {
+                    const void* arrays[3] = {x, y, z};
+                    CS_TRY(minMaxCoordinatesDev(ctx_, rb, arrays, 3, n, dev));
+                }
+                if (done) CS_TRY(resort_.binMovers(ctx_, tileLeaves));
+                cstone_box next;
+                CS_TRY(reduceBox(dev, &next));
+                for (int k = 0; k < 6; ++k)
+                    boxHolds = boxHolds && next.lim[k] == box_.lim[k];
+                if (!boxHolds)
+                {
+                    box_          = next;
+                    measureFirst_ = true;
+                    ++boxRedos_;
+                }
+            }
+            else if (done) { CS_TRY(resort_.binMovers(ctx_, tileLeaves)); }
+            if (done && boxHolds)
+            {
                 int found[4];
                 CS_TRY(toHost(found, ctx_->devScalars + RESORT_SCALARS, sizeof found));
                 const uint32_t markers = uint32_t(found[0]), J = uint32_t(found[2]), movers = uint32_t(found[3]);
@@ -615,6 +657,11 @@ public:
                 }
                 else { resortBackoff_ = 4; }
             }
+        }
+        if (speculate && !boxChecked)
+        {
+            // (cannot happen: the conditions of the speculation are those of the attempt above; a box is never left unmeasured)
+            CS_TRY(updateBox(x, y, z, n));
         }
         if (n && !resorted)
         {
@@ -1188,6 +1235,20 @@ private:
         pendingMsg_ = buf;
     }
 
+    /*! below some 6e6 particles per rank the chain of small launches of the re-sort and its read-back cost more than the
+     *  digit passes they replace: measured in round 3, every particle drifting, re-sorted against radix-sorted: 0.73 / 0.60
+     *  ms per sync at 1e6, 0.91 / 0.90 at 3e6, 0.90 / 0.95 at 6e6, 1.49 / 1.53 at 1.25e7, 2.62 / 2.66 at 2.5e7, 3.36 / 3.7
+     *  at 5e7 (tools/mr_bench.py --rccl) */
+    static size_t resortMinParticles()
+    {
+        static const size_t v = []
+        {
+            const char* e = std::getenv("CSTONE_MR_RESORT_MIN");
+            return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(6) << 20;
+        }();
+        return v;
+    }
+
     //! tests: CSTONE_MR_FAIL_AT="<rank>:<point>" makes that rank fail at the named point of sync()
     void injectFailure(const char* point)
     {
@@ -1279,6 +1340,16 @@ private:
             CS_TRY(minMaxCoordinatesDev(ctx_, rb, arrays, 3, n, dev));
         }
         else { CS_HIP(ctx_, hipMemcpyAsync(dev, nothing, sizeof nothing, hipMemcpyHostToDevice, ctx_->stream)); }
+        cstone_box next;
+        CS_TRY(reduceBox(dev, &next));
+        box_ = next;
+        return CSTONE_OK;
+    }
+
+    /*! dev: (lo, -hi) of this rank's particles per axis, six doubles on the device, room for a seventh.  All-reduces them
+     *  with the status word, reads them back and applies the box rule to box_ -> *next (box_ itself is not changed). */
+    int reduceBox(double* dev, cstone_box* next)
+    {
         // seventh value: the status of this rank (0, or -(rank + 1) if it has a failure pending); MIN over the ranks
         statusD_ = pending_ ? -double(rank_ + 1) : 0.0;
         CS_HIP(ctx_, hipMemcpyAsync(dev + 6, &statusD_, sizeof statusD_, hipMemcpyHostToDevice, ctx_->stream));
@@ -1286,13 +1357,14 @@ private:
         double ext[7];
         CS_TRY(toHost(ext, dev, sizeof ext));
         if (ext[6] < 0) return agreed(int(-ext[6]) - 1);
+        *next = box_;
         double fit[6];
         for (int d = 0; d < 3; ++d)
         {
             fit[2 * d] = ext[2 * d], fit[2 * d + 1] = -ext[2 * d + 1];
             if (box_.bc[d] == 1) fit[2 * d] = box_.lim[2 * d], fit[2 * d + 1] = box_.lim[2 * d + 1];
         }
-        if (firstCall_) { std::copy(fit, fit + 6, box_.lim); }
+        if (firstCall_) { std::copy(fit, fit + 6, next->lim); }
         else
         {
             // limitBoxShrinking (R/sfc/box.hpp:415-431), evaluated in T like the reference
@@ -1300,9 +1372,9 @@ private:
             for (int d = 0; d < 3; ++d)
             {
                 T lo = T(box_.lim[2 * d]), hi = T(box_.lim[2 * d + 1]);
-                T len               = hi - lo;
-                box_.lim[2 * d]     = std::min(T(fit[2 * d]), T(lo + shrink * len));
-                box_.lim[2 * d + 1] = std::max(T(fit[2 * d + 1]), T(hi - shrink * len));
+                T len                = hi - lo;
+                next->lim[2 * d]     = std::min(T(fit[2 * d]), T(lo + shrink * len));
+                next->lim[2 * d + 1] = std::max(T(fit[2 * d + 1]), T(hi - shrink * len));
             }
         }
         return CSTONE_OK;
@@ -1621,6 +1693,9 @@ private:
     float haloExt_  = 1.0f;
     float theta_    = 0.5f;
     int sortMode_   = CSTONE_SORT_INCREMENTAL;
+    bool speculativeBox_ = std::getenv("CSTONE_NO_SPECULATIVE_BOX") == nullptr;
+    bool measureFirst_   = false; // the last box was not the one before it: measure the extents before encoding
+    int boxRedos_        = 0;     // syncs whose speculative keys were thrown away because the box had changed
     bool useLet_    = std::getenv("CSTONE_MR_OWNER_SIDE") == nullptr; // halos through the locally essential tree (default)
     std::unique_ptr<FocusLet<K, T>> let_;
     const K* resortTree_ = nullptr; // the leaves of my own key range (and their number) the next sync's re-sort starts from

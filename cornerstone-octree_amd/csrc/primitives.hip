@@ -504,6 +504,17 @@ int minMaxCoordinatesDev(cstone_hip_ctx* ctx, int real_bits, const void* const* 
     return minMaxArraysDev<double>(ctx, (const double* const*)xs, numArrays, n, devOut);
 }
 
+//! {min, max} per axis as T (what the encode kernels measure on the way) -> (min, -max) as doubles at devOut
+int extentsToReduceOperand(cstone_hip_ctx* ctx, int real_bits, const void* extents, double* devOut)
+{
+    if (real_bits == 32)
+        hipLaunchKernelGGL(minNegMaxKernel<float>, 1, 64, 0, ctx->stream, (const float*)extents, 3, devOut);
+    else
+        hipLaunchKernelGGL(minNegMaxKernel<double>, 1, 64, 0, ctx->stream, (const double*)extents, 3, devOut);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
 int minMaxCoordinates(cstone_hip_ctx* ctx, int real_bits, const void* const* xs, int numArrays, size_t n, double* out)
 {
     if (real_bits == 32) return minMaxArrays<float>(ctx, (const float* const*)xs, numArrays, n, out);
