@@ -199,6 +199,10 @@ def main():
                     help="native only: 1 = owner-side halo discovery instead of the locally essential tree")
     ap.add_argument("--fail-at", default="", help="native only: after one good sync, rank 1 is made to fail at this point "
                                                   "of the next sync (CSTONE_MR_FAIL_AT); every rank must get an error")
+    ap.add_argument("--spec-box", type=int, default=0,
+                    help="native only: this many syncs through two domains, one encoding with the previous box while it "
+                         "measures the extents (the default), one measuring first (CSTONE_NO_SPECULATIVE_BOX); particles "
+                         "jitter inside fixed extents (the box holds) except for two steps that push them outwards")
     a = ap.parse_args()
     dist.init_process_group("gloo")
     rank, P = dist.get_rank(), dist.get_world_size()
@@ -252,6 +256,45 @@ def main():
                                 bucket_focus=16, box_lim=lim, box_bc=bc)
     ok = True
     report = []
+    if a.spec_box:
+        # the speculative box of the multi-rank sync (domain_mr.hip): same results as measuring first, whether the box
+        # holds (most steps here) or not (steps 3 and 4), on every rank
+        os.environ["CSTONE_NO_SPECULATIVE_BOX"] = "1"
+        dom_b = make_native(backend, max(64, N // (100 * P)), 16, lim, bc, curve, a.key_bits, a.real_bits, a.owner_side)
+        del os.environ["CSTONE_NO_SPECULATIVE_BOX"]
+        g = torch.Generator(device=dev).manual_seed(77 + rank)
+        xa, ya, za, ha = x, y, z, h
+        for s_ in range(a.spec_box):
+            ra = dom.sync(xa, ya, za, ha)
+            rb = dom_b.sync(xa.clone(), ya.clone(), za.clone(), ha.clone())
+            same = ra["start"] == rb["start"] and ra["end"] == rb["end"] and list(ra["lim"]) == list(rb["lim"])
+            for k in ("keys", "x", "y", "z", "h"):
+                same = same and bool(torch.equal(ra[k], rb[k]))
+            va, vb = dom.view(), dom_b.view()
+            same = same and (va.num_focus_leaves, va.start_cell, va.end_cell, va.num_global_leaves) == (
+                vb.num_focus_leaves, vb.start_cell, vb.end_cell, vb.num_global_leaves)
+            ok &= same
+            report.append(dict(sync=s_, same=same, lim=[float(v) for v in ra["lim"]], resorts=int(va.resorts)))
+            st, en = ra["start"], ra["end"]
+            xa, ya, za, ha = [ra[k][st:en].clone() for k in "xyzh"]
+            if s_ in (2, 3):   # everybody drifts outwards a little: all extents move, on every rank
+                for c in (xa, ya, za):
+                    c.sub_(0.5).mul_(1.002).add_(0.5)
+            else:              # jitter inside the global extents of the cloud: the box stays what it is
+                for c, d in zip((xa, ya, za), range(3)):
+                    lo, hi = float(ra["lim"][2 * d]), float(ra["lim"][2 * d + 1])
+                    keep = (c <= lo) | (c >= hi)  # (the particles that define the extents stay where they are)
+                    moved = c + (torch.rand(c.numel(), dtype=c.dtype, device=c.device, generator=g) - 0.5) * 2e-4
+                    c.copy_(torch.where(keep, c, moved.clamp_(lo, hi)))
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+        # the speculating domain re-sorted where the box held (at least two of the quiet steps)
+        ok = ok and int(dom.view().resorts) >= 2
+        if rank == 0:
+            print("DIST_RESULT " + json.dumps(dict(ok=ok, ranks=P, report=report)))
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
     if a.fail_at:
         # collective-safe failure: one good sync, then rank 1 fails inside the next one; nobody may hang, everybody must
         # see an error, and the domain must work again afterwards

@@ -230,3 +230,12 @@ def test_native_domain_tree_deepens_over_resorted_syncs(owner_side):
     steps = [e for e in r["report"] if "contract_step" in e]
     assert len(steps) == 14 and all(e["neighbors"] == e["found"] for e in steps)
     assert steps[-1]["focus_leaves"] != steps[0]["focus_leaves"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pbc", [0])
+def test_native_domain_speculative_box_equals_measuring_first(pbc):
+    """the multi-rank sync encodes with the box of the previous sync when it is going to re-sort, and measures the extents
+    on the way (csrc/domain_mr.hip): every result equals that of a domain that measures first, through steps in which the
+    box holds and steps in which it grows (3 ranks, open boundaries)"""
+    _launch(3, "hip", 60000, 1, pbc, 29741, impl="native", extra=["--spec-box", "7"], timeout=400)
