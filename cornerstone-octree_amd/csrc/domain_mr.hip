@@ -617,7 +617,7 @@ public:
             T* extentsDev = reinterpret_cast<T*>(scal_.as<char>() + 256); // {min, max} per axis, measured by the encode
             CS_TRY(computeKeysResort(ctx_, curve_, kb, rb, x, y, z, keysIn ? keys_.p : nullptr, n, box_, &ra,
                                      speculate ? extentsDev : nullptr, &done));
-            bool boxHolds = true;
+            bool boxHolds = true, foundHere = false;
             if (speculate)
             {
                 boxChecked = true;
@@ -629,7 +629,14 @@ public:
                     const void* arrays[3] = {x, y, z};
                     CS_TRY(minMaxCoordinatesDev(ctx_, rb, arrays, 3, n, dev));
                 }
-                if (done) CS_TRY(resort_.binMovers(ctx_, tileLeaves));
+                if (done)
+                {
+                    CS_TRY(resort_.binMovers(ctx_, tileLeaves));
+                    // (the re-sort's counters travel with the reduced extents: one synchronisation for both)
+                    CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars + 40, ctx_->devScalars + RESORT_SCALARS, 4 * sizeof(int),
+                                                hipMemcpyDeviceToHost, ctx_->stream));
+                    foundHere = true;
+                }
                 cstone_box next;
                 CS_TRY(reduceBox(dev, &next));
                 for (int k = 0; k < 6; ++k)
@@ -645,7 +652,8 @@ public:
             if (done && boxHolds)
             {
                 int found[4];
-                CS_TRY(toHost(found, ctx_->devScalars + RESORT_SCALARS, sizeof found));
+                if (foundHere) { std::copy(ctx_->hostScalars + 40, ctx_->hostScalars + 44, found); }
+                else { CS_TRY(toHost(found, ctx_->devScalars + RESORT_SCALARS, sizeof found)); }
                 const uint32_t markers = uint32_t(found[0]), J = uint32_t(found[2]), movers = uint32_t(found[3]);
                 if ((found[1] & 7) == 0 && movers <= n / 8)
                 {
