@@ -69,8 +69,8 @@ __global__ __launch_bounds__(256) void protectAncestorsKernel(const K* __restric
         }
         opsOut[i] = op;
     }
-    // (a plain store: every wave writes the same value, and atomics of tens of thousands of waves on one address serialise)
-    if (__any(op != 1) && (threadIdx.x & 63) == 0) *reinterpret_cast<volatile int*>(changed) = 1;
+    // (set once: updates of tens of thousands of waves to one address serialise in the L2, reads of it do not)
+    if (__any(op != 1) && (threadIdx.x & 63) == 0 && *reinterpret_cast<volatile int*>(changed) == 0) atomicOr(changed, 1);
 }
 
 //! leafOps[i] = ops[leafToInternal[numInternal + i]] for i < numLeaves, leafOps[numLeaves] = 0

@@ -118,9 +118,9 @@ __global__ __launch_bounds__(256) void protectAncestorsKernel(const K* __restric
         ops[i] = op;
     }
     uint64_t changed = __ballot(op != 1);
-    // (a flag, not a count: tens of thousands of waves adding to ONE address serialise in the L2 -- 0.1 ms at 2.5 million
-    //  nodes; plain stores of the same value do not)
-    if ((threadIdx.x & 63u) == 0 && changed) *reinterpret_cast<volatile int*>(numChanged) = 1;
+    // (a flag, not a count; set once: tens of thousands of waves updating ONE address serialise in the L2 -- atomics and
+    //  plain stores alike, the stores 2-3 times worse --, reading it does not)
+    if ((threadIdx.x & 63u) == 0 && changed && *reinterpret_cast<volatile int*>(numChanged) == 0) atomicOr(numChanged, 1);
 }
 
 /*! enforceKeySingle, R/focus/rebalance.hpp:199-250, one lane per mandatory key.  status: 0 converged, 1 cancelMerge,
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(256) void leafOpsCountKernel(const NodeIdx* __restr
     }
     else if (i == numLeaves) { leafOps[i] = 0; }
     const uint64_t b = __ballot(op != 1);
-    if ((threadIdx.x & 63u) == 0 && b) *reinterpret_cast<volatile int*>(changed) = 1; // (a flag, see protectAncestorsKernel)
+    if ((threadIdx.x & 63u) == 0 && b && *reinterpret_cast<volatile int*>(changed) == 0) atomicOr(changed, 1); // (a flag, see protectAncestorsKernel)
 }
 
 //! one int from the device scalars to the host (synchronises the stream)

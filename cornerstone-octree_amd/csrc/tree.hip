@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void nodeOpsKernel(const K* __restrict__ tree,
         ops[i] = uint32_t(op);
     }
     else if (i == numNodes) { ops[i] = 0; }
-    // (a plain store: every wave writes the same value, and atomics of tens of thousands of waves on one address serialise)
-    if (__any(op != 1) && (threadIdx.x & 63) == 0) *reinterpret_cast<volatile int*>(changed) = 1;
+    // (set once: updates of tens of thousands of waves to one address serialise in the L2, reads of it do not)
+    if (__any(op != 1) && (threadIdx.x & 63) == 0 && *reinterpret_cast<volatile int*>(changed) == 0) atomicOr(changed, 1);
 }
 
 //! new leaf j descends from the old node src with ops[src] <= j < ops[src+1]        R/tree/csarray.hpp:360-385

@@ -153,10 +153,12 @@ if perk:
                "particles": 1e8, "gather_calibration": calib,
                "kernels": table}, open(f"profiles/{tag}_kernel_hbm_traffic.json", "w"), indent=1)
 # the multi-rank sync at the per-GPU size of the 8-GPU point (tools/mr_bench.py --rccl --particles 1.25e7): kernels per
-# sync, averaged over the last 10 syncs of the trace (a sync starts with its one encodeHistogramKernel launch)
+# sync, averaged over the last 10 syncs of the trace (a sync is counted from its encode launch to the next one's: the
+# leaf-table kernels in front of the encode belong to the following sync in this bookkeeping, the sums are unaffected)
 for trace in glob.glob(os.path.join(src, "mr", "**", "*kernel_trace.csv"), recursive=True):
     rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "encodeHistogramKernel" in r["Kernel_Name"]]
+    # (a sync computes its keys exactly once: in encodeResortKernel when it re-sorts, in encodeHistogramKernel otherwise)
+    starts = [i for i, r in enumerate(rows) if "encodeHistogramKernel" in r["Kernel_Name"] or "encodeResortKernel" in r["Kernel_Name"]]
     if len(starts) < 12:
         continue
     use = starts[-11:]
