@@ -309,8 +309,8 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
                                                           size_t n, DBox<T> box, const uint16_t* __restrict__ encTable,
                                                           ResortArgs<K> ra, T* __restrict__ extentPartials)
 {
-    // (a wave flushes at half of this, one iteration adds at most 64 * VEC; larger stages -- fewer atomics on the list's
-    //  counter -- cost more in residency than they save: 4x the stage +0.04 ms, 8x +0.24 ms at 1e8 particles)
+    // (larger stages -- fewer atomics on the list's counter -- cost more in residency than they save: 4x the stage
+    //  +0.04 ms, 8x +0.24 ms at 1e8 particles)
     constexpr unsigned STAGE = 64 * VEC * 2;
     __shared__ uint16_t enc2[HILBERT ? HILBERT_STATES * 64 : 1];
     __shared__ K stageKey[4][STAGE];
@@ -364,6 +364,9 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
         const uint64_t mm = __ballot(mover);
         if (mm)
         {
+            // flush only when these movers would not fit any more: the stage is nearly full at every flush, which halves
+            // the number of atomics on the list's ONE counter (tens of thousands of them serialise in the L2)
+            if (staged + unsigned(__popcll(mm)) > STAGE) flush();
             if (mover)
             {
                 const unsigned off = staged + unsigned(__popcll(mm & below));
@@ -437,7 +440,6 @@ __global__ __launch_bounds__(256) void encodeResortKernel(const T* __restrict__ 
         for (int v = 0; v < VEC; ++v)
             out[v] = classify(out[v], base + v, valid, valid ? in.word : 0, valid ? in.rank : 0);
         if (valid) __builtin_memcpy(__builtin_assume_aligned(ra.keysOut + base, sizeof(K) * VEC), out, sizeof out);
-        if (staged >= STAGE / 2) flush();
     }
     // elements behind the last full vector: first wave of block 0
     if (blockIdx.x == 0 && threadIdx.x < 64)
