@@ -744,12 +744,45 @@ __device__ __forceinline__ void waveBitonicSort(uint32_t (&d)[R], unsigned lane)
     }
 }
 
+// ---- two elements per lane: lane l of a segment holds the elements 2 l (register 0) and 2 l + 1 (register 1) of its
+//      leaf, so that a leaf of up to 64 slots takes HALF a wave and a wave step sorts two leaves (or four of up to 32
+//      slots).  Six of the 21 steps of the 64-element network are then compare-exchanges inside a lane (two
+//      instructions for both registers, no cross-lane move, no select), the others run on both registers at half the
+//      lane distance.
+__device__ __forceinline__ void inLaneExchange(uint32_t (&d)[2])
+{
+    const uint32_t lo = min(d[0], d[1]);
+    d[1]              = max(d[0], d[1]);
+    d[0]              = lo;
+}
+//! first step of the merge of two sorted blocks of K/2 elements each: element e against the mirrored element
+//! e ^ (K - 1), i.e. (lane, register) against (lane ^ M, other register), M = K/2 - 1; LOWBIT = K/4 in lane space
+template<int M, unsigned LOWBIT>
+__device__ __forceinline__ void mirrorExchange(uint32_t (&d)[2], unsigned lane)
+{
+    const uint32_t o1 = laneXor<M>(d[1], lane), o0 = laneXor<M>(d[0], lane);
+    const bool upper  = (lane & LOWBIT) != 0;
+    d[0]              = upper ? max(d[0], o1) : min(d[0], o1);
+    d[1]              = upper ? max(d[1], o0) : min(d[1], o0);
+}
+//! ascending sort of the 2 * SEG elements of every segment of SEG lanes (SEG = 32: 64 elements, SEG = 16: 32)
+template<int SEG>
+__device__ __forceinline__ void pairSort(uint32_t (&d)[2], unsigned lane)
+{
+    inLaneExchange(d);                                                                       // blocks of 2
+    mirrorExchange<1, 1u>(d, lane), inLaneExchange(d);                                       // 4
+    mirrorExchange<3, 2u>(d, lane), cmpExchange<1, 1u, 2>(d, lane), inLaneExchange(d);       // 8
+    mirrorExchange<7, 4u>(d, lane), halfClean<2, 2>(d, lane), inLaneExchange(d);             // 16
+    mirrorExchange<15, 8u>(d, lane), halfClean<4, 2>(d, lane), inLaneExchange(d);            // 32
+    if constexpr (SEG >= 32) { mirrorExchange<31, 16u>(d, lane), halfClean<8, 2>(d, lane), inLaneExchange(d); } // 64
+}
+
 #ifdef CSTONE_WAVE_OCC4
 #define CSTONE_WAVE_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
 #else
 #define CSTONE_WAVE_OCC
 #endif
-template<class K, int G, bool PACK>
+template<class K, int G, int MODE>
 __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
     const K* __restrict__ keysIn, const K* __restrict__ leafLo, const uint32_t* __restrict__ leafPos,
     const uint32_t* __restrict__ inOffset, const uint32_t* __restrict__ layoutNew, const K* __restrict__ binKeys,
@@ -898,7 +931,7 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
         if (!finishLeaf(f, rTag, key, idx, d)) exactLeaf(f, R, key, idx);
     };
 
-    if constexpr (!PACK)
+    if constexpr (MODE == 0)
     {
         // The leaves of this wave: wave, wave + 4, ...  A ROLLED loop: the body (load, 64-element network, store) is a few
         // hundred instructions and stays in the instruction cache; unrolled over the wave's 16 leaves the kernel was
@@ -948,17 +981,14 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
         }
         return;
     }
-    // ---- The leaves of this wave: a contiguous quarter of the tile, in a ROLLED loop: the body (load, network, store) is
-    // a few hundred instructions and stays in the instruction cache; unrolled over the wave's 16 leaves the kernel was
-    // 24-41 thousand instructions (190-330 KB of code streaming through the instruction cache) and took 0.7-0.9 ms
-    // whatever the network cost.  The keys of the NEXT step are requested before the current one is sorted.
-    // The kernel is bound by instruction issue, i.e. by the number of STEPS, and a leaf of a uniform cloud holds anything
-    // between an eighth of a bucket and a bucket: a step therefore takes FOUR consecutive leaves when none of them has more
-    // than 16 slots (each in a segment of 16 lanes, the network stops at blocks of 16), TWO when both have at most 32,
-    // ONE otherwise.  Everything that describes "the leaf" below is per lane.
+    if constexpr (MODE == 1)
+    {
+        // ---- two elements per lane (see pairSort): a step takes TWO consecutive leaves of up to 64 slots (a segment of
+        //      32 lanes each) or FOUR of up to 32 slots (16 lanes each); a leaf with more than 64 slots has the wave
+        //      to itself as in the other flavours.  The wave's leaves: a contiguous quarter of the tile.
 #ifdef CSTONE_RESORT_TRACE
-    RESORT_TRACE(1)
-    long long trSteps = 0, trIssue = 0, trWait = 0, trSort = 0, trFinish = 0, trT = clock64();
+        RESORT_TRACE(1)
+        long long trSteps = 0, trIssue = 0, trWait = 0, trSort = 0, trFinish = 0, trT = clock64();
 #define WAVE_TRACE(acc)                                                                                                \
     {                                                                                                                  \
         const long long now_ = clock64();                                                                              \
@@ -968,122 +998,146 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
 #else
 #define WAVE_TRACE(acc)
 #endif
-    const uint32_t per    = (nl + 3u) / 4u;
-    const uint32_t kBegin = min(nl, wave * per), kEnd = min(nl, kBegin + per);
-    if (kBegin >= kEnd) return;
-    // log2 of the segment size for the step that starts at leaf q (leaves of the next wave's quarter are not mine)
-    auto segmentBits = [&](uint32_t q) -> unsigned
-    {
-        const uint32_t s0 = slotsK[q];
-        const uint32_t s1 = q + 1 < kEnd ? slotsK[q + 1] : 0u;
-        const uint32_t s2 = q + 2 < kEnd ? slotsK[q + 2] : 0u;
-        const uint32_t s3 = q + 3 < kEnd ? slotsK[q + 3] : 0u;
-        const uint32_t m2 = max(s0, s1), m4 = max(m2, max(s2, s3));
-#ifdef CSTONE_WAVE_NO_PACKING
-        return 6u;
-#endif
-        return m4 <= 16u ? 4u : (m2 <= 32u ? 5u : 6u);
-    };
-    auto leafAt = [&](uint32_t q, unsigned bits)
-    {
-        const uint32_t kk = q + (lane >> bits);
-        const bool mine   = kk < kEnd;
-        Leaf f            = leafOf(mine ? kk : q);
-        if (!mine) f.nOld = f.nInc = f.nNew = f.slots = 0;
-        return f;
-    };
-    // one element per lane, sorted within segments of (1 << bits) lanes: the new content of the segments' leaves
-    auto finishSegments = [&](const Leaf& f, unsigned bits, uint32_t slot, K key, uint32_t idx, uint32_t d)
-    {
-        const uint32_t below   = uint32_t(__shfl_up(int(d), 1));
-        const bool clash       = slot != 0 && d != ~0u && below != ~0u && (d >> 8) == (below >> 8);
-        const uint64_t clashes = __ballot(clash);
-        const unsigned base    = lane - slot; // first lane of my segment
-        const uint64_t segment = bits == 6 ? ~0ull : (((1ull << (1u << bits)) - 1ull) << base);
-        const bool exact       = (clashes & segment) != 0; // equal leading bits somewhere in MY leaf
-        uint16_t* place        = sPlace[wave];
-        if (d != ~0u) place[base + (d & 0xFFu)] = uint16_t(slot); // the sorted element in this lane: slot -> place
-        __builtin_amdgcn_wave_barrier();
-        if (key != HOLE && !exact)
+        const uint32_t per    = (nl + 3u) / 4u;
+        const uint32_t kBegin = min(nl, wave * per), kEnd = min(nl, kBegin + per);
+        if (kBegin >= kEnd) return;
+        // log2 of the segment size in lanes for the step that starts at leaf q; 6: one leaf, more than 64 slots
+        auto segBits = [&](uint32_t q) -> unsigned
         {
-            const uint32_t at = place[lane];
-            if (at < f.nNew)
-            {
-                keysOut[f.ok + at]  = key;
-                orderOut[f.ok + at] = idx;
-            }
+            const uint32_t s0 = slotsK[q];
+            const uint32_t s1 = q + 1 < kEnd ? slotsK[q + 1] : 0u;
+            const uint32_t s2 = q + 2 < kEnd ? slotsK[q + 2] : 0u;
+            const uint32_t s3 = q + 3 < kEnd ? slotsK[q + 3] : 0u;
+            if (s0 > 64u) return 6u;
+            const uint32_t m2 = max(s0, s1), m4 = max(m2, max(s2, s3));
+            // (a second leaf with more than 64 slots waits for its own step: the segment next to the first stays empty)
+            return m4 <= 32u ? 4u : 5u;
+        };
+        auto leafAt2 = [&](uint32_t q, unsigned bits, uint32_t secondSlots)
+        {
+            const uint32_t seg = bits == 6 ? 0u : (lane >> bits);
+            const uint32_t kk  = q + seg;
+            bool mine          = kk < kEnd;
+            if (bits == 5 && seg == 1 && secondSlots > 64u) mine = false;
+            Leaf f = leafOf(mine ? kk : q);
+            if (!mine) f.nOld = f.nInc = f.nNew = f.slots = 0;
+            return f;
+        };
+        //! leaves the step at q with `bits` consumes
+        auto stepLeaves = [&](uint32_t q, unsigned bits) -> uint32_t
+        {
+            if (bits == 6) return 1u;
+            if (bits == 4) return 4u;
+            return (q + 1 < kEnd && slotsK[q + 1] > 64u) ? 1u : 2u;
+        };
+        uint32_t k    = kBegin;
+        unsigned bits = segBits(k);
+        Leaf cur      = leafAt2(k, bits, k + 1 < kEnd ? slotsK[k + 1] : 0u);
+        K keyN[2]        = {HOLE, HOLE};
+        uint32_t idxN[2] = {0, 0};
+        if (bits != 6)
+        {
+            const uint32_t sl = lane & ((1u << bits) - 1u);
+            loadSlot(cur, 2 * sl, keyN[0], idxN[0]);
+            loadSlot(cur, 2 * sl + 1, keyN[1], idxN[1]);
         }
-        __builtin_amdgcn_wave_barrier();
-        if (exact) exactLeaf(f, 1, &key, &idx);
-    };
-
-    uint32_t k    = kBegin;
-    unsigned bits = segmentBits(k);
-    Leaf cur      = leafAt(k, bits);
-    K keyN        = HOLE;
-    uint32_t idxN = 0;
-    if (cur.slots <= 64) loadSlot(cur, lane & ((1u << bits) - 1u), keyN, idxN);
 #pragma unroll 1
-    while (k < kEnd)
-    {
-        const Leaf f        = cur;
-        const unsigned b    = bits;
-        const K key         = keyN;
-        const uint32_t idx  = idxN;
-        const uint32_t slot = lane & ((1u << b) - 1u);
-        k += 64u >> b;
-        keyN = HOLE, idxN = 0;
-        if (k < kEnd)
+        while (k < kEnd)
         {
-            bits = segmentBits(k);
-            cur  = leafAt(k, bits);
-            if (cur.slots <= 64) loadSlot(cur, lane & ((1u << bits) - 1u), keyN, idxN);
-        }
-#ifdef CSTONE_RESORT_TRACE
-        ++trSteps;
-        WAVE_TRACE(trIssue)
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // (the keys of this step: all but the two loads just issued)
-        WAVE_TRACE(trWait)
-#endif
-        if (!__any(f.slots != 0)) continue;
-        if (f.slots > 64) // (only with one leaf for the whole wave)
-        {
-            if (f.slots <= 128) { bigLeaf(f, std::integral_constant<int, 2>{}); }
-            else { bigLeaf(f, std::integral_constant<int, 4>{}); }
-            continue;
-        }
-        // nothing arrived and what stayed is still in order (a departure leaves the largest key behind, so only
-        // departures from the end of a leaf pass): the content goes out as it came in
-        const K below     = K(__shfl_up((unsigned long long)key, 1));
-        const bool behind = slot != 0 && key < below;
-        if (!__any(f.nInc != 0 || behind))
-        {
-            if (slot < f.nNew)
+            const Leaf f          = cur;
+            const unsigned b      = bits;
+            const K key[2]        = {keyN[0], keyN[1]};
+            const uint32_t idx[2] = {idxN[0], idxN[1]};
+            const uint32_t sl     = lane & ((1u << (b == 6 ? 5u : b)) - 1u);
+            k += stepLeaves(k, b);
+            keyN[0] = keyN[1] = HOLE, idxN[0] = idxN[1] = 0;
+            if (k < kEnd)
             {
-                keysOut[f.ok + slot]  = key;
-                orderOut[f.ok + slot] = idx;
+                bits = segBits(k);
+                cur  = leafAt2(k, bits, k + 1 < kEnd ? slotsK[k + 1] : 0u);
+                if (bits != 6)
+                {
+                    const uint32_t sn = lane & ((1u << bits) - 1u);
+                    loadSlot(cur, 2 * sn, keyN[0], idxN[0]);
+                    loadSlot(cur, 2 * sn + 1, keyN[1], idxN[1]);
+                }
             }
-            continue;
-        }
-        uint32_t d[1] = {digestOf(f, key, slot)};
-        if (b == 6) waveSort64<1, 64>(d, lane);
-        else if (b == 5) waveSort64<1, 32>(d, lane);
-        else waveSort64<1, 16>(d, lane);
-        WAVE_TRACE(trSort)
-        finishSegments(f, b, slot, key, idx, d[0]);
-        WAVE_TRACE(trFinish)
-    }
 #ifdef CSTONE_RESORT_TRACE
-    if (g_resortTrace && threadIdx.x == 0)
-    {
-        uint64_t* tr = g_resortTrace + size_t(blockIdx.x) * RESORT_TRACE_SLOTS;
-        tr[2] = wall_clock64(), tr[3] = uint64_t(trSteps), tr[4] = uint64_t(trIssue), tr[5] = uint64_t(trWait),
-        tr[6] = uint64_t(trSort), tr[7] = uint64_t(trFinish);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tr[8] = wall_clock64();
-    }
+            ++trSteps;
+            WAVE_TRACE(trIssue)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // (the keys of this step: all but the loads just issued)
+            WAVE_TRACE(trWait)
+#endif
+            if (b == 6)
+            {
+                if (f.slots <= 128) { bigLeaf(f, std::integral_constant<int, 2>{}); }
+                else { bigLeaf(f, std::integral_constant<int, 4>{}); }
+                continue;
+            }
+            if (!__any(f.slots != 0)) continue;
+            // the element in front of (lane, 0) is (lane - 1, 1), the one in front of (lane, 1) is (lane, 0)
+            const K front = K(__shfl_up((unsigned long long)key[1], 1));
+            // nothing arrived and what stayed is still in order: the content goes out as it came in
+            const bool behind = (sl != 0 && key[0] < front) || key[1] < key[0];
+            if (!__any(f.nInc != 0 || behind))
+            {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                {
+                    if (2 * sl + r < f.nNew)
+                    {
+                        keysOut[f.ok + 2 * sl + r]  = key[r];
+                        orderOut[f.ok + 2 * sl + r] = idx[r];
+                    }
+                }
+                continue;
+            }
+            uint32_t d[2] = {digestOf(f, key[0], 2 * sl), digestOf(f, key[1], 2 * sl + 1)};
+            if (b == 5) pairSort<32>(d, lane);
+            else pairSort<16>(d, lane);
+            WAVE_TRACE(trSort)
+            // equal leading bits among neighbours of the new order?  (by segment: ballot masked with the segment's lanes)
+            const uint32_t dFront  = uint32_t(__shfl_up(int(d[1]), 1));
+            const bool clash0      = sl != 0 && d[0] != ~0u && dFront != ~0u && (d[0] >> 8) == (dFront >> 8);
+            const bool clash1      = d[1] != ~0u && d[0] != ~0u && (d[1] >> 8) == (d[0] >> 8);
+            const uint64_t clashes = __ballot(clash0 || clash1);
+            const unsigned base    = lane - sl; // first lane of my segment
+            const uint64_t segment = ((b == 5 ? 0xFFFFFFFFull : 0xFFFFull)) << base;
+            const bool exact       = (clashes & segment) != 0;
+            uint16_t* place        = sPlace[wave] + 2u * base; // 2 * SEG entries per segment
+            if (d[0] != ~0u) place[d[0] & 0xFFu] = uint16_t(2 * sl);
+            if (d[1] != ~0u) place[d[1] & 0xFFu] = uint16_t(2 * sl + 1);
+            __builtin_amdgcn_wave_barrier();
+            if (!exact)
+            {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                {
+                    if (key[r] == HOLE) continue;
+                    const uint32_t at = place[2 * sl + r];
+                    if (at < f.nNew)
+                    {
+                        keysOut[f.ok + at]  = key[r];
+                        orderOut[f.ok + at] = idx[r];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (exact) exactLeaf(f, 2, key, idx);
+            WAVE_TRACE(trFinish)
+        }
+#ifdef CSTONE_RESORT_TRACE
+        if (g_resortTrace && threadIdx.x == 0)
+        {
+            uint64_t* tr = g_resortTrace + size_t(blockIdx.x) * RESORT_TRACE_SLOTS;
+            tr[2] = wall_clock64(), tr[3] = uint64_t(trSteps), tr[4] = uint64_t(trIssue), tr[5] = uint64_t(trWait),
+            tr[6] = uint64_t(trSort), tr[7] = uint64_t(trFinish);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tr[8] = wall_clock64();
+        }
 #endif
 #undef WAVE_TRACE
+    }
 }
 
 /*! Positions of the leaf boundaries of ANOTHER tree (the focus tree after its rebalance) in the keys this re-sort has just
@@ -1281,19 +1335,18 @@ int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, 
     static const bool scanLeaves  = std::getenv("CSTONE_RESORT_SCAN") != nullptr;
     static const char* waveAllEnv = std::getenv("CSTONE_RESORT_WAVE_ALL");
     const bool waveAll = !scanLeaves && !alwaysCount && (waveAllEnv ? waveAllEnv[0] == '1' : numMovers >= grid);
-    // leaves that are less than half full on average: several of them per wave step (the kernel's PACK flavour; with
-    // fuller leaves there is rarely a pair to take and its bookkeeping costs 12-24 %; CSTONE_RESORT_PACK=0/1 forces either)
-    static const char* packEnv = std::getenv("CSTONE_RESORT_PACK");
-    const bool pack            = packEnv ? packEnv[0] == '1' : n_ < size_t(J) * 32u;
+    // leaves that are less than half full on average: two or four of them per wave step, two elements per lane (the
+    // kernel's flavour 1, pairSort; with fuller leaves it saves a few per cent when everything moves and loses more when
+    // most leaves are still in order -- a step then sorts two leaves if either needs it; CSTONE_RESORT_PAIRS=0/1 forces)
+    const char* pairsEnv        = std::getenv("CSTONE_RESORT_PAIRS"); // (read at every launch: the tests switch it)
+    const bool pairs            = pairsEnv ? pairsEnv[0] == '1' : n_ < size_t(J) * 32u;
+#define CSTONE_LEAF_WAVE_MODE(G, MODE)                                                                                 \
+    hipLaunchKernelGGL((leafSortWaveKernel<K, G, MODE>), grid, 256, 0, ctx->stream, keysIn, leafLo_.as<K>(),           \
+                       leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), layoutNew_.as<uint32_t>(), binKeys_.as<K>(), \
+                       binIdx_.as<uint32_t>(), J, alwaysCount, waveAll, keysOut, orderOut)
 #define CSTONE_LEAF_WAVE(G)                                                                                            \
-    if (pack)                                                                                                          \
-        hipLaunchKernelGGL((leafSortWaveKernel<K, G, true>), grid, 256, 0, ctx->stream, keysIn, leafLo_.as<K>(),       \
-                           leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), layoutNew_.as<uint32_t>(),               \
-                           binKeys_.as<K>(), binIdx_.as<uint32_t>(), J, alwaysCount, waveAll, keysOut, orderOut);      \
-    else                                                                                                               \
-        hipLaunchKernelGGL((leafSortWaveKernel<K, G, false>), grid, 256, 0, ctx->stream, keysIn, leafLo_.as<K>(),      \
-                           leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), layoutNew_.as<uint32_t>(),               \
-                           binKeys_.as<K>(), binIdx_.as<uint32_t>(), J, alwaysCount, waveAll, keysOut, orderOut)
+    if (pairs) CSTONE_LEAF_WAVE_MODE(G, 1);                                                                            \
+    else CSTONE_LEAF_WAVE_MODE(G, 0)
     if (leavesPerTile == 64)
     {
         if (!waveAll) CSTONE_LEAF_SORT(64, false);
@@ -1315,6 +1368,7 @@ int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, 
     else return fail(ctx, CSTONE_E_INTERNAL, "resort: %d leaves per workgroup not instantiated", leavesPerTile);
 #undef CSTONE_LEAF_SORT
 #undef CSTONE_LEAF_WAVE
+#undef CSTONE_LEAF_WAVE_MODE
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

@@ -9,6 +9,15 @@ import numpy as np
 import pytest
 
 
+@pytest.fixture(autouse=True, params=["auto", "one-per-lane", "two-per-lane"])
+def leaf_pass_flavour(request, monkeypatch):
+    """every test of this module runs with the leaf pass choosing its flavour itself (by the fill of the leaves) and with
+    either flavour of leafSortWaveKernel forced (CSTONE_RESORT_PAIRS, csrc/resort.hip)"""
+    if request.param != "auto":
+        monkeypatch.setenv("CSTONE_RESORT_PAIRS", "0" if request.param == "one-per-lane" else "1")
+    yield
+
+
 class _Stepper:
     """a client's time-stepping loop: the arrays a sync returns are moved in place and handed to the next sync"""
 

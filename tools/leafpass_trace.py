@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""phase budget of the leaf pass for tiles with movers (leafSortWaveKernel) from a CSTONE_RESORT_TRACE build:
+"""phase budget of the leaf pass for tiles with movers (leafSortWaveKernel, the flavour with two elements per lane:
+run with CSTONE_RESORT_PAIRS=1 at sizes where it is not the default) from a CSTONE_RESORT_TRACE build:
    tools/build_variant.sh rtrace -DCSTONE_RESORT_TRACE resort
    CSTONE_HIP_LIB=.../lib/variants/rtrace.so python tools/leafpass_trace.py [particles] [jiggle|drift]"""
 import ctypes as C
