@@ -703,16 +703,15 @@ __device__ __forceinline__ void halfClean(uint32_t (&v)[N], unsigned lane)
 /*! N independent ascending sorts of 64 values each (register n of every lane: one sort): bitonic network without
  *  direction flags -- every merge of two sorted blocks starts with a compare-exchange against the MIRRORED position
  *  (distance k - 1), followed by half-cleaners at distances k/4 ... 1, the lower lane always keeps the minimum. */
-template<int N, int S = 64>
+template<int N>
 __device__ __forceinline__ void waveSort64(uint32_t (&v)[N], unsigned lane)
 {
-    cmpExchange<1, 1u, N>(v, lane);                            // blocks of 2
-    cmpExchange<3, 2u, N>(v, lane), halfClean<1, N>(v, lane);  // 4
-    cmpExchange<7, 4u, N>(v, lane), halfClean<2, N>(v, lane);  // 8
-    cmpExchange<15, 8u, N>(v, lane), halfClean<4, N>(v, lane); // 16
-    // S < 64: the wave holds 64 / S independent sorts of S values in consecutive lanes (several small leaves at once)
-    if constexpr (S >= 32) { cmpExchange<31, 16u, N>(v, lane), halfClean<8, N>(v, lane); }
-    if constexpr (S >= 64) { cmpExchange<63, 32u, N>(v, lane), halfClean<16, N>(v, lane); }
+    cmpExchange<1, 1u, N>(v, lane);                              // blocks of 2
+    cmpExchange<3, 2u, N>(v, lane), halfClean<1, N>(v, lane);    // 4
+    cmpExchange<7, 4u, N>(v, lane), halfClean<2, N>(v, lane);    // 8
+    cmpExchange<15, 8u, N>(v, lane), halfClean<4, N>(v, lane);   // 16
+    cmpExchange<31, 16u, N>(v, lane), halfClean<8, N>(v, lane);  // 32
+    cmpExchange<63, 32u, N>(v, lane), halfClean<16, N>(v, lane); // 64
 }
 
 //! ascending sort of the 64 R values d[r] (element 64 r + lane) of a wave
