@@ -1338,7 +1338,8 @@ int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, 
     // kernel's flavour 1, pairSort; with fuller leaves it saves a few per cent when everything moves and loses more when
     // most leaves are still in order -- a step then sorts two leaves if either needs it; CSTONE_RESORT_PAIRS=0/1 forces)
     const char* pairsEnv        = std::getenv("CSTONE_RESORT_PAIRS"); // (read at every launch: the tests switch it)
-    const bool pairs            = pairsEnv ? pairsEnv[0] == '1' : n_ < size_t(J) * 32u;
+    // (... and with fuller leaves when more than 3 % of the particles changed their leaf: hardly a leaf is still in order then)
+    const bool pairs = pairsEnv ? pairsEnv[0] == '1' : (n_ < size_t(J) * 32u || size_t(numMovers) * 32u > n_);
 #define CSTONE_LEAF_WAVE_MODE(G, MODE)                                                                                 \
     hipLaunchKernelGGL((leafSortWaveKernel<K, G, MODE>), grid, 256, 0, ctx->stream, keysIn, leafLo_.as<K>(),           \
                        leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), layoutNew_.as<uint32_t>(), binKeys_.as<K>(), \
