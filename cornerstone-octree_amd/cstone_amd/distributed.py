@@ -209,6 +209,12 @@ class NativeDistributedDomain:
             ctx._chk(ctx.lib.cstone_hip_domain_mr_set_theta(self.h, C.c_float(theta)), "domain_mr_set_theta")
         self._keep = None
 
+    SORT_INCREMENTAL, SORT_FROM_SCRATCH, SORT_ALL_DIGITS = 0, 1, 2  # CSTONE_SORT_*
+
+    def set_sort_mode(self, mode):
+        """how a sync orders this rank's particles (identical results): cstone_hip_domain_mr_set_sort_mode"""
+        self.ctx._chk(self.ctx.lib.cstone_hip_domain_mr_set_sort_mode(self.h, C.c_int(mode)), "domain_mr_set_sort_mode")
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.cstone_hip_domain_mr_destroy(self.h)

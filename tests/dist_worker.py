@@ -262,6 +262,7 @@ def main():
         os.environ["CSTONE_NO_SPECULATIVE_BOX"] = "1"
         dom_b = make_native(backend, max(64, N // (100 * P)), 16, lim, bc, curve, a.key_bits, a.real_bits, a.owner_side)
         del os.environ["CSTONE_NO_SPECULATIVE_BOX"]
+        dom_b.set_sort_mode(dom_b.SORT_ALL_DIGITS)  # ... and never re-sorts (cstone_hip_domain_mr_set_sort_mode)
         g = torch.Generator(device=dev).manual_seed(77 + rank)
         xa, ya, za, ha = x, y, z, h
         for s_ in range(a.spec_box):
@@ -289,8 +290,8 @@ def main():
         flag = torch.tensor([1 if ok else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
-        # the speculating domain re-sorted where the box held (at least two of the quiet steps)
-        ok = ok and int(dom.view().resorts) >= 2
+        # the speculating domain re-sorted where the box held (at least two of the quiet steps), the other one never
+        ok = ok and int(dom.view().resorts) >= 2 and int(dom_b.view().resorts) == 0
         if rank == 0:
             print("DIST_RESULT " + json.dumps(dict(ok=ok, ranks=P, report=report)))
         dist.destroy_process_group()
