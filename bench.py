@@ -11,7 +11,14 @@ reference include/cstone/domain/domain.hpp:196-243 with the stages a rank execut
     layout scan -> gather x,y,z into SFC order.
 Inputs are synthetic uniform-random particles, resident in HBM before the timed region starts.
 
-Usage: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank per GPU)
+Usage: python bench.py --gpus N --steps K --warmup W
+  N > 1 without a launcher (no WORLD_SIZE in the environment): this process starts N ranks itself -- a child
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`, one rank per GPU over
+  RCCL -- BEFORE it makes any GPU call, relays rank 0's JSON line and exits with the child's code.  Under a launcher
+  (WORLD_SIZE / RANK / LOCAL_RANK set) it is one of the ranks.
+  --path single | mr   which Domain::sync runs: cstone_hip_domain_sync_scratch (one rank only) or the multi-rank
+                       cstone_hip_domain_mr_sync (default for N > 1; with N = 1 an RCCL world of one rank)
+  --dist uniform | plummer | clustered   the cloud (cstone_amd/clouds.py)
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -45,46 +52,62 @@ def parse():
     p.add_argument("--neighbor-targets", type=float, default=1e7,
                    help="after the timed region: findNeighbors for this many particles of the synced domain (0: skip)")
     p.add_argument("--cpu-sample", type=float, default=4e6, help="particles in the CPU baseline sample")
+    p.add_argument("--path", default=None, choices=["single", "mr"],
+                   help="single: cstone_hip_domain_sync_scratch (N = 1 only); mr: cstone_hip_domain_mr_sync with RCCL "
+                        "collectives (default for N > 1; at N = 1 a world of one rank: the same code path as the N-GPU run)")
+    p.add_argument("--dist", default="uniform", choices=["uniform", "plummer", "clustered"],
+                   help="the particle cloud (cstone_amd/clouds.py): BASELINE configs[3] / [2] / [4]")
+    p.add_argument("--no-mr-extra", action="store_true",
+                   help="N = 1, --path single: skip extras.mr_path_world_of_one (the same cloud through the multi-rank path)")
+    p.add_argument("--launch-only", action="store_true",
+                   help="start the ranks, let each print its RANK / WORLD_SIZE / LOCAL_RANK and leave (no GPU work): the "
+                        "check that --gpus N really starts N ranks")
+    p.add_argument("--master-port", type=int, default=0, help="rendezvous port of the ranks this process starts (0: a free one)")
     return p.parse_args()
+
+
+def launch_ranks(args):
+    """--gpus N > 1 and no launcher around us: start the N ranks (one per GPU, torch.distributed.run over 127.0.0.1) as a
+    CHILD of this process, which has not touched the GPU and never will; relay what rank 0 prints; return the child's
+    exit code.  (The reference starts its GPU ranks with one MPI rank per device the same way,
+    test/integration_mpi/CMakeLists.txt:53-59.)"""
+    import socket
+    import subprocess
+
+    port = args.master_port
+    if not port:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CSTONE_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:  # rank 0's JSON line (and, with --launch-only, one line per rank)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
 
 
 class SyncPipeline:
     """Steady-state domain.sync through the C ABI: cstone_hip_domain_sync on device-resident arrays."""
 
     def __init__(self, ctx, n, key_bits, real_bits, curve, bucket, bucket_focus, seed, dist="uniform"):
-        import math
-
         import torch
 
         import cstone_amd
+        from cstone_amd import clouds
         from cstone_amd.domain import Domain
 
-        self.ctx, self.n, self.kb, self.rb = ctx, n, key_bits, real_bits
+        self.ctx, self.n, self.kb, self.rb, self.dist = ctx, n, key_bits, real_bits, dist
         cv = cstone_amd.HILBERT if curve == "hilbert" else cstone_amd.MORTON
         dev = ctx.device
         rdt = torch.float64 if real_bits == 64 else torch.float32
-        g = torch.Generator(device=dev).manual_seed(seed)
-        if dist == "plummer":
-            # Plummer sphere of scale radius 1 cut at r = 10 (BASELINE configs[2]); h from the local density so that a
-            # sphere of radius 2h holds about 100 particles
-            u = torch.rand(n, dtype=torch.float64, device=dev, generator=g).clamp_(1e-12, 1.0)
-            r = (u.pow(-2.0 / 3.0) - 1.0).clamp_min_(1e-12).rsqrt().clamp_(max=10.0)
-            ct = 2 * torch.rand(n, dtype=torch.float64, device=dev, generator=g) - 1
-            ph = 2 * math.pi * torch.rand(n, dtype=torch.float64, device=dev, generator=g)
-            st = (1 - ct * ct).sqrt()
-            self.x, self.y, self.z = (r * st * ph.cos()).to(rdt), (r * st * ph.sin()).to(rdt), (r * ct).to(rdt)
-            rho = 3.0 * n / (4 * math.pi) * (1 + r * r).pow(-2.5)
-            self.h = (0.5 * (3.0 * 100.0 / (4 * math.pi * rho)).pow(1 / 3)).clamp_(max=1.0).to(rdt)
-            del u, r, ct, ph, st, rho
-            lim = [-10.001, 10.001] * 3
-        else:
-            self.x = torch.rand(n, dtype=rdt, device=dev, generator=g)
-            self.y = torch.rand(n, dtype=rdt, device=dev, generator=g)
-            self.z = torch.rand(n, dtype=rdt, device=dev, generator=g)
-            # h ~ 1.2 * (3*100/(4 pi N))^(1/3) / 2  (about 100 neighbours inside 2h), SURVEY 8(d)
-            h0 = 0.6 * (3.0 * 100 / (4 * 3.141592653589793 * n)) ** (1.0 / 3.0)
-            self.h = torch.full((n,), h0, dtype=rdt, device=dev)
-            lim = [0, 1] * 3
+        # the cloud (SURVEY.md section 8d; cstone_amd/clouds.py): uniform in the unit cube, the reference's Plummer sphere
+        # (test/coord_samples/plummer.hpp restated, srand48(42)) or the 8-blob mixture; open boundaries: the domain
+        # measures its box itself (makeGlobalBox + limitBoxShrinking), `lim` is only where it starts from
+        self.x, self.y, self.z, self.h, lim = clouds.make_cloud(dist, n, n, dev, rdt, seed)
         self.keys = torch.zeros(n, dtype=cstone_amd.key_torch_dtype(key_bits), device=dev)
         # the scratch tuple of the client (R/domain/domain.hpp:196-206: at least three vectors there as well)
         self.scratch = [torch.empty(n, dtype=rdt, device=dev) for _ in range(int(os.environ.get("CSTONE_BENCH_SCRATCH", "3")))]
@@ -139,35 +162,32 @@ class SyncPipeline:
         n = self.x.numel()
         m = max(1, n // 100)
         idx = torch.randint(0, n, (m,), device=self.x.device, generator=self.g)
-        h0 = float(self.h[0])
+        hh = self.h[idx]
         for a in (self.x, self.y, self.z):
-            d = (torch.rand(m, dtype=a.dtype, device=a.device, generator=self.g) - 0.5) * (4 * h0)
-            a[idx] = (a[idx] + d).clamp_(0.0, 1.0)
+            d = (torch.rand(m, dtype=a.dtype, device=a.device, generator=self.g) - 0.5) * (4 * hh)
+            a[idx] = (a[idx] + d).clamp_(0.0, 1.0) if self.dist == "uniform" else a[idx] + d
 
-    def drift(self, frac=0.1):
-        """displace EVERY particle by up to frac * h per coordinate (a time step at a Courant number of that order)"""
+    def drift(self, frac=0.1, clamp=None):
+        """displace EVERY particle by up to frac * h per coordinate (a time step at a Courant number of that order).  The
+        uniform cloud of the headline is kept inside [0, 1] (its box then stays what it is: the steady state of a
+        periodic or walled simulation); a Plummer sphere or the blobs are NOT clamped: their outermost particles move and
+        the open box follows them"""
         import torch
 
         if not hasattr(self, "g"):
             self.g = torch.Generator(device=self.x.device).manual_seed(1234)
-        h0 = float(self.h[0])
+        clamp = (self.dist == "uniform") if clamp is None else clamp
         for a in (self.x, self.y, self.z):
             d = torch.rand(a.numel(), dtype=a.dtype, device=a.device, generator=self.g)
-            a.add_(d.sub_(0.5).mul_(2 * frac * h0)).clamp_(0.0, 1.0)
+            a.add_(d.sub_(0.5).mul_(2 * frac).mul_(self.h))
+            if clamp:
+                a.clamp_(0.0, 1.0)
             del d
 
     def drift_unclamped(self, frac=0.1):
         """the same displacement without keeping the particles inside [0, 1]: the outermost particles of the open box
         move, so the box of the reference's limitBoxShrinking rule changes with every sync"""
-        import torch
-
-        if not hasattr(self, "g"):
-            self.g = torch.Generator(device=self.x.device).manual_seed(1234)
-        h0 = float(self.h[0])
-        for a in (self.x, self.y, self.z):
-            d = torch.rand(a.numel(), dtype=a.dtype, device=a.device, generator=self.g)
-            a.add_(d.sub_(0.5).mul_(2 * frac * h0))
-            del d
+        self.drift(frac, clamp=False)
 
     def find_neighbors(self, targets, ngmax):
         """cstone_hip_find_neighbors on the synced domain's own tree view (NOT part of the timed metric)"""
@@ -224,34 +244,32 @@ class DistributedPipeline:
     of the cloud (the first sync moves (N-1)/N of it); before every step a random 1% of the assigned particles is
     displaced by up to 2h so that the steady-state exchange really moves particles across the boundaries."""
 
-    def __init__(self, ctx, n_local, n_global, key_bits, real_bits, curve, bucket, bucket_focus, seed):
+    def __init__(self, ctx, n_local, n_global, key_bits, real_bits, curve, bucket, bucket_focus, seed, dist="uniform",
+                 rank=0, world=1, backend="nccl"):
         import torch
 
         import cstone_amd
-        from cstone_amd.distributed import NativeDistributedDomain
+        from cstone_amd import clouds
+        from cstone_amd.distributed import NativeDistributedDomain, RcclCollectives
 
-        self.torch = torch
+        self.torch, self.dist = torch, dist
         dev = ctx.device
         rdt = torch.float64 if real_bits == 64 else torch.float32
-        self.g = torch.Generator(device=dev).manual_seed(seed)
-        self.x, self.y, self.z = [torch.rand(n_local, dtype=rdt, device=dev, generator=self.g) for _ in range(3)]
-        self.h0 = 0.6 * (3.0 * 100 / (4 * 3.141592653589793 * n_global)) ** (1.0 / 3.0)
-        self.h = torch.full((n_local,), self.h0, dtype=rdt, device=dev)
+        self.g = torch.Generator(device=dev).manual_seed(seed + 1000 * rank)
+        # this rank's share: a random 1/N of the global cloud
+        self.x, self.y, self.z, self.h, lim = clouds.make_cloud(dist, n_local, n_global, dev, rdt, seed, rank, world)
         cv = cstone_amd.HILBERT if curve == "hilbert" else cstone_amd.MORTON
         self.native = True  # the multi-rank sync inside libcstone_hip (cstone_hip_domain_mr_sync)
         self.transport = "torch.distributed callbacks"
-        import torch.distributed as dist
-
-        from cstone_amd.distributed import RcclCollectives
-
         coll = None
-        if dist.get_backend() == "nccl" and os.environ.get("CSTONE_BENCH_TORCH_COLL") != "1":
+        self.rccl_ranks = 0
+        if backend == "nccl" and os.environ.get("CSTONE_BENCH_TORCH_COLL") != "1":
             # the data path: RCCL from C++ on the library's stream (csrc/comm_rccl.hip); torch.distributed only carries the
             # RCCL id at start-up and serves the bench's own barriers and the max over the ranks
             coll = RcclCollectives(ctx)
+            self.rccl_ranks = coll.size  # size of the communicator cstone_hip_comm_rccl_create really built
             self.transport = "RCCL inside libcstone_hip (cstone_hip_comm_rccl, collectives on the library's stream)"
-        self.dom = NativeDistributedDomain(ctx, cv, key_bits, real_bits, bucket, bucket_focus, [0, 1] * 3, (0, 0, 0),
-                                           coll=coll)
+        self.dom = NativeDistributedDomain(ctx, cv, key_bits, real_bits, bucket, bucket_focus, lim, (0, 0, 0), coll=coll)
         self.f_leaves = self.g_leaves = 0
         self.assigned = n_local
         self.halos = 0
@@ -262,16 +280,20 @@ class DistributedPipeline:
         n = self.x.numel()
         m = max(1, n // 100)
         idx = torch.randint(0, n, (m,), device=self.x.device, generator=self.g)
+        hh = self.h[idx]
         for a in (self.x, self.y, self.z):
-            d = (torch.rand(m, dtype=a.dtype, device=a.device, generator=self.g) - 0.5) * (4 * self.h0)
-            a[idx] = (a[idx] + d).clamp_(0.0, 1.0)
+            d = (torch.rand(m, dtype=a.dtype, device=a.device, generator=self.g) - 0.5) * (4 * hh)
+            a[idx] = (a[idx] + d).clamp_(0.0, 1.0) if self.dist == "uniform" else a[idx] + d
 
-    def drift(self, frac=0.1):
+    def drift(self, frac=0.1, clamp=None):
         """displace EVERY assigned particle by up to frac * h per coordinate (the same motion as on one GPU)"""
         torch = self.torch
+        clamp = (self.dist == "uniform") if clamp is None else clamp
         for a in (self.x, self.y, self.z):
             d = torch.rand(a.numel(), dtype=a.dtype, device=a.device, generator=self.g)
-            a.add_(d.sub_(0.5).mul_(2 * frac * self.h0)).clamp_(0.0, 1.0)
+            a.add_(d.sub_(0.5).mul_(2 * frac).mul_(self.h))
+            if clamp:
+                a.clamp_(0.0, 1.0)
             del d
 
     def step(self):
@@ -409,44 +431,64 @@ def cpu_baseline(n_sample, key_bits, real_bits, curve, bucket_focus, min_seconds
 
 def main():
     args = parse()
+    launched = os.environ.get("WORLD_SIZE") is not None  # under torch.distributed.run (the driver's, or our own child)
+    if not launched and args.gpus > 1:
+        # N ranks asked for and no launcher around us: start them (before anything here touches the GPU) and relay
+        sys.exit(launch_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_only:
+        print(json.dumps({"launch_only": True, "rank": rank, "world_size": world, "local_rank": local_rank,
+                          "gpus_requested": args.gpus, "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}),
+              flush=True)
+        return
+    if launched and world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); the world size counts", file=sys.stderr)
+    path = args.path or ("mr" if world > 1 or os.environ.get("CSTONE_BENCH_FORCE_DIST") == "1" else "single")
+    if path == "single" and world > 1:
+        sys.exit("bench.py: --path single is the one-rank Domain::sync; several ranks need --path mr")
+
     import torch
 
     import cstone_amd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # CSTONE_BENCH_BACKEND=gloo: rehearsal of the N-rank bench logic with several processes on ONE GPU (the numbers mean
+    # nothing then: host-staged collectives, shared device)
+    backend = os.environ.get("CSTONE_BENCH_BACKEND", "nccl")
+    distributed = path == "mr"
+
+    def init_group():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # CSTONE_BENCH_BACKEND=gloo: rehearsal of the N-rank bench logic with several processes on ONE GPU (the numbers
-        # mean nothing then: host-staged collectives, shared device)
-        backend = os.environ.get("CSTONE_BENCH_BACKEND", "nccl")
+        if world == 1 and "MASTER_PORT" not in os.environ:  # the RCCL world of one rank on one GPU
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend)
-            local_rank = 0
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if backend != "nccl":
+        local_rank = 0
+    if distributed:
+        init_group()
     torch.cuda.set_device(local_rank)
     ctx = cstone_amd.Context(local_rank)
 
     n_global = int(args.particles)
     n_local = n_global // world
     bucket_global = max(64, n_global // (100 * world))
-    distributed = world > 1 or os.environ.get("CSTONE_BENCH_FORCE_DIST") == "1"
     if distributed:
-        if world == 1:  # rehearsal of the RCCL code path on one GPU
-            import torch.distributed as dist
-
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29555")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         pipe = DistributedPipeline(ctx, n_local, n_global, args.key_bits, args.real_bits, args.curve, bucket_global,
-                                   args.bucket_focus, seed=42 + rank)
+                                   args.bucket_focus, seed=42, dist=args.dist, rank=rank, world=world, backend=backend)
     else:
         pipe = SyncPipeline(ctx, n_local, args.key_bits, args.real_bits, args.curve, bucket_global, args.bucket_focus,
-                            seed=42 + rank)
+                            seed=42 + rank, dist=args.dist)
 
     def barrier():
         if distributed:
@@ -535,6 +577,12 @@ def main():
         timed_stages["sort_pass"] = timed_stages["sort_pass_iota"] = (0.0, 0)
         del rk, rv, work
         invariants_ok = pipe.invariants(n_local * world)
+    # what the output says about the headline pipeline (later sections replace `pipe`)
+    head = {"f_leaves": pipe.f_leaves, "g_leaves": pipe.g_leaves,
+            "n_scratch": len(pipe.scratch) if hasattr(pipe, "scratch") else 1}
+    if distributed:
+        head.update(assigned=pipe.assigned, halos=pipe.halos, stats=dict(pipe.stats), transport=pipe.transport,
+                    rccl_ranks=pipe.rccl_ranks, resorts=int(pipe.dom.view().resorts))
     extras = {}
     if not distributed and not args.no_variants:
         # the same syncs with the radix sort forced over ALL key digits (what the reference's GPU path does every time;
@@ -622,41 +670,91 @@ def main():
                                           "ms_per_step": per1 * 1e3, "value": n1 / per1, "unit": "particles/s",
                                           "leaves": leaves1}
         del xs, order
-        # BASELINE configs[2]: the same number of Plummer-sphere particles (deep, very uneven tree), full Domain::sync and
-        # findNeighbors on the domain's octree; reported next to the headline number, not part of it
-        f_leaves_uniform, g_leaves_uniform = pipe.f_leaves, pipe.g_leaves
+        # BASELINE configs[2]: the same number of Plummer-sphere particles (the reference's recipe, deep and very uneven
+        # tree), full Domain::sync as a client runs it -- tight box measured by the domain, EVERY particle displaced by
+        # <= 0.1 h before every sync and NOT clamped, so the outermost particles move the open box -- and findNeighbors on
+        # the domain's octree; reported next to the headline number, not part of it
         del pipe
         torch.cuda.empty_cache()
+        t2 = time.perf_counter()
         pl = SyncPipeline(ctx, n_local, args.key_bits, args.real_bits, args.curve, bucket_global, args.bucket_focus,
                           seed=7, dist="plummer")
+        torch.cuda.synchronize()
+        gen_s = time.perf_counter() - t2
+        pipe = pl  # (run_syncs steps `pipe`)
         barrier()
         t3 = time.perf_counter()
         pl.first_sync()
         barrier()
         first_pl = time.perf_counter() - t3
-        pl.step()
-        barrier()
-        t4 = time.perf_counter()
-        for _ in range(args.steps):
-            pl.step()
-        barrier()
-        per = (time.perf_counter() - t4) / args.steps
+        run_syncs(2, pl.drift)
+        st0 = pl.dom.stats()
+        ctx.profile_enable(0 if args.no_stage_timers else 1)
+        ctx.profile_reset()
+        per = run_syncs(args.steps, pl.drift) / args.steps
+        st1 = pl.dom.stats()
+        pl_stage = {k: round(ctx.profile_get(k)[0] / args.steps, 4) for k in cstone_amd.STAGES if ctx.profile_get(k)[1]}
         pl.note_leaves()
-        pl_stats = pl.dom.stats()
-        extras["plummer"] = {"workload": f"{n_local:.0e} Plummer-sphere particles (r <= 10), bucketFocus {args.bucket_focus}",
-                             "first_sync_ms": first_pl * 1e3, "ms_per_step": per * 1e3, "value": n_local / per,
-                             "unit": "particles/s", "focus_leaves": pl.f_leaves,
-                             "syncs": {k: pl_stats[k] for k in ("syncs", "resorts", "resort_fallbacks", "box_redos")},
+        vb = pl.dom.view().box
+        lim = [float(v) for v in list(vb.lim)]
+        run_syncs(2, None)
+        st2 = pl.dom.stats()
+        per0 = run_syncs(args.steps, None) / args.steps
+        st3 = pl.dom.stats()
+        counters = ("syncs", "resorts", "resort_fallbacks", "box_redos", "full_sort_fallbacks")
+        extras["plummer"] = {"workload": f"{n_local:.0e} particles of the reference's Plummer sphere (test/coord_samples/"
+                                         f"plummer.hpp restated: srand48(42), R < 100, scale 3 pi / 16, centre of mass at the "
+                                         f"origin), h = half the radius that holds 100 particles at the local density, "
+                                         f"bucketFocus {args.bucket_focus}, tight open box; before every sync EVERY particle is "
+                                         f"displaced by <= 0.1 h per coordinate, not clamped",
+                             "generation_s": gen_s, "first_sync_ms": first_pl * 1e3, "ms_per_step": per * 1e3,
+                             "value": n_local / per, "unit": "particles/s", "focus_leaves": pl.f_leaves, "box": lim,
+                             "syncs": {k: st1[k] - st0[k] for k in counters} | {"last_movers": st1["last_movers"]},
+                             "stage_ms_per_step": pl_stage,
+                             "zero_motion": {"ms_per_step": per0 * 1e3, "value": n_local / per0,
+                                             "syncs": {k: st3[k] - st2[k] for k in counters},
+                                             "note": "the same cloud with nothing moving between the syncs (round 3's number)"},
                              "find_neighbors": pl.find_neighbors(args.neighbor_targets, 0)
                              if args.neighbor_targets > 0 else None}
-        pipe = pl
-        pipe.f_leaves, pipe.g_leaves = f_leaves_uniform, g_leaves_uniform  # config reports the headline workload
+    if not distributed and world == 1 and not args.no_mr_extra:
+        # the curve's first point must be comparable with the others: the same cloud through the code path the N-GPU runs
+        # take (cstone_hip_domain_mr_sync, collectives served by RCCL with a communicator of ONE rank)
+        keep = pipe
+        pipe = None
+        del keep
+        torch.cuda.empty_cache()
+        init_group()
+        mr = DistributedPipeline(ctx, n_local, n_global, args.key_bits, args.real_bits, args.curve, bucket_global,
+                                 args.bucket_focus, seed=42, dist=args.dist, rank=0, world=1, backend=backend)
+        pipe = mr
+        distributed = True  # (barrier() now includes the process group's)
+        barrier()
+        t6 = time.perf_counter()
+        mr.first_sync()
+        barrier()
+        first_mr = time.perf_counter() - t6
+        run_syncs(args.warmup, mr.drift)
+        ctx.profile_enable(0)
+        dt = run_syncs(args.steps, mr.drift) / args.steps
+        ctx.profile_enable(0 if args.no_stage_timers else 1)
+        ctx.profile_reset()
+        run_syncs(args.steps, mr.drift)
+        mr_stage = {k: round(ctx.profile_get(k)[0] / args.steps, 4) for k in cstone_amd.STAGES if ctx.profile_get(k)[1]}
+        extras["mr_path_world_of_one"] = {
+            "workload": "the headline cloud and motion through cstone_hip_domain_mr_sync (the N-GPU code path) on one rank",
+            "ms_per_step": dt * 1e3, "value": n_local / dt, "unit": "particles/s", "first_sync_ms": first_mr * 1e3,
+            "stage_ms_per_step": mr_stage, "transport": mr.transport, "rccl_ranks": mr.rccl_ranks,
+            "syncs_resorted_total": int(mr.dom.view().resorts), "invariants_ok": mr.invariants(n_local)}
+        distributed = False
+        pipe = None
+        del mr
+        torch.distributed.destroy_process_group()
     ctx.profile_enable(False)
     ctx.sync()  # raises if a device-side check tripped
 
     if rank == 0:
         kbytes, rbytes = args.key_bits // 8, args.real_bits // 8
-        n_scratch = len(pipe.scratch) if hasattr(pipe, "scratch") else 1
+        n_scratch = head["n_scratch"]
         # ---- roofline.  Every kernel that moves the particle arrays, with its ALGORITHMIC bytes per launch (DESIGN.md
         # section 3) over its launch time measured live with HIP events on the context's stream (stage timers).  The
         # top-level fields are those of the kernel with the largest total time inside the timed syncs.
@@ -768,7 +866,7 @@ def main():
             "vs_baseline": None,
             "dtype": f"u{args.key_bits}/f{args.real_bits}",
             "data": "synthetic",
-            "config": {"workload": f"{n_global:.0e} uniform particles, {args.key_bits}-bit {args.curve} keys, "
+            "config": {"workload": f"{n_global:.0e} {args.dist} particles, {args.key_bits}-bit {args.curve} keys, "
                                    f"f{args.real_bits} coordinates, bucketFocus {args.bucket_focus}, "
                                    f"bucket {bucket_global}, time-stepping loop: before every sync EVERY particle is "
                                    f"displaced by <= 0.1 h per coordinate (outside the timed intervals, each sync is "
@@ -780,12 +878,14 @@ def main():
                                    + ("" if not distributed else
                                       f"; {world} rank(s): SFC domain decomposition, particle exchange, locally essential "
                                       f"tree and halo exchange with all_to_all over RCCL"),
-                       "particles_per_gpu": n_local, "focus_leaves": pipe.f_leaves, "global_leaves": pipe.g_leaves,
+                       "particles_per_gpu": n_local, "focus_leaves": head["f_leaves"], "global_leaves": head["g_leaves"],
+                       "path": path, "dist": args.dist, "self_launched": os.environ.get("CSTONE_BENCH_SELF_LAUNCHED") == "1",
                        **({"syncs_timed": timed_stats} if timed_stats else {}),
-                       **({"invariants_ok": invariants_ok, "rank0_assigned": pipe.assigned, "rank0_halos": pipe.halos,
-                           "rank0_exchange": dict(pipe.stats),
+                       **({"invariants_ok": invariants_ok, "rank0_assigned": head["assigned"], "rank0_halos": head["halos"],
+                           "rank0_exchange": head["stats"], "rccl_ranks": head["rccl_ranks"],
+                           "rank0_syncs_resorted_total": head["resorts"],
                            "orchestration": "libcstone_hip (cstone_hip_domain_mr_sync)",
-                           "transport": pipe.transport} if distributed else {})},
+                           "transport": head["transport"]} if distributed else {})},
             "roofline": roofline,
             "stage_ms_per_step": stage_ms,
             "first_sync_ms": first_sync_ms,

@@ -434,10 +434,19 @@ class Oracle(_CpuImpl):
         assert rc == 0, rc
         return x, y, z
 
+    def plummer(self, n, real_bits=64):
+        """the reference's Plummer sphere (test/coord_samples/plummer.hpp, srand48(42)), serial"""
+        x, y, z = [np.empty(n, dtype=real_dtype(real_bits)) for _ in range(3)]
+        rc = self._f("plummer")(C.c_int(real_bits), C.c_size_t(n), _p(x), _p(y), _p(z))
+        assert rc == 0, rc
+        return x, y, z
+
 
 class Reference(_CpuImpl):
     prefix = "cstone_ref_"
     libpath = os.path.join(HERE, "_ref", "libcstone_ref.so")
+
+    plummer = Oracle.plummer  # (cstone_ref_plummer: the reference's own plummer<T>(n))
 
 
 def reference_available():

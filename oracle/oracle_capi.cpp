@@ -574,6 +574,50 @@ int cstone_oracle_random_uniform(int real_bits, unsigned seed, size_t n, const d
                     });
 }
 
+/*! the Plummer sphere of the reference's benchmarks (test/coord_samples/plummer.hpp:17-79), restated: drand48 behind
+ *  srand48(42), R = 1 / sqrt(u^(-2/3) - 1) kept while R < 100, Z = (1 - 2u) R, theta = 2 pi u, everything scaled by
+ *  3 pi / 16 and moved so that the centre of mass (equal masses 1/n, accumulated in T like the reference) is the origin.
+ *  Serial by construction (one random stream); 1e8 particles take about 15 s. */
+int cstone_oracle_plummer(int real_bits, size_t n, void* x, void* y, void* z)
+{
+    return withReal(real_bits,
+                    [&](auto t)
+                    {
+                        using T = decltype(t);
+                        srand48(42);
+                        T* pos[3] = {(T*)x, (T*)y, (T*)z};
+                        const T conv = T(3.0 * M_PI / 16.0);
+                        size_t i = 0;
+                        while (i < n)
+                        {
+                            T R = T(1.0 / std::sqrt(std::pow(drand48(), -2.0 / 3.0) - 1.0));
+                            if (R < T(100.0))
+                            {
+                                T Z     = T((1.0 - 2.0 * drand48()) * R);
+                                T theta = T(2 * M_PI * drand48());
+                                // (the reference calls the C functions sqrt / cos / sin unqualified: double
+                                //  arithmetic on the T-valued operands, rounded to T at the assignment)
+                                T X     = T(std::sqrt(double(R * R - Z * Z)) * std::cos(double(theta)));
+                                T Y     = T(std::sqrt(double(R * R - Z * Z)) * std::sin(double(theta)));
+                                pos[0][i] = X * conv, pos[1][i] = Y * conv, pos[2][i] = Z * conv;
+                                ++i;
+                            }
+                        }
+                        T mcm = 0, mass = T(1) / T(n), xcm[3] = {0, 0, 0};
+                        for (i = 0; i < n; ++i)
+                        {
+                            mcm += mass;
+                            for (int k = 0; k < 3; ++k)
+                                xcm[k] += mass * pos[k][i];
+                        }
+                        for (int k = 0; k < 3; ++k)
+                            xcm[k] /= mcm;
+                        for (i = 0; i < n; ++i)
+                            for (int k = 0; k < 3; ++k)
+                                pos[k][i] -= xcm[k];
+                    });
+}
+
 //! child[2 * num_nodes], prefix[num_nodes] of the binary radix tree over tree[0 .. num_nodes]
 int cstone_oracle_binary_tree(int key_bits, const void* tree, int num_nodes, int* child, void* prefix)
 {

@@ -22,6 +22,8 @@
 #include "cstone/tree/continuum.hpp"
 #include "cstone/tree/csarray.hpp"
 #include "cstone/tree/octree.hpp"
+// the reference's own Plummer generator, included where it lies (test/coord_samples/plummer.hpp)
+#include "../test/coord_samples/plummer.hpp"
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -495,6 +497,27 @@ int cstone_ref_continuum(int key_bits, int kind, double n0, unsigned bucket, dou
                 leaves = int(c.size());
             });
     return leaves;
+}
+
+//! plummer<T>(n) of test/coord_samples/plummer.hpp (pins cstone_oracle_plummer)
+int cstone_ref_plummer(int real_bits, size_t n, void* x, void* y, void* z)
+{
+    if (real_bits == 64)
+    {
+        auto pos = plummer<double>(n);
+        std::copy(pos[0].begin(), pos[0].end(), (double*)x);
+        std::copy(pos[1].begin(), pos[1].end(), (double*)y);
+        std::copy(pos[2].begin(), pos[2].end(), (double*)z);
+    }
+    else if (real_bits == 32)
+    {
+        auto pos = plummer<float>(n);
+        std::copy(pos[0].begin(), pos[0].end(), (float*)x);
+        std::copy(pos[1].begin(), pos[1].end(), (float*)y);
+        std::copy(pos[2].begin(), pos[2].end(), (float*)z);
+    }
+    else return -1;
+    return 0;
 }
 
 int cstone_ref_num_threads()

@@ -17,6 +17,7 @@ import torch.distributed as dist  # noqa: E402
 p = argparse.ArgumentParser()
 p.add_argument("--particles", type=float, default=2e7, help="global")
 p.add_argument("--syncs", type=int, default=8)
+p.add_argument("--dist", default="uniform", choices=["uniform", "plummer", "clustered"])
 p.add_argument("--rccl", action="store_true", help="backend nccl: RCCL collectives from inside libcstone_hip")
 a = p.parse_args()
 if a.rccl:
@@ -34,7 +35,8 @@ from bench import DistributedPipeline  # noqa: E402
 
 n = int(a.particles)
 ctx = cstone_amd.Context(0)
-pipe = DistributedPipeline(ctx, n // P, n, 64, 64, "hilbert", max(64, n // (100 * P)), 64, 42 + rank)
+pipe = DistributedPipeline(ctx, n // P, n, 64, 64, "hilbert", max(64, n // (100 * P)), 64, seed=42, dist=a.dist, rank=rank,
+                           world=P, backend="nccl" if a.rccl else "gloo")
 pipe.first_sync()
 for _ in range(2):
     pipe.drift()
