@@ -606,18 +606,17 @@ def main():
 
         # the same time-stepping loop with the radix sort forced over ALL key digits (what the reference's GPU path does
         # every time) ...
-        os.environ["CSTONE_FULL_SORT"] = "1"
+        pipe.dom.set_sort_mode(pipe.dom.SORT_ALL_DIGITS)  # cstone_hip_domain_set_sort_mode
         run_syncs(1, move)
         extras["all_digits_sorted"] = timed_variant(move)
         extras["all_digits_sorted"]["note"] = "the headline loop, every sync sorted from scratch over all 8 key digits"
-        del os.environ["CSTONE_FULL_SORT"]
         # ... and sorted from scratch the cheaper way: radix passes over the digits above the previous tree's leaf level +
         # run fix-up, no use of the previous order
-        os.environ["CSTONE_NO_RESORT"] = "1"
+        pipe.dom.set_sort_mode(pipe.dom.SORT_FROM_SCRATCH)
         run_syncs(1, move)
         extras["sorted_from_scratch"] = timed_variant(move)
         extras["sorted_from_scratch"]["note"] = "the headline loop without the incremental re-sort"
-        del os.environ["CSTONE_NO_RESORT"]
+        pipe.dom.set_sort_mode(pipe.dom.SORT_INCREMENTAL)
         run_syncs(1, move)
         # other motions: 1 % of the particles displaced by up to 2h, and none at all (every sync gets back exactly what
         # the previous one returned: the friendliest input)

@@ -195,7 +195,8 @@ int cstone_hip_comm_rccl_ops(cstone_hip_comm_rccl* comm, cstone_hip_comm_ops* op
 int cstone_hip_comm_rccl_destroy(cstone_hip_comm_rccl* comm)
 {
     if (!comm) return CSTONE_OK;
-    (void)hipStreamSynchronize(comm->ctx->stream);
+    if (ctxAlive(comm->ctx)) (void)hipStreamSynchronize(comm->ctx->stream);
+    else (void)hipDeviceSynchronize(); // (the context went first: nothing of it is touched)
     RcclApi* api = rccl(nullptr);
     if (api && comm->comm) (void)api->commDestroy(comm->comm);
     delete comm;

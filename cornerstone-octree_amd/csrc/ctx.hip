@@ -1,15 +1,71 @@
 // runtime part of the C ABI: context, memory, copies, stage timers
 // replaces R/cuda/device_vector.{h,cu}, cuda_stubs.h:48-57, errorcheck.cuh (R = reference include/cstone)
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
-
 #include <cstring>
+#include <mutex>
+#include <unordered_set>
 
 #include "ctx.hpp"
 #include "hilbert_tables.hpp"
 
 namespace cship
 {
+
+namespace
+{
+std::mutex gRegistryMutex;
+std::unordered_set<const cstone_hip_ctx*>& registry()
+{
+    static std::unordered_set<const cstone_hip_ctx*> live;
+    return live;
+}
+
+// roctx ranges (the reference's tracing hooks): librocprofiler-sdk-roctx (what rocprofv3
+// --marker-trace listens to), else the older libroctx64; opened on first use, absent libraries just leave no ranges
+using RangePush = int (*)(const char*);
+using RangePop  = int (*)();
+RangePush gRangePush = nullptr;
+RangePop gRangePop   = nullptr;
+bool loadRoctx()
+{
+    static const bool ok = []
+    {
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so",
+                                 "libroctx64.so.4"})
+        {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))
+            {
+                gRangePush = reinterpret_cast<RangePush>(dlsym(h, "roctxRangePushA"));
+                gRangePop  = reinterpret_cast<RangePop>(dlsym(h, "roctxRangePop"));
+                if (gRangePush && gRangePop) return true;
+            }
+        }
+        return false;
+    }();
+    return ok;
+}
+
+const char* stageName(int stage)
+{
+    static const char* names[CSTONE_NUM_STAGES] = {"cstone:encode",      "cstone:sort_hist",   "cstone:sort_pass",
+                                                   "cstone:gather",      "cstone:node_counts", "cstone:rebalance",
+                                                   "cstone:link_octree", "cstone:halos",       "cstone:neighbors",
+                                                   "cstone:minmax",      "cstone:sort_pass_iota", "cstone:resort_bins",
+                                                   "cstone:resort_leaves", "cstone:gather_h",  "cstone:place",
+                                                   "cstone:stage15"};
+    return stage >= 0 && stage < CSTONE_NUM_STAGES ? names[stage] : "cstone:?";
+}
+} // namespace
+
+bool ctxAlive(const cstone_hip_ctx* ctx)
+{
+    if (!ctx) return false;
+    std::lock_guard<std::mutex> lock(gRegistryMutex);
+    return registry().count(ctx) != 0;
+}
 
 int arenaReserve(cstone_hip_ctx* ctx, size_t totalBytes)
 {
@@ -50,6 +106,7 @@ static hipEvent_t takeEvent(cstone_hip_ctx* ctx)
 StageTimer::StageTimer(cstone_hip_ctx* c, int stage)
     : ctx(c)
 {
+    if (ctx->markers) (void)gRangePush(stageName(stage)); // (nested ranges nest: every timer pops its own)
     if (!ctx->profiling) return;
     if (ctx->timerDepth++ > 0) return;
     // level 2: only the kernels that move the particle arrays get their two event records (a record costs a few
@@ -67,6 +124,7 @@ StageTimer::StageTimer(cstone_hip_ctx* c, int stage)
 
 StageTimer::~StageTimer()
 {
+    if (ctx->markers) (void)gRangePop();
     if (!ctx->profiling) return;
     --ctx->timerDepth;
     if (idx >= 0) (void)hipEventRecord(ctx->brackets[idx].b, ctx->stream);
@@ -143,6 +201,10 @@ int cstone_hip_ctx_create(cstone_hip_ctx** out, int device, void* stream, int pr
         e = hipMemcpy(ctx->hilbertTables, &t, sizeof t, hipMemcpyHostToDevice);
         if (e != hipSuccess) return giveUp("upload of the Hilbert tables", e);
     }
+    {
+        std::lock_guard<std::mutex> lock(gRegistryMutex);
+        registry().insert(ctx);
+    }
     *out = ctx;
     return CSTONE_OK;
 }
@@ -150,6 +212,11 @@ int cstone_hip_ctx_create(cstone_hip_ctx** out, int device, void* stream, int pr
 int cstone_hip_ctx_destroy(cstone_hip_ctx* ctx)
 {
     if (!ctx) return CSTONE_E_ARG;
+    {
+        // (a second destroy of the same pointer, or a pointer that never was a context: refused, not dereferenced)
+        std::lock_guard<std::mutex> lock(gRegistryMutex);
+        if (registry().erase(ctx) == 0) return CSTONE_E_ARG;
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& b : ctx->brackets)
@@ -197,7 +264,7 @@ int cstone_hip_device_info(cstone_hip_ctx* ctx, int* num_cu, int* wave_size)
 
 int cstone_hip_malloc(cstone_hip_ctx* ctx, void** ptr, size_t bytes)
 {
-    if (!ctx || !ptr) return CSTONE_E_ARG;
+    if (!ctxAlive(ctx) || !ptr) return CSTONE_E_ARG;
     *ptr = nullptr;
     if (bytes == 0) return CSTONE_OK;
     CS_HIP(ctx, hipMalloc(ptr, bytes));
@@ -206,7 +273,13 @@ int cstone_hip_malloc(cstone_hip_ctx* ctx, void** ptr, size_t bytes)
 
 int cstone_hip_free(cstone_hip_ctx* ctx, void* ptr)
 {
-    if (!ctx) return CSTONE_E_ARG;
+    // a client that tears down in the wrong order (buffers freed through a context it has destroyed already) gets an
+    // error code, not a use-after-free; the buffer itself is still released (device memory does not belong to the context)
+    if (!ctxAlive(ctx))
+    {
+        if (ptr) (void)hipFree(ptr);
+        return CSTONE_E_ARG;
+    }
     if (!ptr) return CSTONE_OK;
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     CS_HIP(ctx, hipFree(ptr));
@@ -276,6 +349,14 @@ int cstone_hip_profile_enable(cstone_hip_ctx* ctx, int on)
     if (!ctx) return CSTONE_E_ARG;
     CS_TRY(drainBrackets(ctx));
     ctx->profiling = on < 0 ? 0 : (on > 2 ? 1 : on);
+    return CSTONE_OK;
+}
+
+int cstone_hip_profile_markers(cstone_hip_ctx* ctx, int on)
+{
+    if (!ctx) return CSTONE_E_ARG;
+    if (on && !loadRoctx()) return fail(ctx, CSTONE_E_INTERNAL, "profile_markers: no roctx library could be opened");
+    ctx->markers = on != 0;
     return CSTONE_OK;
 }
 

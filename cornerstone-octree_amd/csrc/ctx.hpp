@@ -41,6 +41,7 @@ struct cstone_hip_ctx
 
     // stage timers
     int profiling  = 0; // 0 off, 1 every stage, 2 only the stages of the kernels that move the particle arrays
+    bool markers   = false; // roctx ranges around every stage (cstone_hip_profile_markers; rocprofv3 --marker-trace)
     int timerDepth = 0; // only the outermost StageTimer of a call records (nested helper launches are part of it)
     struct Bracket
     {
@@ -56,6 +57,11 @@ struct cstone_hip_ctx
 
 namespace cship
 {
+
+//! is ctx a context cstone_hip_ctx_create handed out and cstone_hip_ctx_destroy has not seen yet?  Entry points that
+//! may be called during a client's tear-down (free, the destroy functions) ask before they touch the context: a dead or
+//! unknown pointer gives CSTONE_E_ARG instead of a use-after-free
+bool ctxAlive(const cstone_hip_ctx* ctx);
 
 inline int fail(cstone_hip_ctx* ctx, int code, const char* fmt, ...)
 {

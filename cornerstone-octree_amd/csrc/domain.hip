@@ -784,9 +784,13 @@ int cstone_hip_domain_create(cstone_hip_ctx* ctx, cstone_hip_domain** out, int c
 int cstone_hip_domain_destroy(cstone_hip_domain* dom)
 {
     if (!dom) return CSTONE_E_ARG;
-    (void)hipStreamSynchronize(dom->ctx->stream);
+    // (a domain outliving its context -- a client tearing down in the wrong order: the object and its device buffers are
+    //  still released, the dead context is not touched, the caller learns about it)
+    const bool alive = ctxAlive(dom->ctx);
+    if (alive) (void)hipStreamSynchronize(dom->ctx->stream);
+    else (void)hipDeviceSynchronize();
     delete dom;
-    return CSTONE_OK;
+    return alive ? CSTONE_OK : CSTONE_E_ARG;
 }
 
 int cstone_hip_domain_sync(cstone_hip_domain* dom, void** keys, void** x, void** y, void** z, void** h, size_t n,

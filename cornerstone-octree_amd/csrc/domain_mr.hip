@@ -313,6 +313,7 @@ struct MrBase
     virtual int setHaloMode(int mode)                                                    = 0;
     virtual int setTheta(float theta)                                                    = 0;
     virtual void setSortMode(int mode)                                                   = 0;
+    virtual void contextGone(bool gone)                                                  = 0;
 };
 
 template<class K, class T>
@@ -336,6 +337,7 @@ public:
 
     void setHaloFactor(float f) override { haloExt_ = f; }
     void setSortMode(int mode) override { sortMode_ = mode; }
+    void contextGone(bool gone) override { ctxGone_ = gone; }
     bool mayResort() const
     {
         return sortMode_ == CSTONE_SORT_INCREMENTAL && std::getenv("CSTONE_NO_RESORT") == nullptr &&
@@ -488,7 +490,7 @@ public:
     {
         if (hostLevelRange_)
         {
-            (void)hipStreamSynchronize(ctx_->stream); // a copy into the block may still be queued
+            if (!ctxGone_) (void)hipStreamSynchronize(ctx_->stream); // a copy into the block may still be queued
             (void)hipHostFree(hostLevelRange_);
         }
         if (timing_ && rank_ == 0)
@@ -560,8 +562,16 @@ public:
         for (int k = 0; k < 6; ++k)
             boxSame = boxSame && box_.lim[k] == layoutBox_.lim[k];
         const int tileLeavesSpec = LeafResort<K>::leavesPerTile(bucketFocus_);
+        // What the re-sort of THIS sync starts from: the leaves of my range and their layout as the last COMPLETED sync
+        // left them.  The members are invalidated here and set again only at the end of the tree update below: a sync
+        // that fails half way (a peer's failure, an unmatched halo ...) may have rebalanced, swapped or freed the
+        // buffers resortTree_ points into, and the retry must then sort from scratch instead of reading them.
+        const K* const resortTree       = resortTree_;
+        const int resortLeaves          = resortLeaves_;
+        const uint64_t layoutParticles  = layoutParticles_;
+        resortTree_ = nullptr, resortLeaves_ = 0, layoutParticles_ = 0;
         bool speculate = anyOpen && !firstCall_ && !measureFirst_ && !pending_ && boxSame && n >= resortMinParticles() &&
-                         n == layoutParticles_ && tileLeavesSpec > 0 && resortLeaves_ > 0 && resortBackoff_ == 0 &&
+                         n == layoutParticles && tileLeavesSpec > 0 && resortLeaves > 0 && resortBackoff_ == 0 &&
                          mayResort() && speculativeBox_;
         if (!speculate)
         {
@@ -605,12 +615,12 @@ public:
         for (int k = 0; k < 6; ++k)
             sameBox = sameBox && box_.lim[k] == layoutBox_.lim[k];
         const size_t resortMin = resortMinParticles();
-        const bool tryResort = !firstCall_ && n >= resortMin && n == layoutParticles_ && tileLeaves > 0 && sameBox && resortLeaves_ > 0 &&
+        const bool tryResort = !firstCall_ && n >= resortMin && n == layoutParticles && tileLeaves > 0 && sameBox && resortLeaves > 0 &&
                                resortBackoff_ == 0 && !pending_ && mayResort();
         if (resortBackoff_ > 0) --resortBackoff_;
         if (tryResort)
         {
-            CS_TRY(resort_.prepare(ctx_, resortTree_, layout_.as<uint32_t>(), resortLeaves_, n, keysAlt_.as<K>(),
+            CS_TRY(resort_.prepare(ctx_, resortTree, layout_.as<uint32_t>(), resortLeaves, n, keysAlt_.as<K>(),
                                    lastMovers_ > 100000));
             const ResortArgs<K> ra = resort_.args();
             bool done              = false;
@@ -1277,6 +1287,7 @@ private:
         const std::string m = culprit == rank_ ? pendingMsg_ : "rank " + std::to_string(culprit) + " reported a failure";
         pending_            = 0;
         if (toggled_) cur_ ^= 1, toggled_ = false; // the client's arrays of the last good sync stay untouched by the next one
+        resortTree_ = nullptr, resortLeaves_ = 0, layoutParticles_ = 0; // an abandoned sync is nothing to re-sort from
         return fail(ctx_, code, "%s (the sync was abandoned on every rank)", m.c_str());
     }
 
@@ -1709,6 +1720,7 @@ private:
     const K* resortTree_ = nullptr; // the leaves of my own key range (and their number) the next sync's re-sort starts from
     int resortLeaves_    = 0;
     bool firstCall_ = true;
+    bool ctxGone_   = false; // the destructor runs behind the context's destruction (cstone_hip_domain_mr_destroy)
     bool toggled_   = false; // this sync has switched to the other output buffer set already
     int pending_    = 0; // status of this rank inside sync(): 0, or the error code the peers have to learn about
     uint64_t statusW64_ = 0; // staging of the status words that ride on the collectives (asynchronous copies read them)
@@ -1816,9 +1828,12 @@ int cstone_hip_domain_mr_create(cstone_hip_ctx* ctx, cstone_hip_domain_mr** out,
 int cstone_hip_domain_mr_destroy(cstone_hip_domain_mr* dom)
 {
     if (!dom) return CSTONE_E_ARG;
-    (void)hipStreamSynchronize(dom->ctx->stream);
+    const bool alive = ctxAlive(dom->ctx); // (see cstone_hip_domain_destroy)
+    if (alive) (void)hipStreamSynchronize(dom->ctx->stream);
+    else (void)hipDeviceSynchronize();
+    dom->impl->contextGone(!alive);
     delete dom;
-    return CSTONE_OK;
+    return alive ? CSTONE_OK : CSTONE_E_ARG;
 }
 
 int cstone_hip_domain_mr_sync_props(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z,

@@ -29,6 +29,14 @@ __global__ __launch_bounds__(256) void scaleKernel(T* __restrict__ data, size_t 
     if (i < n) data[i] *= factor;
 }
 
+//! out[i] = in[i + 1] - in[i] for i < n (in holds n + 1 values): sizes from offsets
+__global__ __launch_bounds__(256) void adjacentDifferenceKernel(const uint32_t* __restrict__ in, size_t n,
+                                                                uint32_t* __restrict__ out)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i + 1] - in[i];
+}
+
 template<class T>
 __global__ __launch_bounds__(256) void incrementKernel(const T* __restrict__ in, T* __restrict__ out, size_t n, T value)
 {
@@ -241,6 +249,15 @@ int cstone_hip_scale(cstone_hip_ctx* ctx, int real_bits, void* data, size_t n, d
     unsigned grid = gridFor(n, 256);
     if (real_bits == 32) hipLaunchKernelGGL(scaleKernel<float>, grid, 256, 0, ctx->stream, (float*)data, n, float(factor));
     else hipLaunchKernelGGL(scaleKernel<double>, grid, 256, 0, ctx->stream, (double*)data, n, factor);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int cstone_hip_adjacent_difference_u32(cstone_hip_ctx* ctx, const uint32_t* in, size_t n, uint32_t* out)
+{
+    if (!ctx || (n && (!in || !out)) || in == out) return fail(ctx, CSTONE_E_ARG, "adjacent_difference: bad argument");
+    if (n == 0) return CSTONE_OK;
+    hipLaunchKernelGGL(adjacentDifferenceKernel, gridFor(n, 256), 256, 0, ctx->stream, in, n, out);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

@@ -818,7 +818,13 @@ int findPeers(cstone_hip_ctx* ctx, int curve, const void* prefixes, const int32_
                                errors);
         CS_HIP(ctx, hipGetLastError());
         CS_HIP(ctx, hipMemcpyAsync(peerFlagsHost, dFlag, size_t(numRanks) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        // the traversal reports an overflow of its pair stack through the sticky error word: read it with the flags -- an
+        // incomplete (and then not mutual) peer list must not reach the treelet and count exchanges that follow
+        CS_HIP(ctx, hipMemcpyAsync(ctx->hostScalars + 63, errors, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->hostScalars[63] != 0)
+            return fail(ctx, CSTONE_E_INTERNAL, "find_peers_mac: device-side check failed, code 0x%x (peer list incomplete)",
+                        unsigned(ctx->hostScalars[63]));
         return CSTONE_OK;
     };
     int rc = body();

@@ -535,7 +535,10 @@ private:
         if (!(haveMacs_ && haveCounts_)) // rebalanceStatus_ != valid (:110-113)
             return fail(CSTONE_E_INTERNAL, "update of criteria required before updating the tree structure");
         const K focusStart = assignment[rank_], focusEnd = assignment[rank_ + 1];
-        const bool firstUpdate = prevFocusStart_ == 0 && prevFocusEnd_ == 0;
+        // (the reference recognises its first update by prevFocusStart == prevFocusEnd == 0; a rank 0 whose range is the
+        //  empty [0, 0) would stay "first" for ever and skip the collective of focusTransfer that its peers enter: an
+        //  explicit flag, set on every rank by the same update)
+        const bool firstUpdate = !updatedOnce_;
         if (firstUpdate) prevFocusStart_ = focusStart, prevFocusEnd_ = focusEnd;
 
         std::vector<K> enforced;
@@ -567,6 +570,7 @@ private:
         prevFocusStart_ = focusStart;
         prevFocusEnd_   = focusEnd;
         haveMacs_ = haveCounts_ = false;
+        updatedOnce_ = true;
         ++stats_.treeUpdates;
         // updateGeoCenters (:614-625)
         const int M = numNodesOf(L_);
@@ -1147,6 +1151,7 @@ private:
     bool firstCall_ = true;
     cstone_box box_{}; // the box of the last updateTree (octree_focus_mpi.hpp:689)
     K prevFocusStart_ = 0, prevFocusEnd_ = 0;
+    bool updatedOnce_ = false; // updateTree has run (on every rank: a collective)
     bool haveMacs_ = true, haveCounts_ = true, haveLeafCounts_ = false; // rebalanceStatus_ (:669-677, :733)
     Stats stats_;
 

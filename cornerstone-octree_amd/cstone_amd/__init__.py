@@ -25,7 +25,7 @@ STAGES = {
 EXPORTS = [
     "cstone_hip_ctx_create", "cstone_hip_ctx_destroy", "cstone_hip_ctx_sync", "cstone_hip_last_error",
     "cstone_hip_device_info", "cstone_hip_malloc", "cstone_hip_free", "cstone_hip_memcpy_h2d",
-    "cstone_hip_memcpy_d2h", "cstone_hip_memcpy_d2d", "cstone_hip_memset", "cstone_hip_profile_enable",
+    "cstone_hip_memcpy_d2h", "cstone_hip_memcpy_d2d", "cstone_hip_memset", "cstone_hip_profile_enable", "cstone_hip_profile_markers", "cstone_hip_adjacent_difference_u32",
     "cstone_hip_profile_reset", "cstone_hip_profile_get", "cstone_hip_profile_get_spread", "cstone_hip_compute_sfc_keys",
     "cstone_hip_sort_pairs_temp_bytes", "cstone_hip_sort_pairs", "cstone_hip_sort_keys_ordering", "cstone_hip_sfc_keys_and_ordering", "cstone_hip_sequence_u32", "cstone_hip_gather",
     "cstone_hip_scatter", "cstone_hip_gather_scatter", "cstone_hip_merge_positions", "cstone_hip_minmax", "cstone_hip_minmax_arrays", "cstone_hip_exclusive_scan_u32", "cstone_hip_inclusive_scan_u32", "cstone_hip_lower_bound",
@@ -174,6 +174,10 @@ class Context:
     def profile_enable(self, on=True):
         """True / 1: every stage; 2: only the stages of the kernels that move the particle arrays; False: off"""
         self._chk(self.lib.cstone_hip_profile_enable(self.h, C.c_int(int(on))), "profile_enable")
+
+    def profile_markers(self, on=True):
+        """roctx ranges "cstone:<stage>" around every stage (rocprofv3 --marker-trace)"""
+        self._chk(self.lib.cstone_hip_profile_markers(self.h, C.c_int(int(on))), "profile_markers")
 
     def profile_reset(self):
         self._chk(self.lib.cstone_hip_profile_reset(self.h), "profile_reset")

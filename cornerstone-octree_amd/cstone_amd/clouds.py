@@ -7,8 +7,8 @@ tests; nothing here is part of the product).
               3 pi / 16, centre of mass moved to the origin.  No clamping shell, no hand-set box.  The 48-bit linear
               congruential generator of drand48 (X' = 0x5DEECE66D X + 0xB mod 2^48, POSIX) has a closed-form jump, so the
               whole stream is produced in parallel; the serial part -- which stream positions start an attempt, given the
-              rare rejections -- is a host walk over the ~1.5e-4 N rejected positions.  oracle/oracle.py holds the
-              serial C restatement the tests compare this one with.
+              rare rejections -- is a host walk over the ~1.5e-4 N rejected positions.  (The tests compare it with a
+              serial C restatement that is pinned by the reference's own header.)
   clustered   the mixture of 8 Gaussian blobs (sigma = L / 40) at fixed centres of BASELINE configs[4], clamped to the box
               (the reference's clamped normal_distribution, test/coord_samples/random.hpp:159-174, eight times)
 
@@ -29,11 +29,6 @@ def _lcg_jump(k):
         a, c = (a * a) & MASK48, (a * c + c) & MASK48
         k >>= 1
     return A, C
-
-
-def _signed(v):
-    """a 48-bit constant as the int64 torch multiplies with (two's complement wrap-around keeps the low 64 bits)"""
-    return v
 
 
 class Drand48Stream:
@@ -83,7 +78,6 @@ def plummer_reference(n, device, dtype=None, first=0, count=None, chunk=1 << 24,
     xs, ys, zs = [], [], []
     com = torch.zeros(3, dtype=torch.float64, device=device)
     pos, made = 0, 0  # stream position of the next attempt, particles accepted so far
-    carry = None
     while made < n:
         want = min(chunk, n - made)
         span = 3 * want + 64  # draws looked at in this round

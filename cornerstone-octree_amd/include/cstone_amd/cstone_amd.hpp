@@ -1035,8 +1035,10 @@ public:
     {
         if (!mr_) Context::check(cstone_hip_domain_set_speculative_box(dom_, on ? 1 : 0), "Domain::setSpeculativeBox");
     }
-    //! kept for source compatibility: the flag has no reader in the reference either (domain.hpp:411,661)
-    void setTreeConv(bool) {}
+    //! R/domain/domain.hpp:411: stores the flag like the reference does (its member convergeTrees, :661, has no reader
+    //! there either: the trees converge on the first sync and take one update step per sync afterwards)
+    void setTreeConv(bool flag) { convergeTrees_ = flag; }
+    bool treeConv() const { return convergeTrees_; }
     /*! R/domain/domain.hpp:381-386: the halo ranges of every array (nParticlesWithHalos() elements) are overwritten with
      *  the owners' values; the send/receive buffers of the reference's signature are not needed.  One rank: no halos. */
     template<class... Vectors, class SendBuffer, class ReceiveBuffer>
@@ -1145,6 +1147,7 @@ private:
     cstone_hip_domain* dom_{nullptr};
     std::unique_ptr<MultiRankDomain<KeyType, T>> mr_;
     bool synced_{false};
+    bool convergeTrees_{false};
     LocalIndex endOverride_{0};
     bool haveEndOverride_{false};
     std::size_t prevSize_{0};

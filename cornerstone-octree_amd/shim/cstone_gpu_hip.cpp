@@ -936,17 +936,30 @@ void computeFixedGroups(LocalIndex first, LocalIndex last, unsigned groupSize, G
 template<class Tc, class T, class KeyType>
 void computeGroupSplits(LocalIndex first, LocalIndex last, const Tc* x, const Tc* y, const Tc* z, const T* /*h*/,
                         const KeyType* leaves, TreeNodeIndex numLeaves, const LocalIndex* layout, const Box<Tc> box,
-                        unsigned groupSize, float tolFactor, DeviceVector<LocalIndex>& /*numSplitsPerGroup*/,
+                        unsigned groupSize, float tolFactor, DeviceVector<LocalIndex>& numSplitsPerGroup,
                         DeviceVector<LocalIndex>& groups)
 {
     if (groupSize != 64 && groupSize != 128) throw std::runtime_error("Unsupported spatial group size\n");
-    // (the reference sizes its output after a first pass over split counts; one particle per group is the upper bound)
-    groups.resize(size_t(last - first) + 1);
+    // sized like the reference's (R/traversal/groups_gpu.cu:103-104: room for a tenth more groups than fixed ones); the
+    // entry reports how many entries it needs when that is not enough, and is then called once more
+    const size_t numFixed = (size_t(last - first) + groupSize - 1) / groupSize;
+    groups.reserve(size_t(double(numFixed) * 1.1) + 1);
+    groups.resize(numFixed + 1);
     cstone_box b   = podBox(box);
     uint32_t found = 0;
-    check(cstone_hip_compute_group_splits(hipCtx(), bitsOf<KeyType>, bitsOf<Tc>, first, last, x, y, z, leaves, numLeaves,
-                                          layout, &b, groupSize, tolFactor, rawPtr(groups), groups.size(), &found));
+    int rc = cstone_hip_compute_group_splits(hipCtx(), bitsOf<KeyType>, bitsOf<Tc>, first, last, x, y, z, leaves, numLeaves,
+                                             layout, &b, groupSize, tolFactor, rawPtr(groups), groups.capacity(), &found);
+    if (rc == CSTONE_E_CAPACITY)
+    {
+        groups.reserve(size_t(found) + 1);
+        rc = cstone_hip_compute_group_splits(hipCtx(), bitsOf<KeyType>, bitsOf<Tc>, first, last, x, y, z, leaves, numLeaves,
+                                             layout, &b, groupSize, tolFactor, rawPtr(groups), groups.capacity(), &found);
+    }
+    check(rc);
     groups.resize(size_t(found) + 1);
+    // what the reference leaves in numSplitsPerGroup: the sizes of the new groups (:108-117, `newGroupSizes`)
+    numSplitsPerGroup.resize(found);
+    check(cstone_hip_adjacent_difference_u32(hipCtx(), rawPtr(groups), found, rawPtr(numSplitsPerGroup)));
 }
 template void computeGroupSplits(LocalIndex, LocalIndex, const double*, const double*, const double*, const double*,
                                  const uint64_t*, TreeNodeIndex, const LocalIndex*, const Box<double>, unsigned, float,

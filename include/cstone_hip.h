@@ -98,6 +98,11 @@ extern "C"
     /* on: 0 off, 1 every stage, 2 only ENCODE, SORT_PASS(_IOTA), RESORT_LEAVES, GATHER(_H), HALOS, NEIGHBORS (the kernels that
      * move the particle arrays: eight brackets per sync instead of forty) */
     int cstone_hip_profile_enable(cstone_hip_ctx* ctx, int on);
+    /* on != 0: every stage of every call is also wrapped in a roctx range "cstone:<stage>" (roctxRangePushA / Pop of
+     * librocprofiler-sdk-roctx, opened on first use): `rocprofv3 --marker-trace --kernel-trace` then shows the stage table
+     * of a sync without the event brackets above (the reference's tracing hooks).  Independent of
+     * cstone_hip_profile_enable. */
+    int cstone_hip_profile_markers(cstone_hip_ctx* ctx, int on);
     int cstone_hip_profile_reset(cstone_hip_ctx* ctx);
     /* synchronises the stream; total_ms and launches accumulated since the last reset */
     int cstone_hip_profile_get(cstone_hip_ctx* ctx, int stage, double* total_ms, int* launches);
@@ -198,6 +203,9 @@ extern "C"
     int cstone_hip_fill(cstone_hip_ctx* ctx, int elem_bytes, void* dst, size_t n, const void* value_host);
     int cstone_hip_scale(cstone_hip_ctx* ctx, int real_bits, void* data, size_t n, double factor);
     int cstone_hip_increment(cstone_hip_ctx* ctx, int elem_bits, const void* in, void* out, size_t n, uint64_t value);
+    /* out[i] = in[i + 1] - in[i], i < n (in: n + 1 offsets; in != out): the group sizes computeGroupSplits hands back in
+     * numSplitsPerGroup (R/traversal/groups_gpu.cu:108-117) */
+    int cstone_hip_adjacent_difference_u32(cstone_hip_ctx* ctx, const uint32_t* in, size_t n, uint32_t* out);
     int cstone_hip_count_equal(cstone_hip_ctx* ctx, int elem_bits, const void* data, size_t n, uint64_t value,
                                uint64_t* count_host);
     int cstone_hip_reduce_sum(cstone_hip_ctx* ctx, int elem_bits, const void* data, size_t n, uint64_t init,

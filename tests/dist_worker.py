@@ -302,11 +302,14 @@ def main():
         import cstone_amd
 
         r = dom.sync(x, y, z, h)
+        st, en = r["start"], r["end"]
+        nxt = [r[k][st:en].clone() for k in "xyzh"]
+        for c in nxt[:3]:  # the cloud contracts: the failing sync rebalances its trees before it fails
+            c.sub_(0.5).mul_(0.965).add_(0.5)
         os.environ["CSTONE_MR_FAIL_AT"] = f"1:{a.fail_at}"
         raised, msg = 0, ""
         try:
-            dom.sync(r["x"][r["start"]:r["end"]].clone(), r["y"][r["start"]:r["end"]].clone(),
-                     r["z"][r["start"]:r["end"]].clone(), r["h"][r["start"]:r["end"]].clone())
+            dom.sync(*[c.clone() for c in nxt])
         except cstone_amd.CstoneError as e:
             raised, msg = 1, str(e)
         del os.environ["CSTONE_MR_FAIL_AT"]
@@ -315,11 +318,26 @@ def main():
         named = ("injected" in msg) if rank == 1 else ("rank 1 reported a failure" in msg)
         good = torch.tensor([1 if named else 0])
         dist.all_reduce(good, op=dist.ReduceOp.MIN)
-        r2 = dom.sync(r["x"][r["start"]:r["end"]].clone(), r["y"][r["start"]:r["end"]].clone(),
-                      r["z"][r["start"]:r["end"]].clone(), r["h"][r["start"]:r["end"]].clone())
+        # the retry: same input sizes and box as the failed sync.  What the failed sync left of its tree must not be what
+        # the re-sort starts from: the retry sorts from scratch, the sync after it re-sorts again
+        before = int(dom.view().resorts)
+        r2 = dom.sync(*[c.clone() for c in nxt])
+        retried_from_scratch = int(dom.view().resorts) == before
+        k2 = r2["keys"]
+        sorted2 = bool((k2[1:] >= k2[:-1]).all()) if k2.numel() > 1 else True
         tot = torch.tensor([r2["end"] - r2["start"]], dtype=torch.int64)
         dist.all_reduce(tot)
-        ok = bool(flag.item()) and bool(good.item()) and int(tot.item()) == N
+        r3 = dom.sync(*[r2[k][r2["start"]:r2["end"]].clone() for k in "xyzh"])
+        k3 = r3["keys"]
+        sorted3 = bool((k3[1:] >= k3[:-1]).all()) if k3.numel() > 1 else True
+        resorted_again = int(dom.view().resorts) == before + 1
+        tot3 = torch.tensor([r3["end"] - r3["start"]], dtype=torch.int64)
+        dist.all_reduce(tot3)
+        mine_ok = torch.tensor([1 if (retried_from_scratch and sorted2 and sorted3 and resorted_again) else 0])
+        dist.all_reduce(mine_ok, op=dist.ReduceOp.MIN)
+        ok = (bool(flag.item()) and bool(good.item()) and int(tot.item()) == N and int(tot3.item()) == N and
+              bool(mine_ok.item()))
+        msg = f"{msg} | retry from scratch {retried_from_scratch}, re-sorted afterwards {resorted_again}"
         if rank == 0:
             print("DIST_RESULT " + json.dumps(dict(ok=ok, ranks=P, report=[dict(message=msg)])))
         dist.destroy_process_group()

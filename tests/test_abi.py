@@ -43,6 +43,22 @@ def test_fault_injection_is_compiled_into_the_tests_build_only(monkeypatch):
     assert not [s for s in declared_symbols() if not hasattr(hooked, s)]
 
 
+def test_entries_refuse_a_context_that_is_not_alive():
+    """cstone_hip_free / _malloc / _ctx_destroy on a pointer that is not a live context (a client that tears down in the
+    wrong order, gpurun_out/r3_let1.log) return CSTONE_E_ARG without dereferencing it -- no GPU needed for that"""
+    import cstone_amd
+
+    lib = cstone_amd.load_library()
+    E_ARG = -1  # CSTONE_E_ARG
+    bogus = ctypes.create_string_buffer(512)  # some memory that never was a context
+    p = ctypes.cast(bogus, ctypes.c_void_p)
+    assert lib.cstone_hip_free(p, None) == E_ARG
+    assert lib.cstone_hip_ctx_destroy(p) == E_ARG
+    out = ctypes.c_void_p()
+    assert lib.cstone_hip_malloc(p, ctypes.byref(out), ctypes.c_size_t(16)) == E_ARG and not out.value
+    assert lib.cstone_hip_free(None, None) == E_ARG
+
+
 def test_box_pod_layout_matches_header():
     import cstone_amd
 

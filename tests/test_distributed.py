@@ -43,7 +43,7 @@ def test_signed_key():
 
 def _launch(nproc, backend, particles, syncs, pbc, port, timeout=900, golden="", impl="python", extra=()):
     env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
-    # the multi-rank sync only re-sorts (csrc/resort.hpp) from 3.4e7 particles per rank on: the tests want that path too
+    # the multi-rank sync only re-sorts (csrc/resort.hpp) from 6e6 particles per rank on: the tests want that path too
     env.setdefault("CSTONE_MR_RESORT_MIN", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"),

@@ -19,9 +19,6 @@ GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "gold
 def test_domain_sync_matches_reference(hip, path, full_sort, num_scratch, monkeypatch):
     import torch
 
-    if full_sort:  # the radix passes over ALL key digits instead of the digits above the previous tree's leaf level
-        monkeypatch.setenv("CSTONE_FULL_SORT", "1")
-
     import cstone_amd
     from cstone_amd.domain import Domain
 
@@ -31,6 +28,8 @@ def test_domain_sync_matches_reference(hip, path, full_sort, num_scratch, monkey
     kdt, ksigned = (np.uint64, np.int64) if kb == 64 else (np.uint32, np.int32)
     box = cstone_amd.make_cbox(d["lim"], d["bc"])
     dom = Domain(hip, cstone_amd.HILBERT, kb, rb, int(d["bucket"]), int(d["bucket_focus"]), 0.5, box)
+    if full_sort:  # the radix passes over ALL key digits instead of the digits above the previous tree's leaf level
+        dom.set_sort_mode(dom.SORT_ALL_DIGITS)
     for s in range(int(d["steps"])):
         x, y, z, h = [torch.from_numpy(d[f"in{s}_{c}"].copy()).cuda() for c in "xyzh"]
         assert x.element_size() * 8 == rb

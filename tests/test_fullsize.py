@@ -145,20 +145,16 @@ def test_domain_sync_1e8_plummer_with_neighbors(hip):
     from cstone_amd.domain import Domain
 
     n, bucket_focus = 100_000_000, 64
-    g = torch.Generator(device="cuda").manual_seed(11)
-    u = torch.rand(n, dtype=torch.float64, device="cuda", generator=g).clamp_(1e-12, 1.0)
-    r = (u.pow(-2.0 / 3.0) - 1.0).clamp_min_(1e-12).rsqrt().clamp_(max=10.0)
-    ct = 2 * torch.rand(n, dtype=torch.float64, device="cuda", generator=g) - 1
-    ph = 2 * math.pi * torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
-    st = (1 - ct * ct).sqrt()
-    x, y, z = r * st * ph.cos(), r * st * ph.sin(), r * ct
-    rho = 3.0 * n / (4 * math.pi) * (1 + r * r).pow(-2.5)
-    h = (0.5 * (3.0 * 100.0 / (4 * math.pi * rho)).pow(1 / 3)).clamp_(max=1.0)
-    del u, r, ct, ph, st, rho
+    # the reference's own cloud (test/coord_samples/plummer.hpp restated: srand48(42), R < 100, no clamping shell), h from
+    # the local density; the domain measures its tight box itself
+    from cstone_amd import clouds
+
+    x, y, z, h, lim = clouds.make_cloud("plummer", n, n, "cuda", torch.float64, 0)
+    assert float(x.abs().max()) > 30.0  # the halo of the sphere reaches out to R = 100 * 3 pi / 16
     ident = x * 3.0 + y * 5.0 + z * 7.0 + h
     keys = torch.zeros(n, dtype=torch.int64, device="cuda")
     scratch = torch.empty(n, dtype=torch.float64, device="cuda")
-    box = cstone_amd.make_cbox([-10.001, 10.001] * 3)
+    box = cstone_amd.make_cbox(lim)
     dom = Domain(hip, cstone_amd.HILBERT, 64, 64, n // 100, bucket_focus, 0.5, box)
     for sync in range(2):  # the second call takes the steady-state path (partial radix passes + run fix-up)
         keys, x, y, z, h, scratch, (ident,) = dom.sync(keys, x, y, z, h, scratch, [ident])
@@ -194,7 +190,7 @@ def test_domain_sync_1e8_plummer_with_neighbors(hip):
         last = first + 65536
         _, nc = hip.find_neighbors(x, y, z, h, first, last, v.box, oc, lay, cen, siz, 0)
         hip.sync()
-        assert 20 < float(nc.double().mean()) < 2000  # about 100 by construction; more on the r = 10 cut-off shell
+        assert 20 < float(nc.double().mean()) < 2000  # about 100 by construction
         for i in rng.integers(first, last, 6):
             i = int(i)
             dx, dy, dz = x - x[i], y - y[i], z - z[i]
@@ -243,6 +239,111 @@ def test_domain_sync_clustered_2p5e8(hip):
     assert int(counts.sum(dtype=np.uint64)) == n and counts.max() <= bucket_focus and int(layout[-1]) == n
 
 
+@pytest.mark.parametrize("dist_name,n,n_global", [("uniform", 12_500_000, 100_000_000),
+                                                   ("clustered", 125_000_000, 1_000_000_000)],
+                         ids=["configs3-share-1.25e7-uniform", "configs4-share-1.25e8-clustered"])
+def test_one_ranks_share_through_the_multi_rank_sync(hip, dist_name, n, n_global):
+    """BASELINE configs[3] / configs[4] are 8-GPU runs: ONE rank's share of each (1.25e7 uniform, 1.25e8 clustered
+    particles; h as in the whole cloud) goes through cstone_hip_domain_mr_sync -- the code path of the N-GPU run, RCCL
+    collectives with a communicator of one rank -- over three syncs with every particle drifting: keys sorted and
+    consistent with the coordinates, a property still attached, the focus tree's counts / layout / bucket bound, and
+    neighbour counts of a sample against a brute-force pass"""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    import cstone_amd
+    from cstone_amd import clouds
+    from cstone_amd.distributed import NativeDistributedDomain, RcclCollectives
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        coll = RcclCollectives(hip)
+        assert coll.size == 1
+        x, y, z, h, lim = clouds.make_cloud(dist_name, n, n_global, "cuda", torch.float64, 42, 3, 8)
+        bucket_focus = 64
+        dom = NativeDistributedDomain(hip, cstone_amd.HILBERT, 64, 64, max(64, n_global // 800), bucket_focus, lim,
+                                      (0, 0, 0), coll=coll)
+        g = torch.Generator(device="cuda").manual_seed(9)
+        for sync in range(3):
+            ident = x * 3.0 + y * 5.0 + z * 7.0 + h
+            r = dom.sync(x, y, z, h, props=[ident])
+            hip.sync()
+            st, en = r["start"], r["end"]
+            assert (st, en) == (0, n) and r["x"].numel() == n
+            keys = r["keys"]
+            assert bool((keys[1:] >= keys[:-1]).all())
+            v = dom.view()
+            assert bool((hip.compute_sfc_keys(cstone_amd.HILBERT, 64, r["x"], r["y"], r["z"], v.box) == keys).all())
+            assert bool((r["props"][0] == r["x"] * 3.0 + r["y"] * 5.0 + r["z"] * 7.0 + r["h"]).all())
+            L = v.num_focus_leaves
+            counts = dom.fetch(v.focus_leaf_counts, L, np.uint32)
+            layout = dom.fetch(v.layout, L + 1, np.uint32)
+            assert int(counts.sum(dtype=np.uint64)) == n and counts.max() <= bucket_focus and int(layout[-1]) == n
+            assert np.array_equal(np.diff(layout.astype(np.int64)), counts.astype(np.int64))
+            assert (v.start_cell, v.end_cell) == (0, L)
+            if sync == 2:
+                oc = dom.octree()
+                rng = np.random.default_rng(5)
+                first = int(rng.integers(0, n - 70000))
+                _, nc = hip.find_neighbors(r["x"], r["y"], r["z"], r["h"], first, first + 65536, v.box, oc, oc["layout"],
+                                           oc["centers"], oc["sizes"], 0)
+                hip.sync()
+                for i in rng.integers(first, first + 65536, 5):
+                    i = int(i)
+                    dx, dy, dz = r["x"] - r["x"][i], r["y"] - r["y"][i], r["z"] - r["z"][i]
+                    d2 = dx * dx + dy * dy + dz * dz
+                    assert int(nc[i - first]) == int((d2 < 4.0 * r["h"][i] * r["h"][i]).sum()) - 1
+                    del dx, dy, dz, d2
+            # the client's time step: every particle by up to 0.1 h per coordinate
+            x, y, z, h = [r[k][st:en] for k in "xyzh"]
+            for a in (x, y, z):
+                d = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+                a.add_(d.sub_(0.5).mul_(0.2).mul_(h)).clamp_(0.0, 1.0)
+                del d
+        assert int(dom.view().resorts) >= 1  # the steady state re-sorts from the previous order
+        dom.close()
+        coll.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tear_down_in_the_wrong_order_is_an_error_code_not_a_crash():
+    """gpurun_out/r3_let1.log: a client that destroyed its context first got a SIGSEGV from the buffers it released
+    afterwards.  The library keeps a registry of live contexts: free and the destroy functions on a dead context return
+    CSTONE_E_ARG (and still release what they own)"""
+    import ctypes as C
+
+    import torch
+
+    import cstone_amd
+    from cstone_amd.domain import Domain
+
+    ctx = cstone_amd.Context(0)
+    lib, raw = ctx.lib, C.c_void_p(ctx.h.value if hasattr(ctx.h, "value") else ctx.h)
+    buf = C.c_void_p()
+    assert lib.cstone_hip_malloc(raw, C.byref(buf), C.c_size_t(1 << 20)) == 0
+    n = 50_000
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x, y, z = [torch.rand(n, dtype=torch.float64, device="cuda", generator=g) for _ in range(3)]
+    h = torch.full((n,), 0.01, dtype=torch.float64, device="cuda")
+    dom = Domain(ctx, cstone_amd.HILBERT, 64, 64, 64, 16, 0.5, cstone_amd.make_cbox([0, 1] * 3))
+    dom.sync(torch.zeros(n, dtype=torch.int64, device="cuda"), x, y, z, h, torch.empty_like(x))
+    ctx.sync()
+    dom_handle = C.c_void_p(dom.h.value)
+    dom.h = None  # (the wrapper must not destroy it again)
+    assert lib.cstone_hip_ctx_destroy(raw) == 0
+    ctx.h = None
+    assert lib.cstone_hip_free(raw, buf) == -1           # CSTONE_E_ARG; the buffer is released all the same
+    assert lib.cstone_hip_domain_destroy(dom_handle) == -1
+    assert lib.cstone_hip_ctx_destroy(raw) == -1         # a second destroy of the same pointer
+
+
 def test_encode_sort_tree_1e7_against_reference_digests(hip, oracle):
     """BASELINE configs[1] (10^7 uniform particles: encode + radix sort + cornerstone tree, no halos) BIT FOR BIT against
     the reference: tests/golden/ref_1e7_digests.json holds the SHA-256 of what the reference's own computeSfcKeys,
@@ -286,7 +387,7 @@ def test_resort_full_size_drift(hip):
     """The mover path of the incremental re-sort (csrc/resort.hpp) at BASELINE's full size: 10^8 uniform particles through
     the bench's time-stepping loop -- three steps in which EVERY particle drifts by up to 0.1 h per coordinate (7 % of
     them leave their leaf) and one in which 1 % jump by up to 2h -- once through a domain that may re-sort and once through
-    one that may not (CSTONE_NO_RESORT): keys, coordinates, h, the particle identities, layout and leaf array are equal
+    one that may not (cstone_hip_domain_set_sort_mode): keys, coordinates, h, the particle identities, layout and leaf array are equal
     after every sync, the keys are the encode of the coordinates next to them, and all four syncs were re-sorted."""
     import torch
 
@@ -306,15 +407,9 @@ def test_resort_full_size_drift(hip):
                     s=torch.empty_like(x))
 
     def sync(d, allow):
-        if allow:
-            os.environ.pop("CSTONE_NO_RESORT", None)
-        else:
-            os.environ["CSTONE_NO_RESORT"] = "1"
-        try:
-            d["k"], d["x"], d["y"], d["z"], d["h"], d["s"], (d["id"],) = d["dom"].sync(d["k"], d["x"], d["y"], d["z"],
-                                                                                     d["h"], d["s"], [d["id"]])
-        finally:
-            os.environ.pop("CSTONE_NO_RESORT", None)
+        d["dom"].set_sort_mode(d["dom"].SORT_INCREMENTAL if allow else d["dom"].SORT_FROM_SCRATCH)
+        d["k"], d["x"], d["y"], d["z"], d["h"], d["s"], (d["id"],) = d["dom"].sync(d["k"], d["x"], d["y"], d["z"],
+                                                                                 d["h"], d["s"], [d["id"]])
         hip.sync()
 
     def move(d, kind, seed):

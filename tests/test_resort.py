@@ -2,7 +2,7 @@
 sync returned orders the particles leaf by leaf (stayers in LDS, movers through bins) instead of radix-sorting all keys.
 The reference always sorts from scratch (sortByKeyGpu, primitives_gpu.cu:305-353, via sfc_sorter.hpp), so the re-sort must
 give exactly the stable sort: every test runs the same time-stepping loop through a domain that may re-sort and through one
-that may not (CSTONE_NO_RESORT) and compares everything bit for bit, next to the oracle's keys under the domain's box."""
+that may not (cstone_hip_domain_set_sort_mode: sorted from scratch) and compares everything bit for bit, next to the oracle's keys under the domain's box."""
 import os
 
 import numpy as np
@@ -46,15 +46,10 @@ class _Stepper:
     def sync(self):
         import torch
 
-        if self.allow:
-            os.environ.pop("CSTONE_NO_RESORT", None)
-        else:
-            os.environ["CSTONE_NO_RESORT"] = "1"
-        try:
-            self.keys, self.x, self.y, self.z, self.h, self.scratch, (self.ident,) = self.dom.sync(
-                self.keys, self.x, self.y, self.z, self.h, self.scratch, [self.ident])
-        finally:
-            os.environ.pop("CSTONE_NO_RESORT", None)
+        # (cstone_hip_domain_set_sort_mode: the incremental re-sort, or the radix sort from scratch -- identical results)
+        self.dom.set_sort_mode(self.dom.SORT_INCREMENTAL if self.allow else self.dom.SORT_FROM_SCRATCH)
+        self.keys, self.x, self.y, self.z, self.h, self.scratch, (self.ident,) = self.dom.sync(
+            self.keys, self.x, self.y, self.z, self.h, self.scratch, [self.ident])
         self.hip.sync()
         m = self.x.numel()
         if self.scratch.numel() != m:
