@@ -110,7 +110,7 @@ class SyncPipeline:
         self.x, self.y, self.z, self.h, lim = clouds.make_cloud(dist, n, n, dev, rdt, seed)
         self.keys = torch.zeros(n, dtype=cstone_amd.key_torch_dtype(key_bits), device=dev)
         # the scratch tuple of the client (R/domain/domain.hpp:196-206: at least three vectors there as well)
-        self.scratch = [torch.empty(n, dtype=rdt, device=dev) for _ in range(int(os.environ.get("CSTONE_BENCH_SCRATCH", "3")))]
+        self.scratch = [torch.empty(n, dtype=rdt, device=dev) for _ in range(int(os.environ.get("CSTONE_BENCH_SCRATCH", "4")))]
         self.dom = Domain(ctx, cv, key_bits, real_bits, bucket, bucket_focus, 0.5, cstone_amd.make_cbox(lim))
         self.f_leaves = self.g_leaves = 0
 
@@ -760,9 +760,12 @@ def main():
         models = [  # (kernel, stage, bytes per particle and launch, what the bytes are)
             ("encodeResortKernel" if stage_ms.get("resort_leaves", 0) > 0 else "encodeHistogramKernel", "encode",
              3 * rbytes + 2 * kbytes, "x, y, z and the old key read, the new key written"),
-            ("leafSortWaveKernel", "resort_leaves", 2 * kbytes + 4,
-             "key read; key + old index written (one wave per leaf; with fewer movers than tiles a launch of leafSortKernel "
-             "for the quiet tiles comes first, inside the same bracket)"),
+            (("leafSortWaveKernel<LeafFields> (keys + x, y, z, h in one pass)", "resort_leaves", 2 * kbytes + 4 + 8 * rbytes,
+              "key, x, y, z, h read; key, old index, x, y, z, h written at the leaf's new place (four scratch arrays: the "
+              "field-carrying leaf pass, no gather passes)") if n_scratch >= 4 else
+             ("leafSortWaveKernel", "resort_leaves", 2 * kbytes + 4,
+              "key read; key + old index written (one wave per leaf; with fewer movers than tiles a launch of "
+              "leafSortKernel for the quiet tiles comes first, inside the same bracket)")),
             ("onesweepKernel", "sort_pass", 2 * (kbytes + 4), "key + index read and written"),
             ("onesweepKernel (positions generated)", "sort_pass_iota", 2 * kbytes + 4, "key read; key + index written"),
             (("gatherMultiKernel (x, y, z in one launch)", "gather", 4 + 6 * rbytes,

@@ -67,6 +67,15 @@ bool ctxAlive(const cstone_hip_ctx* ctx)
     return registry().count(ctx) != 0;
 }
 
+int ensureAuxStream(cstone_hip_ctx* ctx)
+{
+    if (ctx->aux) return CSTONE_OK;
+    CS_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    CS_HIP(ctx, hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming));
+    CS_HIP(ctx, hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming));
+    return CSTONE_OK;
+}
+
 int arenaReserve(cstone_hip_ctx* ctx, size_t totalBytes)
 {
     totalBytes = alignUp(totalBytes) + 4096;
@@ -226,7 +235,16 @@ int cstone_hip_ctx_destroy(cstone_hip_ctx* ctx)
     }
     for (auto e : ctx->eventPool)
         (void)hipEventDestroy(e);
+    if (ctx->aux)
+    {
+        (void)hipStreamSynchronize(ctx->aux);
+        (void)hipEventDestroy(ctx->evFork);
+        (void)hipEventDestroy(ctx->evJoin);
+        (void)hipStreamDestroy(ctx->aux);
+    }
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->scanStatus) (void)hipFree(ctx->scanStatus);
+    if (ctx->scanTickets) (void)hipFree(ctx->scanTickets);
     if (ctx->devScalars) (void)hipFree(ctx->devScalars);
     if (ctx->hilbertTables) (void)hipFree(ctx->hilbertTables);
     if (ctx->hostScalars) (void)hipHostFree(ctx->hostScalars);

@@ -33,6 +33,21 @@ struct cstone_hip_ctx
     size_t uploadBytes   = 0;
     size_t uploadCursor  = 0;
 
+    // a second stream of the context's own (ensureAuxStream) for work of one call that does not depend on the rest of
+    // it -- Domain::sync gathers x, y, z there while the trees are updated on `stream` --, and the events that order the
+    // two; whatever runs there is joined back into `stream` before the call returns
+    hipStream_t aux    = nullptr;
+    hipEvent_t evFork  = nullptr;
+    hipEvent_t evJoin  = nullptr;
+
+    // single-launch prefix sums (scan.hip): status words of the chained tiles, two ticket counters, and what tells the
+    // words and tickets of one launch from those of the launches before (no clearing between scans)
+    unsigned long long* scanStatus = nullptr; // [2][scanTilesCap]
+    size_t scanTilesCap            = 0;
+    uint32_t* scanTickets          = nullptr; // [2]
+    uint32_t scanTicketBase[2]     = {0, 0};
+    uint32_t scanGeneration        = 0;
+
     // -1 unknown, else result of the one-time LDS atomic ordering probe of the radix sort (sort.hip)
     int ldsOrderOk = -1;
 
@@ -89,6 +104,22 @@ inline int fail(cstone_hip_ctx* ctx, int code, const char* fmt, ...)
         int rc_ = (expr);                                                                                              \
         if (rc_ != CSTONE_OK) return rc_;                                                                              \
     } while (0)
+
+//! creates ctx->aux and its events on first use
+int ensureAuxStream(cstone_hip_ctx* ctx);
+//! the launches (and stage timers) of a scope go to another stream of the context
+struct StreamScope
+{
+    cstone_hip_ctx* ctx;
+    hipStream_t saved;
+    StreamScope(cstone_hip_ctx* c, hipStream_t s)
+        : ctx(c)
+        , saved(c->stream)
+    {
+        ctx->stream = s;
+    }
+    ~StreamScope() { ctx->stream = saved; }
+};
 
 //! reserve bytes from the arena; grows (with a stream sync) when too small. Pointers stay valid until arenaReset.
 int arenaReserve(cstone_hip_ctx* ctx, size_t totalBytes);

@@ -282,9 +282,51 @@ public:
         const bool tryResort = !firstCall_ && tileLeaves > 0 && layoutLeaves_ == fLeaves_ && fLeaves_ > 0 &&
                                resortBackoff_ == 0 && !boxMoved && mayResort();
         if (resortBackoff_ > 0) --resortBackoff_;
+        // The field-carrying leaf pass (resort.hpp, sortLeavesFields; CSTONE_FUSED_LEAF_PASS=1 and four scratch arrays): x,
+        // y, z, h move with the keys in ONE pass over the particle arrays instead of the leaf pass and the gathers of h and
+        // of x, y, z.  Measured at 1e8 particles, every particle drifting: 2.14 ms against 0.66 + 0.37 + 0.91 ms for the
+        // three passes it replaces (it saves 8 of their 92 bytes per particle, and the ordering network -- bound by
+        // instruction issue -- and the data movement do not overlap inside one wave the way separate kernels on two streams
+        // do): kept selectable, not the default.
+        const bool fusedLeafPass        = std::getenv("CSTONE_FUSED_LEAF_PASS") != nullptr; // (read per sync: tests switch it)
+        const bool carryFields          = numScratch >= 4 && fusedLeafPass;
+        bool fieldsMoved                = false; // x, y, z, h are in their new order already (and radii follow from hmax)
+        // The gather of x, y, z has no consumer inside a sync: with three or more scratch arrays it runs on the context's
+        // second stream, next to the tree updates (chains of small, latency-bound kernels with two read-backs in between)
+        // and the gather of h, and is joined before the call returns.
+        const bool noOverlap = std::getenv("CSTONE_NO_GATHER_OVERLAP") != nullptr; // tuning / tests
+        bool xyzForked = false, xyzJoined = false;
+        auto forkXyzGather = [&](size_t count) -> int
+        {
+            if (fieldsMoved || numScratch < 3 || noOverlap || xyzForked || count == 0) return CSTONE_OK;
+            CS_TRY(ensureAuxStream(ctx_));
+            CS_HIP(ctx_, hipEventRecord(ctx_->evFork, ctx_->stream));
+            CS_HIP(ctx_, hipStreamWaitEvent(ctx_->aux, ctx_->evFork, 0));
+            const void* src[3] = {*xPP, *yPP, *zPP};
+            void* dst[3]       = {scratchAll[0], scratchAll[1], scratchAll[2]};
+            int rc;
+            {
+                StreamScope scope(ctx_, ctx_->aux);
+                rc = cstone_hip_gather_multi(ctx_, sizeof(T), order_.as<uint32_t>(), count, src, dst, 3);
+            }
+            CS_TRY(rc);
+            CS_HIP(ctx_, hipEventRecord(ctx_->evJoin, ctx_->aux));
+            std::swap(*xPP, scratchAll[0]);
+            std::swap(*yPP, scratchAll[1]);
+            std::swap(*zPP, scratchAll[2]);
+            xyzForked = true;
+            return CSTONE_OK;
+        };
+        auto joinXyzGather = [&]() -> int
+        {
+            if (xyzForked && !xyzJoined) CS_HIP(ctx_, hipStreamWaitEvent(ctx_->stream, ctx_->evJoin, 0));
+            xyzJoined = true;
+            return CSTONE_OK;
+        };
         if (tryResort)
         {
-            CS_TRY(resort_.prepare(ctx_, fTree_.as<K>(), layout_.as<uint32_t>(), fLeaves_, n, keysAlt_.as<K>(), true));
+            CS_TRY(resort_.prepare(ctx_, fTree_.as<K>(), layout_.as<uint32_t>(), fLeaves_, n, keysAlt_.as<K>(), true,
+                                   carryFields ? rb : 0));
             const ResortArgs<K> ra = resort_.args();
             bool done              = false;
             CS_TRY(computeKeysResort(ctx_, curve_, kb, rb, *xPP, *yPP, *zPP, keys, n, box_, &ra,
@@ -311,8 +353,23 @@ public:
                 const uint32_t movers  = uint32_t(ctx_->hostScalars[RESORT_SCALARS + 3]);
                 if (!boxChanged && (flags & 7) == 0 && movers <= n / 8)
                 {
-                    CS_TRY(resort_.sortLeaves(ctx_, keysAlt_.as<K>(), keys, order_.as<uint32_t>(), movers, markers, J,
-                                              tileLeaves, (flags & 8) != 0));
+                    if (carryFields)
+                    {
+                        ResortFields rf{rb, {*xPP, *yPP, *zPP, *hPP}, {scratchAll[0], scratchAll[1], scratchAll[2], scratchAll[3]}};
+                        CS_TRY(resort_.sortLeavesFields(ctx_, keysAlt_.as<K>(), keys, order_.as<uint32_t>(), rf, movers,
+                                                        markers, J, tileLeaves));
+                        std::swap(*xPP, scratchAll[0]);
+                        std::swap(*yPP, scratchAll[1]);
+                        std::swap(*zPP, scratchAll[2]);
+                        std::swap(*hPP, scratchAll[3]);
+                        fieldsMoved = true;
+                    }
+                    else
+                    {
+                        CS_TRY(resort_.sortLeaves(ctx_, keysAlt_.as<K>(), keys, order_.as<uint32_t>(), movers, markers, J,
+                                                  tileLeaves, (flags & 8) != 0));
+                        CS_TRY(forkXyzGather(n - markers)); // (the ordering is final: x, y, z follow on the second stream)
+                    }
                     CS_HIP(ctx_, hipMemsetAsync(ctx_->devScalars + 3, 0, sizeof(int), ctx_->stream));
                     sorted      = true;
                     lastMovers_ = movers;
@@ -408,6 +465,7 @@ public:
                                          sortTmp_.p, tb));
             ++fullSortFallbacks_;
         }
+        CS_TRY(forkXyzGather(numAssigned)); // (radix path: the ordering is final from here on)
 
         // ---- GlobalAssignment::distribute on one rank: nothing to exchange; the second sort (assignment.hpp:156) of an
         //      already sorted range is the identity and is skipped.
@@ -447,18 +505,31 @@ public:
         // gatherArrays(h) + segmentMax + scale in one pass over h (every leaf is assigned on one rank: the leaves' particles
         // are all the assigned particles)
         static const bool splitGather = std::getenv("CSTONE_SPLIT_H_GATHER") != nullptr; // tuning: the two-pass form
-        if (splitGather)
+        if (fieldsMoved)
         {
-            CS_TRY(cstone_hip_gather(ctx_, sizeof(T), order_.as<uint32_t>(), numAssigned, *hPP, *scratchPP));
-            std::swap(*hPP, *scratchPP);
-            CS_TRY(cstone_hip_halo_radii(ctx_, rb, *hPP, layout_.as<uint32_t>(), 0, L, L, haloSearchExt_,
-                                         radii_.as<float>()));
+            // h is in SFC order already; the radii follow from the maxima the leaf pass folded per OLD leaf
+            CS_TRY(resort_.radiiOfLeaves(ctx_, L, layout_.as<uint32_t>(), *hPP, rb, haloSearchExt_, radii_.as<float>()));
         }
         else
         {
-            CS_TRY(gatherWithHaloRadii(ctx_, rb, *hPP, order_.as<uint32_t>(), *scratchPP, layout_.as<uint32_t>(), L,
-                                       haloSearchExt_, radii_.as<float>()));
-            std::swap(*hPP, *scratchPP);
+            // where h goes: the first scratch array -- unless x, y, z are still on their way there on the second stream; a
+            // fourth scratch array then takes h (no waiting), with three the gather of h waits for them
+            void** hDst = scratchPP;
+            if (xyzForked && numScratch >= 4) { hDst = &scratchAll[3]; }
+            else { CS_TRY(joinXyzGather()); }
+            if (splitGather)
+            {
+                CS_TRY(cstone_hip_gather(ctx_, sizeof(T), order_.as<uint32_t>(), numAssigned, *hPP, *hDst));
+                std::swap(*hPP, *hDst);
+                CS_TRY(cstone_hip_halo_radii(ctx_, rb, *hPP, layout_.as<uint32_t>(), 0, L, L, haloSearchExt_,
+                                             radii_.as<float>()));
+            }
+            else
+            {
+                CS_TRY(gatherWithHaloRadii(ctx_, rb, *hPP, order_.as<uint32_t>(), *hDst, layout_.as<uint32_t>(), L,
+                                           haloSearchExt_, radii_.as<float>()));
+                std::swap(*hPP, *hDst);
+            }
         }
         CS_HIP(ctx_, hipMemsetAsync(flags_.p, 0, size_t(L) * sizeof(int), ctx_->stream));
         CS_TRY(cstone_hip_find_halos(ctx_, curve_, kb, rb, fPrefixes_.p, fChild_.as<int32_t>(), fItl_.as<int32_t>(),
@@ -467,7 +538,9 @@ public:
         // which is the inclusive scan written above shifted by one.
 
         // ---- updateLayout (domain.hpp:542-604): keys already sit at offset 0; gather the unordered arrays
-        if (numScratch >= 3)
+        CS_TRY(joinXyzGather()); // (the property gathers below go through the buffers x, y, z were read from)
+        if (fieldsMoved || xyzForked) {} // (x, y, z went with the leaf pass, or on the second stream)
+        else if (numScratch >= 3)
         {
             // three free buffers (the caller's scratch tuple, R/domain/domain.hpp:196-206 has three as well): x, y, z go
             // to their new order in ONE pass that reads the ordering once
@@ -546,6 +619,7 @@ public:
         v->sizes                 = fSizes_.p;
         v->halo_flags            = flags_.as<int32_t>();
         v->sfc_order             = order_.as<uint32_t>();
+        v->halo_radii            = radii_.as<float>();
         return CSTONE_OK;
     }
 

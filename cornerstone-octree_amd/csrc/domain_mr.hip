@@ -106,6 +106,79 @@ inline std::vector<int> uniformBinsHost(const std::vector<uint32_t>& counts, int
     return bins;
 }
 
+/*! One update step of the (small, replicated) GLOBAL tree on the host: the decision of nodeOp (tree.hip,
+ *  R/tree/csarray.hpp:270-310) and the expansion of rebalanceKernel (R/tree/csarray.hpp:360-385), restated for the host
+ *  copies of the leaf array and the all-reduced counts that the last sync read back anyway.  The device then only counts
+ *  (and reduces): the read-back between decision and rebalance of cstone_hip_update_octree disappears from a steady-state
+ *  sync.  Returns true if every node op is "keep" (the leaf array is unchanged). */
+template<class K>
+bool globalTreeStepHost(const std::vector<K>& tree, const std::vector<uint32_t>& counts, uint32_t bucket,
+                        std::vector<K>& newTree)
+{
+    const int numNodes = int(counts.size());
+    constexpr unsigned top = maxLevel<K>();
+    auto span = [](unsigned level) { return K(1) << (3u * (top - level)); };
+    auto levelOf = [&](K s) // level of a node of key span s (a power of 8)
+    {
+        unsigned level = top;
+        while (level > 0 && span(level) < s)
+            --level;
+        return level;
+    };
+    std::vector<uint32_t> ops(size_t(numNodes) + 1, 0);
+    bool keepAll = true;
+    for (int i = 0; i < numNodes; ++i)
+    {
+        const K start        = tree[i];
+        const unsigned level = levelOf(K(tree[i + 1] - start));
+        uint32_t op          = 1;
+        bool merged          = false;
+        if (level > 0)
+        {
+            const int sib = int((start >> (3u * (top - level))) & 7u);
+            if (sib > 0)
+            {
+                const int first = i - sib;
+                if (first >= 0 && first + 8 <= numNodes && tree[first + 8] == K(tree[first] + span(level - 1)))
+                {
+                    uint64_t parent = 0;
+                    for (int k = 0; k < 8; ++k)
+                        parent += counts[first + k];
+                    merged = parent <= uint64_t(bucket);
+                }
+            }
+        }
+        if (merged) { op = 0; }
+        else
+        {
+            const uint32_t c = counts[i];
+            if (c > bucket * 512u && level + 3 < top) op = 4096;
+            else if (c > bucket * 64u && level + 2 < top) op = 512;
+            else if (c > bucket * 8u && level + 1 < top) op = 64;
+            else if (c > bucket && level < top) op = 8;
+        }
+        ops[i]  = op;
+        keepAll = keepAll && op == 1;
+    }
+    if (keepAll) return true;
+    newTree.clear();
+    for (int i = 0; i < numNodes; ++i)
+    {
+        const uint32_t cnt = ops[i];
+        if (cnt == 0) continue;
+        const K start        = tree[i];
+        const unsigned level = levelOf(K(tree[i + 1] - start));
+        unsigned down = 0; // cnt in {1, 8, 64, 512, 4096}: 0..4 levels down
+        for (uint32_t c = cnt; c > 1; c /= 8)
+            ++down;
+        const K step = span(level + down);
+        for (uint32_t j = 0; j < cnt; ++j)
+            newTree.push_back(K(start + K(j) * step));
+    }
+    newTree.push_back(tree[numNodes]);
+    return false;
+}
+
 // ---- device helpers ------------------------------------------------------------------------------------------------
 
 //! for each of two keys: the index of the leaf that contains it and that leaf's start and end key (one thread per key);
@@ -176,8 +249,10 @@ __global__ void differencesKernel(const uint64_t* __restrict__ in, int n, uint64
 }
 
 //! keys (already sorted) and x, y, z, h (from their input slots order[i]) of the kept particles to their final slots
-//! (pos[i], or i when pos is null): the two index maps are read once for the five columns
-template<class K, class T>
+//! (pos[i], or i when pos is null): the two index maps are read once for the columns of a launch.  WHICH = 0: all five
+//! columns; 1: keys and h (what the locally essential tree and the halo discovery need); 2: x, y, z (nobody reads them
+//! before the halo exchange: they go out on the context's second stream, next to the tree update)
+template<class K, class T, int WHICH>
 __global__ __launch_bounds__(256) void placeColumnsKernel(const uint32_t* __restrict__ order,
                                                           const uint32_t* __restrict__ pos, size_t m,
                                                           const K* __restrict__ keys, const T* __restrict__ x,
@@ -190,9 +265,17 @@ __global__ __launch_bounds__(256) void placeColumnsKernel(const uint32_t* __rest
     if (i >= m) return;
     const uint32_t s = order[i];
     const size_t d   = pos ? size_t(pos[i]) : i;
-    const K vk = keys[i]; // the kept keys are already in sorted order
-    const T vx = x[s], vy = y[s], vz = z[s], vh = h[s];
-    dk[d] = vk, dx[d] = vx, dy[d] = vy, dz[d] = vz, dh[d] = vh;
+    if constexpr (WHICH != 2)
+    {
+        const K vk = keys[i]; // the kept keys are already in sorted order
+        const T vh = h[s];
+        dk[d] = vk, dh[d] = vh;
+    }
+    if constexpr (WHICH != 1)
+    {
+        const T vx = x[s], vy = y[s], vz = z[s];
+        dx[d] = vx, dy[d] = vy, dz[d] = vz;
+    }
 }
 
 __global__ __launch_bounds__(256) void boxFlagsKernel(const int32_t* __restrict__ boxes, int n,
@@ -291,6 +374,38 @@ __global__ __launch_bounds__(256) void fillIndicesKernel(const int32_t* __restri
     for (uint32_t j = a + sub; j < b; j += 16)
         out[o + (j - a)] = j - base;
 }
+
+//! pinned host block for the read-backs of a sync: an asynchronous copy into PAGEABLE memory makes the host wait for it,
+//! which would turn every one of the copies that are meant to travel behind one synchronisation into a round trip
+struct PinnedBlock
+{
+    char* p      = nullptr;
+    size_t bytes = 0, used = 0;
+    ~PinnedBlock()
+    {
+        if (p) (void)hipHostFree(p);
+    }
+    //! room for `need` more bytes (64-byte aligned); grows only while nothing is handed out (used == 0)
+    void* take(size_t need)
+    {
+        const size_t at = (used + 63) & ~size_t(63);
+        if (at + need > bytes) return nullptr;
+        used = at + need;
+        return p + at;
+    }
+    int reserve(cstone_hip_ctx* ctx, size_t total)
+    {
+        used = 0;
+        if (total <= bytes) return CSTONE_OK;
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (p) CS_HIP(ctx, hipHostFree(p));
+        p = nullptr, bytes = 0;
+        const size_t want = total + total / 2 + 4096;
+        CS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault));
+        bytes = want;
+        return CSTONE_OK;
+    }
+};
 
 //! one set of result arrays
 constexpr int MAX_PROPS = 16;
@@ -527,6 +642,12 @@ public:
         // therefore kept as a pending status; the rank goes on as an EMPTY rank, the status word rides on the next
         // collective (box all-reduce, count all-gathers) and every rank returns an error behind it.
         pending_ = 0, toggled_ = false;
+        if (placeForked_)
+        {
+            // (a sync that was abandoned behind its fork: whatever it left on the second stream comes first)
+            CS_HIP(ctx_, hipStreamWaitEvent(ctx_->stream, ctx_->evJoin, 0));
+            placeForked_ = false;
+        }
         if (numProps < 0 || numProps > MAX_PROPS) setPending(CSTONE_E_ARG, "domain_mr_sync: at most %d properties", MAX_PROPS);
         for (int q = 0; q < numProps && !pending_; ++q)
         {
@@ -704,39 +825,71 @@ public:
 
         tick("2 encode+sort");
         CS_TRY(updateGlobalTree(n));
+        CS_TRY(queueGlobalTreeReadBack());
+
+        // ---- C3 (first half): send ranges on the sorted keys and the counts of everybody.  The assignment follows from
+        //      the global counts that are on their way to the host; it rarely changes from one sync to the next (a
+        //      boundary moves by whole leaves of the global tree), so the cut points for the assignment of the LAST sync
+        //      are computed and all-gathered right behind the counts, and ONE read-back brings global counts, cut points
+        //      and count matrix.  Only a sync whose assignment did change asks again.  (A partially sorted key array --
+        //      runs of equal high digits still to be fixed up -- answers these searches correctly: an assignment boundary
+        //      is a leaf boundary of the global tree and cannot fall inside a run.)
+        std::vector<uint64_t> cut(P_ + 1);
+        std::vector<uint64_t> sendCounts(P_), matrix(size_t(P_) * P_, 0);
+        std::vector<uint64_t> rows(size_t(P_) * (P_ + 1), 0);
+        std::vector<K> cutKeys; // the assignment the queued cut points belong to
+        uint64_t *pinRows = nullptr, *pinCut = nullptr;
+        auto queueCuts = [&](const std::vector<K>& asg) -> int
+        {
+            cutKeys      = asg;
+            K* dq        = reinterpret_cast<K*>(scal_.as<char>() + 2048);
+            uint64_t* dr = reinterpret_cast<uint64_t*>(scal_.as<char>() + 2048 + size_t(P_ + 1) * 8);
+            CS_TRY(cstone_hip_upload(ctx_, dq, asg.data(), size_t(P_ + 1) * sizeof(K)));
+            CS_TRY(cstone_hip_lower_bound(ctx_, kb, keys_.p, n, dq, P_ + 1, dr));
+            // the send counts go from the device into the all-gather
+            uint64_t* send = scal_.as<uint64_t>() + 32;
+            uint64_t* recv = reinterpret_cast<uint64_t*>(scal_.as<char>() + 4096);
+            hipLaunchKernelGGL(differencesKernel, gridFor(P_, 64), 64, 0, ctx_->stream, dr, P_, send);
+            if (!pinRows)
+            {
+                pinRows = static_cast<uint64_t*>(pin_.take(rows.size() * 8));
+                pinCut  = static_cast<uint64_t*>(pin_.take(size_t(P_ + 1) * 8));
+            }
+            if (P_ > 1)
+            {
+                // word P of every row: the status of that rank (0 = fine), see the top of sync()
+                const uint64_t status = pending_ ? 1 : 0;
+                CS_TRY(cstone_hip_upload(ctx_, send + P_, &status, 8));
+                CS_TRY(callComm(comm_.all_gather(comm_.user, send, recv, size_t(P_ + 1) * 8), "all_gather (counts)"));
+                CS_HIP(ctx_, hipMemcpyAsync(pinRows, recv, rows.size() * 8, hipMemcpyDeviceToHost, ctx_->stream));
+            }
+            CS_HIP(ctx_, hipMemcpyAsync(pinCut, dr, size_t(P_ + 1) * 8, hipMemcpyDeviceToHost, ctx_->stream));
+            return CSTONE_OK;
+        };
+        auto takeCuts = [&]()
+        {
+            std::copy(pinCut, pinCut + P_ + 1, cut.begin());
+            if (P_ > 1) std::copy(pinRows, pinRows + rows.size(), rows.begin());
+        };
+        injectFailure("assign");
+        const bool speculateCuts = !firstCall_ && int(assignment_.size()) == P_ + 1 && speculateCuts_;
+        if (speculateCuts) CS_TRY(queueCuts(assignment_));
+        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream)); // global counts (+ leaves), the sort's flag, cut points, matrix
+        takeGlobalTreeReadBack();
+        if (speculateCuts) takeCuts();
         if (partialSort && ctx_->hostScalars[3] != 0)
             CS_TRY(cstone_hip_sort_pairs(ctx_, kb, keys_.p, order_.as<uint32_t>(), n, keysAlt_.p, orderAlt_.as<uint32_t>(),
                                          sortTmp_.p, sortTmp_.bytes));
         CS_TRY(assign());
         tick("3 global tree+assign");
-
-        // ---- C3: send ranges on the sorted keys, counts of everybody, exchange of the leaving particles
-        std::vector<uint64_t> cut(P_ + 1);
+        if (!speculateCuts || cutKeys != assignment_)
         {
-            K* dq      = reinterpret_cast<K*>(scal_.as<char>() + 2048);
-            uint64_t* dr = reinterpret_cast<uint64_t*>(scal_.as<char>() + 2048 + size_t(P_ + 1) * 8);
-            CS_HIP(ctx_, hipMemcpyAsync(dq, assignment_.data(), size_t(P_ + 1) * sizeof(K), hipMemcpyHostToDevice,
-                                        ctx_->stream));
-            CS_TRY(cstone_hip_lower_bound(ctx_, kb, keys_.p, n, dq, P_ + 1, dr));
+            if (speculateCuts) ++cutRedos_;
+            CS_TRY(queueCuts(assignment_));
+            CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
+            takeCuts();
         }
-        // the send counts go from the device into the all-gather; cut points and count matrix come back in one read-back
-        std::vector<uint64_t> sendCounts(P_), matrix(size_t(P_) * P_, 0);
         {
-            uint64_t* dr   = reinterpret_cast<uint64_t*>(scal_.as<char>() + 2048 + size_t(P_ + 1) * 8);
-            uint64_t* send = scal_.as<uint64_t>() + 32;
-            uint64_t* recv = reinterpret_cast<uint64_t*>(scal_.as<char>() + 4096);
-            hipLaunchKernelGGL(differencesKernel, gridFor(P_, 64), 64, 0, ctx_->stream, dr, P_, send);
-            std::vector<uint64_t> rows(size_t(P_) * (P_ + 1), 0);
-            if (P_ > 1)
-            {
-                // word P of every row: the status of that rank (0 = fine), see the top of sync()
-                injectFailure("assign");
-                statusW64_ = pending_ ? 1 : 0; // a member: outlives the asynchronous copy
-                CS_HIP(ctx_, hipMemcpyAsync(send + P_, &statusW64_, 8, hipMemcpyHostToDevice, ctx_->stream));
-                CS_TRY(callComm(comm_.all_gather(comm_.user, send, recv, size_t(P_ + 1) * 8), "all_gather (counts)"));
-                CS_HIP(ctx_, hipMemcpyAsync(rows.data(), recv, rows.size() * 8, hipMemcpyDeviceToHost, ctx_->stream));
-            }
-            CS_TRY(toHost(cut.data(), dr, size_t(P_ + 1) * 8));
             for (int p = 0; p < P_; ++p)
                 sendCounts[p] = cut[p + 1] - cut[p];
             if (P_ == 1) matrix[0] = sendCounts[0];
@@ -872,15 +1025,50 @@ public:
         }
         {
             T* dst[4] = {o.x.as<T>() + M, o.y.as<T>() + M, o.z.as<T>() + M, o.h.as<T>() + M};
+            // keys and h first: the locally essential tree and the halo discovery work on them.  x, y, z are not read
+            // before the halo exchange: they go to their final slots on the context's second stream, next to the tree
+            // update (chains of small kernels and read-backs), and are joined in front of the exchange
+            const bool overlap = useLet_ && overlapPlace_;
+            if (overlap) CS_TRY(ensureAuxStream(ctx_));
             if (na)
             {
                 StageTimer timer(ctx_, CSTONE_STAGE_PLACE);
-                hipLaunchKernelGGL((placeColumnsKernel<K, T>), gridFor(na, 256), 256, 0, ctx_->stream, keptO,
-                                   nb ? posA_.as<uint32_t>() : nullptr, size_t(na), keptKeys, x, y, z, h, keysM, dst[0],
-                                   dst[1], dst[2], dst[3]);
+                if (overlap)
+                    hipLaunchKernelGGL((placeColumnsKernel<K, T, 1>), gridFor(na, 256), 256, 0, ctx_->stream, keptO,
+                                       nb ? posA_.as<uint32_t>() : nullptr, size_t(na), keptKeys, x, y, z, h, keysM, dst[0],
+                                       dst[1], dst[2], dst[3]);
+                else
+                    hipLaunchKernelGGL((placeColumnsKernel<K, T, 0>), gridFor(na, 256), 256, 0, ctx_->stream, keptO,
+                                       nb ? posA_.as<uint32_t>() : nullptr, size_t(na), keptKeys, x, y, z, h, keysM, dst[0],
+                                       dst[1], dst[2], dst[3]);
             }
-            for (int c = 0; c < 4 && nb; ++c)
-                CS_TRY(cstone_hip_scatter(ctx_, sizeof(T), posB_.as<uint32_t>(), nb, recvSorted[c], dst[c]));
+            if (nb) CS_TRY(cstone_hip_scatter(ctx_, sizeof(T), posB_.as<uint32_t>(), nb, recvSorted[3], dst[3]));
+            if (overlap)
+            {
+                CS_HIP(ctx_, hipEventRecord(ctx_->evFork, ctx_->stream));
+                CS_HIP(ctx_, hipStreamWaitEvent(ctx_->aux, ctx_->evFork, 0));
+                int rc = CSTONE_OK;
+                {
+                    StreamScope scope(ctx_, ctx_->aux);
+                    if (na)
+                    {
+                        StageTimer timer(ctx_, CSTONE_STAGE_PLACE);
+                        hipLaunchKernelGGL((placeColumnsKernel<K, T, 2>), gridFor(na, 256), 256, 0, ctx_->stream, keptO,
+                                           nb ? posA_.as<uint32_t>() : nullptr, size_t(na), keptKeys, x, y, z, h, keysM,
+                                           dst[0], dst[1], dst[2], dst[3]);
+                    }
+                    for (int c = 0; c < 3 && nb && rc == CSTONE_OK; ++c)
+                        rc = cstone_hip_scatter(ctx_, sizeof(T), posB_.as<uint32_t>(), nb, recvSorted[c], dst[c]);
+                }
+                CS_TRY(rc);
+                CS_HIP(ctx_, hipEventRecord(ctx_->evJoin, ctx_->aux));
+                placeForked_ = true;
+            }
+            else
+            {
+                for (int c = 0; c < 3 && nb; ++c)
+                    CS_TRY(cstone_hip_scatter(ctx_, sizeof(T), posB_.as<uint32_t>(), nb, recvSorted[c], dst[c]));
+            }
         }
         for (int q = 0; q < numProps; ++q)
         {
@@ -1103,6 +1291,12 @@ public:
 
         }
         tick("6 halo discovery");
+        if (placeForked_)
+        {
+            // x, y, z of the assigned block are needed from here on (a block that has to be moved, the halo exchange)
+            CS_HIP(ctx_, hipStreamWaitEvent(ctx_->stream, ctx_->evJoin, 0));
+            placeForked_ = false;
+        }
         // ---- room for the halos on both sides of the assigned block
         const uint64_t total = nlo + nm + nhi;
         uint64_t off = M - std::min(M, nlo); // start of the arrays handed out
@@ -1422,6 +1616,38 @@ private:
             CS_HIP(ctx_, hipMemcpy(gCounts_.p, c0.data(), c0.size() * 4, hipMemcpyHostToDevice));
             gLeaves_ = leaves;
         }
+        if (!firstCall_ && hostGlobalStep_ && int(gLeavesHost_.size()) == gLeaves_ + 1 && int(gCountsHost_.size()) == gLeaves_)
+        {
+            // later calls take exactly ONE update step (assignment.hpp:92-98).  The tree is small and replicated and the
+            // host holds its leaves and the all-reduced counts of the last sync (assign() read them): the decision and the
+            // new leaf array are made here; the device counts this rank's keys, the counts are reduced, and assign() reads
+            // them back together with everything else the sync needs at that point -- no read-back in between
+            std::vector<K> fresh;
+            const bool same = globalTreeStepHost<K>(gLeavesHost_, gCountsHost_, bucket_, fresh);
+            if (!same)
+            {
+                const int leaves = int(fresh.size()) - 1;
+                CS_TRY(ensureTree(gTree_, gCounts_, gCap_, leaves + 1));
+                gLeavesHost_.swap(fresh);
+                CS_TRY(cstone_hip_upload(ctx_, gTree_.p, gLeavesHost_.data(), gLeavesHost_.size() * sizeof(K)));
+                gLeaves_ = leaves;
+            }
+            gTreeSame_ = same;
+            CS_TRY(cstone_hip_compute_node_counts(ctx_, kb, gTree_.p, gCounts_.as<uint32_t>(), gLeaves_, keys_.p, n,
+                                                  0xFFFFFFFFu));
+            if (P_ > 1)
+            {
+                CS_TRY(gLocalCounts_.ensure(ctx_, size_t(gLeaves_) * sizeof(uint32_t)));
+                CS_HIP(ctx_, hipMemcpyAsync(gLocalCounts_.p, gCounts_.p, size_t(gLeaves_) * sizeof(uint32_t),
+                                            hipMemcpyDeviceToDevice, ctx_->stream));
+                CS_TRY(callComm(comm_.all_reduce(comm_.user, gCounts_.p, size_t(gLeaves_), 1, 0), "all_reduce (counts)"));
+                hipLaunchKernelGGL(maxWithLocalKernel, gridFor(size_t(gLeaves_), 256), 256, 0, ctx_->stream,
+                                   gCounts_.as<uint32_t>(), gLocalCounts_.as<uint32_t>(), gLeaves_);
+            }
+            gLeavesOnHost_ = true;
+            return CSTONE_OK;
+        }
+        gLeavesOnHost_ = false;
         int steps = 0;
         while (true)
         {
@@ -1453,13 +1679,33 @@ private:
         return CSTONE_OK;
     }
 
+    //! the read-back of the global counts (and of the leaf array, when the device made it): queued into the pinned
+    //! block, not waited for; takeGlobalTreeReadBack() behind the synchronisation
+    int queueGlobalTreeReadBack()
+    {
+        CS_TRY(pin_.reserve(ctx_, size_t(gLeaves_) * 4 + size_t(gLeaves_ + 1) * sizeof(K) + size_t(P_ + 1) * (P_ + 2) * 8 + 1024));
+        pinCounts_ = static_cast<uint32_t*>(pin_.take(size_t(gLeaves_) * 4));
+        CS_HIP(ctx_, hipMemcpyAsync(pinCounts_, gCounts_.p, size_t(gLeaves_) * 4, hipMemcpyDeviceToHost, ctx_->stream));
+        pinLeaves_ = nullptr;
+        if (!gLeavesOnHost_)
+        {
+            pinLeaves_ = static_cast<K*>(pin_.take(size_t(gLeaves_ + 1) * sizeof(K)));
+            CS_HIP(ctx_, hipMemcpyAsync(pinLeaves_, gTree_.p, size_t(gLeaves_ + 1) * sizeof(K), hipMemcpyDeviceToHost,
+                                        ctx_->stream));
+        }
+        return CSTONE_OK;
+    }
+    void takeGlobalTreeReadBack()
+    {
+        gCountsHost_.assign(pinCounts_, pinCounts_ + gLeaves_);
+        if (pinLeaves_) gLeavesHost_.assign(pinLeaves_, pinLeaves_ + gLeaves_ + 1);
+    }
+
+    //! makeSfcAssignment + limitBoundaryShifts from the host copies of the global tree (after the read-back completed)
     int assign()
     {
-        std::vector<uint32_t> counts(gLeaves_);
-        std::vector<K> leaves(gLeaves_ + 1);
-        CS_HIP(ctx_, hipMemcpyAsync(counts.data(), gCounts_.p, size_t(gLeaves_) * 4, hipMemcpyDeviceToHost,
-                                    ctx_->stream));
-        CS_TRY(toHost(leaves.data(), gTree_.p, size_t(gLeaves_ + 1) * sizeof(K)));
+        const std::vector<uint32_t>& counts = gCountsHost_;
+        const std::vector<K>& leaves        = gLeavesHost_;
         std::vector<int> bins = uniformBinsHost(counts, P_);
         std::vector<K> fresh(P_ + 1);
         for (int r = 0; r <= P_; ++r)
@@ -1741,6 +1987,17 @@ private:
     DevBuf gTree_, gCounts_, gLocalCounts_;
     int gCap_ = 0, gLeaves_ = 0;
     bool gTreeSame_ = false; // the global leaf array is that of the previous sync
+    std::vector<K> gLeavesHost_;        // host copies of the global tree and its all-reduced counts (assign())
+    std::vector<uint32_t> gCountsHost_;
+    bool gLeavesOnHost_  = false;       // gLeavesHost_ is what gTree_ holds (the host made this sync's update step)
+    PinnedBlock pin_;                   // where the read-backs of a sync arrive
+    uint32_t* pinCounts_ = nullptr;
+    K* pinLeaves_        = nullptr;
+    bool hostGlobalStep_ = std::getenv("CSTONE_MR_DEVICE_GLOBAL_STEP") == nullptr; // (tests: the device-side step)
+    bool speculateCuts_  = std::getenv("CSTONE_MR_NO_SPECULATIVE_CUTS") == nullptr;  // (tests: always ask after assign())
+    int cutRedos_        = 0; // syncs whose assignment changed: cut points asked for twice
+    bool overlapPlace_   = std::getenv("CSTONE_MR_NO_PLACE_OVERLAP") == nullptr; // x, y, z placed on the second stream
+    bool placeForked_    = false; // ... and not joined yet
     DevBuf fTree_, fCounts_, fTmp_;
     int fCap_ = 0, fLeaves_ = 0;
     DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_;

@@ -302,6 +302,22 @@ private:
         const bool inLeaves = keys == leaves_.template as<K>();
         if (inLeaves)
         {
+            // the ends of the curve need no search: a cornerstone array starts with 0 and ends with endKey (and holds
+            // nothing in between 0 and its second key).  With one rank these are all the keys anybody asks for.
+            if (memoVersion_ != treeVersion_) memo_.clear(), memoVersion_ = treeVersion_;
+            for (size_t i = 0; i < m; ++i)
+            {
+                const K q = queries[i];
+                int64_t known = -1;
+                if (q == 0) known = 0;
+                else if (q == 1) known = 1;
+                else if (q == endKey()) known = L_;
+                else if (q == K(endKey() + 1)) known = int64_t(L_) + 1;
+                if (known >= 0 && !memo_.count(q)) memo_[q] = {size_t(L_) + 2, known}; // (valid for any search length)
+            }
+        }
+        if (inLeaves)
+        {
             if (memoVersion_ != treeVersion_) memo_.clear(), memoVersion_ = treeVersion_;
             bool all = true;
             for (size_t i = 0; i < m && all; ++i)
@@ -1048,8 +1064,10 @@ private:
         std::vector<uint32_t> pairCounts(P_, 0);
         uint32_t unmatched = 0;
         LET_TRY(scratchKeys_.ensure(size_t(L + 2) * sizeof(K))); // at most (L + 1) / 2 runs of flagged leaves, 2 keys each
-        LET_TRY(cstone_hip_halo_requests(ctx_, kb, leaves_.p, flags_.as<int32_t>(), L, first, last, ranges.data(), P_,
-                                         scratchKeys_.p, pairCounts.data(), &unmatched));
+        // (one rank: every leaf is mine, nobody to ask -- and no read-back for the answer)
+        if (P_ > 1)
+            LET_TRY(cstone_hip_halo_requests(ctx_, kb, leaves_.p, flags_.as<int32_t>(), L, first, last, ranges.data(), P_,
+                                             scratchKeys_.p, pairCounts.data(), &unmatched));
         // counts of everybody (+ a status word: a halo cell that no peer owns fails the sync on every rank, checkHalos
         // halos.hpp:59-95)
         std::vector<uint64_t> row(P_ + 1, 0), matrix;

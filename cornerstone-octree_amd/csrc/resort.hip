@@ -781,14 +781,68 @@ __device__ __forceinline__ void pairSort(uint32_t (&d)[2], unsigned lane)
 #else
 #define CSTONE_WAVE_OCC
 #endif
-template<class K, int G, int MODE>
+// ---- the FIELD-CARRYING flavour of the leaf pass (round 4).  A sync used to make four passes over the particle arrays:
+//      encode (x, y, z read), leaf pass (keys), gather of h, gather of x, y, z -- 132 bytes per particle.  The lane that
+//      holds slot s of a leaf knows where that slot goes as soon as the leaf is ordered, so it can carry x, y, z, h of the
+//      slot along: they are loaded with the key (the stayers' from the old arrays at the slot's own position: coalesced;
+//      the arrivals' from their bins, where the encode kernel and placeMoversKernel have put them) and stored at the new
+//      place with the key.  The gathers disappear: 8 + 32 bytes read, 12 + 32 written per particle, and the maximum of h
+//      over the leaf's new content -- what Halos::discover wants per leaf -- is folded by the wave on the way.
+template<class T>
+struct LeafFields
+{
+    static constexpr bool on = true;
+    using Real               = T;
+    const T *x, *y, *z, *h;     // the old order (an arrival's values are fetched from its old position)
+    T *ox, *oy, *oz, *oh;       // the new order
+    T* hmax;                    // [J]: max h over the new content of every compact leaf (0 for an empty one)
+};
+struct NoLeafFields
+{
+    static constexpr bool on = false;
+    using Real               = float;
+};
+template<class T>
+struct LeafVal
+{
+    T x, y, z, h;
+};
+
+//! value of lane ^ X for a float or a double (both halves through the VALU permutations above)
+template<int X, class T>
+__device__ __forceinline__ T laneXorReal(T v, unsigned lane)
+{
+    if constexpr (sizeof(T) == 4) { return __uint_as_float(laneXor<X>(__float_as_uint(v), lane)); }
+    else
+    {
+        const uint64_t u  = uint64_t(__double_as_longlong(v));
+        const uint32_t lo = laneXor<X>(uint32_t(u), lane), hi = laneXor<X>(uint32_t(u >> 32), lane);
+        return __longlong_as_double((long long)((uint64_t(hi) << 32) | lo));
+    }
+}
+//! maximum over the 2^BITS lanes of every aligned lane segment
+template<int BITS, class T>
+__device__ __forceinline__ T segmentMaxLanes(T v, unsigned lane)
+{
+    v = fmax(v, laneXorReal<1>(v, lane));
+    v = fmax(v, laneXorReal<2>(v, lane));
+    v = fmax(v, laneXorReal<4>(v, lane));
+    v = fmax(v, laneXorReal<8>(v, lane));
+    if constexpr (BITS >= 5) v = fmax(v, laneXorReal<16>(v, lane));
+    if constexpr (BITS >= 6) v = fmax(v, laneXorReal<32>(v, lane));
+    return v;
+}
+
+template<class K, int G, int MODE, class F>
 __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
     const K* __restrict__ keysIn, const K* __restrict__ leafLo, const uint32_t* __restrict__ leafPos,
     const uint32_t* __restrict__ inOffset, const uint32_t* __restrict__ layoutNew, const K* __restrict__ binKeys,
     const uint32_t* __restrict__ binIdx, uint32_t J, bool alwaysCount, bool allTiles, K* __restrict__ keysOut,
-    uint32_t* __restrict__ orderOut)
+    uint32_t* __restrict__ orderOut, F fl)
 {
     constexpr K HOLE = ~K(0);
+    using Real       = typename F::Real;
+    using Val        = LeafVal<Real>;
     __shared__ uint32_t posK[G + 1], inK[G + 1], outK[G + 1];
     __shared__ K loK[G + 1];
     __shared__ uint32_t slotsK[G + 4]; // old slots + arrivals of every leaf, zeros behind the last one
@@ -832,7 +886,7 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
     //! what the loop needs to know about leaf k
     struct Leaf
     {
-        uint32_t pk, nOld, ik, nInc, ok, nNew, slots;
+        uint32_t pk, nOld, ik, nInc, ok, nNew, slots, k;
         K lo;
         unsigned cut;
     };
@@ -845,18 +899,55 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
         f.slots = f.nOld + f.nInc;
         f.lo    = loK[k];
         f.cut   = cutK[k];
+        f.k     = k;
         return f;
     };
-    // slot s of a leaf: an old position or an arrival
+    // slot s of a leaf: an old position or an arrival (key and old position; requested one wave step ahead)
     auto loadSlot = [&](const Leaf& f, uint32_t s, K& key, uint32_t& idx)
     {
         key = HOLE, idx = 0;
         if (s < f.nOld) key = keysIn[f.pk + s], idx = f.pk + s;
         else if (s < f.slots) key = binKeys[f.ik + (s - f.nOld)], idx = binIdx[f.ik + (s - f.nOld)];
     };
+    // x, y, z, h of the particle that sat at old position idx.  They are requested only once the leaf is ordered, right
+    // in front of the stores: the values then live in registers for a moment instead of across the network (with them
+    // prefetched like the keys the kernel needed 101-116 VGPRs, four waves per SIMD, and the network -- a chain of
+    // dependent cross-lane operations -- starved: 2.3-2.6 ms at 1e8 particles); the latency of these loads is covered
+    // by the other seven waves of the SIMD
+    auto loadFields = [&](uint32_t idx, bool have) -> Val
+    {
+        Val v{0, 0, 0, 0};
+        if constexpr (F::on)
+        {
+            if (have) v = Val{fl.x[idx], fl.y[idx], fl.z[idx], fl.h[idx]};
+        }
+        return v;
+    };
+    // the values requested for the NEXT step are pinned (an empty asm that "uses" them) before the stores of this step go
+    // out: the compiler then waits for those loads HERE, where they have had the whole step to return, instead of at the
+    // top of the next step behind this step's stores -- vmcnt counts loads and stores in one in-order queue, and a wait
+    // placed there has to cover the path of the loop that stores nothing, i.e. it waits for the stores as well
+    auto pinNext = [&](K& key, uint32_t& idx) { asm volatile("" : "+v"(key), "+v"(idx)); };
+    auto storeAt = [&](uint32_t at, K key, uint32_t idx, const Val& val)
+    {
+        keysOut[at]  = key;
+        orderOut[at] = idx;
+        if constexpr (F::on) fl.ox[at] = val.x, fl.oy[at] = val.y, fl.oz[at] = val.z, fl.oh[at] = val.h;
+    };
     auto digestOf = [&](const Leaf& f, K key, uint32_t slot) -> uint32_t
     { return key == HOLE ? ~0u : ((uint32_t((key - f.lo) >> f.cut) << 8) | slot); };
 
+    // the maximum of h over the new content of a leaf whose elements lie in the 2^BITS lanes of a segment (hm: this
+    // lane's candidate, 0 for a lane without an element -- the reference's segmentMax starts from 0 as well); `writer`:
+    // this lane reports for leaf k
+    auto reportHmax = [&](auto bitsTag, Real hm, bool writer, uint32_t k)
+    {
+        if constexpr (F::on)
+        {
+            const Real m = segmentMaxLanes<decltype(bitsTag)::value>(hm, lane);
+            if (writer) fl.hmax[j0 + k] = m;
+        }
+    };
     // the sorted digests of a leaf -> its new content: the place of every slot in the new order goes back to the lane that
     // loaded the slot (and still holds its key) through a 16-bit table per wave in LDS, two LDS accesses per element; that
     // lane stores key and old index at layoutNew[leaf] + place.  false: two neighbours in the new order have equal leading
@@ -880,26 +971,37 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
         for (int r = 0; r < R; ++r)
             if (d[r] != ~0u) place[d[r] & 0xFFu] = uint16_t(lane + 64u * r);
         __builtin_amdgcn_wave_barrier();
+        // (register after register: a leaf of more than 64 slots is rare, and four sets of values at once would set the
+        //  register budget -- i.e. the occupancy -- of the whole kernel)
+        Real hm = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r)
         {
+            const Val val = loadFields(idx[r], key[r] != HOLE);
             if (key[r] == HOLE) continue;
+            hm                = fmax(hm, val.h);
             const uint32_t at = place[lane + 64u * r];
-            if (at < f.nNew)
-            {
-                keysOut[f.ok + at]  = key[r];
-                orderOut[f.ok + at] = idx[r];
-            }
+            if (at < f.nNew) storeAt(f.ok + at, key[r], idx[r], val);
         }
+        reportHmax(std::integral_constant<int, 6>{}, hm, lane == 0, f.k);
         __builtin_amdgcn_wave_barrier();
         return true;
     };
     // exact path: every loaded element counts the elements of its leaf in front of it by (key, old index)
-    auto exactLeaf = [&](const Leaf& f, int R, const K* key, const uint32_t* idx)
+    // (rHmax: also fold the leaf's maximum of h -- the caller has not)
+    auto exactLeaf = [&](const Leaf& f, int R, const K* key, const uint32_t* idx, bool wholeWave)
     {
+        Real hm = 0;
+        for (int r = 0; r < R; ++r)
+        {
+            const Val v = loadFields(idx[r], key[r] != HOLE);
+            if (key[r] != HOLE) hm = fmax(hm, v.h);
+        }
+        if (wholeWave) reportHmax(std::integral_constant<int, 6>{}, hm, lane == 0, f.k);
         for (int r = 0; r < R; ++r)
         {
             if (key[r] == HOLE) continue;
+            const Val val_r = loadFields(idx[r], true);
             uint32_t less = 0;
             for (uint32_t q = 0; q < f.nOld; ++q)
             {
@@ -911,8 +1013,7 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
                 const K kq = binKeys[f.ik + q];
                 less += (kq < key[r] || (kq == key[r] && binIdx[f.ik + q] < idx[r])) ? 1u : 0u;
             }
-            keysOut[f.ok + less]  = key[r];
-            orderOut[f.ok + less] = idx[r];
+            storeAt(f.ok + less, key[r], idx[r], val_r);
         }
     };
     auto bigLeaf = [&](const Leaf& f, auto rTag)
@@ -927,7 +1028,7 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
             d[r] = digestOf(f, key[r], lane + 64u * r);
         }
         waveBitonicSort<R>(d, lane);
-        if (!finishLeaf(f, rTag, key, idx, d)) exactLeaf(f, R, key, idx);
+        if (!finishLeaf(f, rTag, key, idx, d)) exactLeaf(f, R, key, idx, true);
     };
 
     if constexpr (MODE == 0)
@@ -953,7 +1054,12 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
                 cur = leafOf(k + 4);
                 if (cur.slots <= 64) loadSlot(cur, lane, keyN, idxN);
             }
-            if (f.slots == 0) continue;
+            if (f.slots == 0)
+            {
+                if constexpr (F::on)
+                    if (lane == 0) fl.hmax[j0 + f.k] = 0;
+                continue;
+            }
             if (f.slots <= 64)
             {
                 // nothing arrived and what stayed is still in order (a departure leaves the largest key behind, so only
@@ -963,17 +1069,17 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
                     const bool behind = lane != 0 && key1[0] < below;
                     if (f.nInc == 0 && !__any(behind))
                     {
-                        if (lane < f.nNew)
-                        {
-                            keysOut[f.ok + lane]  = key1[0];
-                            orderOut[f.ok + lane] = idx1[0];
-                        }
+                        const Val v = loadFields(idx1[0], key1[0] != HOLE);
+                        reportHmax(std::integral_constant<int, 6>{}, key1[0] != HOLE ? v.h : Real(0), lane == 0, f.k);
+                        pinNext(keyN, idxN);
+                        if (lane < f.nNew) storeAt(f.ok + lane, key1[0], idx1[0], v);
                         continue;
                     }
                 }
                 uint32_t d[1] = {digestOf(f, key1[0], lane)};
                 waveBitonicSort<1>(d, lane);
-                if (!finishLeaf(f, std::integral_constant<int, 1>{}, key1, idx1, d)) exactLeaf(f, 1, key1, idx1);
+                pinNext(keyN, idxN);
+                if (!finishLeaf(f, std::integral_constant<int, 1>{}, key1, idx1, d)) exactLeaf(f, 1, key1, idx1, true);
             }
             else if (f.slots <= 128) { bigLeaf(f, std::integral_constant<int, 2>{}); }
             else { bigLeaf(f, std::integral_constant<int, 4>{}); }
@@ -1019,7 +1125,7 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
             bool mine          = kk < kEnd;
             if (bits == 5 && seg == 1 && secondSlots > 64u) mine = false;
             Leaf f = leafOf(mine ? kk : q);
-            if (!mine) f.nOld = f.nInc = f.nNew = f.slots = 0;
+            if (!mine) f.nOld = f.nInc = f.nNew = f.slots = 0, f.k = ~0u;
             return f;
         };
         //! leaves the step at q with `bits` consumes
@@ -1073,21 +1179,41 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
                 else { bigLeaf(f, std::integral_constant<int, 4>{}); }
                 continue;
             }
-            if (!__any(f.slots != 0)) continue;
+            // x, y, z, h of this lane's two elements, and the max h of every leaf of the step (a segment of 16 or 32 lanes
+            // each; empty leaves report 0)
+            Val val[2];
+            auto stepFields = [&]()
+            {
+                val[0] = loadFields(idx[0], key[0] != HOLE);
+                val[1] = loadFields(idx[1], key[1] != HOLE);
+                if constexpr (F::on)
+                {
+                    Real hm = 0;
+                    if (key[0] != HOLE) hm = fmax(hm, val[0].h);
+                    if (key[1] != HOLE) hm = fmax(hm, val[1].h);
+                    const bool writer = sl == 0 && f.k != ~0u;
+                    if (b == 5) reportHmax(std::integral_constant<int, 5>{}, hm, writer, f.k);
+                    else reportHmax(std::integral_constant<int, 4>{}, hm, writer, f.k);
+                }
+            };
+            if (!__any(f.slots != 0))
+            {
+                stepFields();
+                continue;
+            }
             // the element in front of (lane, 0) is (lane - 1, 1), the one in front of (lane, 1) is (lane, 0)
             const K front = K(__shfl_up((unsigned long long)key[1], 1));
             // nothing arrived and what stayed is still in order: the content goes out as it came in
             const bool behind = (sl != 0 && key[0] < front) || key[1] < key[0];
             if (!__any(f.nInc != 0 || behind))
             {
+                stepFields();
+                pinNext(keyN[0], idxN[0]);
+                pinNext(keyN[1], idxN[1]);
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
                 {
-                    if (2 * sl + r < f.nNew)
-                    {
-                        keysOut[f.ok + 2 * sl + r]  = key[r];
-                        orderOut[f.ok + 2 * sl + r] = idx[r];
-                    }
+                    if (2 * sl + r < f.nNew) storeAt(f.ok + 2 * sl + r, key[r], idx[r], val[r]);
                 }
                 continue;
             }
@@ -1095,6 +1221,8 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
             if (b == 5) pairSort<32>(d, lane);
             else pairSort<16>(d, lane);
             WAVE_TRACE(trSort)
+            pinNext(keyN[0], idxN[0]);
+            pinNext(keyN[1], idxN[1]);
             // equal leading bits among neighbours of the new order?  (by segment: ballot masked with the segment's lanes)
             const uint32_t dFront  = uint32_t(__shfl_up(int(d[1]), 1));
             const bool clash0      = sl != 0 && d[0] != ~0u && dFront != ~0u && (d[0] >> 8) == (dFront >> 8);
@@ -1107,6 +1235,7 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
             if (d[0] != ~0u) place[d[0] & 0xFFu] = uint16_t(2 * sl);
             if (d[1] != ~0u) place[d[1] & 0xFFu] = uint16_t(2 * sl + 1);
             __builtin_amdgcn_wave_barrier();
+            stepFields(); // (behind the network: the values live in registers from here to the stores only)
             if (!exact)
             {
 #pragma unroll
@@ -1114,15 +1243,11 @@ __global__ __launch_bounds__(256) CSTONE_WAVE_OCC void leafSortWaveKernel(
                 {
                     if (key[r] == HOLE) continue;
                     const uint32_t at = place[2 * sl + r];
-                    if (at < f.nNew)
-                    {
-                        keysOut[f.ok + at]  = key[r];
-                        orderOut[f.ok + at] = idx[r];
-                    }
+                    if (at < f.nNew) storeAt(f.ok + at, key[r], idx[r], val[r]);
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (exact) exactLeaf(f, 2, key, idx);
+            if (exact) exactLeaf(f, 2, key, idx, false);
             WAVE_TRACE(trFinish)
         }
 #ifdef CSTONE_RESORT_TRACE
@@ -1149,7 +1274,8 @@ __global__ __launch_bounds__(256) void bracketedPositionsKernel(const K* __restr
                                                                 const uint32_t* __restrict__ numCompact,
                                                                 const uint32_t* __restrict__ coarse,
                                                                 const uint32_t* __restrict__ layoutNew,
-                                                                uint32_t* __restrict__ pos)
+                                                                uint32_t* __restrict__ pos,
+                                                                uint32_t* __restrict__ boundaryLeaf)
 {
     NodeIdx i = blockIdx.x * 256 + threadIdx.x;
     if (i > numNodes) return;
@@ -1171,7 +1297,10 @@ __global__ __launch_bounds__(256) void bracketedPositionsKernel(const K* __restr
     }
     // first index with keys[index] >= key, inside that leaf's new range -- its start, without looking at any key, when
     // the boundary is that of the old leaf itself (most leaves of a tree outlive an update)
-    uint32_t a = layoutNew[lo], len = leafLo[lo] == key ? 0u : layoutNew[lo + 1] - a;
+    const bool onBoundary = leafLo[lo] == key;
+    // (for radiiOfLeaves: the compact leaf the boundary falls into, top bit: it IS that leaf's first key)
+    if (boundaryLeaf) boundaryLeaf[i] = lo | (onBoundary ? 0x80000000u : 0u);
+    uint32_t a = layoutNew[lo], len = onBoundary ? 0u : layoutNew[lo + 1] - a;
     while (len > 0)
     {
         uint32_t half = len >> 1;
@@ -1188,6 +1317,35 @@ __global__ __launch_bounds__(256) void countsOfPositionsKernel(const uint32_t* _
     if (i >= numNodes) return;
     uint32_t c = pos[i + 1] - pos[i];
     counts[i]  = c < maxCount ? c : maxCount;
+}
+
+/*! Halo radii of the leaves of any tree from the per-leaf maxima of h the field-carrying leaf pass folded (hmax, by
+ *  compact leaf of the OLD tree).  A leaf whose two boundaries are first keys of compact leaves a and b holds exactly the
+ *  new content of the compact leaves [a, b): its maximum is theirs.  Any other leaf (a split old leaf, a leaf that starts
+ *  inside the key range of an old one) scans its own particles.  radii = float(max * 2 * ext), 0 for
+ *  an empty leaf: cstone_hip_halo_radii's rule (Halos::discover, R/halos/halos.hpp:128-160). */
+template<class T>
+__global__ __launch_bounds__(256) void radiiFromOldLeavesKernel(const uint32_t* __restrict__ boundaryLeaf, NodeIdx numNodes,
+                                                                const uint32_t* __restrict__ layout,
+                                                                const T* __restrict__ hmax, const T* __restrict__ hSorted,
+                                                                float ext, float* __restrict__ radii)
+{
+    // one lane per leaf: nearly every leaf of the new tree IS an old leaf (one value to fetch); the others loop
+    const NodeIdx i = NodeIdx(blockIdx.x) * 256 + NodeIdx(threadIdx.x);
+    if (i >= numNodes) return;
+    const uint32_t ba = boundaryLeaf[i], bb = boundaryLeaf[i + 1];
+    T m = 0;
+    if ((ba & bb & 0x80000000u) != 0)
+    {
+        for (uint32_t j = ba & 0x7FFFFFFFu; j < (bb & 0x7FFFFFFFu); ++j)
+            m = fmax(m, hmax[j]);
+    }
+    else
+    {
+        for (uint32_t p = layout[i]; p < layout[i + 1]; ++p)
+            m = fmax(m, hSorted[p]);
+    }
+    radii[i] = float(m * 2 * ext);
 }
 
 //! the particles that carry the remove marker: behind every leaf, by ascending old position (idx sorted by the caller)
@@ -1208,7 +1366,7 @@ __global__ __launch_bounds__(256) void placeMarkersKernel(const uint32_t* __rest
 
 template<class K>
 int LeafResort<K>::prepare(cstone_hip_ctx* ctx, const K* tree, const uint32_t* layout, int numLeaves, size_t n,
-                           K* keysOut, bool expectMovers)
+                           K* keysOut, bool expectMovers, int fieldBits)
 {
     StageTimer timer(ctx, CSTONE_STAGE_RESORT_BINS);
     numLeaves_         = numLeaves;
@@ -1232,6 +1390,9 @@ int LeafResort<K>::prepare(cstone_hip_ctx* ctx, const K* tree, const uint32_t* l
     CS_TRY(moverSlot_.ensure(ctx, cap * 4));
     CS_TRY(binKeys_.ensure(ctx, cap * sizeof(K)));
     CS_TRY(binIdx_.ensure(ctx, cap * 4));
+    if (fieldBits) CS_TRY(hmax_.ensure(ctx, ent * size_t(fieldBits / 8)));
+    carryFields_   = fieldBits != 0;
+    boundaryNodes_ = -1;
 
     int* scalars = ctx->devScalars + RESORT_SCALARS;
     CS_HIP(ctx, hipMemsetAsync(scalars, 0, 4 * sizeof(int), ctx->stream)); // [3]: the mover counter
@@ -1341,9 +1502,10 @@ int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, 
     // (... and with fuller leaves when more than 3 % of the particles changed their leaf: hardly a leaf is still in order then)
     const bool pairs = pairsEnv ? pairsEnv[0] == '1' : (n_ < size_t(J) * 32u || size_t(numMovers) * 32u > n_);
 #define CSTONE_LEAF_WAVE_MODE(G, MODE)                                                                                 \
-    hipLaunchKernelGGL((leafSortWaveKernel<K, G, MODE>), grid, 256, 0, ctx->stream, keysIn, leafLo_.as<K>(),           \
-                       leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), layoutNew_.as<uint32_t>(), binKeys_.as<K>(), \
-                       binIdx_.as<uint32_t>(), J, alwaysCount, waveAll, keysOut, orderOut)
+    hipLaunchKernelGGL((leafSortWaveKernel<K, G, MODE, NoLeafFields>), grid, 256, 0, ctx->stream, keysIn,              \
+                       leafLo_.as<K>(), leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), layoutNew_.as<uint32_t>(),  \
+                       binKeys_.as<K>(), binIdx_.as<uint32_t>(), J, alwaysCount, waveAll, keysOut, orderOut,           \
+                       NoLeafFields{})
 #define CSTONE_LEAF_WAVE(G)                                                                                            \
     if (pairs) CSTONE_LEAF_WAVE_MODE(G, 1);                                                                            \
     else CSTONE_LEAF_WAVE_MODE(G, 0)
@@ -1374,6 +1536,84 @@ int LeafResort<K>::sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, 
 }
 
 template<class K>
+int LeafResort<K>::sortLeavesFields(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, uint32_t* orderOut,
+                                    const ResortFields& fields, uint32_t numMovers, uint32_t numMarkers, uint32_t J,
+                                    int leavesPerTile)
+{
+    if (fields.realBits != 32 && fields.realBits != 64) return fail(ctx, CSTONE_E_ARG, "resort: field width %d", fields.realBits);
+    if (!carryFields_) return fail(ctx, CSTONE_E_INTERNAL, "resort: prepare() was not asked for the fields");
+    auto run = [&](auto tTag) -> int
+    {
+        using T = decltype(tTag);
+        if (numMovers)
+        {
+            StageTimer timer(ctx, CSTONE_STAGE_RESORT_BINS);
+            hipLaunchKernelGGL(placeMoversKernel<K>, gridFor(numMovers, 256), 256, 0, ctx->stream, moverKeys_.as<K>(),
+                               moverIdx_.as<uint32_t>(), moverDest_.as<uint32_t>(), moverSlot_.as<uint32_t>(), numMovers,
+                               inOffset_.as<uint32_t>(), binKeys_.as<K>(), binIdx_.as<uint32_t>());
+        }
+        if (numMarkers)
+        {
+            // (particles that leave the domain: keys and old positions behind the last leaf; their fields stay behind)
+            StageTimer timer(ctx, CSTONE_STAGE_RESORT_BINS);
+            uint32_t* idx = binIdx_.as<uint32_t>() + (numMovers - numMarkers);
+            CS_TRY(cstone_hip_sort_keys(ctx, 32, idx, numMarkers));
+            hipLaunchKernelGGL(placeMarkersKernel<K>, gridFor(numMarkers, 256), 256, 0, ctx->stream, idx, numMarkers,
+                               layoutNew_.as<uint32_t>(), (const uint32_t*)(ctx->devScalars + RESORT_SCALARS) + 2,
+                               keysOut, orderOut);
+        }
+        if (J == 0) return CSTONE_OK;
+        StageTimer timer(ctx, CSTONE_STAGE_RESORT_LEAVES);
+        const unsigned grid = (J + unsigned(leavesPerTile) - 1) / unsigned(leavesPerTile);
+        LeafFields<T> fl;
+        fl.x = static_cast<const T*>(fields.in[0]), fl.y = static_cast<const T*>(fields.in[1]);
+        fl.z = static_cast<const T*>(fields.in[2]), fl.h = static_cast<const T*>(fields.in[3]);
+        fl.ox = static_cast<T*>(fields.out[0]), fl.oy = static_cast<T*>(fields.out[1]);
+        fl.oz = static_cast<T*>(fields.out[2]), fl.oh = static_cast<T*>(fields.out[3]);
+        fl.hmax = hmax_.as<T>();
+        // the flavour by the fill of the leaves, as in sortLeaves(); every tile goes through this kernel
+        const char* pairsEnv = std::getenv("CSTONE_RESORT_PAIRS");
+        const bool pairs     = pairsEnv ? pairsEnv[0] == '1' : (n_ < size_t(J) * 32u || size_t(numMovers) * 32u > n_);
+#define CSTONE_LEAF_FIELDS_MODE(G, MODE)                                                                               \
+    hipLaunchKernelGGL((leafSortWaveKernel<K, G, MODE, LeafFields<T>>), grid, 256, 0, ctx->stream, keysIn,             \
+                       leafLo_.as<K>(), leafPos_.as<uint32_t>(), inOffset_.as<uint32_t>(), layoutNew_.as<uint32_t>(),  \
+                       binKeys_.as<K>(), binIdx_.as<uint32_t>(), J, false, true, keysOut, orderOut, fl)
+#define CSTONE_LEAF_FIELDS(G)                                                                                          \
+    if (pairs) CSTONE_LEAF_FIELDS_MODE(G, 1);                                                                          \
+    else CSTONE_LEAF_FIELDS_MODE(G, 0)
+        if (leavesPerTile == 64) { CSTONE_LEAF_FIELDS(64); }
+        else if (leavesPerTile == 32) { CSTONE_LEAF_FIELDS(32); }
+        else if (leavesPerTile == 16) { CSTONE_LEAF_FIELDS(16); }
+        else return fail(ctx, CSTONE_E_INTERNAL, "resort: %d leaves per workgroup not instantiated", leavesPerTile);
+#undef CSTONE_LEAF_FIELDS
+#undef CSTONE_LEAF_FIELDS_MODE
+        CS_HIP(ctx, hipGetLastError());
+        return CSTONE_OK;
+    };
+    return fields.realBits == 32 ? run(float{}) : run(double{});
+}
+
+template<class K>
+int LeafResort<K>::radiiOfLeaves(cstone_hip_ctx* ctx, int numNodes, const uint32_t* layout, const void* hSorted,
+                                 int realBits, float ext, float* radii)
+{
+    if (numNodes <= 0) return CSTONE_OK;
+    if (boundaryNodes_ != numNodes || !carryFields_)
+        return fail(ctx, CSTONE_E_INTERNAL, "resort: radiiOfLeaves without countLeaves for this tree");
+    StageTimer timer(ctx, CSTONE_STAGE_HALOS);
+    if (realBits == 32)
+        hipLaunchKernelGGL(radiiFromOldLeavesKernel<float>, gridFor(size_t(numNodes), 256), 256, 0, ctx->stream,
+                           boundaryLeaf_.as<uint32_t>(), NodeIdx(numNodes), layout, hmax_.as<float>(),
+                           static_cast<const float*>(hSorted), ext, radii);
+    else
+        hipLaunchKernelGGL(radiiFromOldLeavesKernel<double>, gridFor(size_t(numNodes), 256), 256, 0, ctx->stream,
+                           boundaryLeaf_.as<uint32_t>(), NodeIdx(numNodes), layout, hmax_.as<double>(),
+                           static_cast<const double*>(hSorted), ext, radii);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+template<class K>
 int LeafResort<K>::countLeaves(cstone_hip_ctx* ctx, const K* tree, int numNodes, const K* keys, uint32_t maxCount,
                                uint32_t* counts)
 {
@@ -1381,9 +1621,17 @@ int LeafResort<K>::countLeaves(cstone_hip_ctx* ctx, const K* tree, int numNodes,
     StageTimer timer(ctx, CSTONE_STAGE_NODE_COUNTS);
     CS_TRY(arenaReserve(ctx, alignUp(size_t(numNodes + 1) * sizeof(uint32_t)) + 1024));
     auto* pos = (uint32_t*)arenaTake(ctx, size_t(numNodes + 1) * sizeof(uint32_t));
+    // (the field-carrying pass wants to know where every boundary fell: radiiOfLeaves)
+    uint32_t* boundaryLeaf = nullptr;
+    if (carryFields_)
+    {
+        CS_TRY(boundaryLeaf_.ensure(ctx, size_t(numNodes + 1) * sizeof(uint32_t)));
+        boundaryLeaf   = boundaryLeaf_.as<uint32_t>();
+        boundaryNodes_ = numNodes;
+    }
     hipLaunchKernelGGL(bracketedPositionsKernel<K>, gridFor(size_t(numNodes) + 1, 256), 256, 0, ctx->stream, tree,
                        NodeIdx(numNodes), keys, leafLo_.as<K>(), (const uint32_t*)(ctx->devScalars + RESORT_SCALARS) + 2,
-                       haveCoarse_ ? coarse_.as<uint32_t>() : nullptr, layoutNew_.as<uint32_t>(), pos);
+                       haveCoarse_ ? coarse_.as<uint32_t>() : nullptr, layoutNew_.as<uint32_t>(), pos, boundaryLeaf);
     hipLaunchKernelGGL(countsOfPositionsKernel, gridFor(numNodes, 256), 256, 0, ctx->stream, pos, NodeIdx(numNodes),
                        maxCount, counts);
     arenaReset(ctx);

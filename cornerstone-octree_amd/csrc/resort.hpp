@@ -38,6 +38,15 @@ struct ResortArgs
     uint32_t moverCap;
 };
 
+//! the particle arrays a field-carrying leaf pass moves together with the keys: x, y, z, h of the old order (device, n
+//! elements of real_bits / 8 bytes) and where the new order goes; hmaxOut / radii: see LeafResort::sortLeavesFields
+struct ResortFields
+{
+    int realBits;
+    const void* in[4];
+    void* out[4];
+};
+
 //! limits of the leaf pass
 constexpr uint32_t RESORT_TILE_SLOTS = 4224; // slots (old positions + arrivals) of a workgroup's leaves: key + index in
                                              // LDS for quiet tiles (three workgroups per CU), digests for the others
@@ -67,7 +76,7 @@ public:
      *  leading key bits to the leaves, which shortens the search of every mover for its new leaf (worth its 20 us from
      *  some 10^5 movers on) */
     int prepare(cstone_hip_ctx* ctx, const K* tree, const uint32_t* layout, int numLeaves, size_t n, K* keysOut,
-                bool expectMovers = false);
+                bool expectMovers = false, int fieldBits = 0 /* 32 | 64: the leaf pass will carry x, y, z, h */);
     ResortArgs<K> args() const { return args_; }
     /*! bins the movers, new leaf sizes and offsets, limit checks; everything stays on the device: the three scalars at
      *  ctx->devScalars + RESORT_SCALARS tell the host how it went */
@@ -77,6 +86,22 @@ public:
     int sortLeaves(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, uint32_t* orderOut, uint32_t numMovers,
                    uint32_t numMarkers, uint32_t numCompactLeaves, int leavesPerTile, bool largeQuietTiles);
 
+    /*! The leaf pass that also MOVES x, y, z, h (one pass over the particle arrays instead of the leaf pass plus a gather
+     *  per array): lane s of a leaf's wave loads key and fields of slot s, the wave orders the leaf in registers, every
+     *  lane stores key, old index and fields at the leaf's new place.  A mover's fields are fetched from its old position
+     *  (known from its bin one wave step before they are needed).  On the way the wave folds the
+     *  maximum of h over the leaf's new content (hmax per compact leaf): radiiOfLeaves() turns them into the halo radii
+     *  of whatever tree the sync ends up with.  Requires prepare(..., fieldBits). */
+    int sortLeavesFields(cstone_hip_ctx* ctx, const K* keysIn, K* keysOut, uint32_t* orderOut, const ResortFields& fields,
+                         uint32_t numMovers, uint32_t numMarkers, uint32_t numCompactLeaves, int leavesPerTile);
+    /*! radii[i] = float(2 * ext * max h of the particles of leaf i of `tree`) (Halos::discover's rule, as
+     *  cstone_hip_halo_radii) from the maxima sortLeavesFields folded: a leaf whose boundaries both are boundaries of
+     *  the old (compact) leaf table takes the maximum of the old leaves it is made of, any other leaf scans its
+     *  particles in hSorted.  Must follow countLeaves() for the same tree (which notes where every boundary falls);
+     *  layout: offsets of the leaves among the sorted particles. */
+    int radiiOfLeaves(cstone_hip_ctx* ctx, int numNodes, const uint32_t* layout, const void* hSorted, int realBits,
+                      float ext, float* radii);
+
     /*! computeNodeCounts for any cornerstone leaf array over the keys the last sortLeaves ordered (valid until the next
      *  prepare): every boundary is searched inside the one old leaf that holds its key.  counts[i] = min(#keys in
      *  [tree[i], tree[i + 1]), maxCount) */
@@ -85,6 +110,9 @@ public:
 private:
     DevBuf mask_, rank_, popc_, leafLo_, leafPos_, outCount_, incoming_, newCount_, layoutNew_, inOffset_;
     DevBuf moverKeys_, moverIdx_, moverDest_, moverSlot_, binKeys_, binIdx_, coarse_;
+    DevBuf hmax_, boundaryLeaf_; // the field-carrying pass: max h per compact leaf, where the new tree's boundaries fall
+    bool carryFields_  = false;
+    int boundaryNodes_ = -1;     // tree size boundaryLeaf_ was filled for
     bool haveCoarse_ = false;
     ResortArgs<K> args_{};
     int numLeaves_ = 0;

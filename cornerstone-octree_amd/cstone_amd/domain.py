@@ -17,6 +17,7 @@ class DomainView(C.Structure):
         ("child_offsets", C.c_void_p), ("parents", C.c_void_p), ("level_range", C.c_void_p),
         ("internal_to_leaf", C.c_void_p), ("leaf_to_internal", C.c_void_p), ("layout", C.c_void_p),
         ("centers", C.c_void_p), ("sizes", C.c_void_p), ("halo_flags", C.c_void_p), ("sfc_order", C.c_void_p),
+        ("halo_radii", C.c_void_p),
     ]
 
 

@@ -596,6 +596,7 @@ extern "C"
         const void* sizes;      /* T[M][3] */
         const int32_t* halo_flags;
         const uint32_t* sfc_order; /* the ordering kept in the last scratch buffer by the reference (:206) */
+        const float* halo_radii;   /* f32[L]: 2 * haloSearchExt * max h per focus leaf (Halos::discover, halos.hpp:128-160) */
     } cstone_hip_domain_view;
 
     int cstone_hip_domain_create(cstone_hip_ctx* ctx, cstone_hip_domain** out, int curve, int key_bits, int real_bits,
@@ -608,6 +609,9 @@ extern "C"
      * pointers), like the scratch TUPLE of the reference's sync (R/domain/domain.hpp:196-206).  From three buffers on
      * x, y and z are brought into SFC order by ONE kernel that reads the ordering once (cstone_hip_gather_multi: 52
      * instead of 60 bytes per particle for f64); with fewer the arrays rotate through scratch[0] one after the other.
+     * From FOUR buffers on a steady-state sync moves x, y, z and h together with the keys in ONE pass over the particle
+     * arrays (the field-carrying leaf pass of the incremental re-sort, csrc/resort.hpp: 84 instead of 132 bytes per
+     * particle behind the encode; the halo radii come from the per-leaf maxima of h that pass folds).
      * All buffers take part in the pointer exchange: on return *x, *y, *z, *h, props[i] and scratch[q] are a
      * permutation of the buffers passed in.  Same results whatever num_scratch is. */
     int cstone_hip_domain_sync_scratch(cstone_hip_domain* dom, void** keys, void** x, void** y, void** z, void** h,

@@ -13,8 +13,8 @@ GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "gold
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("full_sort,num_scratch", [(False, 1), (True, 1), (False, 3)],
-                         ids=["partial-digit-sort", "all-digits-sorted", "three-scratch-buffers"])
+@pytest.mark.parametrize("full_sort,num_scratch", [(False, 1), (True, 1), (False, 3), (False, 4)],
+                         ids=["partial-digit-sort", "all-digits-sorted", "three-scratch-buffers", "four-scratch-buffers"])
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
 def test_domain_sync_matches_reference(hip, path, full_sort, num_scratch, monkeypatch):
     import torch

@@ -284,7 +284,11 @@ def test_one_ranks_share_through_the_multi_rank_sync(hip, dist_name, n, n_global
             L = v.num_focus_leaves
             counts = dom.fetch(v.focus_leaf_counts, L, np.uint32)
             layout = dom.fetch(v.layout, L + 1, np.uint32)
-            assert int(counts.sum(dtype=np.uint64)) == n and counts.max() <= bucket_focus and int(layout[-1]) == n
+            assert int(counts.sum(dtype=np.uint64)) == n and int(layout[-1]) == n
+            # (the converged tree of the first sync respects the bucket; afterwards a sync takes ONE update step, like the
+            #  reference: a leaf that particles drifted into may exceed the bucket until the next sync splits it)
+            if sync == 0:
+                assert counts.max() <= bucket_focus
             assert np.array_equal(np.diff(layout.astype(np.int64)), counts.astype(np.int64))
             assert (v.start_cell, v.end_cell) == (0, L)
             if sync == 2:

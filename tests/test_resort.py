@@ -9,13 +9,25 @@ import numpy as np
 import pytest
 
 
-@pytest.fixture(autouse=True, params=["auto", "one-per-lane", "two-per-lane"])
+_NUM_SCRATCH = [1]  # scratch arrays a _Stepper hands to its syncs (set by the fixture below)
+
+
+@pytest.fixture(autouse=True, params=["auto", "one-per-lane", "two-per-lane", "auto-fields", "one-per-lane-fields",
+                                      "two-per-lane-fields"])
 def leaf_pass_flavour(request, monkeypatch):
     """every test of this module runs with the leaf pass choosing its flavour itself (by the fill of the leaves) and with
-    either flavour of leafSortWaveKernel forced (CSTONE_RESORT_PAIRS, csrc/resort.hip)"""
-    if request.param != "auto":
-        monkeypatch.setenv("CSTONE_RESORT_PAIRS", "0" if request.param == "one-per-lane" else "1")
+    either flavour of leafSortWaveKernel forced (CSTONE_RESORT_PAIRS, csrc/resort.hip) -- and each of these once with ONE
+    scratch array (the leaf pass orders keys and indices, the fields follow in gather passes) and once with FOUR and
+    CSTONE_FUSED_LEAF_PASS (the field-carrying leaf pass: x, y, z, h move with the keys, the halo radii come from the
+    maxima it folds)"""
+    flavour = request.param.replace("-fields", "")
+    if flavour != "auto":
+        monkeypatch.setenv("CSTONE_RESORT_PAIRS", "0" if flavour == "one-per-lane" else "1")
+    _NUM_SCRATCH[0] = 4 if request.param.endswith("-fields") else 1
+    if request.param.endswith("-fields"):
+        monkeypatch.setenv("CSTONE_FUSED_LEAF_PASS", "1")
     yield
+    _NUM_SCRATCH[0] = 1
 
 
 class _Stepper:
@@ -41,23 +53,31 @@ class _Stepper:
         self.h = torch.from_numpy(rng.uniform(0.001, 0.01, n)).to(rdt).cuda()
         self.ident = torch.arange(n, dtype=rdt, device="cuda")  # follows its particle through every sync
         self.keys = torch.zeros(n, dtype=kdt, device="cuda")
-        self.scratch = torch.empty_like(self.x)
+        self.num_scratch = _NUM_SCRATCH[0]
+        self.scratch = self._new_scratch()
+
+    def _new_scratch(self):
+        import torch
+
+        return torch.empty_like(self.x) if self.num_scratch == 1 else [torch.empty_like(self.x) for _ in range(self.num_scratch)]
 
     def sync(self):
         import torch
 
-        # (cstone_hip_domain_set_sort_mode: the incremental re-sort, or the radix sort from scratch -- identical results)
-        self.dom.set_sort_mode(self.dom.SORT_INCREMENTAL if self.allow else self.dom.SORT_FROM_SCRATCH)
+        # (cstone_hip_domain_set_sort_mode: the incremental re-sort, or the radix sort from scratch -- identical results;
+        #  allow = None: the test has chosen the mode itself)
+        if self.allow is not None:
+            self.dom.set_sort_mode(self.dom.SORT_INCREMENTAL if self.allow else self.dom.SORT_FROM_SCRATCH)
         self.keys, self.x, self.y, self.z, self.h, self.scratch, (self.ident,) = self.dom.sync(
             self.keys, self.x, self.y, self.z, self.h, self.scratch, [self.ident])
         self.hip.sync()
         m = self.x.numel()
-        if self.scratch.numel() != m:
+        if (self.scratch if self.num_scratch == 1 else self.scratch[0]).numel() != m:
             # particles were removed: the client shrinks its arrays to the new size (views of the old buffers would do
             # as well; fresh ones keep every array 16-byte aligned for this test)
             self.keys, self.x, self.y, self.z, self.h, self.ident = [t.clone() for t in (
                 self.keys, self.x, self.y, self.z, self.h, self.ident)]
-            self.scratch = torch.empty_like(self.x)
+            self.scratch = self._new_scratch()
         return dict(keys=self.keys.cpu().numpy(), x=self.x.cpu().numpy(), y=self.y.cpu().numpy(),
                     z=self.z.cpu().numpy(), h=self.h.cpu().numpy(), ident=self.ident.cpu().numpy(), view=self.dom.view())
 
@@ -147,6 +167,9 @@ def test_resort_equals_full_sort_over_a_time_stepping_loop(hip, oracle, monkeypa
         assert np.array_equal(dom_a.fetch(va.sfc_order, m, np.uint32), dom_b.fetch(vb.sfc_order, m, np.uint32)), step
         assert np.array_equal(dom_a.fetch(va.layout, L + 1, np.uint32), dom_b.fetch(vb.layout, L + 1, np.uint32)), step
         assert np.array_equal(dom_a.fetch(va.focus_leaves, L + 1, kdt), dom_b.fetch(vb.focus_leaves, L + 1, kdt)), step
+        # the halo radii (2 * max h per leaf): folded by the leaf pass on one side, by the gather of h on the other
+        ra_, rb_ = dom_a.fetch(va.halo_radii, L, np.float32), dom_b.fetch(vb.halo_radii, L, np.float32)
+        assert np.array_equal(ra_, rb_), (step, kind, np.nonzero(ra_ != rb_)[0][:5])
         # and against the oracle: the keys of the returned coordinates under the domain's box, ascending
         want = oracle.compute_sfc_keys(curve, kb, a["x"], a["y"], a["z"], Box(list(va.box.lim), bc))
         assert np.array_equal(a["keys"].view(kdt), want), (step, kind)
@@ -343,7 +366,7 @@ def test_sort_mode_setters_give_the_same_result(hip, oracle):
     """cstone_hip_domain_set_sort_mode / _set_speculative_box: the client-side switches behind the environment variables
     of the experiments.  Three domains walk the same loop -- incremental (default), from scratch, all digits without box
     speculation -- and agree bit for bit; only the first one re-sorts"""
-    doms = [_Stepper(hip, 64, 64, 64, 1, (0, 0, 0), 90_000, 5, True) for _ in range(3)]
+    doms = [_Stepper(hip, 64, 64, 64, 1, (0, 0, 0), 90_000, 5, None) for _ in range(3)]
     doms[1].dom.set_sort_mode(doms[1].dom.SORT_FROM_SCRATCH)
     doms[2].dom.set_sort_mode(doms[2].dom.SORT_ALL_DIGITS)
     doms[2].dom.set_speculative_box(False)
