@@ -70,7 +70,11 @@ bool ctxAlive(const cstone_hip_ctx* ctx)
 int ensureAuxStream(cstone_hip_ctx* ctx)
 {
     if (ctx->aux) return CSTONE_OK;
-    CS_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    // lowest priority: what runs there (bandwidth-bound bulk moves) must not keep the short kernels of the main stream
+    // from the compute units
+    int least = 0, greatest = 0;
+    CS_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    CS_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, least));
     CS_HIP(ctx, hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming));
     CS_HIP(ctx, hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming));
     return CSTONE_OK;
@@ -243,8 +247,6 @@ int cstone_hip_ctx_destroy(cstone_hip_ctx* ctx)
         (void)hipStreamDestroy(ctx->aux);
     }
     if (ctx->arena) (void)hipFree(ctx->arena);
-    if (ctx->scanStatus) (void)hipFree(ctx->scanStatus);
-    if (ctx->scanTickets) (void)hipFree(ctx->scanTickets);
     if (ctx->devScalars) (void)hipFree(ctx->devScalars);
     if (ctx->hilbertTables) (void)hipFree(ctx->hilbertTables);
     if (ctx->hostScalars) (void)hipHostFree(ctx->hostScalars);

@@ -40,14 +40,6 @@ struct cstone_hip_ctx
     hipEvent_t evFork  = nullptr;
     hipEvent_t evJoin  = nullptr;
 
-    // single-launch prefix sums (scan.hip): status words of the chained tiles, two ticket counters, and what tells the
-    // words and tickets of one launch from those of the launches before (no clearing between scans)
-    unsigned long long* scanStatus = nullptr; // [2][scanTilesCap]
-    size_t scanTilesCap            = 0;
-    uint32_t* scanTickets          = nullptr; // [2]
-    uint32_t scanTicketBase[2]     = {0, 0};
-    uint32_t scanGeneration        = 0;
-
     // -1 unknown, else result of the one-time LDS atomic ordering probe of the radix sort (sort.hip)
     int ldsOrderOk = -1;
 

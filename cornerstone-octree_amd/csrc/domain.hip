@@ -15,6 +15,7 @@
 #include "ctx.hpp"
 #include "devbuf.hpp"
 #include "device_keys.hpp"
+#include "host_tree.hpp"
 #include "resort.hpp"
 #include "scan.hpp"
 
@@ -279,6 +280,7 @@ public:
         //      as the sort of all keys; a box that changed, too many movers or an overfull leaf take the regular path.
         const int tileLeaves = LeafResort<K>::leavesPerTile(bucketFocus_);
         bool sorted          = false;
+        uint32_t resortMarkers = 0; // particles with the remove marker, as the re-sort counted them
         const bool tryResort = !firstCall_ && tileLeaves > 0 && layoutLeaves_ == fLeaves_ && fLeaves_ > 0 &&
                                resortBackoff_ == 0 && !boxMoved && mayResort();
         if (resortBackoff_ > 0) --resortBackoff_;
@@ -348,6 +350,7 @@ public:
                     boxChanged = nextBox(ext, next);
                 }
                 const uint32_t markers = uint32_t(ctx_->hostScalars[RESORT_SCALARS]);
+                resortMarkers          = markers;
                 const int flags        = ctx_->hostScalars[RESORT_SCALARS + 1];
                 const uint32_t J       = uint32_t(ctx_->hostScalars[RESORT_SCALARS + 2]);
                 const uint32_t movers  = uint32_t(ctx_->hostScalars[RESORT_SCALARS + 3]);
@@ -437,12 +440,40 @@ public:
                                bucket_ - 1);
             gLeaves_ = 1;
         }
+        // A sync that was re-sorted knows its number of valid particles already, and the host holds the (small) global tree
+        // and its counts from the last sync: the update step of the global tree is then made on the HOST
+        // (globalTreeStepHost), the device only counts, and the counts travel back with the read-back of the focus-tree
+        // update -- one stream synchronisation and a handful of launches fewer than cstone_hip_update_octree.
+        uint32_t numAssigned = 0;
+        int converged        = 0;
+        const bool hostStep  = sorted && !firstCall_ && hostGlobalStep_ && int(gLeavesHost_.size()) == gLeaves_ + 1 &&
+                              int(gCountsHost_.size()) == gLeaves_;
+        if (hostStep)
+        {
+            numAssigned = uint32_t(n) - resortMarkers;
+            if (numAssigned == 0) return fail(ctx_, CSTONE_E_ARG, "domain_sync: all particles removed");
+            std::vector<K> fresh;
+            const bool same = globalTreeStepHost<K>(gLeavesHost_, gCountsHost_, bucket_, fresh);
+            if (!same)
+            {
+                const int leaves = int(fresh.size()) - 1;
+                CS_TRY(ensureTree(gTree_, gCounts_, gCap_, leaves + 1));
+                gLeavesHost_.swap(fresh);
+                CS_TRY(cstone_hip_upload(ctx_, gTree_.p, gLeavesHost_.data(), gLeavesHost_.size() * sizeof(K)));
+                gLeaves_ = leaves;
+            }
+            converged = same;
+            CS_TRY(cstone_hip_compute_node_counts(ctx_, kb, gTree_.p, gCounts_.as<uint32_t>(), gLeaves_, keys, n,
+                                                  0xFFFFFFFFu));
+            CS_TRY(queueGlobalReadBack(false));
+        }
+        else
+        {
         // particles flagged with the remove marker sort behind the end of the curve and leave the domain: their number
         // is on its way to the host while the global tree is updated (whose own read-back completes the stream)
         hipLaunchKernelGGL(countValidKernel<K>, 1, 1, 0, ctx_->stream, keys, n, ctx_->devScalars + 2);
         CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars + 2, ctx_->devScalars + 2, 2 * sizeof(int), hipMemcpyDeviceToHost,
                                     ctx_->stream));
-        int converged = 0;
         CS_TRY(updateGlobal(keys, n, &converged));
         if (firstCall_)
         {
@@ -455,7 +486,7 @@ public:
             } while (!converged);
         }
         // the copy was queued ahead of the update's own read-back (update_octree synchronises for the new leaf count)
-        const uint32_t numAssigned = uint32_t(ctx_->hostScalars[2]);
+        numAssigned = uint32_t(ctx_->hostScalars[2]);
         if (numAssigned == 0) return fail(ctx_, CSTONE_E_ARG, "domain_sync: all particles removed");
         if (ctx_->hostScalars[3] != 0)
         {
@@ -464,6 +495,9 @@ public:
             CS_TRY(cstone_hip_sort_pairs(ctx_, kb, keys, order_.as<uint32_t>(), n, keysAlt_.p, orderAlt_.as<uint32_t>(),
                                          sortTmp_.p, tb));
             ++fullSortFallbacks_;
+        }
+        // (tree and counts for the host's copy: they arrive behind the next synchronisation of the stream)
+        CS_TRY(queueGlobalReadBack(true));
         }
         CS_TRY(forkXyzGather(numAssigned)); // (radix path: the ordering is final from here on)
 
@@ -493,6 +527,7 @@ public:
         }
         int conv = 0;
         CS_TRY(updateFocus(keys, numAssigned, &conv));
+        takeGlobalReadBack(); // (updateFocus has synchronised the stream: the global counts are here)
 
         // ---- Halos::discover + computeLayout (halos.hpp:128-222) for the assignment [0, L)
         const NodeIdx L = fLeaves_;
@@ -662,6 +697,30 @@ private:
         return CSTONE_OK;
     }
 
+    //! global counts (and, when the device made it, the leaf array) on their way to the pinned block; not waited for
+    int queueGlobalReadBack(bool withLeaves)
+    {
+        CS_TRY(pin_.reserve(ctx_, size_t(gLeaves_) * 4 + size_t(gLeaves_ + 1) * sizeof(K) + 256));
+        pinCounts_ = static_cast<uint32_t*>(pin_.take(size_t(gLeaves_) * 4));
+        CS_HIP(ctx_, hipMemcpyAsync(pinCounts_, gCounts_.p, size_t(gLeaves_) * 4, hipMemcpyDeviceToHost, ctx_->stream));
+        pinLeaves_ = nullptr;
+        if (withLeaves)
+        {
+            pinLeaves_ = static_cast<K*>(pin_.take(size_t(gLeaves_ + 1) * sizeof(K)));
+            CS_HIP(ctx_, hipMemcpyAsync(pinLeaves_, gTree_.p, size_t(gLeaves_ + 1) * sizeof(K), hipMemcpyDeviceToHost,
+                                        ctx_->stream));
+        }
+        pinLeafCount_ = gLeaves_;
+        return CSTONE_OK;
+    }
+    void takeGlobalReadBack()
+    {
+        if (!pinCounts_) return;
+        gCountsHost_.assign(pinCounts_, pinCounts_ + pinLeafCount_);
+        if (pinLeaves_) gLeavesHost_.assign(pinLeaves_, pinLeaves_ + pinLeafCount_ + 1);
+        pinCounts_ = nullptr, pinLeaves_ = nullptr;
+    }
+
     //! updateOctreeGlobal on one rank (tree/update_mpi.hpp:71-94): rebalance with the previous counts, then recount
     int updateGlobal(const K* keys, size_t n, int* converged)
     {
@@ -798,6 +857,13 @@ private:
     bool resortedThisSync_ = false;
     DevBuf gTree_, gCounts_;
     int gCap_ = 0, gLeaves_ = 0;
+    std::vector<K> gLeavesHost_;        // host copies of the global tree and its counts (the host makes its update step)
+    std::vector<uint32_t> gCountsHost_;
+    PinnedBlock pin_;
+    uint32_t* pinCounts_ = nullptr;
+    K* pinLeaves_        = nullptr;
+    int pinLeafCount_    = 0;
+    bool hostGlobalStep_ = std::getenv("CSTONE_DEVICE_GLOBAL_STEP") == nullptr; // (tests: the device-side step)
     DevBuf fTree_, fLeafCounts_, fCounts_, newTree_;
     int fCap_ = 0, fLeaves_ = 0;
     int layoutLeaves_ = -1; // number of leaves layout_ was computed for

@@ -370,14 +370,44 @@ private:
         return cstone_hip_memcpy_d2h(ctx_, matrix.data(), recv, w * 8 * P_);
     }
 
+    //! room for a row of w values of V that a device operation writes (send) and the rows of everybody (recv)
+    template<class V>
+    int rowBuffers(size_t w, V** send, V** recv)
+    {
+        LET_TRY(rowBuf_.ensure(w * sizeof(V) * (size_t(P_) + 1) + 64));
+        *send = rowBuf_.as<V>();
+        *recv = *send + w;
+        return CSTONE_OK;
+    }
+    /*! the rows of everybody for a row that IS ON THE DEVICE already (rowBuffers): all-gather and ONE read-back -- a row
+     *  computed on the device does not travel to the host and back before the collective.  extra / extraBytes: more
+     *  device data that rides on the same read-back (it must lie directly in front of the send row) */
+    template<class V>
+    int gatherRowsDev(size_t w, std::vector<V>& matrix, void* extraHost = nullptr, size_t extraBytes = 0)
+    {
+        V* send = rowBuf_.as<V>() + extraBytes / sizeof(V);
+        V* recv = send + w;
+        matrix.assign(w * P_, V(0));
+        LET_TRY(commCall(comm_.all_gather(comm_.user, send, recv, w * sizeof(V)), "all_gather (rows)"));
+        if (!extraBytes) return cstone_hip_memcpy_d2h(ctx_, matrix.data(), recv, w * sizeof(V) * P_);
+        // [extra | send row | rows of everybody] in one copy
+        std::vector<char> all(extraBytes + w * sizeof(V) * (size_t(P_) + 1));
+        LET_TRY(cstone_hip_memcpy_d2h(ctx_, all.data(), rowBuf_.p, all.size()));
+        std::memcpy(extraHost, all.data(), extraBytes);
+        std::memcpy(matrix.data(), all.data() + extraBytes + w * sizeof(V), w * sizeof(V) * P_);
+        return CSTONE_OK;
+    }
+
     /*! variable all-to-all of elements of elemBytes: sendCounts[p] elements for rank p lie back to back in send (device);
      *  the counts the others send me are exchanged first (the reference probes the message sizes, MPI_Probe /
      *  MPI_Get_count).  anyGlobal = false on return: nobody sends anything, the data collective was skipped */
     int exchangeV(const void* send, const std::vector<uint64_t>& sendCounts, int elemBytes, LetBuf& recv,
-                  std::vector<uint64_t>& recvCounts, bool* anyGlobal = nullptr)
+                  std::vector<uint64_t>& recvCounts, bool* anyGlobal = nullptr,
+                  const std::vector<uint64_t>* knownMatrix = nullptr)
     {
         std::vector<uint64_t> matrix;
-        LET_TRY(gatherRows(sendCounts, matrix));
+        if (knownMatrix) { matrix = *knownMatrix; } // (the count rows came back with an earlier read-back)
+        else { LET_TRY(gatherRows(sendCounts, matrix)); }
         recvCounts.assign(P_, 0);
         uint64_t total = 0, any = 0;
         for (int p = 0; p < P_; ++p)
@@ -576,8 +606,13 @@ private:
             LET_TRY(macRefine(prevFocusStart_, prevFocusEnd_, focusStart, focusEnd, invThetaRefine, box, &refined));
             if (++guard > 8 * maxLevel) return fail(CSTONE_E_INTERNAL, "focus tree: MAC refinement does not end");
         }
-        LET_TRY(translateAssignment(assignment));
-        LET_TRY(syncTreelets());
+        // translateAssignment + the count rows of the treelet exchange: when the assignment keys have to be searched in
+        // the (changed) leaf array anyway, the device turns the search results into this rank's row of treelet sizes, the
+        // rows are all-gathered, and ONE read-back brings the search results and everybody's rows
+        std::vector<uint64_t> treeletMatrix;
+        bool haveTreeletMatrix = false;
+        LET_TRY(translateAssignmentWithCounts(assignment, treeletMatrix, &haveTreeletMatrix));
+        LET_TRY(syncTreelets(haveTreeletMatrix ? &treeletMatrix : nullptr));
         LET_TRY(indexTreelets());
         LET_TRY(translateAssignment(assignment)); // (answered from memory unless keys were rejected: lowerBounds)
         std::copy(assignment, assignment + P_ + 1, globAssignment_.begin());
@@ -776,7 +811,7 @@ private:
 
     /*! translateAssignment (domaindecomp.hpp:183-206): the leaf index ranges of the peers' and my own key ranges; a range
      *  whose boundary keys are not in the tree is narrowed */
-    int translateAssignment(const K* assignment)
+    std::vector<K> assignmentQueries(const K* assignment) const
     {
         std::vector<K> q;
         q.reserve(2 * (P_ + 1));
@@ -784,6 +819,50 @@ private:
             q.push_back(assignment[r]);
         for (int r = 0; r <= P_; ++r)
             q.push_back(K(assignment[r] + 1)); // upper_bound(key) = lower_bound(key + 1)
+        return q;
+    }
+
+    /*! translateAssignment, and -- when the searches have to go to the device -- the matrix of treelet sizes of
+     *  syncTreelets from the same read-back (cstone_hip_peer_range_counts) */
+    int translateAssignmentWithCounts(const K* assignment, std::vector<uint64_t>& matrix, bool* haveMatrix)
+    {
+        *haveMatrix = false;
+        const std::vector<K> q = assignmentQueries(assignment);
+        bool known = P_ == 1 || peers_.empty();
+        if (!known)
+        {
+            // (are all searches answered from memory?  lowerBounds() would not go to the device either)
+            if (memoVersion_ != treeVersion_) memo_.clear(), memoVersion_ = treeVersion_;
+            std::vector<int64_t> idx;
+            std::vector<K> none;
+            LET_TRY(lowerBounds(leaves_.as<K>(), size_t(L_) + 1, none, idx)); // (seeds the memory with the curve's ends)
+            known = true;
+            for (K key : q)
+                known = known && memo_.count(key) != 0;
+        }
+        if (known) return translateAssignment(assignment);
+
+        const size_t m = q.size(), w = size_t(P_);
+        LET_TRY(rowBuf_.ensure((m + w * (size_t(P_) + 1)) * 8 + 64)); // [bounds (m) | my row (w) | rows of everybody]
+        uint64_t* bounds = rowBuf_.as<uint64_t>();
+        LET_TRY(scratchU64_.ensure(m * sizeof(K) + 64));
+        LET_TRY(cstone_hip_upload(ctx_, scratchU64_.p, q.data(), m * sizeof(K)));
+        LET_TRY(cstone_hip_lower_bound(ctx_, kb, leaves_.p, size_t(L_) + 1, scratchU64_.p, int(m), bounds));
+        std::vector<uint8_t> isPeer(P_, 0);
+        for (int peer : peers_)
+            isPeer[peer] = 1;
+        LET_TRY(cstone_hip_peer_range_counts(ctx_, bounds, isPeer.data(), P_, bounds + m));
+        std::vector<uint64_t> found(m);
+        LET_TRY(gatherRowsDev<uint64_t>(w, matrix, found.data(), m * 8));
+        for (size_t i = 0; i < m; ++i)
+            memo_[q[i]] = {size_t(L_) + 1, int64_t(found[i])};
+        *haveMatrix = true;
+        return translateAssignment(assignment); // (answered from memory now)
+    }
+
+    int translateAssignment(const K* assignment)
+    {
+        const std::vector<K> q = assignmentQueries(assignment);
         std::vector<int64_t> idx;
         LET_TRY(lowerBounds(leaves_.as<K>(), size_t(L_) + 1, q, idx));
         auto above = [&](int r) { return int32_t(idx[r]); };              // findNodeAbove(assignment[r])
@@ -803,7 +882,7 @@ private:
      *  keys of such a treelet that the owner does not have are sent back (checkTreelets, exchangeRejectedKeys :98-194)
      *  and removed from the sender's tree; what remains of a treelet (pruneTreelets :118-129) is the node list the owner
      *  serves counts for */
-    int syncTreelets()
+    int syncTreelets(const std::vector<uint64_t>* sizeMatrix = nullptr)
     {
         std::fill(tlCount_.begin(), tlCount_.end(), 0);
         std::fill(tlOffset_.begin(), tlOffset_.end(), 0);
@@ -829,7 +908,16 @@ private:
             at += sendCounts[peer];
         }
         bool any = false;
-        LET_TRY(exchangeV(sendBuf_.p, sendCounts, int(sizeof(K)), treelets_, recvCounts, &any));
+        if (sizeMatrix)
+        {
+            // (what the device computed from the search results must be what the host derives from them)
+            for (int p = 0; p < P_; ++p)
+                if ((*sizeMatrix)[size_t(rank_) * P_ + p] != sendCounts[p])
+                    return fail(CSTONE_E_INTERNAL, "treelet exchange: %llu keys for rank %d, the device counted %llu",
+                                (unsigned long long)sendCounts[p], p,
+                                (unsigned long long)(*sizeMatrix)[size_t(rank_) * P_ + p]);
+        }
+        LET_TRY(exchangeV(sendBuf_.p, sendCounts, int(sizeof(K)), treelets_, recvCounts, &any, sizeMatrix));
         if (!any) return CSTONE_OK;
         uint64_t recvTotal = 0;
         std::vector<uint64_t> rOff(P_ + 1, 0);
@@ -852,34 +940,44 @@ private:
             LET_TRY(cstone_hip_memset(ctx_, tlFlags_.as<uint32_t>() + recvTotal, 0, 4));
             LET_TRY(cstone_hip_exclusive_scan_u32(ctx_, tlFlags_.as<uint32_t>(), tlScan_.as<uint32_t>(),
                                                   size_t(recvTotal) + 1, 0u));
-            // rejected keys per peer = differences of the scan at the treelet boundaries
-            std::vector<uint32_t> map(P_ + 1), at32(P_ + 1);
-            for (int p = 0; p <= P_; ++p)
-                map[p] = uint32_t(rOff[p]);
-            LET_TRY(scratchIdx_.ensure(size_t(P_ + 1) * 8));
-            uint32_t* dmap = scratchIdx_.as<uint32_t>();
-            uint32_t* dval = dmap + (P_ + 1);
-            LET_TRY(cstone_hip_upload(ctx_, dmap, map.data(), size_t(P_ + 1) * 4));
-            LET_TRY(cstone_hip_gather(ctx_, 4, dmap, size_t(P_) + 1, tlScan_.p, dval));
-            LET_TRY(readBack(dval, at32.data(), size_t(P_) + 1));
-            for (int p = 0; p < P_; ++p)
-            {
-                rejCounts[p]  = at32[p + 1] - at32[p];
-                keepCounts[p] = recvCounts[p] - rejCounts[p];
-            }
         }
-        uint64_t rejTotal = 0;
-        for (int p = 0; p < P_; ++p)
-            rejTotal += rejCounts[p];
-        // rejected keys back to their senders, kept keys packed (both keep the rank order of the treelets)
-        LET_TRY(scratchKeys_.ensure(std::max<uint64_t>(rejTotal, 1) * sizeof(K)));
+        // rejected keys back to their senders, kept keys packed (both keep the rank order of the treelets); how many
+        // keys are rejected is not known on the host yet: room for all of them
+        LET_TRY(scratchKeys_.ensure(std::max<uint64_t>(recvTotal, 1) * sizeof(K)));
         LET_TRY(scratchKeys2_.ensure(std::max<uint64_t>(recvTotal, 1) * sizeof(K)));
         if (recvTotal)
             LET_TRY(cstone_hip_partition_keys(ctx_, kb, treelets_.p, tlFlags_.as<uint32_t>(), tlScan_.as<uint32_t>(),
                                               size_t(recvTotal), scratchKeys_.p, scratchKeys2_.p));
-        std::vector<uint64_t> rejRecv;
+        // rejected keys per peer = differences of the scan at the treelet boundaries: this rank's row of the count matrix
+        // is made on the device and goes straight into the all-gather; ONE read-back brings everybody's rows
+        std::vector<uint64_t> rejRecv(P_, 0);
         bool anyRejected = false;
-        LET_TRY(exchangeV(scratchKeys_.p, rejCounts, int(sizeof(K)), recvBuf_, rejRecv, &anyRejected));
+        {
+            uint32_t *send = nullptr, *recv = nullptr;
+            LET_TRY(rowBuffers<uint32_t>(size_t(P_), &send, &recv));
+            if (recvTotal)
+            {
+                std::vector<uint32_t> map(P_ + 1);
+                for (int p = 0; p <= P_; ++p)
+                    map[p] = uint32_t(rOff[p]);
+                LET_TRY(scratchIdx_.ensure(size_t(P_ + 1) * 8));
+                uint32_t* dmap = scratchIdx_.as<uint32_t>();
+                uint32_t* dval = dmap + (P_ + 1);
+                LET_TRY(cstone_hip_upload(ctx_, dmap, map.data(), size_t(P_ + 1) * 4));
+                LET_TRY(cstone_hip_gather(ctx_, 4, dmap, size_t(P_) + 1, tlScan_.p, dval));
+                LET_TRY(cstone_hip_adjacent_difference_u32(ctx_, dval, size_t(P_), send));
+            }
+            else { LET_TRY(cstone_hip_memset(ctx_, send, 0, size_t(P_) * 4)); }
+            std::vector<uint32_t> m32;
+            LET_TRY(gatherRowsDev<uint32_t>(size_t(P_), m32));
+            std::vector<uint64_t> rejMatrix(m32.begin(), m32.end());
+            for (int p = 0; p < P_; ++p)
+            {
+                rejCounts[p]  = rejMatrix[size_t(rank_) * P_ + p];
+                keepCounts[p] = recvCounts[p] - rejCounts[p];
+            }
+            LET_TRY(exchangeV(scratchKeys_.p, rejCounts, int(sizeof(K)), recvBuf_, rejRecv, &anyRejected, &rejMatrix));
+        }
         // the pruned treelets
         treelets_.swap(scratchKeys2_);
         for (int p = 0; p < P_; ++p)
@@ -1064,17 +1162,27 @@ private:
         std::vector<uint32_t> pairCounts(P_, 0);
         uint32_t unmatched = 0;
         LET_TRY(scratchKeys_.ensure(size_t(L + 2) * sizeof(K))); // at most (L + 1) / 2 runs of flagged leaves, 2 keys each
-        // (one rank: every leaf is mine, nobody to ask -- and no read-back for the answer)
-        if (P_ > 1)
-            LET_TRY(cstone_hip_halo_requests(ctx_, kb, leaves_.p, flags_.as<int32_t>(), L, first, last, ranges.data(), P_,
-                                             scratchKeys_.p, pairCounts.data(), &unmatched));
         // counts of everybody (+ a status word: a halo cell that no peer owns fails the sync on every rank, checkHalos
-        // halos.hpp:59-95)
+        // halos.hpp:59-95).  This rank's row is made on the device (cstone_hip_halo_request_rows) and goes straight into
+        // the all-gather: ONE read-back for everybody's rows instead of one for mine and one for theirs
         std::vector<uint64_t> row(P_ + 1, 0), matrix;
-        for (int p = 0; p < P_; ++p)
-            row[p] = 2 * uint64_t(pairCounts[p]);
-        row[P_] = externalFailure ? 2 : (unmatched ? 1 : 0);
-        LET_TRY(gatherRows(row, matrix));
+        if (P_ > 1)
+        {
+            uint64_t *send = nullptr, *recv = nullptr;
+            LET_TRY(rowBuffers<uint64_t>(size_t(P_) + 1, &send, &recv));
+            LET_TRY(cstone_hip_halo_request_rows(ctx_, kb, leaves_.p, flags_.as<int32_t>(), L, first, last, ranges.data(), P_,
+                                                 scratchKeys_.p, send, externalFailure));
+            LET_TRY(gatherRowsDev<uint64_t>(size_t(P_) + 1, matrix));
+            for (int p = 0; p <= P_; ++p)
+                row[p] = matrix[size_t(rank_) * (P_ + 1) + p];
+        }
+        else
+        {
+            // (one rank: every leaf is mine, nobody to ask -- and no read-back for the answer)
+            row[P_] = externalFailure ? 2 : 0;
+            matrix  = row;
+        }
+        (void)pairCounts, (void)unmatched;
         for (int p = 0; p < P_; ++p)
         {
             const uint64_t st = matrix[size_t(p) * (P_ + 1) + P_];

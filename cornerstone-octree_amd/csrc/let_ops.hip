@@ -264,12 +264,90 @@ int cstone_hip_node_layout(cstone_hip_ctx* ctx, const uint32_t* counts, const in
     return CSTONE_OK;
 }
 
+} // extern "C"
+
+namespace
+{
+//! row[p] = 2 * (pairs requested from rank p) as u64, row[numRanks] = status: 2 if the caller has a failure of its own
+//! pending, else 1 if halo cells belong to nobody, else 0 -- the row a rank contributes to the all-gather of
+//! Halos::computeLayout (let.hpp), written where the collective reads it: no trip to the host in between
+__global__ void requestRowKernel(const uint32_t* __restrict__ at, const uint32_t* __restrict__ unmatched, int numRanks,
+                                 int externalFailure, uint64_t* __restrict__ row)
+{
+    const int r = threadIdx.x + blockIdx.x * 64;
+    if (r < numRanks) row[r] = 2ull * uint64_t(at[2 * r + 1] - at[2 * r]);
+    else if (r == numRanks) row[r] = externalFailure ? 2ull : (*unmatched ? 1ull : 0ull);
+}
+
+//! count[p] = number of my leaves over rank p's key range + 1 (its upper boundary key) if p is a peer, else 0: the
+//! treelet sizes of syncTreelets (R/focus/exchange_focus.hpp:61-96) from the lower bounds of the assignment keys
+//! (bounds[r]: first leaf >= assignment[r]; bounds[P + 1 + r]: first leaf >= assignment[r] + 1) -- translateAssignment
+//! (R/domain/domaindecomp.hpp:183-206) evaluated where the numbers are
+__global__ void peerRangeCountsKernel(const uint64_t* __restrict__ bounds, const uint8_t* __restrict__ isPeer, int numRanks,
+                                      uint64_t* __restrict__ row)
+{
+    const int p = threadIdx.x + blockIdx.x * 64;
+    if (p >= numRanks) return;
+    uint64_t c = 0;
+    if (isPeer[p])
+    {
+        const int64_t s = int64_t(bounds[p]);                          // findNodeAbove(assignment[p])
+        int64_t e       = int64_t(bounds[numRanks + 1 + p + 1]) - 1;   // findNodeBelow(assignment[p + 1])
+        if (e < s) e = s;
+        c = uint64_t(e - s) + 1;
+    }
+    row[p] = c;
+}
+} // namespace
+
+extern "C"
+{
+
+static int haloRequestsImpl(cstone_hip_ctx* ctx, int key_bits, const void* leaves, const int32_t* flags, int num_leaves,
+                            int first, int last, const int32_t* ranges_host, int num_ranks, void* pairs_out,
+                            uint32_t* pair_counts_host, uint32_t* unmatched_host, uint64_t* row_dev, int external_failure);
+
 int cstone_hip_halo_requests(cstone_hip_ctx* ctx, int key_bits, const void* leaves, const int32_t* flags, int num_leaves,
                              int first, int last, const int32_t* ranges_host, int num_ranks, void* pairs_out,
                              uint32_t* pair_counts_host, uint32_t* unmatched_host)
 {
-    if (!ctx || badKeyBits(key_bits) || num_leaves < 1 || num_ranks < 1 || !leaves || !flags || !ranges_host ||
-        !pairs_out || !pair_counts_host || !unmatched_host)
+    if (!pair_counts_host || !unmatched_host) return fail(ctx, CSTONE_E_ARG, "halo_requests: bad argument");
+    return haloRequestsImpl(ctx, key_bits, leaves, flags, num_leaves, first, last, ranges_host, num_ranks, pairs_out,
+                            pair_counts_host, unmatched_host, nullptr, 0);
+}
+
+int cstone_hip_halo_request_rows(cstone_hip_ctx* ctx, int key_bits, const void* leaves, const int32_t* flags,
+                                 int num_leaves, int first, int last, const int32_t* ranges_host, int num_ranks,
+                                 void* pairs_out, uint64_t* row_dev, int external_failure)
+{
+    if (!row_dev) return fail(ctx, CSTONE_E_ARG, "halo_request_rows: bad argument");
+    return haloRequestsImpl(ctx, key_bits, leaves, flags, num_leaves, first, last, ranges_host, num_ranks, pairs_out, nullptr,
+                            nullptr, row_dev, external_failure);
+}
+
+int cstone_hip_peer_range_counts(cstone_hip_ctx* ctx, const uint64_t* bounds_dev, const uint8_t* is_peer_host,
+                                 int num_ranks, uint64_t* row_dev)
+{
+    if (!ctx || !bounds_dev || !is_peer_host || num_ranks < 1 || !row_dev)
+        return fail(ctx, CSTONE_E_ARG, "peer_range_counts: bad argument");
+    CS_TRY(arenaReserve(ctx, alignUp(size_t(num_ranks)) + 256));
+    auto* dPeer = (uint8_t*)arenaTake(ctx, size_t(num_ranks));
+    int rc      = cstone_hip_upload(ctx, dPeer, is_peer_host, size_t(num_ranks));
+    if (rc == CSTONE_OK)
+    {
+        hipLaunchKernelGGL(peerRangeCountsKernel, gridFor(size_t(num_ranks), 64), 64, 0, ctx->stream, bounds_dev, dPeer,
+                           num_ranks, row_dev);
+        if (hipGetLastError() != hipSuccess) rc = fail(ctx, CSTONE_E_HIP, "peer_range_counts: launch failed");
+    }
+    arenaReset(ctx);
+    return rc;
+}
+
+static int haloRequestsImpl(cstone_hip_ctx* ctx, int key_bits, const void* leaves, const int32_t* flags, int num_leaves,
+                            int first, int last, const int32_t* ranges_host, int num_ranks, void* pairs_out,
+                            uint32_t* pair_counts_host, uint32_t* unmatched_host, uint64_t* row_dev, int external_failure)
+{
+    if (!ctx || badKeyBits(key_bits) || num_leaves < 1 || num_ranks < 1 || !leaves || !flags || !ranges_host || !pairs_out)
         return fail(ctx, CSTONE_E_ARG, "halo_requests: bad argument");
     const size_t n = size_t(num_leaves) + 1;
     // arena: ranges, the run flags and their scans, the scans at the range boundaries, the counter
@@ -293,9 +371,9 @@ int cstone_hip_halo_requests(cstone_hip_ctx* ctx, int key_bits, const void* leav
     }
     auto body = [&]() -> int
     {
-        CS_HIP(ctx, hipMemcpyAsync(dRanges, ranges_host, size_t(num_ranks) * 2 * sizeof(int32_t), hipMemcpyHostToDevice,
-                                   ctx->stream));
-        CS_HIP(ctx, hipMemcpyAsync(dMap, map.data(), map.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        // (through the pinned ring: these vectors are locals, and the row variant returns before the copies ran)
+        CS_TRY(cstone_hip_upload(ctx, dRanges, ranges_host, size_t(num_ranks) * 2 * sizeof(int32_t)));
+        CS_TRY(cstone_hip_upload(ctx, dMap, map.data(), map.size() * 4));
         CS_HIP(ctx, hipMemsetAsync(counter, 0, 4, ctx->stream));
         hipLaunchKernelGGL(haloRunsKernel, gridFor(n, 256), 256, 0, ctx->stream, flags, num_leaves, first, last, dRanges,
                            num_ranks, starts, ends, counter);
@@ -305,6 +383,14 @@ int cstone_hip_halo_requests(cstone_hip_ctx* ctx, int key_bits, const void* leav
                                                        ctx->stream, (const K*)leaves, num_leaves, starts, ends, startScan,
                                                        endScan, (K*)pairs_out));
         CS_TRY(cstone_hip_gather(ctx, 4, dMap, map.size(), startScan, dAt));
+        if (row_dev)
+        {
+            // the counts stay on the device: the row of the all-gather is written where the collective reads it
+            hipLaunchKernelGGL(requestRowKernel, gridFor(size_t(num_ranks) + 1, 64), 64, 0, ctx->stream, dAt, counter,
+                               num_ranks, external_failure, row_dev);
+            CS_HIP(ctx, hipGetLastError());
+            return CSTONE_OK;
+        }
         CS_HIP(ctx, hipMemcpyAsync(at.data(), dAt, at.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
         CS_HIP(ctx, hipMemcpyAsync(unmatched_host, counter, 4, hipMemcpyDeviceToHost, ctx->stream));
         CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -313,8 +399,9 @@ int cstone_hip_halo_requests(cstone_hip_ctx* ctx, int key_bits, const void* leav
     rc = body();
     arenaReset(ctx);
     CS_TRY(rc);
-    for (int r = 0; r < num_ranks; ++r)
-        pair_counts_host[r] = at[2 * r + 1] - at[2 * r];
+    if (!row_dev)
+        for (int r = 0; r < num_ranks; ++r)
+            pair_counts_host[r] = at[2 * r + 1] - at[2 * r];
     return CSTONE_OK;
 }
 

@@ -482,6 +482,18 @@ extern "C"
     int cstone_hip_halo_requests(cstone_hip_ctx* ctx, int key_bits, const void* leaves, const int32_t* flags,
                                  int num_leaves, int first, int last, const int32_t* ranges_host, int num_ranks,
                                  void* pairs_out, uint32_t* pair_counts_host, uint32_t* unmatched_host);
+    /* halo_requests without the trip to the host: row_dev[p] = 2 * (key pairs requested from rank p) as u64 for p <
+     * num_ranks, row_dev[num_ranks] = status word (2: external_failure != 0, 1: halo cells that belong to no peer, 0: fine)
+     * -- the row this rank contributes to the all-gather of Halos::computeLayout, written where the collective reads it */
+    int cstone_hip_halo_request_rows(cstone_hip_ctx* ctx, int key_bits, const void* leaves, const int32_t* flags,
+                                     int num_leaves, int first, int last, const int32_t* ranges_host, int num_ranks,
+                                     void* pairs_out, uint64_t* row_dev, int external_failure);
+    /* translateAssignment (R/domain/domaindecomp.hpp:183-206) + the treelet sizes of syncTreelets
+     * (R/focus/exchange_focus.hpp:61-96) on the device: bounds_dev[r] = first leaf >= assignment[r], bounds_dev[num_ranks +
+     * 1 + r] = first leaf >= assignment[r] + 1 (r = 0 .. num_ranks: the output of cstone_hip_lower_bound for these 2
+     * (num_ranks + 1) keys); row_dev[p] = leaves over rank p's range + 1 if is_peer_host[p], else 0 */
+    int cstone_hip_peer_range_counts(cstone_hip_ctx* ctx, const uint64_t* bounds_dev, const uint8_t* is_peer_host,
+                                     int num_ranks, uint64_t* row_dev);
     int cstone_hip_ranges_from_keys(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int num_leaves,
                                     const uint32_t* layout, const void* pairs, size_t num_pairs,
                                     uint32_t* range_offsets, uint32_t* range_scan);

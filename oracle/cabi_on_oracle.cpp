@@ -648,6 +648,42 @@ int cstone_hip_halo_requests(cstone_hip_ctx*, int key_bits, const void* leaves, 
                        *unmatched_host = bad;
                    });
 }
+int cstone_hip_halo_request_rows(cstone_hip_ctx* ctx, int key_bits, const void* leaves, const int32_t* flags, int num_leaves,
+                                 int first, int last, const int32_t* ranges_host, int num_ranks, void* pairs_out,
+                                 uint64_t* row_dev, int external_failure)
+{
+    std::vector<uint32_t> pairs(num_ranks, 0);
+    uint32_t unmatched = 0;
+    int rc = cstone_hip_halo_requests(ctx, key_bits, leaves, flags, num_leaves, first, last, ranges_host, num_ranks, pairs_out,
+                                      pairs.data(), &unmatched);
+    if (rc != CSTONE_OK) return rc;
+    for (int r = 0; r < num_ranks; ++r)
+        row_dev[r] = 2ull * pairs[r];
+    row_dev[num_ranks] = external_failure ? 2 : (unmatched ? 1 : 0);
+    return CSTONE_OK;
+}
+int cstone_hip_peer_range_counts(cstone_hip_ctx*, const uint64_t* bounds_dev, const uint8_t* is_peer_host, int num_ranks,
+                                 uint64_t* row_dev)
+{
+    for (int p = 0; p < num_ranks; ++p)
+    {
+        uint64_t c = 0;
+        if (is_peer_host[p])
+        {
+            int64_t s = int64_t(bounds_dev[p]), e = int64_t(bounds_dev[num_ranks + 1 + p + 1]) - 1;
+            if (e < s) e = s;
+            c = uint64_t(e - s) + 1;
+        }
+        row_dev[p] = c;
+    }
+    return CSTONE_OK;
+}
+int cstone_hip_adjacent_difference_u32(cstone_hip_ctx*, const uint32_t* in, size_t n, uint32_t* out)
+{
+    for (size_t i = 0; i < n; ++i)
+        out[i] = in[i + 1] - in[i];
+    return CSTONE_OK;
+}
 int cstone_hip_ranges_from_keys(cstone_hip_ctx*, int key_bits, const void* leaves, int num_leaves, const uint32_t* layout,
                                 const void* pairs, size_t num_pairs, uint32_t* range_offsets, uint32_t* range_scan)
 {
