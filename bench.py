@@ -439,9 +439,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.launch_only:
-        print(json.dumps({"launch_only": True, "rank": rank, "world_size": world, "local_rank": local_rank,
-                          "gpus_requested": args.gpus, "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}),
-              flush=True)
+        line = json.dumps({"launch_only": True, "rank": rank, "world_size": world, "local_rank": local_rank,
+                           "gpus_requested": args.gpus,
+                           "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}) + "\n"
+        os.write(1, line.encode())  # (one write per rank: the ranks share the pipe)
         return
     if launched and world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); the world size counts", file=sys.stderr)

@@ -315,7 +315,9 @@ struct MrBase
 {
     virtual ~MrBase()                                                                    = default;
     virtual int sync(const void* x, const void* y, const void* z, const void* h, size_t n, const void* const* props,
-                     const int* propBytes, int numProps, const void* keysIn) = 0;
+                     const int* propBytes, int numProps, const void* keysIn, const void* mass = nullptr,
+                     int massBits = 0) = 0;
+    virtual int updateExpansionCenters(const void* x, const void* y, const void* z, const void* m, int massBits) = 0;
     virtual int view(cstone_hip_domain_mr_view* out)                                     = 0;
     virtual void setHaloFactor(float f)                                                  = 0;
     virtual int exchangeHalos(void* array, int elemBytes)                                = 0;
@@ -479,6 +481,7 @@ public:
             out->internal_to_leaf = t.internalToLeaf(), out->leaf_to_internal = t.leafToInternal();
             out->layout = t.layout();
             out->centers = t.geoCenters(), out->sizes = t.geoSizes();
+            out->expansion_centers = haveExpansionCenters_ ? t.expansionCenters() : nullptr;
             return CSTONE_OK;
         }
         if (nsSync_ != syncs_)
@@ -494,7 +497,21 @@ public:
         out->internal_to_leaf = nsItl_.as<int32_t>(), out->leaf_to_internal = nsLti_.as<int32_t>();
         out->layout = nsLayout_.as<uint32_t>();
         out->centers = nsCenters_.p, out->sizes = nsSizes_.p;
+        out->expansion_centers = nullptr;
         return CSTONE_OK;
+    }
+
+    int updateExpansionCenters(const void* x, const void* y, const void* z, const void* m, int massBits) override
+    {
+        if (firstCall_ || !useLet_ || !let_) return fail(ctx_, CSTONE_E_ARG, "update_expansion_centers: no sync with the LET yet");
+        if ((massBits != 32 && massBits != 64) || !x || !y || !z || !m)
+            return fail(ctx_, CSTONE_E_ARG, "update_expansion_centers: bad argument");
+        const size_t si = view_.start_index;
+        int rc = let_->updateExpansionCenters(static_cast<const T*>(x) + si, static_cast<const T*>(y) + si,
+                                              static_cast<const T*>(z) + si, static_cast<const char*>(m) + si * size_t(massBits / 8),
+                                              massBits, gTree_.as<K>(), gLeavesHost_.data(), gLeaves_);
+        haveExpansionCenters_ = rc == CSTONE_OK;
+        return rc;
     }
 
     ~MultiRankDomain() override
@@ -530,9 +547,27 @@ public:
      *    7  room for the halos left and right of the assigned block
      *    8  halo all-to-all, keys of the halo particles             R/halos/halos.hpp:224-257
      *  then the bookkeeping reapplySync / exchangeHalos / octree() work from. */
-    int sync(const void* xIn, const void* yIn, const void* zIn, const void* hIn, size_t n, const void* const* props,
-             const int* propBytes, int numProps, const void* keysIn) override
+    int sync(const void* xIn, const void* yIn, const void* zIn, const void* hIn, size_t n, const void* const* propsIn,
+             const int* propBytesIn, int numPropsIn, const void* keysIn, const void* mass, int massBits) override
     {
+        // syncGrav: the masses travel as one more property behind the caller's
+        const bool grav = massBits != 0;
+        const void* propList[MAX_PROPS + 1];
+        int propSizes[MAX_PROPS + 1];
+        const void* const* props = propsIn;
+        const int* propBytes     = propBytesIn;
+        int numProps             = numPropsIn;
+        if (grav)
+        {
+            if (!useLet_) return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync_grav: needs the locally essential tree (CSTONE_MR_HALOS_LET)");
+            if ((massBits != 32 && massBits != 64) || massBits > rb || (n && !mass) || numPropsIn < 0 || numPropsIn >= MAX_PROPS)
+                return fail(ctx_, CSTONE_E_ARG, "domain_mr_sync_grav: masses of 32 or 64 bits (not wider than the coordinates), "
+                                                "at most %d further properties", MAX_PROPS - 1);
+            for (int q = 0; q < numPropsIn; ++q)
+                propList[q] = propsIn[q], propSizes[q] = propBytesIn[q];
+            propList[numPropsIn] = mass, propSizes[numPropsIn] = massBits / 8;
+            props = propList, propBytes = propSizes, numProps = numPropsIn + 1;
+        }
         // A rank-local failure must reach the peers: they are about to enter the collectives of this sync and would wait
         // there for ever.  Failures of the arguments (and the failures injected by the tests, CSTONE_MR_FAIL_AT) are
         // therefore kept as a pending status; the rank goes on as an EMPTY rank, the status word rides on the next
@@ -924,7 +959,7 @@ public:
             // keys and h first: the locally essential tree and the halo discovery work on them.  x, y, z are not read
             // before the halo exchange: they go to their final slots on the context's second stream, next to the tree
             // update (chains of small kernels and read-backs), and are joined in front of the exchange
-            const bool overlap = useLet_ && overlapPlace_;
+            const bool overlap = useLet_ && overlapPlace_ && !grav; // (syncGrav reads x, y, z for the mass centres)
             if (overlap) CS_TRY(ensureAuxStream(ctx_));
             if (na)
             {
@@ -989,8 +1024,22 @@ public:
             //      discovery on it, key-range requests to the owners -- csrc/let.hpp.  h is in SFC order at o.h + M.
             if (!let_) let_ = std::make_unique<FocusLet<K, T>>(ctx_, curve_, rank_, P_, bucketFocus_, theta_, comm_);
             injectFailure("exchange");
-            int rc = let_->update(box_, keysM, size_t(nm), assignment_.data(), gTree_.as<K>(), gCounts_.as<uint32_t>(),
+            int rc;
+            if (grav)
+            {
+                const char* mSorted = o.props[numProps - 1].as<char>() + M * size_t(massBits / 8);
+                rc = let_->updateGrav(box_, keysM, size_t(nm), assignment_.data(), gTree_.as<K>(), gLeavesHost_.data(),
+                                      gCounts_.as<uint32_t>(), gLeaves_, o.x.as<T>() + M, o.y.as<T>() + M, o.z.as<T>() + M,
+                                      mSorted, massBits, o.h.as<T>() + M, haloExt_, &centerDriftTol_,
+                                      pending_ ? rank_ + 1 : 0, gTreeSame_);
+                haveExpansionCenters_ = rc == CSTONE_OK;
+            }
+            else
+            {
+                rc = let_->update(box_, keysM, size_t(nm), assignment_.data(), gTree_.as<K>(), gCounts_.as<uint32_t>(),
                                   gLeaves_, o.h.as<T>() + M, haloExt_, pending_ ? rank_ + 1 : 0, gTreeSame_);
+                haveExpansionCenters_ = false;
+            }
             if (rc != CSTONE_OK)
             {
                 // (a failure of my own that the status word of the tree's last count exchange has told everybody about:
@@ -1892,6 +1941,8 @@ private:
     bool hostGlobalStep_ = std::getenv("CSTONE_MR_DEVICE_GLOBAL_STEP") == nullptr; // (tests: the device-side step)
     bool speculateCuts_  = std::getenv("CSTONE_MR_NO_SPECULATIVE_CUTS") == nullptr;  // (tests: always ask after assign())
     int cutRedos_        = 0; // syncs whose assignment changed: cut points asked for twice
+    float centerDriftTol_      = 1.05f; // Domain::centerDriftTol_ (R/domain/domain.hpp:665)
+    bool haveExpansionCenters_ = false; // the last sync was a syncGrav (or updateExpansionCenters followed it)
     bool overlapPlace_   = std::getenv("CSTONE_MR_NO_PLACE_OVERLAP") == nullptr; // x, y, z placed on the second stream
     bool placeForked_    = false; // ... and not joined yet
     DevBuf fTree_, fCounts_, fTmp_;
@@ -2007,6 +2058,24 @@ int cstone_hip_domain_mr_sync_keys(cstone_hip_domain_mr* dom, const void* keys, 
     if (n && (!x || !y || !z || !h)) return fail(dom->ctx, CSTONE_E_ARG, "domain_mr_sync: null array");
     if (num_props && (!props || !prop_bytes)) return fail(dom->ctx, CSTONE_E_ARG, "domain_mr_sync: null property list");
     return dom->impl->sync(x, y, z, h, n, props, prop_bytes, num_props, keys);
+}
+
+int cstone_hip_domain_mr_sync_grav(cstone_hip_domain_mr* dom, const void* keys, const void* x, const void* y,
+                                   const void* z, const void* h, const void* m, int mass_bits, size_t n,
+                                   const void* const* props, const int* prop_bytes, int num_props)
+{
+    if (!dom) return CSTONE_E_ARG;
+    if (n && (!x || !y || !z || !h || !m)) return fail(dom->ctx, CSTONE_E_ARG, "domain_mr_sync_grav: null array");
+    if (num_props && (!props || !prop_bytes)) return fail(dom->ctx, CSTONE_E_ARG, "domain_mr_sync_grav: null property list");
+    if (mass_bits != 32 && mass_bits != 64) return fail(dom->ctx, CSTONE_E_ARG, "domain_mr_sync_grav: mass_bits %d", mass_bits);
+    return dom->impl->sync(x, y, z, h, n, props, prop_bytes, num_props, keys, m, mass_bits);
+}
+
+int cstone_hip_domain_mr_update_expansion_centers(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z,
+                                                  const void* m, int mass_bits)
+{
+    if (!dom) return CSTONE_E_ARG;
+    return dom->impl->updateExpansionCenters(x, y, z, m, mass_bits);
 }
 
 int cstone_hip_domain_mr_sync(cstone_hip_domain_mr* dom, const void* x, const void* y, const void* z, const void* h,

@@ -351,6 +351,15 @@ __global__ __launch_bounds__(256) void macSpheresKernel(const K* __restrict__ pr
 }
 
 //! R/focus/source_center_gpu.cu:204-212
+//! FocusedOctree::addMacs (R/focus/octree_focus_mpi.hpp:601-610): a leaf whose node fails the MAC counts as a halo leaf
+__global__ __launch_bounds__(256) void addMacsKernel(const char* __restrict__ macs, const NodeIdx* __restrict__ leafToInternal,
+                                                     NodeIdx numLeaves, int32_t* __restrict__ haloFlags)
+{
+    NodeIdx i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= numLeaves) return;
+    if (macs[leafToInternal[i]] && !haloFlags[i]) haloFlags[i] = 1;
+}
+
 template<class T>
 __global__ __launch_bounds__(256) void moveCentersKernel(const T* __restrict__ src, NodeIdx numNodes,
                                                          T* __restrict__ dst)
@@ -1121,6 +1130,18 @@ int cstone_hip_set_mac(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bi
 {
     return macSpheresEntry(ctx, "set_mac", 1, curve, key_bits, real_bits, prefixes, num_nodes, spheres, inv_theta,
                            box_host);
+}
+
+int cstone_hip_add_macs(cstone_hip_ctx* ctx, const char* macs, const int32_t* leaf_to_internal, int num_leaves,
+                        int32_t* halo_flags)
+{
+    if (!ctx || num_leaves < 0 || (num_leaves && (!macs || !leaf_to_internal || !halo_flags)))
+        return fail(ctx, CSTONE_E_ARG, "add_macs: bad argument");
+    if (num_leaves == 0) return CSTONE_OK;
+    hipLaunchKernelGGL(addMacsKernel, gridFor(size_t(num_leaves), 256), 256, 0, ctx->stream, macs, leaf_to_internal,
+                       num_leaves, halo_flags);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
 }
 
 int cstone_hip_move_centers(cstone_hip_ctx* ctx, int real_bits, const void* src, int num_nodes, void* dst)

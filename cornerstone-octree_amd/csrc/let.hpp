@@ -22,6 +22,10 @@
 //   Halos::discover                                  halos/halos.hpp:128-189               discoverHalos()
 //   Halos::computeLayout, exchangeRequestKeys        :205-222, domain/exchange_keys.hpp    computeLayout()
 //   Halos::exchangeHalos                             :232-253                              exchangeHalos()
+//   Domain::syncGrav (the focus-tree part)           domain/domain.hpp:266-318             updateGrav()
+//     FocusedOctree::updateCenters                   focus/octree_focus_mpi.hpp:369-449    updateCenters()
+//     globalFocusExchange (populate / gather / upsweep / extract)   :288-366,763-784       globalCenterExchange()
+//     updateMacs, setMacRadius, addMacs              :479-526,601-610                      updateMacs(), addMacs()
 //
 // The tree stays on the device between the steps; the host sees a few scalars per step (new leaf counts, status words,
 // per-peer counts).  The results -- leaf array, leaf counts, focus assignment, layout, halo flags and halo ranges -- are
@@ -158,6 +162,79 @@ public:
         return CSTONE_OK;
     }
 
+    /*! The focus-tree part of Domain::syncGrav (R/domain/domain.hpp:266-318): like update(), with the tree resolved by the
+     *  VECTOR MAC on the mass centres of the nodes (expansion centres) instead of the minimum-distance MAC.
+     *  x, y, z, m: the rank's assigned particles in the order of keys (device; m: massBits = 32 | 64);
+     *  globalLeavesHost: host copy of the global leaf array (numGlobalLeaves + 1 keys); centerDriftTol: Domain's
+     *  centerDriftTol_ (raised by 0.05 whenever halo cells turn out to belong to nobody, like the reference).
+     *  Afterwards expansionCenters() holds (centre of mass, MAC radius^2) per node.  Collective. */
+    int updateGrav(const cstone_box& box, const K* keys, size_t numKeys, const K* assignment, const K* globalLeaves,
+                   const K* globalLeavesHost, const uint32_t* globalCounts, int numGlobalLeaves, const T* x, const T* y,
+                   const T* z, const void* m, int massBits, const T* h, float haloSearchExt, float* centerDriftTol,
+                   int externalFailure = 0, bool globalTreeSame = false)
+    {
+        const float invThetaEff = 1.0f / theta_ + std::sqrt(3.0f); // invThetaVecMac, R/traversal/macs.hpp:48
+        LET_TRY(init());
+        LET_TRY(findPeers(assignment, globalLeaves, numGlobalLeaves, box, invThetaEff, globalTreeSame));
+        auto centres = [&]() { return updateCenters(x, y, z, m, massBits, globalLeaves, globalLeavesHost, numGlobalLeaves); };
+        if (firstCall_)
+        {
+            // first rough convergence to avoid computing expansion centres of large nodes with a lot of particles (:270-287)
+            LET_TRY(converge(box, keys, numKeys, assignment, globalLeaves, globalCounts, numGlobalLeaves, 1.0f));
+            LET_TRY(updateMinMac(assignment, 1.0f));
+            uint32_t converged = 0;
+            int reps           = 0;
+            while (int(converged) != P_ || reps < 2)
+            {
+                bool conv = false;
+                LET_TRY(updateTree(assignment, box, &conv));
+                LET_TRY(updateCounts(keys, numKeys, globalLeaves, globalCounts, numGlobalLeaves));
+                LET_TRY(centres());
+                LET_TRY(updateMacs(assignment, 1.0f / theta_));
+                LET_TRY(allReduceSum(conv ? 1u : 0u, &converged));
+                if (++reps > 128) return fail(CSTONE_E_INTERNAL, "focus tree (gravity) does not converge");
+            }
+        }
+        uint32_t failed = 0;
+        int guard       = 0;
+        do
+        {
+            LET_TRY(updateMacs(assignment, *centerDriftTol / theta_));
+            bool conv = false;
+            LET_TRY(updateTree(assignment, box, &conv));
+            LET_TRY(updateCounts(keys, numKeys, globalLeaves, globalCounts, numGlobalLeaves));
+            LET_TRY(centres());
+            LET_TRY(updateMacs(assignment, 1.0f / theta_));
+            LET_TRY(discoverHalos(box, h, haloSearchExt));
+            LET_TRY(addMacs());
+            bool unmatched = false;
+            LET_TRY(computeLayout(externalFailure, &unmatched));
+            // (the rows of computeLayout carry everybody's status: `unmatched` is the same on every rank, the
+            //  MPI_Allreduce of :311 is part of that exchange)
+            failed = unmatched ? 1u : 0u;
+            if (failed)
+            {
+                *centerDriftTol += 0.05f;
+                if (++guard > 64) return fail(CSTONE_E_INTERNAL, "syncGrav: halo cells keep falling outside the peers' ranges");
+            }
+        } while (failed);
+        firstCall_ = false;
+        return CSTONE_OK;
+    }
+
+    /*! Domain::updateExpansionCenters (R/domain/domain.hpp:415-421): mass centres of the focus tree from the particles as
+     *  they are now (x, y, z, m: the assigned particles, device) and the MAC radii for 1 / theta.  Collective. */
+    int updateExpansionCenters(const T* x, const T* y, const T* z, const void* m, int massBits, const K* globalLeaves,
+                               const K* globalLeavesHost, int numGlobalLeaves)
+    {
+        LET_TRY(updateCenters(x, y, z, m, massBits, globalLeaves, globalLeavesHost, numGlobalLeaves));
+        return cstone_hip_set_mac(ctx_, curve_, kb, rb, prefixes_.p, numNodesOf(L_), centers_.p, 1.0f / theta_, &box_);
+    }
+
+    //! (centre of mass, MAC radius^2) of every node of the focus tree: Vec4<T>[numNodes()], after updateGrav
+    const T* expansionCenters() const { return centers_.as<T>(); }
+    const char* macs() const { return macs_.as<char>(); }
+
     /*! Halos::exchangeHalos (R/halos/halos.hpp:232-253): array is laid out like the particle buffers of the last
      *  update (numParticlesWithHalos() elements of elemBytes bytes): its assigned range is read, the halo ranges are
      *  overwritten with the owners' values.  Collective. */
@@ -270,7 +347,7 @@ private:
                 &macs_, &centers_, &geoCenters_, &geoSizes_, &opsAll_, &ops_, &scratchKeys_, &scratchKeys2_, &scratchIdx_,
                 &scratchIdx2_, &scratchU64_, &gPrefixes_, &gChild_, &gParents_, &gLevelRange_, &gItl_, &gLti_, &treelets_,
                 &treeletIdx_, &tlFlags_, &tlScan_, &sendBuf_, &recvBuf_, &layout_, &flags_, &radii_, &rangeOffsets_,
-                &rangeScan_, &haloSend_, &haloRecv_, &rowBuf_};
+                &rangeScan_, &haloSend_, &haloRecv_, &rowBuf_, &gSeg_, &gCenters_};
     }
 
     int fail(int code, const char* fmt, ...)
@@ -538,6 +615,7 @@ private:
         LET_TRY(cstone_hip_build_octree(ctx_, kb, globalLeaves, GL, gPrefixes_.p, gChild_.as<int32_t>(),
                                         gParents_.as<int32_t>(), gLevelRange_.as<int32_t>(), gItl_.as<int32_t>(),
                                         gLti_.as<int32_t>()));
+        LET_TRY(readBack(gLevelRange_.as<int32_t>(), gLevelHost_, size_t(maxLevel) + 2)); // (upsweeps over the global tree)
         std::vector<uint64_t> a64(P_ + 1);
         for (int r = 0; r <= P_; ++r)
             a64[r] = uint64_t(assignment[r]);
@@ -1031,6 +1109,7 @@ private:
                      int numGlobalLeaves)
     {
         const int L = L_, M = numNodesOf(L), I = numInternalOf(L);
+        numKeys_ = numKeys;
         LET_TRY(leafCounts_.ensure(size_t(L) * 4));
         LET_TRY(cstone_hip_compute_node_counts(ctx_, kb, leaves_.p, leafCounts_.as<uint32_t>(), L, keys, numKeys,
                                                0xFFFFFFFFu));
@@ -1098,6 +1177,163 @@ private:
         return CSTONE_OK;
     }
 
+    //! sum of one value per rank
+    int allReduceSum(uint32_t mine, uint32_t* sum)
+    {
+        *sum = mine;
+        if (P_ == 1) return CSTONE_OK;
+        LET_TRY(rowBuf_.ensure(64));
+        LET_TRY(cstone_hip_upload(ctx_, rowBuf_.p, &mine, 4));
+        LET_TRY(commCall(comm_.all_reduce(comm_.user, rowBuf_.p, 1, 1, 0), "all_reduce (flag)"));
+        return readBack(rowBuf_.as<uint32_t>(), sum);
+    }
+
+    /*! updateMacs (octree_focus_mpi.hpp:505-526): MAC radii from the expansion centres in centers_ (setMacRadius) and the
+     *  marks of the nodes that fail the MAC against my focus */
+    int updateMacs(const K* assignment, float invTheta)
+    {
+        const int M = numNodesOf(L_);
+        LET_TRY(cstone_hip_set_mac(ctx_, curve_, kb, rb, prefixes_.p, M, centers_.p, invTheta, &box_));
+        LET_TRY(macs_.ensure(size_t(M)));
+        LET_TRY(cstone_hip_memset(ctx_, macs_.p, 0, size_t(M)));
+        std::vector<int64_t> idx;
+        LET_TRY(lowerBounds(leaves_.as<K>(), size_t(L_), {assignment[rank_], assignment[rank_ + 1]}, idx));
+        const int fStart = int(idx[0]), fEnd = int(idx[1]);
+        if (fEnd > fStart)
+            LET_TRY(cstone_hip_mark_macs(ctx_, curve_, kb, rb, prefixes_.p, child_.as<int32_t>(), centers_.p, &box_,
+                                         leaves_.as<K>() + fStart, fEnd - fStart, 0, macs_.as<char>()));
+        haveMacs_ = true;
+        return CSTONE_OK;
+    }
+
+    //! addMacs (:601-610): a leaf whose node fails the MAC becomes a halo leaf
+    int addMacs() { return cstone_hip_add_macs(ctx_, macs_.as<char>(), lti_.as<int32_t>() + numInternalOf(L_), L_, flags_.as<int32_t>()); }
+
+    /*! updateCenters (octree_focus_mpi.hpp:369-449): mass centres of my leaves from the particles, upsweep, the nodes
+     *  that are larger than any rank's domain through the global tree (globalCenterExchange), the peers' regions from
+     *  the peers, upsweep */
+    int updateCenters(const T* x, const T* y, const T* z, const void* m, int massBits, const K* globalLeaves,
+                      const K* globalLeavesHost, int numGlobalLeaves)
+    {
+        const int L = L_, M = numNodesOf(L), I = numInternalOf(L);
+        const int first = assignment_[rank_].start, last = assignment_[rank_].end;
+        LET_TRY(centers_.ensure(size_t(M) * 4 * sizeof(T)));
+        // temporary pre-halo layout: offsets of MY leaves among my particles, zero-sized ranges everywhere else
+        LET_TRY(scratchIdx2_.ensure(size_t(L + 2) * 4));
+        uint32_t* lay = scratchIdx2_.as<uint32_t>();
+        LET_TRY(cstone_hip_memset(ctx_, lay, 0, size_t(first + 1) * 4));
+        if (last > first)
+            LET_TRY(cstone_hip_inclusive_scan_u32(ctx_, leafCounts_.as<uint32_t>() + first, lay + first + 1,
+                                                  size_t(last - first)));
+        if (L > last)
+        {
+            // (leaves behind mine hold nothing of mine: they all start where my particles end)
+            const uint32_t total = uint32_t(numKeys_);
+            LET_TRY(cstone_hip_fill(ctx_, 4, lay + last + 1, size_t(L - last), &total));
+        }
+        LET_TRY(cstone_hip_leaf_source_centers(ctx_, rb, massBits, rb, x, y, z, m, lti_.as<int32_t>() + I, L, lay,
+                                               centers_.p));
+        LET_TRY(readBack(levelRange_.as<int32_t>(), levelHost_, size_t(maxLevel) + 2));
+        LET_TRY(cstone_hip_upsweep_centers(ctx_, rb, maxLevel, levelHost_, child_.as<int32_t>(), centers_.p));
+        if (P_ > 1)
+        {
+            LET_TRY(globalCenterExchange(globalLeaves, globalLeavesHost, numGlobalLeaves));
+            // the peers' regions from their owners (peerExchange of SourceCenterType, :436-447), like the counts
+            std::vector<uint64_t> sendCounts(P_, 0), recvCounts(P_, 0);
+            uint64_t sendTotal = 0, recvTotal = 0;
+            for (int peer : peers_)
+            {
+                sendCounts[peer] = tlCount_[peer];
+                recvCounts[peer] = uint64_t(assignment_[peer].count());
+                sendTotal += sendCounts[peer];
+                recvTotal += recvCounts[peer];
+            }
+            const int e = int(4 * sizeof(T));
+            LET_TRY(sendBuf_.ensure(std::max<uint64_t>(sendTotal, 1) * e));
+            LET_TRY(recvBuf_.ensure(std::max<uint64_t>(recvTotal, 1) * e));
+            if (sendTotal)
+                LET_TRY(cstone_hip_gather(ctx_, e, treeletIdx_.as<uint32_t>(), size_t(sendTotal), centers_.p, sendBuf_.p));
+            LET_TRY(allToAll(sendBuf_.p, sendCounts, e, recvBuf_.p, recvCounts));
+            uint64_t at = 0;
+            for (int peer : peers_)
+            {
+                if (recvCounts[peer])
+                    LET_TRY(cstone_hip_scatter(ctx_, e, lti_.as<uint32_t>() + I + assignment_[peer].start,
+                                               size_t(recvCounts[peer]), recvBuf_.template as<char>() + at * e, centers_.p));
+                at += recvCounts[peer];
+            }
+            LET_TRY(cstone_hip_upsweep_centers(ctx_, rb, maxLevel, levelHost_, child_.as<int32_t>(), centers_.p));
+        }
+        return CSTONE_OK;
+    }
+
+    /*! globalFocusExchange for the expansion centres (octree_focus_mpi.hpp:288-366,763-784): every rank contributes the
+     *  centres of the global leaves inside its focus (populateGlobal), the segments are gathered (gatherGlobalLeaves; an
+     *  all-gather of segments padded to the longest), the global tree is swept up, and the leaves of my focus tree that
+     *  neither I nor a peer own take their centres from the global nodes of the same key range (extractGlobal) */
+    int globalCenterExchange(const K* globalLeaves, const K* gl, int GL)
+    {
+        const int L = L_, I = numInternalOf(L);
+        const int e = int(4 * sizeof(T));
+        const int GM = numNodesOf(GL), GI = numInternalOf(GL);
+        // findNodeAbove(globalLeaves, key) for the assignment of the last tree update (host copy of the global leaves)
+        auto above = [&](K key) { return int(std::lower_bound(gl, gl + GL + 1, key) - gl); };
+        std::vector<int> displ(P_ + 1);
+        for (int r = 0; r < P_; ++r)
+            displ[r] = above(globAssignment_[r]);
+        displ[P_] = GL;
+        int longest = 1;
+        for (int r = 0; r < P_; ++r)
+            longest = std::max(longest, displ[r + 1] - displ[r]);
+        const int gFirst = above(prevFocusStart_), gLast = above(prevFocusEnd_);
+        const int mine   = gLast - gFirst;
+        if (mine != displ[rank_ + 1] - displ[rank_] || gFirst != displ[rank_])
+            return fail(CSTONE_E_INTERNAL, "global centre exchange: my global leaves [%d, %d), the assignment says [%d, %d)",
+                        gFirst, gLast, displ[rank_], displ[rank_ + 1]);
+        // populateGlobal: the focus node of every global leaf of mine
+        LET_TRY(gSeg_.ensure(size_t(longest) * e * (size_t(P_) + 1)));
+        LET_TRY(gCenters_.ensure(size_t(std::max(GM, GL) + 1) * e * 2));
+        char* seg     = gSeg_.as<char>();
+        char* all     = seg + size_t(longest) * e;
+        char* leafCen = gCenters_.as<char>();                    // [GL] in leaf order
+        char* nodeCen = leafCen + size_t(GL + 1) * e;            // [GM] in node order
+        LET_TRY(cstone_hip_memset(ctx_, seg, 0, size_t(longest) * e));
+        if (mine > 0)
+        {
+            LET_TRY(scratchIdx_.ensure(size_t(mine + 1) * 4));
+            LET_TRY(cstone_hip_locate_nodes(ctx_, kb, globalLeaves + gFirst, size_t(mine) + 1, prefixes_.p,
+                                            levelRange_.as<int32_t>(), scratchIdx_.as<int32_t>()));
+            LET_TRY(cstone_hip_gather(ctx_, e, scratchIdx_.as<uint32_t>(), size_t(mine), centers_.p, seg));
+        }
+        LET_TRY(commCall(comm_.all_gather(comm_.user, seg, all, size_t(longest) * e), "all_gather (global leaf centres)"));
+        for (int r = 0; r < P_; ++r)
+            if (displ[r + 1] > displ[r])
+                LET_TRY(cstone_hip_memcpy_d2d(ctx_, leafCen + size_t(displ[r]) * e, all + size_t(r) * longest * e,
+                                              size_t(displ[r + 1] - displ[r]) * e));
+        // the global tree: leaf quantities to node order, upsweep (the linked octree of the global tree is findPeers')
+        LET_TRY(cstone_hip_memset(ctx_, nodeCen, 0, size_t(GM) * e));
+        LET_TRY(cstone_hip_scatter(ctx_, e, gLti_.as<uint32_t>() + GI, size_t(GL), leafCen, nodeCen));
+        LET_TRY(cstone_hip_upsweep_centers(ctx_, rb, maxLevel, gLevelHost_, gChild_.as<int32_t>(), nodeCen));
+        // extractGlobal: the leaves outside my range and the peers' ranges, run by run
+        int32_t cur = 0;
+        auto extractRun = [&](int32_t a, int32_t b) -> int
+        {
+            if (b <= a) return CSTONE_OK;
+            LET_TRY(scratchIdx_.ensure(size_t(b - a + 1) * 4));
+            LET_TRY(cstone_hip_locate_nodes(ctx_, kb, leaves_.as<K>() + a, size_t(b - a) + 1, gPrefixes_.p,
+                                            gLevelRange_.as<int32_t>(), scratchIdx_.as<int32_t>()));
+            return cstone_hip_gather_scatter(ctx_, e, scratchIdx_.as<uint32_t>(), lti_.as<uint32_t>() + I + a, size_t(b - a),
+                                             nodeCen, centers_.p);
+        };
+        for (const LetRange& r : assignment_)
+        {
+            if (r.start == r.end) continue;
+            LET_TRY(extractRun(cur, r.start));
+            cur = r.end;
+        }
+        return extractRun(cur, L);
+    }
+
     //! converge (octree_focus_mpi.hpp:535-553): update until the tree of EVERY rank has stopped changing
     int converge(const cstone_box& box, const K* keys, size_t numKeys, const K* assignment, const K* globalLeaves,
                  const uint32_t* globalCounts, int numGlobalLeaves, float invThetaEff)
@@ -1150,8 +1386,9 @@ private:
      *  R/domain/layout.hpp:150-165), the key ranges I want from every peer (exchangeRequestKeys,
      *  R/domain/exchange_keys.hpp:63-119) and the index ranges the peers want from me, the ranges the halos arrive in
      *  (computeHaloRecvList, layout.hpp:175-190) */
-    int computeLayout(int externalFailure)
+    int computeLayout(int externalFailure, bool* unmatchedOut = nullptr)
     {
+        if (unmatchedOut) *unmatchedOut = false;
         const int L = L_, first = assignment_[rank_].start, last = assignment_[rank_].end;
         LET_TRY(cstone_hip_node_layout(ctx_, leafCounts_.as<uint32_t>(), flags_.as<int32_t>(), first, last, L,
                                        layout_.as<uint32_t>()));
@@ -1186,6 +1423,12 @@ private:
         for (int p = 0; p < P_; ++p)
         {
             const uint64_t st = matrix[size_t(p) * (P_ + 1) + P_];
+            if (st == 1 && unmatchedOut)
+            {
+                // syncGrav: the caller loosens its MAC and tries again (on every rank: they all read the same rows)
+                *unmatchedOut = true;
+                return CSTONE_OK;
+            }
             if (st == 1)
                 return fail(CSTONE_E_INTERNAL,
                             "halo discovery: rank %d found halo cells that belong to none of its peers (the sync was "
@@ -1282,6 +1525,7 @@ private:
     Stats stats_;
 
     int L_ = 0; // leaves of the focus tree
+    size_t numKeys_ = 0; // assigned particles of the last updateCounts
     int levelBound_ = maxLevel;          // no leaf is deeper than this (treeChanged)
     uint64_t treeVersion_ = 0, memoVersion_ = 0;
     std::map<K, std::pair<size_t, int64_t>> memo_; // lowerBounds in the current leaf array: key -> (keys searched, index)
@@ -1290,6 +1534,9 @@ private:
     LetBuf counts_, leafCounts_, macs_, centers_, geoCenters_, geoSizes_;
     LetBuf opsAll_, ops_, scratchKeys_, scratchKeys2_, scratchIdx_, scratchIdx2_, scratchU64_;
     LetBuf gPrefixes_, gChild_, gParents_, gLevelRange_, gItl_, gLti_; // linked octree of the global tree (peer search)
+    LetBuf gSeg_, gCenters_;                  // global centre exchange: my segment + everybody's, leaf and node centres
+    int32_t levelHost_[maxLevel + 2]  = {0};  // level ranges of the focus tree / the global tree on the host (upsweeps)
+    int32_t gLevelHost_[maxLevel + 2] = {0};
 
     std::vector<int> peers_;
     std::vector<K> peersAssignment_; // what the peers were computed for

@@ -44,7 +44,7 @@ class MrOctree(C.Structure):
                 ("leaf_counts", C.c_void_p), ("prefixes", C.c_void_p), ("child_offsets", C.c_void_p),
                 ("parents", C.c_void_p), ("level_range", C.c_void_p), ("internal_to_leaf", C.c_void_p),
                 ("leaf_to_internal", C.c_void_p), ("layout", C.c_void_p), ("centers", C.c_void_p),
-                ("sizes", C.c_void_p)]
+                ("sizes", C.c_void_p), ("expansion_centers", C.c_void_p)]
 
 
 class _DevMem:
@@ -235,7 +235,23 @@ class NativeDistributedDomain:
         self.ctx._chk(self.ctx.lib.cstone_hip_domain_mr_view_get(self.h, C.byref(v)), "domain_mr_view_get")
         return v
 
-    def sync(self, x, y, z, h, props=(), keys=None):
+    def sync_grav(self, x, y, z, h, m, props=(), keys=None):
+        """Domain::syncGrav: like sync, the masses m follow their particles (they come back as out["m"]) and the focus tree
+        is resolved by the vector MAC on the nodes' mass centres (octree()["expansion_centers"] afterwards)"""
+        out = self.sync(x, y, z, h, props=props, keys=keys, mass=m)
+        return out
+
+    def update_expansion_centers(self, x, y, z, m):
+        """Domain::updateExpansionCenters on arrays laid out like the last sync's results"""
+        rc = self.ctx.lib.cstone_hip_domain_mr_update_expansion_centers(self.h, C.c_void_p(x.data_ptr()),
+                                                                        C.c_void_p(y.data_ptr()), C.c_void_p(z.data_ptr()),
+                                                                        C.c_void_p(m.data_ptr()), C.c_int(m.element_size() * 8))
+        if rc != 0 and self.coll.error is not None:
+            err, self.coll.error = self.coll.error, None
+            raise err
+        self.ctx._chk(rc, "domain_mr_update_expansion_centers")
+
+    def sync(self, x, y, z, h, props=(), keys=None, mass=None):
         """returns dict(keys, x, y, z, h, start, end[, props]) of tensors that alias the domain-owned result arrays (valid
         until the next but one sync); props: further fields (rows of 1..32 bytes) that follow their particles; keys: optional
         key array whose remove markers flag particles that leave the domain"""
@@ -247,11 +263,17 @@ class NativeDistributedDomain:
         parr = (C.c_void_p * max(1, k))(*[t.data_ptr() for t in props])
         rows = [int(np.prod(t.shape[1:])) if t.dim() > 1 else 1 for t in props]
         pbytes = (C.c_int * max(1, k))(*[t.element_size() * r for t, r in zip(props, rows)])
-        self._keep = (x, y, z, h, props, keys)
-        rc = self.ctx.lib.cstone_hip_domain_mr_sync_keys(self.h, C.c_void_p(keys.data_ptr() if keys is not None else 0),
-                                                         C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
-                                                         C.c_void_p(z.data_ptr()), C.c_void_p(h.data_ptr()),
-                                                         C.c_size_t(x.numel()), parr, pbytes, C.c_int(k))
+        self._keep = (x, y, z, h, props, keys, mass)
+        if mass is not None:
+            rc = self.ctx.lib.cstone_hip_domain_mr_sync_grav(
+                self.h, C.c_void_p(keys.data_ptr() if keys is not None else 0), C.c_void_p(x.data_ptr()),
+                C.c_void_p(y.data_ptr()), C.c_void_p(z.data_ptr()), C.c_void_p(h.data_ptr()), C.c_void_p(mass.data_ptr()),
+                C.c_int(mass.element_size() * 8), C.c_size_t(x.numel()), parr, pbytes, C.c_int(k))
+        else:
+            rc = self.ctx.lib.cstone_hip_domain_mr_sync_keys(self.h, C.c_void_p(keys.data_ptr() if keys is not None else 0),
+                                                             C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                             C.c_void_p(z.data_ptr()), C.c_void_p(h.data_ptr()),
+                                                             C.c_size_t(x.numel()), parr, pbytes, C.c_int(k))
         if rc != 0 and self.coll.error is not None:
             err, self.coll.error = self.coll.error, None
             raise err
@@ -272,6 +294,8 @@ class NativeDistributedDomain:
         out["lim"] = np.array([lim[i] for i in range(6)])
         out["props"] = [wrap(v.props[q], props[q].dtype, n * props[q].element_size() * rows[q])
                         .view((n,) + tuple(props[q].shape[1:])) for q in range(len(props))]
+        if mass is not None:  # (the masses travelled as one more property behind the caller's)
+            out["m"] = wrap(v.props[len(props)], mass.dtype, n * mass.element_size())
         return out
 
     def exchange_halos(self, field):
@@ -306,7 +330,8 @@ class NativeDistributedDomain:
                     level_range=wrap(o.level_range, torch.int32, cstone_amd.max_level(self.kb) + 2),
                     internal_to_leaf=wrap(o.internal_to_leaf, torch.int32, M),
                     leaf_to_internal=wrap(o.leaf_to_internal, torch.int32, M), layout=wrap(o.layout, torch.int32, L + 1),
-                    centers=wrap(o.centers, rdt, 3 * M).view(M, 3), sizes=wrap(o.sizes, rdt, 3 * M).view(M, 3))
+                    centers=wrap(o.centers, rdt, 3 * M).view(M, 3), sizes=wrap(o.sizes, rdt, 3 * M).view(M, 3),
+                    expansion_centers=(wrap(o.expansion_centers, rdt, 4 * M).view(M, 4) if o.expansion_centers else None))
 
     def reapply_sync(self, field):
         """Domain::reapplySync: field (laid out like the INPUT arrays of the last sync, rows of 1..32 bytes) follows its

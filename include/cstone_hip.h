@@ -406,6 +406,10 @@ extern "C"
     int cstone_hip_set_mac(cstone_hip_ctx* ctx, int curve, int key_bits, int real_bits, const void* prefixes,
                            int num_nodes, void* spheres, float inv_theta, const cstone_box* box_host);
     int cstone_hip_move_centers(cstone_hip_ctx* ctx, int real_bits, const void* src, int num_nodes, void* dst);
+    /* FocusedOctree::addMacs (R/focus/octree_focus_mpi.hpp:601-610): halo_flags[i] = 1 for every leaf i whose node
+     * (leaf_to_internal[i], the leaf part of the map) carries a MAC mark */
+    int cstone_hip_add_macs(cstone_hip_ctx* ctx, const char* macs, const int32_t* leaf_to_internal, int num_leaves,
+                            int32_t* halo_flags);
     int cstone_hip_leaf_source_centers(cstone_hip_ctx* ctx, int coord_bits, int mass_bits, int center_bits,
                                        const void* x, const void* y, const void* z, const void* m,
                                        const int32_t* leaf_to_internal, int num_leaves, const uint32_t* layout,
@@ -749,6 +753,21 @@ extern "C"
     int cstone_hip_domain_mr_sync_keys(cstone_hip_domain_mr* dom, const void* keys, const void* x, const void* y,
                                        const void* z, const void* h, size_t n, const void* const* props,
                                        const int* prop_bytes, int num_props);
+    /* Domain::syncGrav (R/domain/domain.hpp:246-325) on the RCCL route: like _sync_keys, with the masses m (n values of
+     * mass_bits = 32 | 64 bits, device) following their particles as ONE MORE property behind the num_props given ones
+     * (view.props[num_props] afterwards), and the focus tree resolved by the vector MAC on the mass centres of its nodes:
+     * FocusedOctree::updateCenters with the global centre exchange, updateMacs, addMacs and the retry with a larger centre
+     * drift tolerance when halo cells belong to nobody (:288-317), restated in csrc/let.hpp (FocusLet::updateGrav) and
+     * compared with the reference's syncGrav under MPI (oracle/let_check.cpp, `grav`).  cstone_hip_domain_mr_octree_get
+     * then also hands out the expansion centres.  Halo mode CSTONE_MR_HALOS_LET only. */
+    int cstone_hip_domain_mr_sync_grav(cstone_hip_domain_mr* dom, const void* keys, const void* x, const void* y,
+                                       const void* z, const void* h, const void* m, int mass_bits, size_t n,
+                                       const void* const* props, const int* prop_bytes, int num_props);
+    /* Domain::updateExpansionCenters (R/domain/domain.hpp:415-421): mass centres and MAC radii of the focus tree from the
+     * particles as they are NOW; x, y, z, m: arrays laid out like the result arrays of the last sync (their assigned range
+     * is read).  Collective. */
+    int cstone_hip_domain_mr_update_expansion_centers(cstone_hip_domain_mr* dom, const void* x, const void* y,
+                                                      const void* z, const void* m, int mass_bits);
     int cstone_hip_domain_mr_view_get(cstone_hip_domain_mr* dom, cstone_hip_domain_mr_view* out);
     /* Domain::exchangeHalos (R/domain/domain.hpp:381-386): repeats the halo exchange of the last sync for one more
      * field; array (device; elements of 1, 2, 4, 8, 12, 16, 24 or 32 bytes, e.g. Vec3<float>, Vec4<double>) is laid out
@@ -798,6 +817,8 @@ extern "C"
         const uint32_t* layout; /* u32[num_leaves + 1] */
         const void* centers;    /* T[num_nodes][3] */
         const void* sizes;      /* T[num_nodes][3] */
+        const void* expansion_centers; /* T[num_nodes][4]: (centre of mass, MAC radius^2) after _sync_grav /
+                                          _update_expansion_centers (FocusedOctree::expansionCenters), else NULL */
     } cstone_hip_domain_mr_octree;
     int cstone_hip_domain_mr_octree_get(cstone_hip_domain_mr* dom, cstone_hip_domain_mr_octree* out);
 

@@ -516,6 +516,63 @@ int cstone_hip_geo_mac_spheres(cstone_hip_ctx*, int curve, int key_bits, int rea
                                 });
                    });
 }
+int cstone_hip_set_mac(cstone_hip_ctx*, int curve, int key_bits, int real_bits, const void* prefixes, int num_nodes,
+                       void* spheres, float inv_theta, const cstone_box* box_host)
+{
+    return withKey(key_bits,
+                   [&](auto k)
+                   {
+                       using K = decltype(k);
+                       withReal(real_bits,
+                                [&](auto t)
+                                {
+                                    using T = decltype(t);
+                                    macSpheres<K, T>(Curve(curve), 1, (const K*)prefixes, num_nodes, (T*)spheres,
+                                                     inv_theta, mkBox<T>(box_host));
+                                });
+                   });
+}
+int cstone_hip_add_macs(cstone_hip_ctx*, const char* macs, const int32_t* leaf_to_internal, int num_leaves,
+                        int32_t* halo_flags)
+{
+    for (int i = 0; i < num_leaves; ++i)
+        if (macs[leaf_to_internal[i]] && !halo_flags[i]) halo_flags[i] = 1;
+    return CSTONE_OK;
+}
+int cstone_hip_leaf_source_centers(cstone_hip_ctx*, int coord_bits, int mass_bits, int center_bits, const void* x,
+                                   const void* y, const void* z, const void* m, const int32_t* leaf_to_internal,
+                                   int num_leaves, const uint32_t* layout, void* centers)
+{
+    if (coord_bits == 64 && mass_bits == 64 && center_bits == 64)
+        leafSourceCenters((const double*)x, (const double*)y, (const double*)z, (const double*)m, leaf_to_internal,
+                          num_leaves, layout, (double*)centers);
+    else if (coord_bits == 64 && mass_bits == 32 && center_bits == 64)
+        leafSourceCenters((const double*)x, (const double*)y, (const double*)z, (const float*)m, leaf_to_internal,
+                          num_leaves, layout, (double*)centers);
+    else if (coord_bits == 32 && mass_bits == 32 && center_bits == 32)
+        leafSourceCenters((const float*)x, (const float*)y, (const float*)z, (const float*)m, leaf_to_internal,
+                          num_leaves, layout, (float*)centers);
+    else return CSTONE_E_ARG;
+    return CSTONE_OK;
+}
+int cstone_hip_upsweep_centers(cstone_hip_ctx*, int real_bits, int num_levels, const int32_t* level_range_host,
+                               const int32_t* child_offsets, void* centers)
+{
+    return withReal(real_bits,
+                    [&](auto t)
+                    {
+                        using T = decltype(t);
+                        upsweepCenters<T>(num_levels, level_range_host, child_offsets, (T*)centers);
+                    });
+}
+int cstone_hip_gather_scatter(cstone_hip_ctx*, int elem_bytes, const uint32_t* map_in, const uint32_t* map_out, size_t n,
+                              const void* src, void* dst)
+{
+    for (size_t i = 0; i < n; ++i)
+        std::memcpy((char*)dst + size_t(map_out[i]) * elem_bytes, (const char*)src + size_t(map_in[i]) * elem_bytes,
+                    size_t(elem_bytes));
+    return CSTONE_OK;
+}
 int cstone_hip_find_peers_mac(cstone_hip_ctx*, int curve, int key_bits, int real_bits, const void* prefixes,
                               const int32_t* child_offsets, const int32_t* level_range, const uint64_t* assignment_host,
                               int num_ranks, int my_rank, const cstone_box* box_host, float inv_theta_eff,

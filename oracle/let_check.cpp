@@ -12,7 +12,7 @@
 //   oracle/_ref/let_check_hip  linked against libcstone_hip.so: the HIP kernels behind the same state machine on the
 //                              MI355X box, the ranks of mpiexec sharing the GPU (tests/test_let.py, -m gpu)
 //
-// usage: let_check <k64f64|k32f32|k64f32> <numParticles> <syncs> <bucket> <bucketFocus> <bcx> <bcy> <bcz> <kind> <seed>
+// usage: let_check <k64f64|k32f32|k64f32> <numParticles> <syncs> <bucket> <bucketFocus> <bcx> <bcy> <bcz> <kind> <seed> [grav]
 //        kind: 0 uniform, 1 blobs (imbalanced), 2 drifting blob (the assignment moves every sync)
 #include <mpi.h>
 
@@ -142,6 +142,8 @@ void expectEqual(const char* what, int sync, const A* a, size_t na, const B* b, 
     }
 }
 
+int gArgc = 0;
+
 template<class K, class T>
 int run(int rank, int P, char** argv)
 {
@@ -152,6 +154,8 @@ int run(int rank, int P, char** argv)
     const int kind     = std::atoi(argv[9]);
     const unsigned seed = unsigned(std::atoi(argv[10]));
     const float theta  = 0.5f;
+    // 11th argument "grav": Domain::syncGrav against FocusLet::updateGrav (expansion centres and MAC radii compared as well)
+    const bool grav = gArgc > 11 && std::string(argv[11]) == "grav";
 
     // the same cloud on every rank, every rank keeps a random share
     std::mt19937 gen(seed);
@@ -162,7 +166,7 @@ int run(int rank, int P, char** argv)
         for (double& v : c)
             v = 0.2 + 0.6 * uni(gen);
     const T top = T(1) - T(1) / T(1 << (sizeof(T) == 8 ? 30 : 20));
-    std::vector<T> x, y, z, h;
+    std::vector<T> x, y, z, h, m;
     for (size_t i = 0; i < N; ++i)
     {
         double p[3];
@@ -177,6 +181,7 @@ int run(int rank, int P, char** argv)
         y.push_back(std::min(std::max(T(p[1]), T(0)), top));
         z.push_back(std::min(std::max(T(p[2]), T(0)), top));
         h.push_back(T(hh));
+        m.push_back(T(0.5 + hh * 25.0) / T(N)); // (masses that differ from particle to particle)
     }
     std::vector<K> keys(x.size());
     std::vector<T> s1, s2, s3;
@@ -195,9 +200,11 @@ int run(int rank, int P, char** argv)
     auto letOwner = std::make_unique<cship::FocusLet<K, T>>(ctx, CSTONE_HILBERT, rank, P, bucketFocus, theta, ops);
     cship::FocusLet<K, T>& let = *letOwner;
 
+    float driftTol = 1.05f; // Domain::centerDriftTol_ (R/domain/domain.hpp:665)
     for (int s = 0; s < syncs; ++s)
     {
-        dom.sync(keys, x, y, z, h, std::tuple{}, std::tie(s1, s2, s3));
+        if (grav) dom.syncGrav(keys, x, y, z, h, m, std::tuple{}, std::tie(s1, s2, s3));
+        else dom.sync(keys, x, y, z, h, std::tuple{}, std::tie(s1, s2, s3));
         MPI_Barrier(MPI_COMM_WORLD);
         const LocalIndex st = dom.startIndex(), en = dom.endIndex();
 
@@ -216,8 +223,20 @@ int run(int rank, int P, char** argv)
         OnDevice<K> dKeys(ctx, keys.data() + st, en - st), dGl(ctx, gl.data(), gl.size());
         OnDevice<unsigned> dGc(ctx, gc.data(), gc.size());
         OnDevice<T> dH(ctx, h.data() + st, en - st);
-        int rc = let.update(cb, dKeys.get(), en - st, assignment.data(), dGl.get(), dGc.get(), int(gl.size()) - 1, dH.get(),
+        int rc;
+        if (grav)
+        {
+            OnDevice<T> dX(ctx, x.data() + st, en - st), dY(ctx, y.data() + st, en - st), dZ(ctx, z.data() + st, en - st),
+                dM(ctx, m.data() + st, en - st);
+            rc = let.updateGrav(cb, dKeys.get(), en - st, assignment.data(), dGl.get(), gl.data(), dGc.get(),
+                                int(gl.size()) - 1, dX.get(), dY.get(), dZ.get(), dM.get(), int(8 * sizeof(T)), dH.get(), 1.0f,
+                                &driftTol);
+        }
+        else
+        {
+            rc = let.update(cb, dKeys.get(), en - st, assignment.data(), dGl.get(), dGc.get(), int(gl.size()) - 1, dH.get(),
                             1.0f);
+        }
         int rcAll = rc != 0;
         MPI_Allreduce(MPI_IN_PLACE, &rcAll, 1, MPI_INT, MPI_SUM, MPI_COMM_WORLD);
         if (rcAll)
@@ -228,7 +247,8 @@ int run(int rank, int P, char** argv)
         }
 
         // ---- comparison
-        std::vector<int> peers = findPeersMac(rank, ga.assignment(), ga.octree(), dom.box(), invThetaMinMac(theta));
+        std::vector<int> peers = findPeersMac(rank, ga.assignment(), ga.octree(), dom.box(),
+                                              grav ? invThetaVecMac(theta) : invThetaMinMac(theta));
         expectEqual("peers", s, peers.data(), peers.size(), let.peers().data(), let.peers().size());
         const auto& ft = dom.focusTree_;
         auto fl        = ft.treeLeaves();
@@ -261,6 +281,14 @@ int run(int rank, int P, char** argv)
                     fetch(ctx, let.geoCenters(), size_t(M) * 3).data(), size_t(M) * 3);
         expectEqual("node sizes", s, reinterpret_cast<const T*>(ft.geoSizesAcc_.data()), ft.geoSizesAcc_.size() * 3,
                     fetch(ctx, let.geoSizes(), size_t(M) * 3).data(), size_t(M) * 3);
+        if (grav)
+        {
+            // expansion centres (centre of mass) and MAC radii^2 of EVERY node, the MAC marks, the drift tolerance
+            expectEqual("expansion centres + MAC radii", s, reinterpret_cast<const T*>(ft.centers_.data()),
+                        ft.centers_.size() * 4, fetch(ctx, let.expansionCenters(), size_t(M) * 4).data(), size_t(M) * 4);
+            expectEqual("MAC marks", s, ft.macs_.data(), ft.macs_.size(), fetch(ctx, let.macs(), size_t(M)).data(), size_t(M));
+            expectEqual("centerDriftTol", s, &dom.centerDriftTol_, 1, &driftTol, 1);
+        }
         // the halo exchange: x with its halo ranges wiped must come back as the reference left it (8-byte elements);
         // a 3-byte field derived from the keys as well
         if (let.numParticlesWithHalos() == x.size())
@@ -353,6 +381,7 @@ int main(int argc, char** argv)
     MPI_Comm_rank(MPI_COMM_WORLD, &rank);
     MPI_Comm_size(MPI_COMM_WORLD, &P);
     rankG = rank;
+    gArgc = argc;
     if (argc < 11)
     {
         if (rank == 0) std::fprintf(stderr, "usage: see the head of oracle/let_check.cpp\n");

@@ -199,6 +199,9 @@ def main():
                     help="native only: 1 = owner-side halo discovery instead of the locally essential tree")
     ap.add_argument("--fail-at", default="", help="native only: after one good sync, rank 1 is made to fail at this point "
                                                   "of the next sync (CSTONE_MR_FAIL_AT); every rank must get an error")
+    ap.add_argument("--grav", type=int, default=0,
+                    help="native only: this many Domain::syncGrav calls (cstone_hip_domain_mr_sync_grav): masses follow their "
+                         "particles, the root's expansion centre is the global centre of mass, neighbour counts complete")
     ap.add_argument("--spec-box", type=int, default=0,
                     help="native only: this many syncs through two domains, one encoding with the previous box while it "
                          "measures the extents (the default), one measuring first (CSTONE_NO_SPECULATIVE_BOX); particles "
@@ -292,6 +295,48 @@ def main():
         ok = bool(flag.item())
         # the speculating domain re-sorted where the box held (at least two of the quiet steps), the other one never
         ok = ok and int(dom.view().resorts) >= 2 and int(dom_b.view().resorts) == 0
+        if rank == 0:
+            print("DIST_RESULT " + json.dumps(dict(ok=ok, ranks=P, report=report)))
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
+    if a.grav:
+        # Domain::syncGrav on the RCCL route (the LET state machine itself is compared with the reference in
+        # oracle/let_check.cpp `grav`; here: the entry point end to end on several ranks)
+        mass = torch.from_numpy((0.5 + 10.0 * hglob[mine]) / N).to(dev).to(rdt if a.real_bits == 64 else torch.float32)
+        xa, ya, za, ha, ma = x, y, z, h, mass
+        for s_ in range(a.grav):
+            ident = xa * 3.0 + ya * 5.0 + za * 7.0 + ha
+            r = dom.sync_grav(xa, ya, za, ha, ma, props=[ident])
+            st, en = r["start"], r["end"]
+            same = bool(torch.equal(r["props"][0][st:en], (r["x"] * 3.0 + r["y"] * 5.0 + r["z"] * 7.0 + r["h"])[st:en]))
+            k = r["keys"]
+            same = same and (bool((k[1:] >= k[:-1]).all()) if k.numel() > 1 else True)
+            # masses stayed attached: m is a function of h here
+            want_m = ((0.5 + 10.0 * r["h"][st:en].double()) / N).to(r["m"].dtype)
+            same = same and bool(torch.allclose(r["m"][st:en], want_m, rtol=1e-6, atol=0))
+            oc = dom.octree()
+            ec = oc["expansion_centers"]
+            same = same and ec is not None
+            # the root's expansion centre is the centre of mass of the WHOLE cloud (the global centre exchange)
+            loc = torch.stack([(r["m"][st:en].double() * r[c][st:en].double()).sum() for c in "xyz"] +
+                              [r["m"][st:en].double().sum()]).cpu()
+            dist.all_reduce(loc)
+            com = (loc[:3] / loc[3]).numpy()
+            root = ec[0, :3].double().cpu().numpy()
+            close = bool(np.allclose(root, com, rtol=1e-5 if a.real_bits == 32 else 1e-10, atol=1e-7 if a.real_bits == 32 else 1e-12))
+            same = same and close and float(ec[:, 3].min()) >= 0.0
+            tot = torch.tensor([en - st], dtype=torch.int64)
+            dist.all_reduce(tot)
+            same = same and int(tot.item()) == N
+            ok &= same
+            report.append(dict(grav_sync=s_, ok=same, root=[float(v) for v in root], com=[float(v) for v in com],
+                               focus_leaves=int(dom.view().num_focus_leaves)))
+            xa, ya, za, ha, ma = [r[c][st:en].clone() for c in ("x", "y", "z", "h", "m")]
+            for c, vcol in zip((xa, ya, za), range(3)):
+                c.add_(0.004 * torch.sin(7.0 * (xa + vcol))).clamp_(0.0, top)
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
         if rank == 0:
             print("DIST_RESULT " + json.dumps(dict(ok=ok, ranks=P, report=report)))
         dist.destroy_process_group()

@@ -30,7 +30,9 @@ def test_bench_gpus_n_starts_n_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-only"],
                        capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    import re
+
+    lines = [json.loads(m.group(0)) for m in re.finditer(r"\{[^{}]*\}", r.stdout)]
     assert sorted(j["rank"] for j in lines) == [0, 1]
     assert all(j["world_size"] == 2 and j["launch_only"] and j["gpus_requested"] == 2 for j in lines)
     assert sorted(j["local_rank"] for j in lines) == [0, 1] and all(j["master"].startswith("127.0.0.1:") for j in lines)

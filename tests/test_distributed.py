@@ -239,3 +239,15 @@ def test_native_domain_speculative_box_equals_measuring_first(pbc):
     on the way (csrc/domain_mr.hip): every result equals that of a domain that measures first, through steps in which the
     box holds and steps in which it grows (3 ranks, open boundaries)"""
     _launch(3, "hip", 60000, 1, pbc, 29741, impl="native", extra=["--spec-box", "7"], timeout=400)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,real_bits", [(1, 64), (3, 64), (4, 32)])
+def test_native_domain_sync_grav(nproc, real_bits):
+    """cstone_hip_domain_mr_sync_grav end to end (gloo ranks sharing the GPU): the masses follow their particles, keys
+    sorted, nothing lost, and the root node's expansion centre equals the centre of mass of the whole cloud -- which only
+    the global centre exchange can know.  (The state machine itself == the reference's syncGrav: tests/test_let.py.)"""
+    r = _launch(nproc, "hip", 40000, 1, 0, 29760 + nproc, impl="native",
+                extra=["--grav", "3", "--real-bits", str(real_bits)], timeout=600)
+    steps = [e for e in r["report"] if "grav_sync" in e]
+    assert len(steps) == 3 and all(e["ok"] for e in steps)

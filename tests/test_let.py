@@ -59,6 +59,27 @@ def test_let_equals_reference_with_ranks_that_are_no_peers():
     assert paths["leavesFromGlobal"] > 0
 
 
+# ---- Domain::syncGrav (R/domain/domain.hpp:246-325): the focus tree resolved by the vector MAC on the mass centres of
+#      its nodes.  FocusLet::updateGrav against the reference's syncGrav: everything above plus the expansion centres and
+#      MAC radii^2 of EVERY node, the MAC marks and the centre drift tolerance, `==`
+@pytest.mark.parametrize("ranks,args", [
+    (1, ("k64f64", 12000, 3, 64, 16, 0, 0, 0, 1, 7)),
+    (2, ("k64f64", 16000, 3, 64, 16, 0, 0, 0, 1, 7)),
+    (3, ("k64f32", 15000, 3, 64, 16, 1, 1, 0, 0, 11)),
+    (5, ("k32f32", 20000, 3, 64, 16, 0, 1, 2, 1, 11)),
+])
+def test_let_sync_grav_equals_reference(ranks, args):
+    paths = run(ranks, *args, "grav")
+    assert paths["treeUpdates"] >= ranks * args[2]
+
+
+def test_let_sync_grav_with_ranks_that_are_no_peers():
+    """12 ranks, drifting blobs: far regions take their mass centres from the global tree (globalFocusExchange:
+    populateGlobal, gatherGlobalLeaves, the upsweep of the global tree, extractGlobal)"""
+    paths = run(12, "k64f64", 90000, 3, 64, 16, 1, 1, 1, 2, 11, "grav", timeout=1500)
+    assert paths["leavesFromGlobal"] > 0 and paths["focusTransfers"] > 0
+
+
 # ---- the same comparisons with the HIP kernels underneath (libcstone_hip.so instead of the CPU restatement): the ranks
 #      of mpiexec share the GPU of the box
 @pytest.mark.gpu
@@ -73,6 +94,18 @@ def test_let_equals_reference_with_ranks_that_are_no_peers():
 def test_hip_let_equals_reference(ranks, args):
     assert os.path.exists(EXE_HIP), "oracle/_ref/let_check_hip not built (make -C oracle)"
     paths = run(ranks, *args, exe=EXE_HIP)
+    assert paths["treeUpdates"] >= ranks * args[2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,args", [
+    (1, ("k64f64", 12000, 3, 64, 16, 0, 0, 0, 1, 7)),
+    (3, ("k64f32", 15000, 3, 64, 16, 1, 1, 0, 0, 11)),
+    (5, ("k64f64", 30000, 3, 64, 16, 0, 1, 2, 2, 11)),
+])
+def test_hip_let_sync_grav_equals_reference(ranks, args):
+    assert os.path.exists(EXE_HIP), "oracle/_ref/let_check_hip not built (make -C oracle)"
+    paths = run(ranks, *args, "grav", exe=EXE_HIP)
     assert paths["treeUpdates"] >= ranks * args[2]
 
 
