@@ -480,6 +480,8 @@ def main():
         init_group()
     torch.cuda.set_device(local_rank)
     ctx = cstone_amd.Context(local_rank)
+    if os.environ.get("CSTONE_BENCH_MARKERS") == "1":  # roctx ranges per stage (rocprofv3 --marker-trace)
+        ctx.profile_markers(True)
 
     n_global = int(args.particles)
     n_local = n_global // world
@@ -763,7 +765,8 @@ def main():
              3 * rbytes + 2 * kbytes, "x, y, z and the old key read, the new key written"),
             (("leafSortWaveKernel<LeafFields> (keys + x, y, z, h in one pass)", "resort_leaves", 2 * kbytes + 4 + 8 * rbytes,
               "key, x, y, z, h read; key, old index, x, y, z, h written at the leaf's new place (four scratch arrays: the "
-              "field-carrying leaf pass, no gather passes)") if n_scratch >= 4 else
+              "field-carrying leaf pass, no gather passes; opt-in, DESIGN.md section 10)")
+             if n_scratch >= 4 and os.environ.get("CSTONE_FUSED_LEAF_PASS") is not None else
              ("leafSortWaveKernel", "resort_leaves", 2 * kbytes + 4,
               "key read; key + old index written (one wave per leaf; with fewer movers than tiles a launch of "
               "leafSortKernel for the quiet tiles comes first, inside the same bracket)")),
@@ -781,7 +784,7 @@ def main():
             # node keys): their stage averages say nothing about the full-size launches and stay out of the table
             models = [m for m in models if m[1] not in ("gather", "sort_pass", "sort_pass_iota")]
         tjson = None
-        for tname in ("r03_kernel_hbm_traffic.json", "r02_kernel_hbm_traffic.json"):
+        for tname in ("r04_kernel_hbm_traffic.json", "r03_kernel_hbm_traffic.json", "r02_kernel_hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and tjson is None:
                 tjson = (tname, json.load(open(tpath)))

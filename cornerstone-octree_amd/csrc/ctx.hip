@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <unordered_set>
@@ -315,6 +316,25 @@ int cstone_hip_memcpy_h2d(cstone_hip_ctx* ctx, void* dst, const void* src, size_
     return CSTONE_OK;
 }
 
+namespace
+{
+/*! a few bytes from the pinned ring to the device with an ordinary kernel (one lane per byte, or per word when both
+ *  ends allow).  hipMemcpyAsync does the same with a blit kernel that ends on a system-scope release: while a bandwidth
+ *  kernel runs on the second stream (placeColumnsKernel of the multi-rank sync) that release did not complete before
+ *  the other kernel had finished (profiles/r04_mr_sync_api_sequence.json: a 264-byte copy that lasted 102 us) and
+ *  everything queued behind the copy waited with it */
+__global__ __launch_bounds__(256) void ringToDeviceKernel(char* __restrict__ dst, const char* __restrict__ src, size_t bytes,
+                                                           bool words)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (words)
+    {
+        if (i * 4 < bytes) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+    }
+    else if (i < bytes) { dst[i] = src[i]; }
+}
+} // namespace
+
 int cstone_hip_upload(cstone_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
     if (!ctx) return CSTONE_E_ARG;
@@ -334,7 +354,16 @@ int cstone_hip_upload(cstone_hip_ctx* ctx, void* dst, const void* src, size_t by
         off = 0;
     }
     std::memcpy(ctx->uploadStage + off, src, bytes);
-    CS_HIP(ctx, hipMemcpyAsync(dst, ctx->uploadStage + off, bytes, hipMemcpyHostToDevice, ctx->stream));
+    static const bool blit = std::getenv("CSTONE_UPLOAD_BLIT") != nullptr; // (A/B: the runtime's copy instead)
+    if (blit) { CS_HIP(ctx, hipMemcpyAsync(dst, ctx->uploadStage + off, bytes, hipMemcpyHostToDevice, ctx->stream)); }
+    else
+    {
+        const bool words = (reinterpret_cast<uintptr_t>(dst) % 4 == 0) && (bytes % 4 == 0);
+        const size_t lanes = words ? bytes / 4 : bytes;
+        hipLaunchKernelGGL(ringToDeviceKernel, dim3(unsigned((lanes + 255) / 256)), dim3(256), 0, ctx->stream,
+                           static_cast<char*>(dst), ctx->uploadStage + off, bytes, words);
+        CS_HIP(ctx, hipGetLastError());
+    }
     ctx->uploadCursor = off + bytes;
     return CSTONE_OK;
 }

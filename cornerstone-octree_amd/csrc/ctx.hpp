@@ -134,7 +134,8 @@ int minMaxCoordinates(cstone_hip_ctx* ctx, int real_bits, const void* const* xs,
 int minMaxCoordinatesDev(cstone_hip_ctx* ctx, int real_bits, const void* const* xs, int numArrays, size_t n,
                          double* devOut);
 //! {min, max} per axis as T on the device -> (min, -max) as doubles: the operand of the box all-reduce
-int extentsToReduceOperand(cstone_hip_ctx* ctx, int real_bits, const void* extents, double* devOut);
+int extentsToReduceOperand(cstone_hip_ctx* ctx, int real_bits, const void* extents, double* devOut, double status,
+                           const int* counters);
 
 //! encode + the sort's digit histograms in one kernel (sfc.hip); *fused = false: hist untouched (unaligned input)
 //! extentsOut (device, 6 reals {xmin, xmax, ymin, ...}, or nullptr): the extents of x, y, z measured by the same pass;

@@ -680,27 +680,27 @@ public:
             CS_TRY(computeKeysResort(ctx_, curve_, kb, rb, x, y, z, keysIn ? keys_.p : nullptr, n, box_, &ra,
                                      speculate ? extentsDev : nullptr, &done));
             bool boxHolds = true, foundHere = false;
+            int counters[4] = {0, 0, 0, 0};
             if (speculate)
             {
                 boxChecked = true;
                 // (the keys above were computed with the box of the previous sync: was it still the box?)
                 double* dev = scal_.as<double>();
-                if (done) { CS_TRY(extentsToReduceOperand(ctx_, rb, extentsDev, dev)); }
+                if (done)
+                {
+                    CS_TRY(resort_.binMovers(ctx_, tileLeaves));
+                    // (the re-sort's counters and this rank's status word become part of the operand: one launch, and
+                    //  one copy and one synchronisation bring the reduced extents and the counters)
+                    CS_TRY(extentsToReduceOperand(ctx_, rb, extentsDev, dev, statusWord(), ctx_->devScalars + RESORT_SCALARS));
+                    foundHere = true;
+                }
                 else
                 {
                     const void* arrays[3] = {x, y, z};
                     CS_TRY(minMaxCoordinatesDev(ctx_, rb, arrays, 3, n, dev));
                 }
-                if (done)
-                {
-                    CS_TRY(resort_.binMovers(ctx_, tileLeaves));
-                    // (the re-sort's counters travel with the reduced extents: one synchronisation for both)
-                    CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars + 40, ctx_->devScalars + RESORT_SCALARS, 4 * sizeof(int),
-                                                hipMemcpyDeviceToHost, ctx_->stream));
-                    foundHere = true;
-                }
                 cstone_box next;
-                CS_TRY(reduceBox(dev, &next));
+                CS_TRY(reduceBox(dev, &next, foundHere, foundHere ? counters : nullptr));
                 for (int k = 0; k < 6; ++k)
                     boxHolds = boxHolds && next.lim[k] == box_.lim[k];
                 if (!boxHolds)
@@ -714,7 +714,7 @@ public:
             if (done && boxHolds)
             {
                 int found[4];
-                if (foundHere) { std::copy(ctx_->hostScalars + 40, ctx_->hostScalars + 44, found); }
+                if (foundHere) { std::copy(counters, counters + 4, found); }
                 else { CS_TRY(toHost(found, ctx_->devScalars + RESORT_SCALARS, sizeof found)); }
                 const uint32_t markers = uint32_t(found[0]), J = uint32_t(found[2]), movers = uint32_t(found[3]);
                 if ((found[1] & 7) == 0 && movers <= n / 8)
@@ -1506,14 +1506,22 @@ private:
 
     /*! dev: (lo, -hi) of this rank's particles per axis, six doubles on the device, room for a seventh.  All-reduces them
      *  with the status word, reads them back and applies the box rule to box_ -> *next (box_ itself is not changed). */
-    int reduceBox(double* dev, cstone_box* next)
+    //! seventh value of the box reduction: the status of this rank (0, or -(rank + 1) if it has a failure pending)
+    double statusWord() const { return pending_ ? -double(rank_ + 1) : 0.0; }
+
+    /*! MIN over the ranks of dev[0..6] = (min, -max) per axis + status.  statusSet: the operand is complete (the kernel
+     *  that wrote the extents wrote the status too); counters: four ints behind the operand come back in the same copy */
+    int reduceBox(double* dev, cstone_box* next, bool statusSet = false, int* counters = nullptr)
     {
-        // seventh value: the status of this rank (0, or -(rank + 1) if it has a failure pending); MIN over the ranks
-        statusD_ = pending_ ? -double(rank_ + 1) : 0.0;
-        CS_HIP(ctx_, hipMemcpyAsync(dev + 6, &statusD_, sizeof statusD_, hipMemcpyHostToDevice, ctx_->stream));
+        if (!statusSet)
+        {
+            const double status = statusWord();
+            CS_TRY(cstone_hip_upload(ctx_, dev + 6, &status, sizeof status));
+        }
         if (P_ > 1) CS_TRY(callComm(comm_.all_reduce(comm_.user, dev, 7, 0, 1), "all_reduce (box)"));
-        double ext[7];
-        CS_TRY(toHost(ext, dev, sizeof ext));
+        double ext[9];
+        CS_TRY(toHost(ext, dev, counters ? sizeof ext : 7 * sizeof(double)));
+        if (counters) std::memcpy(counters, ext + 7, 4 * sizeof(int));
         if (ext[6] < 0) return agreed(int(-ext[6]) - 1);
         *next = box_;
         double fit[6];
@@ -1916,7 +1924,6 @@ private:
     int pending_    = 0; // status of this rank inside sync(): 0, or the error code the peers have to learn about
     uint64_t statusW64_ = 0; // staging of the status words that ride on the collectives (asynchronous copies read them)
     uint32_t statusW32_ = 0;
-    double statusD_     = 0;
     std::string pendingMsg_;
     bool timing_    = std::getenv("CSTONE_MR_TIMING") != nullptr;
     bool noMargin_  = std::getenv("CSTONE_MR_NO_MARGIN") != nullptr; // tests: no room left for halos, the block is moved

@@ -504,13 +504,30 @@ int minMaxCoordinatesDev(cstone_hip_ctx* ctx, int real_bits, const void* const* 
     return minMaxArraysDev<double>(ctx, (const double* const*)xs, numArrays, n, devOut);
 }
 
-//! {min, max} per axis as T (what the encode kernels measure on the way) -> (min, -max) as doubles at devOut
-int extentsToReduceOperand(cstone_hip_ctx* ctx, int real_bits, const void* extents, double* devOut)
+namespace
+{
+//! the whole operand of the box reduction of a multi-rank sync in one launch (see extentsToReduceOperand)
+template<class T>
+__global__ void reduceOperandKernel(const T* __restrict__ res, double* __restrict__ out, double status,
+                                    const int* __restrict__ counters)
+{
+    int i = threadIdx.x;
+    if (i < 3) out[2 * i] = double(res[2 * i]), out[2 * i + 1] = -double(res[2 * i + 1]);
+    if (i == 3) out[6] = status;
+    if (counters && i >= 4 && i < 8) reinterpret_cast<int*>(out + 7)[i - 4] = counters[i - 4];
+}
+} // namespace
+
+/*! {min, max} per axis as T (what the encode kernels measure on the way) -> (min, -max) as doubles at devOut[0..5],
+ *  the rank's status word at devOut[6] (it used to be a host-to-device copy of its own) and, behind the operand, four
+ *  counters of the caller (the re-sort's: they travel to the host in the same copy as the reduced extents) */
+int extentsToReduceOperand(cstone_hip_ctx* ctx, int real_bits, const void* extents, double* devOut, double status,
+                           const int* counters)
 {
     if (real_bits == 32)
-        hipLaunchKernelGGL(minNegMaxKernel<float>, 1, 64, 0, ctx->stream, (const float*)extents, 3, devOut);
+        hipLaunchKernelGGL(reduceOperandKernel<float>, 1, 64, 0, ctx->stream, (const float*)extents, devOut, status, counters);
     else
-        hipLaunchKernelGGL(minNegMaxKernel<double>, 1, 64, 0, ctx->stream, (const double*)extents, 3, devOut);
+        hipLaunchKernelGGL(reduceOperandKernel<double>, 1, 64, 0, ctx->stream, (const double*)extents, devOut, status, counters);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

@@ -51,6 +51,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scanSumsKernel(ScanJobs jobs, unsi
     if (threadIdx.x == 0 && jobs.total[blockIdx.x]) *jobs.total[blockIdx.x] = carry;
 }
 
+/*! SUMS_SCANNED: sums[] holds the exclusive scan of the tile sums (scanSumsKernel ran); otherwise the raw tile sums, and
+ *  every workgroup adds up those of the tiles before its own (few tiles: one launch less; the last workgroup also
+ *  leaves the grand total) */
+template<bool SUMS_SCANNED>
 __global__ __launch_bounds__(SCAN_BLOCK) void blockScanKernel(ScanJobs jobs, size_t n, bool inclusive)
 {
     __shared__ uint32_t ws[4];
@@ -65,7 +69,22 @@ __global__ __launch_bounds__(SCAN_BLOCK) void blockScanKernel(ScanJobs jobs, siz
         v[k] = (base + k < n) ? in[base + k] : 0u;
         s += v[k];
     }
-    uint32_t run = jobs.sums[blockIdx.y][blockIdx.x] + blockExclusiveScan256(s, ws, nullptr);
+    uint32_t before;
+    if constexpr (SUMS_SCANNED) { before = jobs.sums[blockIdx.y][blockIdx.x]; }
+    else
+    {
+        const uint32_t* __restrict__ sums = jobs.sums[blockIdx.y];
+        uint32_t mine = 0;
+        for (unsigned t = threadIdx.x; t < blockIdx.x; t += SCAN_BLOCK)
+            mine += sums[t];
+        uint32_t tilesBefore;
+        blockExclusiveScan256(mine, ws, &tilesBefore);
+        __syncthreads(); // (ws is used again below)
+        before = jobs.init[blockIdx.y] + tilesBefore;
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && jobs.total[blockIdx.y])
+            *jobs.total[blockIdx.y] = before + sums[blockIdx.x];
+    }
+    uint32_t run = before + blockExclusiveScan256(s, ws, nullptr);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k)
     {
@@ -99,8 +118,15 @@ static int scanJobs(cstone_hip_ctx* ctx, ScanJobs jobs, int count, size_t n, boo
             return fail(ctx, CSTONE_E_INTERNAL, "scan: arena exhausted (caller must reserve %zu extra bytes)", bytes * count);
     }
     hipLaunchKernelGGL(blockSumKernel, dim3(blocks, count), SCAN_BLOCK, 0, ctx->stream, jobs, n);
-    hipLaunchKernelGGL(scanSumsKernel, count, SCAN_BLOCK, 0, ctx->stream, jobs, blocks);
-    hipLaunchKernelGGL(blockScanKernel, dim3(blocks, count), SCAN_BLOCK, 0, ctx->stream, jobs, n, inclusive);
+    // up to 1024 tiles (2e6 elements) every workgroup sums the tile sums before its own itself (at most four loads per
+    // lane): two launches instead of three for the scans over leaves and tiles of a sync
+    if (blocks <= 4 * SCAN_BLOCK)
+        hipLaunchKernelGGL(blockScanKernel<false>, dim3(blocks, count), SCAN_BLOCK, 0, ctx->stream, jobs, n, inclusive);
+    else
+    {
+        hipLaunchKernelGGL(scanSumsKernel, count, SCAN_BLOCK, 0, ctx->stream, jobs, blocks);
+        hipLaunchKernelGGL(blockScanKernel<true>, dim3(blocks, count), SCAN_BLOCK, 0, ctx->stream, jobs, n, inclusive);
+    }
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

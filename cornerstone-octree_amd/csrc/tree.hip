@@ -296,6 +296,46 @@ __global__ __launch_bounds__(256) void upsweepLevelKernel(int level, const NodeI
     }
 }
 
+/*! the levels topLevel .. 0 (at most 8^4 nodes each) in ONE workgroup, a barrier between two levels: four launches
+ *  less per upsweep than a launch per level.  The sums of a level are read back through the L2 (agent-scope loads: a
+ *  line fetched into this CU's L1 before its values were written must not answer) */
+constexpr int UPSWEEP_FUSED_TOP = 4;
+__global__ __launch_bounds__(1024) void upsweepTopLevelsKernel(int topLevel, const NodeIdx* __restrict__ levelRange,
+                                                               const NodeIdx* __restrict__ childOffsets, uint32_t* q)
+{
+    for (int level = topLevel; level >= 0; --level)
+    {
+        NodeIdx start = levelRange[level], end = levelRange[level + 1];
+        for (NodeIdx i = start + threadIdx.x; i < end; i += 1024)
+        {
+            NodeIdx c = childOffsets[i];
+            if (c)
+            {
+                uint64_t s = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    s += __hip_atomic_load(q + c + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(q + i, uint32_t(s < 0xFFFFFFFFull ? s : 0xFFFFFFFFull), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
+//! the bottom-up sum from level `from` down to the root: a launch per level above the fused top levels
+static void launchUpsweep(cstone_hip_ctx* ctx, int from, const NodeIdx* levelRange, const NodeIdx* childOffsets,
+                          uint32_t* counts)
+{
+    unsigned grid = unsigned(ctx->numCu) * 4;
+    int level     = from;
+    for (; level > UPSWEEP_FUSED_TOP; --level)
+        hipLaunchKernelGGL(upsweepLevelKernel, grid, 256, 0, ctx->stream, level, levelRange, childOffsets, counts);
+    if (level >= 0)
+        hipLaunchKernelGGL(upsweepTopLevelsKernel, 1, 1024, 0, ctx->stream, level, levelRange, childOffsets, counts);
+}
+
 // ---- geometric node centers, R/sfc/box.hpp:335-352 (compiled with -ffp-contract=off like the encode)
 template<class K, class T>
 __global__ __launch_bounds__(256) void nodeCentersKernel(const K* __restrict__ prefixes, NodeIdx numNodes,
@@ -433,13 +473,16 @@ int buildLinkedOctree(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int
 int upsweepSumLevels(cstone_hip_ctx* ctx, int numLevelsPlus2, const int32_t* levelRangeHost, const int32_t* levelRange,
                      const int32_t* childOffsets, uint32_t* counts)
 {
-    for (int level = numLevelsPlus2 - 2; level >= 0; --level)
+    int level = numLevelsPlus2 - 2;
+    for (; level > UPSWEEP_FUSED_TOP; --level)
     {
         int size = levelRangeHost[level + 1] - levelRangeHost[level];
         if (size <= 0) continue;
         unsigned grid = std::min(unsigned(ctx->numCu) * 4, gridFor(size_t(size), 256));
         hipLaunchKernelGGL(upsweepLevelKernel, grid, 256, 0, ctx->stream, level, levelRange, childOffsets, counts);
     }
+    if (level >= 0)
+        hipLaunchKernelGGL(upsweepTopLevelsKernel, 1, 1024, 0, ctx->stream, level, levelRange, childOffsets, counts);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }
@@ -583,9 +626,7 @@ int cstone_hip_upsweep_sum(cstone_hip_ctx* ctx, int num_levels_plus2, const int3
 {
     if (!ctx || !level_range || !child_offsets || !counts || num_levels_plus2 < 2)
         return fail(ctx, CSTONE_E_ARG, "upsweep_sum: bad argument");
-    unsigned grid = unsigned(ctx->numCu) * 4;
-    for (int level = num_levels_plus2 - 2; level >= 0; --level)
-        hipLaunchKernelGGL(upsweepLevelKernel, grid, 256, 0, ctx->stream, level, level_range, child_offsets, counts);
+    launchUpsweep(ctx, num_levels_plus2 - 2, level_range, child_offsets, counts);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }
@@ -609,10 +650,8 @@ int cstone_hip_upsweep_sum_bounded(cstone_hip_ctx* ctx, int num_levels_plus2, co
 {
     if (!ctx || !level_range || !child_offsets || !counts || num_levels_plus2 < 2 || deepest_level < 0)
         return fail(ctx, CSTONE_E_ARG, "upsweep_sum_bounded: bad argument");
-    unsigned grid = unsigned(ctx->numCu) * 4;
     // (the nodes of the deepest level are leaves: the first level with anything to sum is the one above)
-    for (int level = std::min(num_levels_plus2 - 2, deepest_level - 1); level >= 0; --level)
-        hipLaunchKernelGGL(upsweepLevelKernel, grid, 256, 0, ctx->stream, level, level_range, child_offsets, counts);
+    launchUpsweep(ctx, std::min(num_levels_plus2 - 2, deepest_level - 1), level_range, child_offsets, counts);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

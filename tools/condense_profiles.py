@@ -75,7 +75,8 @@ for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), 
         a[1] += 1
     for (k, c), (s, n) in acc.items():
         means[k][c] = s / n
-json.dump(means, open(f"profiles/{tag}_sort_pmc_means.json", "w"), indent=1)
+if means:  # (only when the sort's PMC passes were part of the run: no empty files)
+    json.dump(means, open(f"profiles/{tag}_sort_pmc_means.json", "w"), indent=1)
 o = means.get("onesweepKernel", {})
 if "FETCH_SIZE" in o and "WRITE_SIZE" in o:
     fetch, write = 2.0 * o["FETCH_SIZE"] * 1024, o["WRITE_SIZE"] * 1024
@@ -188,6 +189,23 @@ if glob.glob(os.path.join(src, "mr_api", "*hip_api_trace.csv")):
     subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "mr_trace.py"),
                     os.path.join(src, "mr_api"), "--json", f"profiles/{tag}_mr_sync_api_sequence.json"],
                    check=True, stdout=subprocess.DEVNULL)
+# roctx ranges of the stages (cstone_hip_profile_markers; rocprofv3 --marker-trace): time per stage and sync from the
+# marker trace alone, without the event brackets of cstone_hip_profile_enable
+for trace in glob.glob(os.path.join(src, "markers", "**", "*marker_api_trace.csv"), recursive=True):
+    per = defaultdict(lambda: [0, 0.0])
+    for row in csv.DictReader(open(trace)):
+        name = row.get("Function") or row.get("Name") or ""
+        if not name.startswith("cstone:"):
+            continue
+        per[name][0] += 1
+        per[name][1] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+    if per:
+        json.dump({"source": "rocprofv3 --marker-trace --kernel-trace of `CSTONE_BENCH_MARKERS=1 python bench.py --steps 3 ...`: "
+                             "roctx ranges cstone:<stage> pushed by the library's stage timers (HOST time between push and "
+                             "pop: the launches of a stage, not the kernels' run time)",
+                   "ranges": sorted(({"range": k, "count": v[0], "host_us_total": round(v[1], 1)} for k, v in per.items()),
+                                    key=lambda e: -e["host_us_total"])},
+                  open(f"profiles/{tag}_stage_marker_ranges.json", "w"), indent=1)
 print("wrote", sorted(os.listdir("profiles")))
 
 # the JSON line bench.py printed under the profiler (its live roofline number belongs next to the kernel stats)

@@ -37,7 +37,10 @@ for r in api[a + 1:b]:
         us = (int(k["End_Timestamp"]) - int(k["Start_Timestamp"])) / 1e3
         gpu_us += us
         what = re.sub(r"^void |cship::\(anonymous namespace\)::|cship::", "", k["Kernel_Name"]).split("(")[0][:70]
-        what = f"{what} [{us:.1f} us]"
+        # (when the kernel ran on the GPU, relative to the first call of the sync, and on which HSA queue: kernels of the
+        #  second stream overlap those of the first)
+        what = (f"{what} [{us:.1f} us; gpu {(int(k['Start_Timestamp']) - t0) / 1e3:.1f}..{(int(k['End_Timestamp']) - t0) / 1e3:.1f}"
+                f" q{k.get('Queue_Id', '?')}]")
     seq.append((round((int(r["Start_Timestamp"]) - t0) / 1e3, 1), f, what))
     print(f"{seq[-1][0]:8.1f} {f:22s} {what}")
 wall = (int(api[b]["Start_Timestamp"]) - t0) / 1e3
