@@ -169,11 +169,31 @@ __global__ __launch_bounds__(256) void unpackRowsKernel(const T* __restrict__ ro
     h[i] = rows[4 * i + 3];
 }
 
-//! out[p] = in[p + 1] - in[p] for p < n: the send counts from the cut points
-__global__ void differencesKernel(const uint64_t* __restrict__ in, int n, uint64_t* __restrict__ out)
+/*! the cut points of an assignment in the sorted keys and what follows from them, in one launch (it used to be a search,
+ *  a difference and an upload): cut[p] = first key >= assignment[p] for p <= P, send[p] = cut[p + 1] - cut[p] for
+ *  p < P (this rank's row of the count matrix) and send[P] = the rank's status word.  A lane searches both ends of its
+ *  range itself: nothing to wait for */
+template<class K>
+__global__ void cutPointsKernel(const K* __restrict__ keys, size_t n, const K* __restrict__ assignment, int P,
+                                uint64_t* __restrict__ cut, uint64_t* __restrict__ send, uint64_t status)
 {
+    auto firstNotBelow = [&](K v)
+    {
+        size_t lo = 0, len = n;
+        while (len > 0)
+        {
+            size_t half = len / 2;
+            if (keys[lo + half] < v) lo += half + 1, len -= half + 1;
+            else len = half;
+        }
+        return uint64_t(lo);
+    };
     int p = blockIdx.x * 64 + threadIdx.x;
-    if (p < n) out[p] = in[p + 1] - in[p];
+    if (p > P) return;
+    uint64_t mine = firstNotBelow(assignment[p]);
+    cut[p]        = mine;
+    if (p < P) send[p] = firstNotBelow(assignment[p + 1]) - mine;
+    else send[P] = status;
 }
 
 //! keys (already sorted) and x, y, z, h (from their input slots order[i]) of the kept particles to their final slots
@@ -776,11 +796,13 @@ public:
             K* dq        = reinterpret_cast<K*>(scal_.as<char>() + 2048);
             uint64_t* dr = reinterpret_cast<uint64_t*>(scal_.as<char>() + 2048 + size_t(P_ + 1) * 8);
             CS_TRY(cstone_hip_upload(ctx_, dq, asg.data(), size_t(P_ + 1) * sizeof(K)));
-            CS_TRY(cstone_hip_lower_bound(ctx_, kb, keys_.p, n, dq, P_ + 1, dr));
-            // the send counts go from the device into the all-gather
+            // the send counts go from the device into the all-gather; word P of every row: the status of that rank
+            // (0 = fine), see the top of sync()
             uint64_t* send = scal_.as<uint64_t>() + 32;
             uint64_t* recv = reinterpret_cast<uint64_t*>(scal_.as<char>() + 4096);
-            hipLaunchKernelGGL(differencesKernel, gridFor(P_, 64), 64, 0, ctx_->stream, dr, P_, send);
+            hipLaunchKernelGGL(cutPointsKernel<K>, gridFor(size_t(P_) + 1, 64), 64, 0, ctx_->stream, keys_.as<K>(), n, dq, P_,
+                               dr, send, uint64_t(pending_ ? 1 : 0));
+            CS_HIP(ctx_, hipGetLastError());
             if (!pinRows)
             {
                 pinRows = static_cast<uint64_t*>(pin_.take(rows.size() * 8));
@@ -788,9 +810,6 @@ public:
             }
             if (P_ > 1)
             {
-                // word P of every row: the status of that rank (0 = fine), see the top of sync()
-                const uint64_t status = pending_ ? 1 : 0;
-                CS_TRY(cstone_hip_upload(ctx_, send + P_, &status, 8));
                 CS_TRY(callComm(comm_.all_gather(comm_.user, send, recv, size_t(P_ + 1) * 8), "all_gather (counts)"));
                 CS_HIP(ctx_, hipMemcpyAsync(pinRows, recv, rows.size() * 8, hipMemcpyDeviceToHost, ctx_->stream));
             }

@@ -37,6 +37,17 @@ __global__ __launch_bounds__(256) void adjacentDifferenceKernel(const uint32_t* 
     if (i < n) out[i] = in[i + 1] - in[i];
 }
 
+__global__ __launch_bounds__(256) void gatherTablesKernel(const uint32_t* __restrict__ map, const uint32_t* __restrict__ a,
+                                                          size_t nA, const uint32_t* __restrict__ b, size_t nB,
+                                                          const uint32_t* __restrict__ c, size_t nC,
+                                                          uint32_t* __restrict__ out)
+{
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < nA) out[i] = a ? a[map[i]] : 0u;
+    else if (i < nA + nB) out[i] = b[map[i]];
+    else if (i < nA + nB + nC) out[i] = c[i - nA - nB];
+}
+
 template<class T>
 __global__ __launch_bounds__(256) void incrementKernel(const T* __restrict__ in, T* __restrict__ out, size_t n, T value)
 {
@@ -249,6 +260,18 @@ int cstone_hip_scale(cstone_hip_ctx* ctx, int real_bits, void* data, size_t n, d
     unsigned grid = gridFor(n, 256);
     if (real_bits == 32) hipLaunchKernelGGL(scaleKernel<float>, grid, 256, 0, ctx->stream, (float*)data, n, float(factor));
     else hipLaunchKernelGGL(scaleKernel<double>, grid, 256, 0, ctx->stream, (double*)data, n, factor);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int cstone_hip_gather_tables_u32(cstone_hip_ctx* ctx, const uint32_t* map, const uint32_t* a, size_t n_a,
+                                 const uint32_t* b, size_t n_b, const uint32_t* c, size_t n_c, uint32_t* out)
+{
+    const size_t n = n_a + n_b + n_c;
+    if (!ctx || (n && !out) || ((n_a + n_b) && !map) || (n_b && !b) || (n_c && !c))
+        return fail(ctx, CSTONE_E_ARG, "gather_tables: bad argument");
+    if (n == 0) return CSTONE_OK;
+    hipLaunchKernelGGL(gatherTablesKernel, gridFor(n, 256), 256, 0, ctx->stream, map, a, n_a, b, n_b, c, n_c, out);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

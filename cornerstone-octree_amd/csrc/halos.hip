@@ -264,8 +264,14 @@ __global__ __launch_bounds__(HALO_WAVES * 64) void findHalosKernel(
 constexpr int RADII_LEAVES_PER_BLOCK = 16;
 template<class Th>
 __global__ __launch_bounds__(256) void haloRadiiKernel(const Th* __restrict__ h, const uint32_t* __restrict__ layout,
-                                                       NodeIdx first, NodeIdx last, float ext, float* __restrict__ radii)
+                                                       NodeIdx first, NodeIdx last, float ext, float* __restrict__ radii,
+                                                       NodeIdx numLeaves)
 {
+    // the leaves outside [first, last) have no particles here: radius 0 (what used to be a memset of the whole array
+    // in front of this launch), spread over the workgroups
+    const NodeIdx outside = numLeaves - (last - first);
+    for (NodeIdx o = NodeIdx(blockIdx.x) * 256 + NodeIdx(threadIdx.x); o < outside; o += NodeIdx(gridDim.x) * 256)
+        radii[o < first ? o : o + (last - first)] = 0.0f;
     const unsigned sub = threadIdx.x & 15u;
     NodeIdx k = NodeIdx(blockIdx.x) * RADII_LEAVES_PER_BLOCK + NodeIdx(threadIdx.x >> 4);
     if (first + k >= last) return; // whole 16-lane groups leave together: the shuffles below stay inside a group
@@ -381,15 +387,18 @@ int cstone_hip_halo_radii(cstone_hip_ctx* ctx, int h_bits, const void* h, const 
         return fail(ctx, CSTONE_E_ARG, "halo_radii: bad argument");
     if (num_leaves == 0) return CSTONE_OK;
     StageTimer timer(ctx, CSTONE_STAGE_HALOS);
-    CS_HIP(ctx, hipMemsetAsync(radii, 0, size_t(num_leaves) * sizeof(float), ctx->stream));
-    if (last == first) return CSTONE_OK;
+    if (last == first)
+    {
+        CS_HIP(ctx, hipMemsetAsync(radii, 0, size_t(num_leaves) * sizeof(float), ctx->stream));
+        return CSTONE_OK;
+    }
     unsigned grid = gridFor(size_t(last - first), RADII_LEAVES_PER_BLOCK);
     if (h_bits == 32)
         hipLaunchKernelGGL(haloRadiiKernel<float>, grid, 256, 0, ctx->stream, (const float*)h, layout, first, last, ext,
-                           radii);
+                           radii, num_leaves);
     else if (h_bits == 64)
         hipLaunchKernelGGL(haloRadiiKernel<double>, grid, 256, 0, ctx->stream, (const double*)h, layout, first, last,
-                           ext, radii);
+                           ext, radii, num_leaves);
     else
         return fail(ctx, CSTONE_E_ARG, "halo_radii: h_bits %d unsupported", h_bits);
     CS_HIP(ctx, hipGetLastError());

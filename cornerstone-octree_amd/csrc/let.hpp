@@ -1171,8 +1171,9 @@ private:
             // second upsweep with the peer data present
             LET_TRY(cstone_hip_upsweep_sum(ctx_, maxLevel + 2, levelRange_.as<int32_t>(), child_.as<int32_t>(),
                                            counts_.as<uint32_t>()));
+            // (one rank: no leaf count came from anybody else, leafCounts_ is what this gather would bring back)
+            LET_TRY(cstone_hip_gather(ctx_, 4, lti_.as<uint32_t>() + I, size_t(L), counts_.p, leafCounts_.p));
         }
-        LET_TRY(cstone_hip_gather(ctx_, 4, lti_.as<uint32_t>() + I, size_t(L), counts_.p, leafCounts_.p));
         haveCounts_ = haveLeafCounts_ = true;
         return CSTONE_OK;
     }
@@ -1370,10 +1371,8 @@ private:
         LET_TRY(radii_.ensure(size_t(L) * 4));
         LET_TRY(flags_.ensure(size_t(L) * 4));
         // layout[0 .. last - first] = offsets of the assigned leaves among the assigned particles
-        LET_TRY(cstone_hip_memset(ctx_, layout_.p, 0, 4));
-        if (last > first)
-            LET_TRY(cstone_hip_inclusive_scan_u32(ctx_, leafCounts_.as<uint32_t>() + first, layout_.as<uint32_t>() + 1,
-                                                  size_t(last - first)));
+        LET_TRY(cstone_hip_offsets_from_counts_u32(ctx_, leafCounts_.as<uint32_t>() + first, layout_.as<uint32_t>(),
+                                                   size_t(last - first)));
         LET_TRY(cstone_hip_halo_radii(ctx_, rb, h, layout_.as<uint32_t>(), first, last, L, searchExt, radii_.as<float>()));
         LET_TRY(cstone_hip_memset(ctx_, flags_.p, 0, size_t(L) * 4));
         if (last > first)
@@ -1475,11 +1474,10 @@ private:
             uint32_t* dmap = scratchIdx_.as<uint32_t>();
             uint32_t* dval = dmap + map.size();
             LET_TRY(cstone_hip_upload(ctx_, dmap, map.data(), map.size() * 4));
-            if (numSendRanges_) LET_TRY(cstone_hip_gather(ctx_, 4, dmap, nA, rangeScan_.p, dval));
-            LET_TRY(cstone_hip_gather(ctx_, 4, dmap + nA, nB, layout_.p, dval + nA));
             // ... and the level ranges of the tree: the exact depth for the bounds of the next update (treeChanged)
             const size_t nC = size_t(maxLevel) + 2;
-            LET_TRY(cstone_hip_memcpy_d2d(ctx_, dval + nA + nB, levelRange_.p, nC * 4));
+            LET_TRY(cstone_hip_gather_tables_u32(ctx_, dmap, numSendRanges_ ? rangeScan_.as<uint32_t>() : nullptr, nA,
+                                                 layout_.as<uint32_t>(), nB, levelRange_.as<uint32_t>(), nC, dval));
             val.resize(nA + nB + nC);
             LET_TRY(readBack(dval, val.data(), val.size()));
             levelRangeHost_.assign(val.begin() + nA + nB, val.end());

@@ -678,6 +678,15 @@ int cstone_hip_inclusive_scan_u32(cstone_hip_ctx* ctx, const uint32_t* in, uint3
     return rc;
 }
 
+int cstone_hip_offsets_from_counts_u32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n)
+{
+    if (!ctx || !out || (n && (!in || in == out))) return fail(ctx, CSTONE_E_ARG, "offsets_from_counts: bad argument");
+    CS_TRY(arenaReserve(ctx, scanArenaBytes(n)));
+    int rc = scanU32(ctx, in, out, n, 0u, false, out + n);
+    arenaReset(ctx);
+    return rc;
+}
+
 int cstone_hip_lower_bound(cstone_hip_ctx* ctx, int key_bits, const void* keys, size_t n, const void* values,
                            int num_values, uint64_t* result)
 {

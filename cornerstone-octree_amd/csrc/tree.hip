@@ -235,23 +235,28 @@ __global__ __launch_bounds__(256) void unsortedLayoutKernel(const K* __restrict_
 }
 
 // order and internalToLeaf may be the same buffer (lane i reads order[i] before writing internalToLeaf[i])
+/*! everything between the sort of the node keys and the linking in one launch: the two index maps from the sort's
+ *  order, the child offsets cleared for linkKernel (it writes those of the internal nodes only), and -- first wave of the
+ *  first workgroup -- where each level starts among the sorted keys */
+template<class K>
 __global__ __launch_bounds__(256) void invertOrderKernel(const uint32_t* order, NodeIdx numNodes,
                                                          NodeIdx numInternal, NodeIdx* internalToLeaf,
-                                                         NodeIdx* __restrict__ leafToInternal)
+                                                         NodeIdx* __restrict__ leafToInternal,
+                                                         const K* __restrict__ prefixes, NodeIdx* __restrict__ levelRange,
+                                                         NodeIdx* __restrict__ childOffsets)
 {
     NodeIdx i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 64)
+    {
+        unsigned l = threadIdx.x;
+        if (l <= maxLevel<K>()) levelRange[l] = NodeIdx(lowerBound(prefixes, size_t(numNodes), toPrefix<K>(K(0), 3 * l)));
+        if (l == maxLevel<K>() + 1) levelRange[l] = numNodes;
+    }
+    if (i <= numNodes) childOffsets[i] = 0;
     if (i >= numNodes) return;
     uint32_t o        = order[i];
     leafToInternal[o] = i;
     internalToLeaf[i] = NodeIdx(o) - numInternal;
-}
-
-template<class K>
-__global__ void levelRangeKernel(const K* __restrict__ prefixes, NodeIdx numNodes, NodeIdx* __restrict__ levelRange)
-{
-    unsigned l = threadIdx.x;
-    if (l <= maxLevel<K>()) levelRange[l] = NodeIdx(lowerBound(prefixes, size_t(numNodes), toPrefix<K>(K(0), 3 * l)));
-    if (l == maxLevel<K>() + 1) levelRange[l] = numNodes;
 }
 
 template<class K>
@@ -296,44 +301,16 @@ __global__ __launch_bounds__(256) void upsweepLevelKernel(int level, const NodeI
     }
 }
 
-/*! the levels topLevel .. 0 (at most 8^4 nodes each) in ONE workgroup, a barrier between two levels: four launches
- *  less per upsweep than a launch per level.  The sums of a level are read back through the L2 (agent-scope loads: a
- *  line fetched into this CU's L1 before its values were written must not answer) */
-constexpr int UPSWEEP_FUSED_TOP = 4;
-__global__ __launch_bounds__(1024) void upsweepTopLevelsKernel(int topLevel, const NodeIdx* __restrict__ levelRange,
-                                                               const NodeIdx* __restrict__ childOffsets, uint32_t* q)
-{
-    for (int level = topLevel; level >= 0; --level)
-    {
-        NodeIdx start = levelRange[level], end = levelRange[level + 1];
-        for (NodeIdx i = start + threadIdx.x; i < end; i += 1024)
-        {
-            NodeIdx c = childOffsets[i];
-            if (c)
-            {
-                uint64_t s = 0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    s += __hip_atomic_load(q + c + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(q + i, uint32_t(s < 0xFFFFFFFFull ? s : 0xFFFFFFFFull), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __threadfence();
-        __syncthreads();
-    }
-}
-
-//! the bottom-up sum from level `from` down to the root: a launch per level above the fused top levels
+/*! the bottom-up sum from level `from` down to the root, a launch per level.  (Round 4 tried the top five levels -- at
+ *  most 8^4 nodes each -- in ONE workgroup with a barrier between two levels: 38 us against 5 x 4.6 us for the
+ *  launches it replaced; back-to-back launches of one stream leave no gap on the device, and a level inside the
+ *  workgroup costs two dependent memory round trips just the same.) */
 static void launchUpsweep(cstone_hip_ctx* ctx, int from, const NodeIdx* levelRange, const NodeIdx* childOffsets,
                           uint32_t* counts)
 {
     unsigned grid = unsigned(ctx->numCu) * 4;
-    int level     = from;
-    for (; level > UPSWEEP_FUSED_TOP; --level)
+    for (int level = from; level >= 0; --level)
         hipLaunchKernelGGL(upsweepLevelKernel, grid, 256, 0, ctx->stream, level, levelRange, childOffsets, counts);
-    if (level >= 0)
-        hipLaunchKernelGGL(upsweepTopLevelsKernel, 1, 1024, 0, ctx->stream, level, levelRange, childOffsets, counts);
 }
 
 // ---- geometric node centers, R/sfc/box.hpp:335-352 (compiled with -ffp-contract=off like the encode)
@@ -441,10 +418,8 @@ int buildOctree(cstone_hip_ctx* ctx, const K* leaves, NodeIdx numLeaves, K* pref
     // a node key of level l has its sentinel bit at 3 l: no digit pass over the zeros above the deepest level
     CS_TRY(sortPairsArena<K>(ctx, prefixes, order, size_t(numNodes), 3 * std::min(deepestLevel, int(maxLevel<K>())) + 1));
     // order -> (leafToInternal, internalToLeaf); reading and writing internalToLeaf[i] in the same lane is safe
-    hipLaunchKernelGGL(invertOrderKernel, gridFor(numNodes, 256), 256, 0, ctx->stream, order, numNodes, numInternal,
-                       internalToLeaf, leafToInternal);
-    hipLaunchKernelGGL(levelRangeKernel<K>, 1, 64, 0, ctx->stream, prefixes, numNodes, levelRange);
-    CS_HIP(ctx, hipMemsetAsync(childOffsets, 0, size_t(numNodes + 1) * sizeof(NodeIdx), ctx->stream));
+    hipLaunchKernelGGL(invertOrderKernel<K>, gridFor(size_t(numNodes) + 1, 256), 256, 0, ctx->stream, order, numNodes,
+                       numInternal, internalToLeaf, leafToInternal, prefixes, levelRange, childOffsets);
     if (numInternal > 0)
         hipLaunchKernelGGL(linkKernel<K>, gridFor(numInternal, 256), 256, 0, ctx->stream, prefixes, numInternal,
                            leafToInternal, levelRange, childOffsets, parents);
@@ -473,16 +448,13 @@ int buildLinkedOctree(cstone_hip_ctx* ctx, int key_bits, const void* leaves, int
 int upsweepSumLevels(cstone_hip_ctx* ctx, int numLevelsPlus2, const int32_t* levelRangeHost, const int32_t* levelRange,
                      const int32_t* childOffsets, uint32_t* counts)
 {
-    int level = numLevelsPlus2 - 2;
-    for (; level > UPSWEEP_FUSED_TOP; --level)
+    for (int level = numLevelsPlus2 - 2; level >= 0; --level)
     {
         int size = levelRangeHost[level + 1] - levelRangeHost[level];
         if (size <= 0) continue;
         unsigned grid = std::min(unsigned(ctx->numCu) * 4, gridFor(size_t(size), 256));
         hipLaunchKernelGGL(upsweepLevelKernel, grid, 256, 0, ctx->stream, level, levelRange, childOffsets, counts);
     }
-    if (level >= 0)
-        hipLaunchKernelGGL(upsweepTopLevelsKernel, 1, 1024, 0, ctx->stream, level, levelRange, childOffsets, counts);
     CS_HIP(ctx, hipGetLastError());
     return CSTONE_OK;
 }

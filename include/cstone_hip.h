@@ -175,6 +175,10 @@ extern "C"
      * exclusive: out[i] = init + sum(in[0..i)), n outputs.  in == out allowed. */
     int cstone_hip_exclusive_scan_u32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t init);
     int cstone_hip_inclusive_scan_u32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n);
+    /* the exclusive scan with its grand total behind it: out[i] = sum(in[0..i)) for i <= n (n + 1 outputs; in != out) --
+     * offsets from counts in one call (the reference's fill(0) + inclusive scan to out + 1, e.g. computeNodeLayout,
+     * R/domain/layout.hpp:150-165) */
+    int cstone_hip_offsets_from_counts_u32(cstone_hip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n);
 
     /* lowerBoundGpu, range form (R/primitives/primitives_gpu.h:70-71): result[q] = index of the first element of
      * the sorted keys[n] that is >= values[q] (unsigned compare); values and result are device arrays.
@@ -206,6 +210,12 @@ extern "C"
     /* out[i] = in[i + 1] - in[i], i < n (in: n + 1 offsets; in != out): the group sizes computeGroupSplits hands back in
      * numSplitsPerGroup (R/traversal/groups_gpu.cu:108-117) */
     int cstone_hip_adjacent_difference_u32(cstone_hip_ctx* ctx, const uint32_t* in, size_t n, uint32_t* out);
+    /* up to three small u32 tables into ONE output array (then one copy brings them to the host): out[i] = a[map[i]]
+     * for i < n_a (zeros when a is null), out[n_a + j] = b[map[n_a + j]] for j < n_b, out[n_a + n_b + k] = c[k] for
+     * k < n_c.  The read-back at the end of Halos::computeLayout (R/domain/layout.hpp:175-190: where the halos of each
+     * peer arrive, how many go out to each, the level ranges of the tree) */
+    int cstone_hip_gather_tables_u32(cstone_hip_ctx* ctx, const uint32_t* map, const uint32_t* a, size_t n_a,
+                                     const uint32_t* b, size_t n_b, const uint32_t* c, size_t n_c, uint32_t* out);
     int cstone_hip_count_equal(cstone_hip_ctx* ctx, int elem_bits, const void* data, size_t n, uint64_t value,
                                uint64_t* count_host);
     int cstone_hip_reduce_sum(cstone_hip_ctx* ctx, int elem_bits, const void* data, size_t n, uint64_t init,

@@ -735,6 +735,28 @@ int cstone_hip_peer_range_counts(cstone_hip_ctx*, const uint64_t* bounds_dev, co
     }
     return CSTONE_OK;
 }
+int cstone_hip_offsets_from_counts_u32(cstone_hip_ctx*, const uint32_t* in, uint32_t* out, size_t n)
+{
+    uint32_t run = 0;
+    for (size_t i = 0; i < n; ++i)
+    {
+        out[i] = run;
+        run += in[i];
+    }
+    out[n] = run;
+    return CSTONE_OK;
+}
+int cstone_hip_gather_tables_u32(cstone_hip_ctx*, const uint32_t* map, const uint32_t* a, size_t n_a, const uint32_t* b,
+                                 size_t n_b, const uint32_t* c, size_t n_c, uint32_t* out)
+{
+    for (size_t i = 0; i < n_a; ++i)
+        out[i] = a ? a[map[i]] : 0u;
+    for (size_t j = 0; j < n_b; ++j)
+        out[n_a + j] = b[map[n_a + j]];
+    for (size_t k = 0; k < n_c; ++k)
+        out[n_a + n_b + k] = c[k];
+    return CSTONE_OK;
+}
 int cstone_hip_adjacent_difference_u32(cstone_hip_ctx*, const uint32_t* in, size_t n, uint32_t* out)
 {
     for (size_t i = 0; i < n; ++i)

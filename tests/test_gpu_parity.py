@@ -175,8 +175,23 @@ def test_minmax_and_scans(hip, rb):
         hip.exclusive_scan(vd, out, init=5)
         ref = np.concatenate([[0], np.cumsum(v, dtype=np.uint64)[:-1]]).astype(np.uint32) + 5
         assert np.array_equal(host(out), ref)
+        offs = _torch().full((n + 1,), 77, dtype=vd.dtype, device=vd.device)
+        hip.offsets_from_counts(vd, offs)  # the exclusive scan with its total behind it
+        assert np.array_equal(host(offs), np.concatenate([[0], np.cumsum(v, dtype=np.uint64)]).astype(np.uint32))
         hip.inclusive_scan(vd, vd)  # in place
         assert np.array_equal(host(vd), np.cumsum(v, dtype=np.uint64).astype(np.uint32))
+    # no counts: the one offset is zero
+    offs = _torch().full((1,), 77, dtype=_torch().int32, device="cuda")
+    hip.offsets_from_counts(offs[:0], offs)
+    assert int(offs[0]) == 0
+    # three small tables into one array (the read-back at the end of the halo layout)
+    a, b, c = (rng.integers(0, 1 << 31, m, dtype=np.uint32) for m in (50, 900, 23))
+    for n_a, n_b, use_a in ((7, 300, True), (7, 300, False), (0, 1, True), (300, 0, True)):
+        imap = np.concatenate([rng.integers(0, a.size, n_a), rng.integers(0, b.size, n_b)]).astype(np.uint32)
+        out = _torch().zeros(n_a + n_b + c.size, dtype=dev(a).dtype, device="cuda")
+        hip.gather_tables(dev(imap), dev(a) if use_a else None, n_a, dev(b), n_b, dev(c), out)
+        ref = np.concatenate([a[imap[:n_a]] if use_a else np.zeros(n_a, np.uint32), b[imap[n_a:]], c])
+        assert np.array_equal(host(out).astype(np.uint32), ref)
 
 
 def _sorted_keys(oracle, curve, kb, n, box, rb, seed, kind):
