@@ -444,6 +444,11 @@ def main():
                            "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}) + "\n"
         os.write(1, line.encode())  # (one write per rank: the ranks share the pipe)
         return
+    # the ONE JSON line is all that may appear on stdout: whatever else writes to file descriptor 1 from here on (RCCL
+    # prints a version banner there when a communicator is created) goes to stderr, the line itself to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if launched and world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); the world size counts", file=sys.stderr)
     path = args.path or ("mr" if world > 1 or os.environ.get("CSTONE_BENCH_FORCE_DIST") == "1" else "single")
@@ -900,7 +905,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample), args.key_bits, args.real_bits, args.curve,
                                                args.bucket_focus)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         torch.distributed.destroy_process_group()
 

@@ -252,6 +252,7 @@ int cstone_hip_ctx_destroy(cstone_hip_ctx* ctx)
     if (ctx->hilbertTables) (void)hipFree(ctx->hilbertTables);
     if (ctx->hostScalars) (void)hipHostFree(ctx->hostScalars);
     if (ctx->uploadStage) (void)hipHostFree(ctx->uploadStage);
+    if (ctx->downloadStage) (void)hipHostFree(ctx->downloadStage);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CSTONE_OK;
@@ -261,8 +262,7 @@ int cstone_hip_ctx_sync(cstone_hip_ctx* ctx)
 {
     if (!ctx) return CSTONE_E_ARG;
     // sticky device-side error word (bounded spins, traversal stack overflow ...)
-    CS_HIP(ctx, hipMemcpyAsync(ctx->hostScalars + 63, ctx->devScalars + 63, sizeof(int), hipMemcpyDeviceToHost,
-                               ctx->stream));
+    CS_TRY(copyToPinned(ctx, ctx->hostScalars + 63, ctx->devScalars + 63, sizeof(int)));
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->hostScalars[63] != 0)
     {
@@ -323,7 +323,7 @@ namespace
  *  kernel runs on the second stream (placeColumnsKernel of the multi-rank sync) that release did not complete before
  *  the other kernel had finished (profiles/r04_mr_sync_api_sequence.json: a 264-byte copy that lasted 102 us) and
  *  everything queued behind the copy waited with it */
-__global__ __launch_bounds__(256) void ringToDeviceKernel(char* __restrict__ dst, const char* __restrict__ src, size_t bytes,
+__global__ __launch_bounds__(256) void smallCopyKernel(char* __restrict__ dst, const char* __restrict__ src, size_t bytes,
                                                            bool words)
 {
     size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
@@ -334,6 +334,55 @@ __global__ __launch_bounds__(256) void ringToDeviceKernel(char* __restrict__ dst
     else if (i < bytes) { dst[i] = src[i]; }
 }
 } // namespace
+
+} // extern "C"
+
+namespace cship
+{
+static bool runtimeCopies()
+{
+    static const bool v = std::getenv("CSTONE_D2H_BLIT") != nullptr; // (A/B: the runtime's copies instead)
+    return v;
+}
+
+int copyToPinned(cstone_hip_ctx* ctx, void* pinnedDst, const void* devSrc, size_t bytes)
+{
+    if (bytes == 0) return CSTONE_OK;
+    if (bytes > (size_t(64) << 10) || runtimeCopies())
+    {
+        CS_HIP(ctx, hipMemcpyAsync(pinnedDst, devSrc, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return CSTONE_OK;
+    }
+    const bool words = (reinterpret_cast<uintptr_t>(pinnedDst) % 4 == 0) && (reinterpret_cast<uintptr_t>(devSrc) % 4 == 0) &&
+                       (bytes % 4 == 0);
+    const size_t lanes = words ? bytes / 4 : bytes;
+    hipLaunchKernelGGL(smallCopyKernel, dim3(unsigned((lanes + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<char*>(pinnedDst), static_cast<const char*>(devSrc), bytes, words);
+    CS_HIP(ctx, hipGetLastError());
+    return CSTONE_OK;
+}
+
+int copyToHost(cstone_hip_ctx* ctx, void* dst, const void* devSrc, size_t bytes)
+{
+    if (bytes == 0) return CSTONE_OK;
+    constexpr size_t stageBytes = size_t(64) << 10;
+    if (bytes > stageBytes || runtimeCopies())
+    {
+        CS_HIP(ctx, hipMemcpyAsync(dst, devSrc, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return CSTONE_OK;
+    }
+    if (!ctx->downloadStage)
+        CS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->downloadStage), stageBytes, hipHostMallocDefault));
+    CS_TRY(copyToPinned(ctx, ctx->downloadStage, devSrc, bytes));
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(dst, ctx->downloadStage, bytes);
+    return CSTONE_OK;
+}
+} // namespace cship
+
+extern "C"
+{
 
 int cstone_hip_upload(cstone_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
@@ -360,7 +409,7 @@ int cstone_hip_upload(cstone_hip_ctx* ctx, void* dst, const void* src, size_t by
     {
         const bool words = (reinterpret_cast<uintptr_t>(dst) % 4 == 0) && (bytes % 4 == 0);
         const size_t lanes = words ? bytes / 4 : bytes;
-        hipLaunchKernelGGL(ringToDeviceKernel, dim3(unsigned((lanes + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(smallCopyKernel, dim3(unsigned((lanes + 255) / 256)), dim3(256), 0, ctx->stream,
                            static_cast<char*>(dst), ctx->uploadStage + off, bytes, words);
         CS_HIP(ctx, hipGetLastError());
     }
@@ -372,9 +421,7 @@ int cstone_hip_memcpy_d2h(cstone_hip_ctx* ctx, void* dst, const void* src, size_
 {
     if (!ctx) return CSTONE_E_ARG;
     if (bytes == 0) return CSTONE_OK;
-    CS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return CSTONE_OK;
+    return copyToHost(ctx, dst, src, bytes);
 }
 
 int cstone_hip_memcpy_d2d(cstone_hip_ctx* ctx, void* dst, const void* src, size_t bytes)

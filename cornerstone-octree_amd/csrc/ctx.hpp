@@ -29,6 +29,7 @@ struct cstone_hip_ctx
     int* devScalars  = nullptr; // [64]
 
     // pinned staging ring for small host-to-device uploads that must not synchronise the stream (cstone_hip_upload)
+    char* downloadStage  = nullptr; // pinned, 64 KiB: copyToHost() into pageable memory goes through it
     char* uploadStage    = nullptr;
     size_t uploadBytes   = 0;
     size_t uploadCursor  = 0;
@@ -37,6 +38,8 @@ struct cstone_hip_ctx
     // it -- Domain::sync gathers x, y, z there while the trees are updated on `stream` --, and the events that order the
     // two; whatever runs there is joined back into `stream` before the call returns
     hipStream_t aux    = nullptr;
+    bool auxBusy       = false; // between a fork onto the second stream and its join: a bandwidth kernel may be running
+                                // there, and workgroups of 1024 lanes would not find a CU until it has drained (sort.hip)
     hipEvent_t evFork  = nullptr;
     hipEvent_t evJoin  = nullptr;
 
@@ -99,6 +102,15 @@ inline int fail(cstone_hip_ctx* ctx, int code, const char* fmt, ...)
 
 //! creates ctx->aux and its events on first use
 int ensureAuxStream(cstone_hip_ctx* ctx);
+
+/*! a few bytes from the device to PINNED host memory (hipHostMalloc: the context's hostScalars, a PinnedBlock ...) on the
+ *  context's stream, by an ordinary kernel that stores through the mapped host pointer; the host reads them behind the
+ *  next synchronisation of the stream.  hipMemcpyAsync does this with a blit kernel, and blit kernels that ran next to a
+ *  bandwidth kernel on the context's second stream were seen to end only when that kernel had drained (0.3 ms, 0.85 ms
+ *  for 16 bytes; profiles/r04 traces), with everything queued behind them.  More than 64 KiB go the runtime's way. */
+int copyToPinned(cstone_hip_ctx* ctx, void* pinnedDst, const void* devSrc, size_t bytes);
+//! the same into ANY host memory (through a pinned block of the context) -- synchronises the stream
+int copyToHost(cstone_hip_ctx* ctx, void* dst, const void* devSrc, size_t bytes);
 //! the launches (and stage timers) of a scope go to another stream of the context
 struct StreamScope
 {

@@ -298,6 +298,7 @@ public:
         // and the gather of h, and is joined before the call returns.
         const bool noOverlap = std::getenv("CSTONE_NO_GATHER_OVERLAP") != nullptr; // tuning / tests
         bool xyzForked = false, xyzJoined = false;
+        ctx_->auxBusy  = false; // (a sync that failed behind its fork may have left it set)
         auto forkXyzGather = [&](size_t count) -> int
         {
             if (fieldsMoved || numScratch < 3 || noOverlap || xyzForked || count == 0) return CSTONE_OK;
@@ -313,6 +314,7 @@ public:
             }
             CS_TRY(rc);
             CS_HIP(ctx_, hipEventRecord(ctx_->evJoin, ctx_->aux));
+            ctx_->auxBusy = true;
             std::swap(*xPP, scratchAll[0]);
             std::swap(*yPP, scratchAll[1]);
             std::swap(*zPP, scratchAll[2]);
@@ -322,7 +324,8 @@ public:
         auto joinXyzGather = [&]() -> int
         {
             if (xyzForked && !xyzJoined) CS_HIP(ctx_, hipStreamWaitEvent(ctx_->stream, ctx_->evJoin, 0));
-            xyzJoined = true;
+            xyzJoined     = true;
+            ctx_->auxBusy = false;
             return CSTONE_OK;
         };
         if (tryResort)
@@ -337,8 +340,7 @@ public:
             {
                 CS_TRY(resort_.binMovers(ctx_, tileLeaves));
                 // one read-back: the extents (slots 16..27) and what the re-sort found (28..31)
-                CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars + 16, ctx_->devScalars + 16, 16 * sizeof(int),
-                                            hipMemcpyDeviceToHost, ctx_->stream));
+                CS_TRY(copyToPinned(ctx_, ctx_->hostScalars + 16, ctx_->devScalars + 16, 16 * sizeof(int)));
                 CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
                 bool boxChanged = false;
                 cstone_box next = box_;
@@ -406,7 +408,7 @@ public:
             double lim[6];
             if (measured)
             {
-                CS_HIP(ctx_, hipMemcpyAsync(extentsHost, extentsDev, 6 * sizeof(T), hipMemcpyDeviceToHost, ctx_->stream));
+                CS_TRY(copyToPinned(ctx_, extentsHost, extentsDev, 6 * sizeof(T)));
                 CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
                 for (int k = 0; k < 6; ++k)
                     lim[k] = double(extentsHost[k]);
@@ -472,8 +474,7 @@ public:
         // particles flagged with the remove marker sort behind the end of the curve and leave the domain: their number
         // is on its way to the host while the global tree is updated (whose own read-back completes the stream)
         hipLaunchKernelGGL(countValidKernel<K>, 1, 1, 0, ctx_->stream, keys, n, ctx_->devScalars + 2);
-        CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars + 2, ctx_->devScalars + 2, 2 * sizeof(int), hipMemcpyDeviceToHost,
-                                    ctx_->stream));
+        CS_TRY(copyToPinned(ctx_, ctx_->hostScalars + 2, ctx_->devScalars + 2, 2 * sizeof(int)));
         CS_TRY(updateGlobal(keys, n, &converged));
         if (firstCall_)
         {
@@ -702,13 +703,12 @@ private:
     {
         CS_TRY(pin_.reserve(ctx_, size_t(gLeaves_) * 4 + size_t(gLeaves_ + 1) * sizeof(K) + 256));
         pinCounts_ = static_cast<uint32_t*>(pin_.take(size_t(gLeaves_) * 4));
-        CS_HIP(ctx_, hipMemcpyAsync(pinCounts_, gCounts_.p, size_t(gLeaves_) * 4, hipMemcpyDeviceToHost, ctx_->stream));
+        CS_TRY(copyToPinned(ctx_, pinCounts_, gCounts_.p, size_t(gLeaves_) * 4));
         pinLeaves_ = nullptr;
         if (withLeaves)
         {
             pinLeaves_ = static_cast<K*>(pin_.take(size_t(gLeaves_ + 1) * sizeof(K)));
-            CS_HIP(ctx_, hipMemcpyAsync(pinLeaves_, gTree_.p, size_t(gLeaves_ + 1) * sizeof(K), hipMemcpyDeviceToHost,
-                                        ctx_->stream));
+            CS_TRY(copyToPinned(ctx_, pinLeaves_, gTree_.p, size_t(gLeaves_ + 1) * sizeof(K)));
         }
         pinLeafCount_ = gLeaves_;
         return CSTONE_OK;
@@ -760,8 +760,7 @@ private:
         // levels up to the bound (one of them may be empty), the next sync reads the block
         if (!pinnedLevels_)
             CS_HIP(ctx_, hipHostMalloc(reinterpret_cast<void**>(&pinnedLevels_), 32 * sizeof(NodeIdx), hipHostMallocDefault));
-        CS_HIP(ctx_, hipMemcpyAsync(pinnedLevels_, fLevelRange_.p, (maxLevel<K>() + 2) * sizeof(NodeIdx),
-                                    hipMemcpyDeviceToHost, ctx_->stream));
+        CS_TRY(copyToPinned(ctx_, pinnedLevels_, fLevelRange_.p, (maxLevel<K>() + 2) * sizeof(NodeIdx)));
         levelsPending_ = true;
         return CSTONE_OK;
     }
@@ -789,7 +788,7 @@ private:
                          (uint32_t*)scalars + 1);
         arenaReset(ctx_);
         CS_TRY(rc);
-        CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars, scalars, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx_->stream));
+        CS_TRY(copyToPinned(ctx_, ctx_->hostScalars, scalars, 2 * sizeof(int)));
         CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
         *converged           = ctx_->hostScalars[0] == 0;
         const NodeIdx newL   = ctx_->hostScalars[1];
@@ -800,9 +799,14 @@ private:
             CS_TRY(newTree_.ensure(ctx_, size_t(newL + 1) * sizeof(K)));
             CS_TRY(cstone_hip_rebalance_tree(ctx_, 8 * sizeof(K), fTree_.p, L, newL, leafOps_.as<int32_t>(),
                                              newTree_.p));
-            CS_TRY(ensureTree(fTree_, fLeafCounts_, fCap_, newL));
-            CS_HIP(ctx_, hipMemcpyAsync(fTree_.p, newTree_.p, size_t(newL + 1) * sizeof(K), hipMemcpyDeviceToDevice,
-                                        ctx_->stream));
+            // the new leaf array BECOMES the tree (the two buffers change places; the counts are made anew below).  It
+            // used to be copied back: 18 MB at 10^8 particles, a blit with a handful of waves that got next to nothing
+            // of the memory system while the gather of x, y, z ran on the second stream -- 0.62 ms during which the
+            // rest of the tree update waited (profiles/r04: the copy ended with the gather)
+            std::swap(fTree_.p, newTree_.p);
+            std::swap(fTree_.bytes, newTree_.bytes);
+            CS_TRY(fLeafCounts_.ensure(ctx_, size_t(newL) * sizeof(uint32_t)));
+            fCap_    = int(std::min(fTree_.bytes / sizeof(K) - 1, fLeafCounts_.bytes / sizeof(uint32_t)));
             fLeaves_ = newL;
             CS_TRY(buildFocusOctree());
         }

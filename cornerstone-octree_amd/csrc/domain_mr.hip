@@ -599,6 +599,7 @@ public:
             CS_HIP(ctx_, hipStreamWaitEvent(ctx_->stream, ctx_->evJoin, 0));
             placeForked_ = false;
         }
+        ctx_->auxBusy = false;
         if (numProps < 0 || numProps > MAX_PROPS) setPending(CSTONE_E_ARG, "domain_mr_sync: at most %d properties", MAX_PROPS);
         for (int q = 0; q < numProps && !pending_; ++q)
         {
@@ -770,8 +771,7 @@ public:
             // inside a run: the update is not affected by an unfinished order)
             partialSort = startPass > 0;
             if (partialSort)
-                CS_HIP(ctx_, hipMemcpyAsync(ctx_->hostScalars + 3, tooLong, sizeof(int), hipMemcpyDeviceToHost,
-                                            ctx_->stream));
+                CS_TRY(copyToPinned(ctx_, ctx_->hostScalars + 3, tooLong, sizeof(int)));
         }
 
         tick("2 encode+sort");
@@ -811,9 +811,9 @@ public:
             if (P_ > 1)
             {
                 CS_TRY(callComm(comm_.all_gather(comm_.user, send, recv, size_t(P_ + 1) * 8), "all_gather (counts)"));
-                CS_HIP(ctx_, hipMemcpyAsync(pinRows, recv, rows.size() * 8, hipMemcpyDeviceToHost, ctx_->stream));
+                CS_TRY(copyToPinned(ctx_, pinRows, recv, rows.size() * 8));
             }
-            CS_HIP(ctx_, hipMemcpyAsync(pinCut, dr, size_t(P_ + 1) * 8, hipMemcpyDeviceToHost, ctx_->stream));
+            CS_TRY(copyToPinned(ctx_, pinCut, dr, size_t(P_ + 1) * 8));
             return CSTONE_OK;
         };
         auto takeCuts = [&]()
@@ -1012,7 +1012,8 @@ public:
                 }
                 CS_TRY(rc);
                 CS_HIP(ctx_, hipEventRecord(ctx_->evJoin, ctx_->aux));
-                placeForked_ = true;
+                placeForked_  = true;
+                ctx_->auxBusy = true;
             }
             else
             {
@@ -1105,8 +1106,7 @@ public:
             // this domain now and are looked at then, behind many later synchronisations of the stream
             if (!hostLevelRange_)
                 CS_HIP(ctx_, hipHostMalloc(reinterpret_cast<void**>(&hostLevelRange_), 32 * sizeof(NodeIdx), hipHostMallocDefault));
-            CS_HIP(ctx_, hipMemcpyAsync(hostLevelRange_, fLevelRange_.p, (maxLevel<K>() + 2) * sizeof(NodeIdx),
-                                        hipMemcpyDeviceToHost, ctx_->stream));
+            CS_TRY(copyToPinned(ctx_, hostLevelRange_, fLevelRange_.p, (maxLevel<K>() + 2) * sizeof(NodeIdx)));
             levelRangePending_ = true;
             const int L = fLeaves_;
             CS_TRY(layout_.ensure(ctx_, size_t(L + 1) * sizeof(uint32_t)));
@@ -1259,7 +1259,8 @@ public:
         {
             // x, y, z of the assigned block are needed from here on (a block that has to be moved, the halo exchange)
             CS_HIP(ctx_, hipStreamWaitEvent(ctx_->stream, ctx_->evJoin, 0));
-            placeForked_ = false;
+            placeForked_  = false;
+            ctx_->auxBusy = false;
         }
         // ---- room for the halos on both sides of the assigned block
         const uint64_t total = nlo + nm + nhi;
@@ -1457,9 +1458,7 @@ private:
 
     int toHost(void* dst, const void* src, size_t bytes)
     {
-        CS_HIP(ctx_, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx_->stream));
-        CS_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
-        return CSTONE_OK;
+        return copyToHost(ctx_, dst, src, bytes); // (any host memory; synchronises the stream)
     }
 
     int ensureSortScratch(size_t n)
@@ -1657,13 +1656,12 @@ private:
     {
         CS_TRY(pin_.reserve(ctx_, size_t(gLeaves_) * 4 + size_t(gLeaves_ + 1) * sizeof(K) + size_t(P_ + 1) * (P_ + 2) * 8 + 1024));
         pinCounts_ = static_cast<uint32_t*>(pin_.take(size_t(gLeaves_) * 4));
-        CS_HIP(ctx_, hipMemcpyAsync(pinCounts_, gCounts_.p, size_t(gLeaves_) * 4, hipMemcpyDeviceToHost, ctx_->stream));
+        CS_TRY(copyToPinned(ctx_, pinCounts_, gCounts_.p, size_t(gLeaves_) * 4));
         pinLeaves_ = nullptr;
         if (!gLeavesOnHost_)
         {
             pinLeaves_ = static_cast<K*>(pin_.take(size_t(gLeaves_ + 1) * sizeof(K)));
-            CS_HIP(ctx_, hipMemcpyAsync(pinLeaves_, gTree_.p, size_t(gLeaves_ + 1) * sizeof(K), hipMemcpyDeviceToHost,
-                                        ctx_->stream));
+            CS_TRY(copyToPinned(ctx_, pinLeaves_, gTree_.p, size_t(gLeaves_ + 1) * sizeof(K)));
         }
         return CSTONE_OK;
     }

@@ -826,11 +826,10 @@ int findPeers(cstone_hip_ctx* ctx, int curve, const void* prefixes, const int32_
                                childOffsets, levelRange, dSpan, numSpan, dAsg, numRanks, b, invThetaEff, dFlag, tables,
                                errors);
         CS_HIP(ctx, hipGetLastError());
-        CS_HIP(ctx, hipMemcpyAsync(peerFlagsHost, dFlag, size_t(numRanks) * 4, hipMemcpyDeviceToHost, ctx->stream));
         // the traversal reports an overflow of its pair stack through the sticky error word: read it with the flags -- an
         // incomplete (and then not mutual) peer list must not reach the treelet and count exchanges that follow
-        CS_HIP(ctx, hipMemcpyAsync(ctx->hostScalars + 63, errors, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        CS_TRY(copyToPinned(ctx, ctx->hostScalars + 63, errors, sizeof(int)));
+        CS_TRY(copyToHost(ctx, peerFlagsHost, dFlag, size_t(numRanks) * 4)); // (synchronises the stream)
         if (ctx->hostScalars[63] != 0)
             return fail(ctx, CSTONE_E_INTERNAL, "find_peers_mac: device-side check failed, code 0x%x (peer list incomplete)",
                         unsigned(ctx->hostScalars[63]));
@@ -862,8 +861,7 @@ __global__ __launch_bounds__(256) void leafOpsCountKernel(const NodeIdx* __restr
 //! one int from the device scalars to the host (synchronises the stream)
 int readScalar(cstone_hip_ctx* ctx, int slot, int* out)
 {
-    CS_HIP(ctx, hipMemcpyAsync(ctx->hostScalars + slot, ctx->devScalars + slot, sizeof(int), hipMemcpyDeviceToHost,
-                               ctx->stream));
+    CS_TRY(copyToPinned(ctx, ctx->hostScalars + slot, ctx->devScalars + slot, sizeof(int)));
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = ctx->hostScalars[slot];
     return CSTONE_OK;
@@ -1006,7 +1004,7 @@ int cstone_hip_focus_update_ops(cstone_hip_ctx* ctx, int key_bits, const void* p
     }
     CS_TRY(rc);
     CS_HIP(ctx, hipGetLastError());
-    CS_HIP(ctx, hipMemcpyAsync(ctx->hostScalars + 10, sc, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CS_TRY(copyToPinned(ctx, ctx->hostScalars + 10, sc, 4 * sizeof(int)));
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int changedNodes = ctx->hostScalars[10], status = ctx->hostScalars[11], changedLeaves = ctx->hostScalars[12];
     int converged = changedNodes == 0;                 // protectAncestors (R/focus/rebalance.hpp:171-184)

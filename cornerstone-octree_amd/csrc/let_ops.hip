@@ -391,9 +391,9 @@ static int haloRequestsImpl(cstone_hip_ctx* ctx, int key_bits, const void* leave
             CS_HIP(ctx, hipGetLastError());
             return CSTONE_OK;
         }
-        CS_HIP(ctx, hipMemcpyAsync(at.data(), dAt, at.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-        CS_HIP(ctx, hipMemcpyAsync(unmatched_host, counter, 4, hipMemcpyDeviceToHost, ctx->stream));
-        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        CS_TRY(copyToPinned(ctx, ctx->hostScalars + 9, counter, 4));
+        CS_TRY(copyToHost(ctx, at.data(), dAt, at.size() * 4)); // (synchronises the stream)
+        *unmatched_host = uint32_t(ctx->hostScalars[9]);
         return CSTONE_OK;
     };
     rc = body();

@@ -1112,7 +1112,11 @@ int sortPairs(cstone_hip_ctx* ctx, K* keys, uint32_t* vals, size_t n, K* keysAlt
     t.errors  = (uint32_t*)ctx->devScalars + 63; // sticky; reported by cstone_hip_ctx_sync
     t.status  = words + headerWords(P);
 
-    bool large       = n >= largeTileThreshold();
+    // (16 Ki-pair tiles are workgroups of 1024 lanes: while a bandwidth kernel of the same context fills the CUs from the
+    //  second stream -- the gather of x, y, z, placeColumnsKernel -- four of its workgroups never finish on one CU at the
+    //  same moment, and the first digit pass of the tree's node sort sat there until that kernel had drained: 0.28 ms
+    //  (single-rank sync) and 0.73 ms (multi-rank) instead of 0.02 ms at 2.6 million node keys)
+    bool large       = n >= largeTileThreshold() && !ctx->auxBusy;
     size_t tile      = large ? SortCfg<K, LARGE_BLOCK>::TILE : SortCfg<K, SMALL_BLOCK>::TILE;
     size_t usedBytes = (headerWords(P) + size_t(P) * (n / tile) * RADIX) * sizeof(uint32_t);
     if (histogramState != 2) CS_HIP(ctx, hipMemsetAsync(temp, 0, usedBytes, ctx->stream));

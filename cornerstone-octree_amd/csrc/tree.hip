@@ -369,8 +369,8 @@ int updateOctree(cstone_hip_ctx* ctx, const K* keys, size_t n, uint32_t bucket, 
         rc = scanU32(ctx, ops, ops, size_t(numNodes) + 1, 0u, false, (uint32_t*)scalars + 1);
         if (rc == CSTONE_OK)
         {
-            hipError_t e = hipMemcpyAsync(ctx->hostScalars, scalars, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            rc = copyToPinned(ctx, ctx->hostScalars, scalars, 2 * sizeof(int));
+            hipError_t e = rc == CSTONE_OK ? hipStreamSynchronize(ctx->stream) : hipSuccess;
             if (e != hipSuccess) rc = fail(ctx, CSTONE_E_HIP, "update_octree: %s", hipGetErrorString(e));
         }
         if (rc == CSTONE_OK)
@@ -515,7 +515,7 @@ int cstone_hip_compute_node_ops(cstone_hip_ctx* ctx, int key_bits, const void* t
     int rc = scanU32(ctx, ops, ops, size_t(num_nodes) + 1, 0u, false, (uint32_t*)scalars + 1);
     arenaReset(ctx);
     CS_TRY(rc);
-    CS_HIP(ctx, hipMemcpyAsync(ctx->hostScalars, scalars, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CS_TRY(copyToPinned(ctx, ctx->hostScalars, scalars, 2 * sizeof(int)));
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *converged_host     = ctx->hostScalars[0] == 0;
     *new_num_nodes_host = ctx->hostScalars[1];

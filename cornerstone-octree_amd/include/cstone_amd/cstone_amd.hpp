@@ -763,6 +763,44 @@ public:
         Context::check(cstone_hip_domain_mr_sync_keys(dom_, keys, x, y, z, h, n, pp, pb, np), "MultiRankDomain::sync");
         Context::check(cstone_hip_domain_mr_view_get(dom_, &view_), "MultiRankDomain::view");
     }
+    /*! Domain::syncGrav (R/domain/domain.hpp:246-325): like syncKeys (keys may be null), the masses m follow their
+     *  particles as one more property behind the given ones -- masses() afterwards -- and the focus tree is resolved by
+     *  the vector MAC on the mass centres of its nodes (expansionCenters()).  Tm: float or double */
+    template<class Tm, class... Props>
+    void syncGrav(const KeyType* keys, const T* x, const T* y, const T* z, const T* h, const Tm* m, std::size_t n,
+                  const Props*... properties)
+    {
+        static_assert(std::is_same_v<Tm, float> || std::is_same_v<Tm, double>);
+        constexpr int np = sizeof...(Props);
+        const void* pp[np + 1] = {static_cast<const void*>(properties)..., nullptr};
+        const int pb[np + 1]   = {int(sizeof(Props))..., 0};
+        Context::check(cstone_hip_domain_mr_sync_grav(dom_, keys, x, y, z, h, m, int(sizeof(Tm)) * 8, n, pp, pb, np),
+                       "MultiRankDomain::syncGrav");
+        Context::check(cstone_hip_domain_mr_view_get(dom_, &view_), "MultiRankDomain::view");
+        massProp_ = np;
+    }
+    //! the masses of the last syncGrav, laid out like x() (device)
+    template<class Tm>
+    Tm* masses() const
+    {
+        return massProp_ < 0 ? nullptr : property<Tm>(massProp_);
+    }
+    /*! Domain::updateExpansionCenters (R/domain/domain.hpp:415-421): mass centres and MAC radii of the focus tree from
+     *  the particles as they are now (arrays laid out like the result arrays; collective) */
+    template<class Tm>
+    void updateExpansionCenters(const T* x, const T* y, const T* z, const Tm* m)
+    {
+        Context::check(cstone_hip_domain_mr_update_expansion_centers(dom_, x, y, z, m, int(sizeof(Tm)) * 8),
+                       "MultiRankDomain::updateExpansionCenters");
+    }
+    //! FocusedOctree::expansionCenters(): (centre of mass, MAC radius^2) per node of the focus tree after syncGrav /
+    //! updateExpansionCenters, device pointer to 4 values of T per node; null before
+    const T* expansionCenters() const
+    {
+        cstone_hip_domain_mr_octree o;
+        Context::check(cstone_hip_domain_mr_octree_get(dom_, &o), "MultiRankDomain::expansionCenters");
+        return static_cast<const T*>(o.expansion_centers);
+    }
     template<class V>
     V* property(int i) const
     {
@@ -836,6 +874,7 @@ public:
 private:
     cstone_hip_domain_mr* dom_ = nullptr;
     cstone_hip_domain_mr_view view_{};
+    int massProp_ = -1;
 };
 
 /*! cstone::Domain<KeyType, T, GpuTag> (R/domain/domain.hpp:66-699).

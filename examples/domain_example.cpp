@@ -118,5 +118,16 @@ int main(int argc, char** argv)
     auto nsView = mr.octreeProperties();
     std::printf("its tree over local + halo particles: %d leaves\n", nsView.numLeafNodes);
     bool same = mr.nParticles() == x.size() && nsView.numLeafNodes > 0;
+    // Domain::syncGrav: the masses follow their particles, the focus tree carries mass centres and MAC radii
+    const auto first = mr.startIndex();
+    mr.syncGrav(static_cast<const KeyType*>(nullptr), mr.x() + first, mr.y() + first, mr.z() + first, mr.h() + first,
+                mr.property<float>(0) + first, mr.nParticles());
+    syncGpu();
+    const T* centers = mr.expansionCenters();
+    std::vector<T> root(4, T(-1));
+    if (centers) Context::check(cstone_hip_memcpy_d2h(Context::get(), root.data(), centers, 4 * sizeof(T)), "centre of the root");
+    std::printf("syncGrav: centre of mass of the root (%.4f, %.4f, %.4f), %u particles, masses %s\n", double(root[0]),
+                double(root[1]), double(root[2]), mr.nParticles(), mr.masses<float>() ? "attached" : "MISSING");
+    same = same && centers && mr.masses<float>() && mr.nParticles() == x.size() && root[0] > T(0.4) && root[0] < T(0.6);
     return sorted && same && followed && groupsOk ? 0 : 1;
 }

@@ -18,8 +18,9 @@ args_key_passes = 8  # one standalone sort of 64-bit keys
 
 
 def _json_line(out):
-    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out[-2000:]
+    # the bench's contract: ONE JSON line on stdout and nothing else (banners of libraries it loads go to stderr)
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out[-2000:]
     return json.loads(lines[0])
 
 

@@ -189,6 +189,20 @@ if glob.glob(os.path.join(src, "mr_api", "*hip_api_trace.csv")):
     subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "mr_trace.py"),
                     os.path.join(src, "mr_api"), "--json", f"profiles/{tag}_mr_sync_api_sequence.json"],
                    check=True, stdout=subprocess.DEVNULL)
+# wall time per multi-rank sync without a profiler (tools/mr_bench.py --rccl, world of one rank)
+plain = os.path.join(src, "mr_plain.log")
+if os.path.exists(plain):
+    import re
+    rows = []
+    for line in open(plain):
+        m = re.search(r"(\d+) RCCL rank\(s\) on one GPU, ([\d.e+]+) particles: ([\d.]+) ms per sync", line)
+        if m:
+            rows.append({"rccl_ranks": int(m.group(1)), "particles": float(m.group(2)), "ms_per_sync": float(m.group(3))})
+    json.dump({"source": "python3 tools/mr_bench.py --rccl --particles N --syncs 20 (no profiler): cstone_hip_domain_mr_sync, RCCL "
+                         "world of one rank, every particle displaced by <= 0.1 h before every sync (outside the timed "
+                         "intervals), wall clock around each sync", "runs": rows},
+              open(f"profiles/{tag}_mr_sync_times.json", "w"), indent=1)
+
 # roctx ranges of the stages (cstone_hip_profile_markers; rocprofv3 --marker-trace): time per stage and sync from the
 # marker trace alone, without the event brackets of cstone_hip_profile_enable
 for trace in glob.glob(os.path.join(src, "markers", "**", "*marker_api_trace.csv"), recursive=True):

@@ -55,7 +55,7 @@ for _ in range(a.syncs):
     dt += time.perf_counter() - t0
 dt /= a.syncs
 if rank == 0:
-    print(f"{P} {'RCCL' if a.rccl else 'gloo'} rank(s) on one GPU, {n:.1e} particles: {dt*1e3:.2f} ms per sync; rank 0: assigned {pipe.assigned}, "
+    print(f"{P} {'RCCL' if a.rccl else 'gloo'} rank(s) on one GPU, {n:.3g} particles: {dt*1e3:.2f} ms per sync; rank 0: assigned {pipe.assigned}, "
           f"halos {pipe.halos}, {pipe.stats}, syncs re-sorted: {pipe.dom.view().resorts}", flush=True)
 del pipe
 dist.destroy_process_group()

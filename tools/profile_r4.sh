@@ -15,6 +15,11 @@ done
 # the multi-rank sync at the per-GPU size of the 8-GPU strong-scaling point, RCCL world of one rank
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/mr -o mr --output-format csv -- python3 $R/tools/mr_bench.py --rccl --particles 1.25e7 --syncs 14 > $O/mr_stdout.log 2>&1
 echo "mr trace done" >> $O/progress.log
+# ... and without a profiler around it: the wall time per sync at four sizes (condensed into r04_mr_sync_times.json)
+for n in 1.25e7 2.5e7 5e7 1e8; do
+  timeout -k 10 200 python3 $R/tools/mr_bench.py --rccl --particles $n --syncs 20 2>&1 | grep "ms per sync" >> $O/mr_plain.log
+done
+echo "mr plain done" >> $O/progress.log
 # the same multi-rank sync as a sequence of HIP API calls with their kernels (tools/mr_trace.py)
 timeout -k 10 300 rocprofv3 --hip-trace --kernel-trace -d $O/mr_api -o mr --output-format csv -- python3 $R/tools/mr_bench.py --rccl --particles 1.25e7 --syncs 8 > $O/mr_api_stdout.log 2>&1
 echo "mr api trace done" >> $O/progress.log
