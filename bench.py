@@ -612,6 +612,15 @@ def main():
                                           if ctx.profile_get(k)[1]},
                     "syncs": {k: st1[k] - st0[k] for k in st1 if k != "last_movers"} | {"last_movers": st1["last_movers"]}}
 
+        # the headline loop on ONE stream: the gather of x, y, z not next to the tree update but behind it -- what the
+        # gather takes when nothing shares the memory system with it (the library reads the switch at every sync)
+        os.environ["CSTONE_NO_GATHER_OVERLAP"] = "1"
+        run_syncs(1, move)
+        extras["one_stream"] = timed_variant(move)
+        extras["one_stream"]["note"] = ("the headline loop with CSTONE_NO_GATHER_OVERLAP=1: every kernel of a sync on the "
+                                        "context's one stream")
+        del os.environ["CSTONE_NO_GATHER_OVERLAP"]
+        run_syncs(1, move)
         # the same time-stepping loop with the radix sort forced over ALL key digits (what the reference's GPU path does
         # every time) ...
         pipe.dom.set_sort_mode(pipe.dom.SORT_ALL_DIGITS)  # cstone_hip_domain_set_sort_mode
@@ -817,6 +826,14 @@ def main():
                           "bytes": what, "bytes_per_launch": bytes_launch, "avg_ms": ms / launches, "min_ms": lo,
                           "median_ms": med, "max_ms": hi, "total_ms_per_step": ms / args.steps, "achieved": gbs,
                           "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel)})
+            alone = extras.get("one_stream", {}).get("stage_ms_per_step", {}).get(stage)
+            if stage == "gather" and n_scratch >= 3 and alone and not distributed:
+                # in the timed syncs this launch runs on the context's second stream next to the tree update, which takes
+                # bandwidth from it; on its own (extras.one_stream, the same run):
+                table[-1]["concurrent"] = "on the second stream, next to the tree update and the linked-octree build"
+                table[-1]["alone"] = {"avg_ms": alone, "achieved": bytes_launch / (alone * 1e-3) / 1e9,
+                                      "frac": bytes_launch / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "measured_on": "extras.one_stream"}
         top = max(table, key=lambda r: r["total_ms_per_step"]) if table else None
         sync_bytes = sum(r["bytes_per_launch"] * r["launches"] for r in table) / args.steps
         # the radix pass the north star singles out: not part of a steady-state sync any more (the re-sort replaces it);

@@ -69,6 +69,7 @@ def test_bench_single_rank_contract():
     assert mr["rccl_ranks"] == 1 and mr["value"] > 0 and mr["invariants_ok"] is True
     assert j["config"]["path"] == "single" and j["config"]["dist"] == "uniform"
     assert j["extras"]["encode_sort_tree_1e7"]["leaves"] > 0  # BASELINE configs[1]
+    assert j["extras"]["one_stream"]["value"] > 0  # the headline loop without the second stream
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
 
