@@ -118,7 +118,8 @@ def test_peer_range_counts(hip):
             e = max(e, s)
             want.append((e - s) + 1 if peer[p] else 0)
         row = torch.full((P,), -1, dtype=torch.int64, device="cuda")
-        hip._chk(hip.lib.cstone_hip_peer_range_counts(hip.h, ptr(dev(bounds)), (C.c_uint8 * P)(*peer.tolist()), C.c_int(P),
+        db = dev(bounds)
+        hip._chk(hip.lib.cstone_hip_peer_range_counts(hip.h, ptr(db), (C.c_uint8 * P)(*peer.tolist()), C.c_int(P),
                                                       ptr(row)), "peer_range_counts")
         hip.sync()
         assert [int(v) for v in host(row, np.uint64)] == want
@@ -132,13 +133,13 @@ def test_add_macs_and_adjacent_difference(hip):
         macs = (rng.random(M) < 0.2).astype(np.int8)
         lti = rng.permutation(M)[:L].astype(np.int32)  # node of every leaf
         flags = (rng.random(L) < 0.1).astype(np.int32)
-        df = dev(flags)
-        hip._chk(hip.lib.cstone_hip_add_macs(hip.h, ptr(torch.from_numpy(macs).cuda()), ptr(dev(lti)), C.c_int(L), ptr(df)),
-                 "add_macs")
+        df, dm, dl = dev(flags), torch.from_numpy(macs).cuda(), dev(lti)  # (named: a temporary's block would be reused)
+        hip._chk(hip.lib.cstone_hip_add_macs(hip.h, ptr(dm), ptr(dl), C.c_int(L), ptr(df)), "add_macs")
         want = np.where(macs[lti] != 0, 1, flags)  # FocusedOctree::addMacs: marked leaves become halo candidates
         assert np.array_equal(df.cpu().numpy(), want)
         offs = np.concatenate([[0], np.cumsum(rng.integers(0, 50, L))]).astype(np.uint32)
         out = torch.zeros(L, dtype=torch.int32, device="cuda")
-        hip._chk(hip.lib.cstone_hip_adjacent_difference_u32(hip.h, ptr(dev(offs)), C.c_size_t(L), ptr(out)),
+        do = dev(offs)
+        hip._chk(hip.lib.cstone_hip_adjacent_difference_u32(hip.h, ptr(do), C.c_size_t(L), ptr(out)),
                  "adjacent_difference")
         assert np.array_equal(host(out, np.uint32), np.diff(offs))
