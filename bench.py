@@ -859,6 +859,24 @@ def main():
                                                              "min_ms": iota_spread[0], "median_ms": iota_spread[1],
                                                              "max_ms": iota_spread[2]}},
                         "measured_on": radix_source}
+            ad = extras.get("all_digits_sorted")
+            if ad and not distributed:
+                # SURVEY section 8(d)'s model of the WHOLE sort of (key, index) pairs: the keys read once for the digit
+                # histograms + P digit passes of 2 (K + 4) bytes = K + P * 2 * (K + 4) bytes per pair (200 at K = 8, P = 8).
+                # Measured on extras.all_digits_sorted: the digit passes, the pass that generates the positions and the
+                # histogram step; the digits are COUNTED inside the encode kernel there (its extra time over the encode of
+                # the headline's syncs is added)
+                st = ad["stage_ms_per_step"]
+                counting = max(0.0, st.get("encode", 0.0) - stage_ms.get("encode", 0.0))
+                sort_ms = st.get("sort_pass", 0.0) + st.get("sort_pass_iota", 0.0) + st.get("sort_hist", 0.0) + counting
+                passes = kbytes
+                bytes_pair = kbytes + passes * 2 * (kbytes + 4)
+                if sort_ms > 0:
+                    onesweep["whole_sort"] = {"model_bytes_per_pair": bytes_pair, "passes": passes, "ms": sort_ms,
+                                              "digit_counting_inside_the_encode_ms": counting,
+                                              "achieved": bytes_pair * n_sorted / (sort_ms * 1e-3) / 1e9,
+                                              "frac": bytes_pair * n_sorted / (sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "measured_on": "extras.all_digits_sorted (all digit passes of one sync)"}
         if distributed and onesweep and sort_ms_in_syncs > (top["total_ms_per_step"] if top else 0.0):
             # several ranks below the re-sort's size: the digit passes are the largest share of a rank's sync.  Their stage
             # also holds the small sorts, so the kernel is priced on this rank's share of the particles measured on its own

@@ -220,6 +220,70 @@ for trace in glob.glob(os.path.join(src, "markers", "**", "*marker_api_trace.csv
                    "ranges": sorted(({"range": k, "count": v[0], "host_us_total": round(v[1], 1)} for k, v in per.items()),
                                     key=lambda e: -e["host_us_total"])},
                   open(f"profiles/{tag}_stage_marker_ranges.json", "w"), indent=1)
+# the numbers README.md and DESIGN.md quote, in one place and straight from the files above (and from
+# profiles/{tag}_bench_line.json, the default `python bench.py` run of the same tree without a profiler)
+def _numbers():
+    out = [f"# {tag}: the numbers the documents quote (generated by tools/condense_profiles.py from profiles/{tag}_*)", ""]
+    path = f"profiles/{tag}_bench_line.json"
+    if os.path.exists(path):
+        b = json.load(open(path))
+        ex = b.get("extras", {})
+        out += [f"* headline (`{tag}_bench_line.json`): {b['ms_per_step']:.3f} ms per sync = {b['value']:.3e} {b['unit']}, "
+                f"n_gpus {b['n_gpus']}, first sync {b.get('first_sync_ms', 0):.1f} ms"]
+        for k in b["roofline"]["kernels"]:
+            alone = k.get("alone")
+            out += [f"  * `{k['kernel']}`: {k['bytes_per_launch'] / 1e9:.2f} GB in {k['avg_ms']:.3f} ms = {k['achieved'] / 1e3:.2f} "
+                    f"TB/s = {k['frac']:.3f} of the peak; PMC traffic {((k['traffic'] or 0) / 1e9):.2f} GB"
+                    + (f"; alone {alone['avg_ms']:.3f} ms = {alone['frac']:.3f}" if alone else "")]
+        sy, ow = b["roofline"]["sync"], b["roofline"].get("onesweep") or {}
+        out += [f"  * whole sync: {sy['algorithmic_bytes_per_step'] / 1e9:.1f} GB per sync = {sy['achieved'] / 1e3:.2f} TB/s = "
+                f"{sy['frac']:.3f}"]
+        if ow:
+            out += [f"  * digit pass: {ow['avg_launch_ms']:.4f} ms per launch = {ow['frac']:.3f} of the peak "
+                    f"({ow['launches']} launches, {ow['measured_on']})"]
+            ws = ow.get("whole_sort")
+            if ws:
+                out += [f"  * whole sort on the {ws['model_bytes_per_pair']} B/pair model: {ws['ms']:.3f} ms = "
+                        f"{ws['achieved'] / 1e3:.2f} TB/s = {ws['frac']:.3f}"]
+        out += ["  * stages (ms per sync): " + ", ".join(f"{k} {v:.3f}" for k, v in b["stage_ms_per_step"].items() if v)]
+        for name in ("one_stream", "moving_particles", "zero_motion", "sorted_from_scratch", "all_digits_sorted",
+                     "open_box_moving_extremes", "encode_sort_tree_1e7", "mr_path_world_of_one"):
+            if name in ex and isinstance(ex[name], dict) and "ms_per_step" in ex[name]:
+                out += [f"* extras.{name}: {ex[name]['ms_per_step']:.3f} ms"]
+        if "plummer" in ex:
+            pl = ex["plummer"]
+            out += [f"* extras.plummer: {pl['ms_per_step']:.3f} ms drifting ({pl['syncs']}), "
+                    f"{pl['zero_motion']['ms_per_step']:.3f} ms with nothing moving, {pl['focus_leaves']} leaves, "
+                    f"findNeighbors {pl['find_neighbors']['targets_per_s']:.3e} targets/s at "
+                    f"{pl['find_neighbors']['mean_neighbors']:.1f} neighbours"]
+        fn = ex.get("find_neighbors")
+        if fn:
+            out += [f"* extras.find_neighbors: {fn[0]['targets_per_s']:.3e} targets/s, {fn[0]['mean_neighbors']:.1f} neighbours"]
+        cb = b.get("cpu_baseline")
+        if cb:
+            out += [f"* cpu_baseline ({cb['kind']}, {cb['cores']} cores): {cb['value']:.3e} {cb['unit']}"]
+    path = f"profiles/{tag}_mr_sync_times.json"
+    if os.path.exists(path):
+        out += ["* multi-rank sync, RCCL world of one, no profiler (`%s_mr_sync_times.json`): " % tag +
+                ", ".join(f"{r['particles']:.3g}: {r['ms_per_sync']} ms" for r in json.load(open(path))["runs"])]
+    path = f"profiles/{tag}_mr_sync_api_sequence.json"
+    if os.path.exists(path):
+        a = json.load(open(path))
+        out += [f"* multi-rank sync at 1.25e7, API calls per sync (`{tag}_mr_sync_api_sequence.json`): {a['api_calls_per_sync']}, "
+                f"kernels and copies on the GPU {a['gpu_busy_us']:.0f} us"]
+    path = f"profiles/{tag}_bench_kernel_launches.json"
+    if os.path.exists(path):
+        rows = {r["kernel"]: r for r in json.load(open(path))["kernels"]}
+        for k in ("onesweepKernel", "encodeResortKernel", "leafSortWaveKernel", "gatherMultiKernel", "gatherHaloRadiiKernel",
+                  "binMoversKernel", "placeMoversKernel"):
+            if k in rows:
+                r = rows[k]
+                out += [f"* rocprofv3 kernel trace, `{k}`: {r['launches_full_size']} full-size launches, average "
+                        f"{r['avg_us_full_size']:.1f} us, median {r['median_us_full_size']:.1f} us"]
+    open(f"profiles/{tag}_numbers.md", "w").write("\n".join(out) + "\n")
+
+
+_numbers()
 print("wrote", sorted(os.listdir("profiles")))
 
 # the JSON line bench.py printed under the profiler (its live roofline number belongs next to the kernel stats)
