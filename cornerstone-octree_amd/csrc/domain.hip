@@ -129,6 +129,7 @@ struct DomainBase
     virtual void setSortMode(int mode)                   = 0;
     virtual void setSpeculativeBox(bool on)              = 0;
     virtual int reapplySync(const void* in, size_t n, int elemBytes, void* out) = 0;
+    virtual int updateExpansionCenters(const void* x, const void* y, const void* z, const void* m, int massBits) = 0;
     virtual void stats(cstone_hip_domain_stats* out)     = 0;
 };
 
@@ -607,6 +608,7 @@ public:
         startIndex_ = 0;
         endIndex_   = numAssigned;
         lastN_      = n;
+        haveExpansion_ = false; // (the tree and the particles' order may have changed)
         bufSize_    = numAssigned;
         ++syncs_;
         firstCall_  = false;
@@ -656,7 +658,31 @@ public:
         v->halo_flags            = flags_.as<int32_t>();
         v->sfc_order             = order_.as<uint32_t>();
         v->halo_radii            = radii_.as<float>();
+        v->expansion_centers     = haveExpansion_ ? fExpansion_.p : nullptr;
         return CSTONE_OK;
+    }
+
+    /*! Domain::updateExpansionCenters (R/domain/domain.hpp:415-421) on one rank = FocusedOctree::updateCenters without its
+     *  exchanges (octree_focus_mpi.hpp:369-449: computeLeafSourceCenter, upsweep with CombineSourceCenter) + setMac for
+     *  1 / theta: (centre of mass, MAC radius^2) per node of the focus tree.  x, y, z, m: the arrays of the last sync's
+     *  results (all of them are assigned on one rank), device */
+    int updateExpansionCenters(const void* x, const void* y, const void* z, const void* m, int massBits) override
+    {
+        if (lastN_ == 0 || fLeaves_ < 1) return fail(ctx_, CSTONE_E_ARG, "update_expansion_centers: no sync yet");
+        if ((massBits != 32 && massBits != 64) || !x || !y || !z || !m)
+            return fail(ctx_, CSTONE_E_ARG, "update_expansion_centers: bad argument");
+        const NodeIdx L = fLeaves_, I = (L - 1) / 7, M = L + I;
+        CS_TRY(fExpansion_.ensure(ctx_, size_t(M) * 4 * sizeof(T)));
+        CS_TRY(cstone_hip_leaf_source_centers(ctx_, 8 * sizeof(T), massBits, 8 * sizeof(T), x, y, z, m,
+                                              fLti_.as<int32_t>() + I, L, layout_.as<uint32_t>(), fExpansion_.p));
+        int32_t levels[maxLevel<K>() + 2];
+        CS_TRY(copyToHost(ctx_, levels, fLevelRange_.p, sizeof levels)); // (which levels exist: synchronises the stream)
+        CS_TRY(cstone_hip_upsweep_centers(ctx_, 8 * sizeof(T), int(maxLevel<K>()), levels, fChild_.as<int32_t>(),
+                                          fExpansion_.p));
+        CS_TRY(cstone_hip_set_mac(ctx_, curve_, 8 * sizeof(K), 8 * sizeof(T), fPrefixes_.p, M, fExpansion_.p, 1.0f / theta_,
+                                  &box_));
+        haveExpansion_ = true;
+        return cstone_hip_ctx_sync(ctx_);
     }
 
     /*! Domain::reapplySync (R/domain/domain.hpp:334-378) without an exchange: the kept particles in SFC order */
@@ -879,6 +905,8 @@ private:
     int deepestBound_      = int(maxLevel<K>()); // no leaf of the current focus tree is deeper
     int fullSortFallbacks_ = 0;
     DevBuf fPrefixes_, fChild_, fParents_, fLevelRange_, fItl_, fLti_, fCenters_, fSizes_;
+    DevBuf fExpansion_;          // T[M][4]: centre of mass + MAC radius^2 per node (updateExpansionCenters)
+    bool haveExpansion_ = false; // ... of the tree of the last sync
     DevBuf ops_, ops2_, leafOps_, layout_, radii_, flags_;
 };
 
@@ -955,6 +983,33 @@ int cstone_hip_domain_sync_scratch(cstone_hip_domain* dom, void** keys, void** x
     for (int q = 0; q < num_scratch; ++q)
         if (!scratch[q]) return fail(dom->ctx, CSTONE_E_ARG, "domain_sync: null scratch buffer %d", q);
     return dom->impl->sync(keys, x, y, z, h, n, scratch, num_scratch, props, prop_bytes, num_props);
+}
+
+int cstone_hip_domain_update_expansion_centers(cstone_hip_domain* dom, const void* x, const void* y, const void* z,
+                                               const void* m, int mass_bits)
+{
+    if (!dom) return CSTONE_E_ARG;
+    return dom->impl->updateExpansionCenters(x, y, z, m, mass_bits);
+}
+
+int cstone_hip_domain_sync_grav(cstone_hip_domain* dom, void** keys, void** x, void** y, void** z, void** h, void** m,
+                                int mass_bits, size_t n, void** scratch, int num_scratch, void** props,
+                                const int* prop_bytes, int num_props)
+{
+    if (!dom || !m || !*m || (mass_bits != 32 && mass_bits != 64) || num_props < 0 || (num_props && (!props || !prop_bytes)))
+        return fail(dom ? dom->ctx : nullptr, CSTONE_E_ARG, "domain_sync_grav: bad argument");
+    // the masses follow their particles as one more property behind the caller's
+    std::vector<void*> pp(props, props + num_props);
+    std::vector<int> pb(prop_bytes, prop_bytes + num_props);
+    pp.push_back(*m);
+    pb.push_back(mass_bits / 8);
+    int rc = cstone_hip_domain_sync_scratch(dom, keys, x, y, z, h, n, scratch, num_scratch, pp.data(), pb.data(),
+                                            num_props + 1);
+    for (int q = 0; q < num_props; ++q)
+        props[q] = pp[q];
+    *m = pp[num_props];
+    if (rc != CSTONE_OK) return rc;
+    return dom->impl->updateExpansionCenters(*x, *y, *z, *m, mass_bits);
 }
 
 int cstone_hip_domain_view_get(cstone_hip_domain* dom, cstone_hip_domain_view* out)

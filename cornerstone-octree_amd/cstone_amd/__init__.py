@@ -25,7 +25,7 @@ STAGES = {
 EXPORTS = [
     "cstone_hip_ctx_create", "cstone_hip_ctx_destroy", "cstone_hip_ctx_sync", "cstone_hip_last_error",
     "cstone_hip_device_info", "cstone_hip_malloc", "cstone_hip_free", "cstone_hip_memcpy_h2d",
-    "cstone_hip_memcpy_d2h", "cstone_hip_memcpy_d2d", "cstone_hip_memset", "cstone_hip_profile_enable", "cstone_hip_profile_markers", "cstone_hip_domain_mr_sync_grav", "cstone_hip_domain_mr_update_expansion_centers", "cstone_hip_add_macs", "cstone_hip_halo_request_rows", "cstone_hip_peer_range_counts", "cstone_hip_adjacent_difference_u32", "cstone_hip_offsets_from_counts_u32", "cstone_hip_gather_tables_u32",
+    "cstone_hip_memcpy_d2h", "cstone_hip_memcpy_d2d", "cstone_hip_memset", "cstone_hip_profile_enable", "cstone_hip_profile_markers", "cstone_hip_domain_mr_sync_grav", "cstone_hip_domain_mr_update_expansion_centers", "cstone_hip_add_macs", "cstone_hip_halo_request_rows", "cstone_hip_peer_range_counts", "cstone_hip_adjacent_difference_u32", "cstone_hip_offsets_from_counts_u32", "cstone_hip_domain_sync_grav", "cstone_hip_domain_update_expansion_centers", "cstone_hip_gather_tables_u32",
     "cstone_hip_profile_reset", "cstone_hip_profile_get", "cstone_hip_profile_get_spread", "cstone_hip_compute_sfc_keys",
     "cstone_hip_sort_pairs_temp_bytes", "cstone_hip_sort_pairs", "cstone_hip_sort_keys_ordering", "cstone_hip_sfc_keys_and_ordering", "cstone_hip_sequence_u32", "cstone_hip_gather",
     "cstone_hip_scatter", "cstone_hip_gather_scatter", "cstone_hip_merge_positions", "cstone_hip_minmax", "cstone_hip_minmax_arrays", "cstone_hip_exclusive_scan_u32", "cstone_hip_inclusive_scan_u32", "cstone_hip_lower_bound",

@@ -18,6 +18,7 @@ class DomainView(C.Structure):
         ("internal_to_leaf", C.c_void_p), ("leaf_to_internal", C.c_void_p), ("layout", C.c_void_p),
         ("centers", C.c_void_p), ("sizes", C.c_void_p), ("halo_flags", C.c_void_p), ("sfc_order", C.c_void_p),
         ("halo_radii", C.c_void_p),
+        ("expansion_centers", C.c_void_p),
     ]
 
 
@@ -82,6 +83,53 @@ class Domain:
         sout = [by_ptr[sarr[i]] for i in range(len(scr))]
         pout = [by_ptr[parr[i]] for i in range(len(props))]
         return keys[:m], out[0][:m], out[1][:m], out[2][:m], out[3][:m], (sout if many else sout[0]), [t[:m] for t in pout]
+
+    def sync_grav(self, keys, x, y, z, h, m, scratch, props=()):
+        """Domain::syncGrav on one rank (cstone_hip_domain_sync_grav): like sync with a LIST of scratch tensors; the masses m
+        follow their particles; returns (keys, x, y, z, h, m, scratch, props), view().expansion_centers is set.  Like every
+        property, the buffer behind m must offer n elements of the COORDINATES' size (a float32 m next to float64
+        coordinates: hand in the first n elements of a tensor of 2 n)"""
+        assert all(t.untyped_storage().nbytes() - t.storage_offset() * t.element_size() >= x.numel() * x.element_size()
+                   for t in (m, *props)), "property buffers must offer n elements of the coordinates' size"
+        import torch
+
+        def whole(t):  # all bytes of t's storage from its first element on
+            off = t.storage_offset() * t.element_size()
+            return torch.empty(0, dtype=torch.uint8, device=t.device).set_(t.untyped_storage(), off,
+                                                                          (t.untyped_storage().nbytes() - off,))
+
+        scr = list(scratch)
+        tensors = [x, y, z, h, m] + scr + list(props)
+        by_ptr = {t.data_ptr(): t for t in tensors}
+        raw = {t.data_ptr(): whole(t) for t in tensors}
+        n = x.numel()
+        pk = C.c_void_p(keys.data_ptr())
+        ptrs = [C.c_void_p(t.data_ptr()) for t in (x, y, z, h, m)]
+        sarr = (C.c_void_p * len(scr))(*[t.data_ptr() for t in scr])
+        parr = (C.c_void_p * max(1, len(props)))(*[t.data_ptr() for t in props])
+        pbytes = (C.c_int * max(1, len(props)))(*[t.element_size() for t in props])
+        rc = self.ctx.lib.cstone_hip_domain_sync_grav(self.h, C.byref(pk), C.byref(ptrs[0]), C.byref(ptrs[1]), C.byref(ptrs[2]),
+                                                      C.byref(ptrs[3]), C.byref(ptrs[4]), C.c_int(m.element_size() * 8),
+                                                      C.c_size_t(n), sarr, C.c_int(len(scr)), parr, pbytes,
+                                                      C.c_int(len(props)))
+        self.ctx._chk(rc, "domain_sync_grav")
+        cnt = self.view().num_particles_with_halos
+
+        def typed(ptr, like):
+            # the buffers were exchanged among x, y, z, h, m, scratch and props: a field may now live in a buffer that was
+            # handed in with another element type (every buffer offers n elements of the coordinates' size, see the header)
+            return raw[ptr][: cnt * like.element_size()].view(like.dtype)
+
+        out = [typed(p.value, t) for p, t in zip(ptrs, (x, y, z, h, m))]
+        return (keys[:cnt], *out, [by_ptr[sarr[i]] for i in range(len(scr))],
+                [typed(parr[i], props[i]) for i in range(len(props))])
+
+    def update_expansion_centers(self, x, y, z, m):
+        """Domain::updateExpansionCenters on arrays laid out like the last sync's results"""
+        rc = self.ctx.lib.cstone_hip_domain_update_expansion_centers(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                                     C.c_void_p(z.data_ptr()), C.c_void_p(m.data_ptr()),
+                                                                     C.c_int(m.element_size() * 8))
+        self.ctx._chk(rc, "domain_update_expansion_centers")
 
     def reapply_sync(self, field):
         """Domain::reapplySync: field (n rows of the last sync's input, 1..32 bytes each) in the order of the result"""

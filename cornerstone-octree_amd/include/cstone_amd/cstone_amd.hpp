@@ -1074,6 +1074,29 @@ public:
     {
         if (!mr_) Context::check(cstone_hip_domain_set_speculative_box(dom_, on ? 1 : 0), "Domain::setSpeculativeBox");
     }
+    /*! Domain::updateExpansionCenters (R/domain/domain.hpp:415-421): (centre of mass, MAC radius^2) per node of the focus
+     *  tree from the particles as they are now; x, y, z, m: arrays laid out like the result arrays of the last sync.
+     *  sync(keys, x, y, z, h, std::tie(m, ...), scratch) followed by this call is Domain::syncGrav on one rank (the tree
+     *  does not depend on the MACs there); on several ranks: MultiRankDomain::syncGrav */
+    template<class Tm>
+    void updateExpansionCenters(const DeviceVector<T>& x, const DeviceVector<T>& y, const DeviceVector<T>& z,
+                                const DeviceVector<Tm>& m)
+    {
+        static_assert(std::is_same_v<Tm, float> || std::is_same_v<Tm, double>);
+        if (mr_) { mr_->updateExpansionCenters(x.data(), y.data(), z.data(), m.data()); }
+        else
+        {
+            Context::check(cstone_hip_domain_update_expansion_centers(dom_, x.data(), y.data(), z.data(), m.data(),
+                                                                      int(sizeof(Tm)) * 8),
+                           "Domain::updateExpansionCenters");
+        }
+    }
+    //! FocusedOctree::expansionCenters(): device pointer to 4 values of T per node of the focus tree, null before
+    //! updateExpansionCenters / after the next sync
+    const T* expansionCenters() const
+    {
+        return mr_ ? mr_->expansionCenters() : static_cast<const T*>(view().expansion_centers);
+    }
     //! R/domain/domain.hpp:411: stores the flag like the reference does (its member convergeTrees, :661, has no reader
     //! there either: the trees converge on the first sync and take one update step per sync afterwards)
     void setTreeConv(bool flag) { convergeTrees_ = flag; }

@@ -96,6 +96,16 @@ int main(int argc, char** argv)
         groupsOk = groupsOk && go[g] > go[g - 1] && go[g] - go[g - 1] <= 64;
     std::printf("target groups: %zu (fixed: %u): %s\n", go.size() - 1, fixed.numGroups, groupsOk ? "ok" : "BAD");
 
+    // Domain::syncGrav on one rank = sync with the masses among the properties (above) + updateExpansionCenters
+    domain.updateExpansionCenters(x, y, z, mass);
+    std::vector<T> rootCentre(4, T(-1));
+    if (domain.expansionCenters())
+        Context::check(cstone_hip_memcpy_d2h(Context::get(), rootCentre.data(), domain.expansionCenters(), 4 * sizeof(T)),
+                       "root centre");
+    std::printf("expansion centre of the root: (%.4f, %.4f, %.4f), MAC radius^2 %.4f\n", double(rootCentre[0]),
+                double(rootCentre[1]), double(rootCentre[2]), double(rootCentre[3]));
+    followed = followed && rootCentre[0] > T(0.4) && rootCentre[0] < T(0.6) && rootCentre[3] > T(0);
+
     auto k = toHost(keys);
     bool sorted = true;
     for (std::size_t i = 1; i < k.size(); ++i)

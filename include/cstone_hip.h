@@ -623,6 +623,8 @@ extern "C"
         const int32_t* halo_flags;
         const uint32_t* sfc_order; /* the ordering kept in the last scratch buffer by the reference (:206) */
         const float* halo_radii;   /* f32[L]: 2 * haloSearchExt * max h per focus leaf (Halos::discover, halos.hpp:128-160) */
+        const void* expansion_centers; /* T[M][4]: (centre of mass, MAC radius^2) per node after _sync_grav /
+                                          _update_expansion_centers of THIS sync's tree, else NULL */
     } cstone_hip_domain_view;
 
     int cstone_hip_domain_create(cstone_hip_ctx* ctx, cstone_hip_domain** out, int curve, int key_bits, int real_bits,
@@ -635,14 +637,28 @@ extern "C"
      * pointers), like the scratch TUPLE of the reference's sync (R/domain/domain.hpp:196-206).  From three buffers on
      * x, y and z are brought into SFC order by ONE kernel that reads the ordering once (cstone_hip_gather_multi: 52
      * instead of 60 bytes per particle for f64); with fewer the arrays rotate through scratch[0] one after the other.
-     * From FOUR buffers on a steady-state sync moves x, y, z and h together with the keys in ONE pass over the particle
-     * arrays (the field-carrying leaf pass of the incremental re-sort, csrc/resort.hpp: 84 instead of 132 bytes per
-     * particle behind the encode; the halo radii come from the per-leaf maxima of h that pass folds).
+     * From three buffers on that gather runs on a second stream of the context, next to the tree update; with FOUR, h
+     * goes through the fourth while x, y, z are still on their way.  (CSTONE_FUSED_LEAF_PASS=1 with four buffers selects
+     * the field-carrying leaf pass of the incremental re-sort instead -- x, y, z, h moved with the keys, 84 instead of
+     * 92 bytes per particle behind the encode; measured slower, DESIGN.md 4c, kept for comparison.)
      * All buffers take part in the pointer exchange: on return *x, *y, *z, *h, props[i] and scratch[q] are a
      * permutation of the buffers passed in.  Same results whatever num_scratch is. */
     int cstone_hip_domain_sync_scratch(cstone_hip_domain* dom, void** keys, void** x, void** y, void** z, void** h,
                                        size_t n, void** scratch, int num_scratch, void** props, const int* prop_bytes,
                                        int num_props);
+    /* Domain::syncGrav on ONE rank (R/domain/domain.hpp:246-325): with no peers the focus tree is the tree of sync (every
+     * node is inside the focus: the MACs decide nothing), so this is _sync_scratch with the masses m (n values of
+     * mass_bits = 32 | 64 bits; *m is exchanged like the other arrays, so its buffer offers n elements of the
+     * coordinates' size like every property buffer) as one more property, followed by
+     * _update_expansion_centers = Domain::updateExpansionCenters (:415-421): (centre of mass, MAC radius^2 for 1 / theta)
+     * per node of the focus tree in view.expansion_centers (computeLeafSourceCenter, the CombineSourceCenter upsweep and
+     * setMac of R/focus/source_center.hpp).  x, y, z, m of _update_expansion_centers: arrays laid out like the result
+     * arrays of the last sync.  Several ranks: cstone_hip_domain_mr_sync_grav. */
+    int cstone_hip_domain_sync_grav(cstone_hip_domain* dom, void** keys, void** x, void** y, void** z, void** h, void** m,
+                                    int mass_bits, size_t n, void** scratch, int num_scratch, void** props,
+                                    const int* prop_bytes, int num_props);
+    int cstone_hip_domain_update_expansion_centers(cstone_hip_domain* dom, const void* x, const void* y, const void* z,
+                                                   const void* m, int mass_bits);
     int cstone_hip_domain_view_get(cstone_hip_domain* dom, cstone_hip_domain_view* out);
     /* Domain::setHaloFactor (R/domain/domain.hpp:412): extra search factor of the halo discovery (default 1.0), lets a
      * client take several integration steps between syncs */

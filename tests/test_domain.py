@@ -241,3 +241,88 @@ def test_domain_sync_random_configurations_against_oracle(hip, oracle, seed):
         for a, d in ((x, 0), (y, 1), (z, 2)):
             a += (rng.normal(0, 0.003, m) * (hi[d] - lo[d])).astype(rdt)
             np.clip(a, rdt(lo[d]), np.nextafter(rdt(hi[d]), rdt(lo[d])), out=a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kb,rb,mass_bits", [(64, 64, 64), (64, 64, 32), (32, 32, 32)])
+def test_domain_sync_grav_expansion_centers_equal_the_oracle(hip, oracle, kb, rb, mass_bits):
+    """Domain::syncGrav on one rank (cstone_hip_domain_sync_grav): the tree is the tree of sync, the masses follow their
+    particles, and (centre of mass, MAC radius^2) of every node equal computeLeafSourceCenter + the CombineSourceCenter
+    upsweep + setMac of the oracle (pinned against the reference's own functions in tests/test_focus.py) bit for bit --
+    over three syncs with moving particles; updateExpansionCenters afterwards with other masses likewise"""
+    import torch
+
+    import cstone_amd
+    from cstone_amd.domain import Domain
+    from oracle.oracle import HILBERT, Box, max_level
+
+    rng = np.random.default_rng(77 + kb + rb + mass_bits)
+    n, bucket_focus, theta = 40000, 16, 0.58
+    rdt = np.float64 if rb == 64 else np.float32
+    mdt = np.float64 if mass_bits == 64 else np.float32
+    kdt = np.uint64 if kb == 64 else np.uint32
+    bc = (0, 1, 0)
+    lim = [-1.0, 1.0, 0.0, 2.0, -0.5, 0.5]
+    centers = rng.uniform(-0.5, 0.5, (5, 3))
+    pos = centers[rng.integers(0, 5, n)] + rng.normal(0, 0.08, (n, 3))
+    x = np.clip(pos[:, 0], -0.99, 0.99).astype(rdt)
+    y = np.clip(pos[:, 1] + 1.0, 0.01, 1.99).astype(rdt)
+    z = np.clip(pos[:, 2], -0.49, 0.49).astype(rdt)
+    h = rng.uniform(0.002, 0.01, n).astype(rdt)
+    m = rng.uniform(0.5, 2.0, n).astype(mdt)
+    dom = Domain(hip, HILBERT, kb, rb, 64 * bucket_focus, bucket_focus, theta, cstone_amd.make_cbox(lim, bc))
+    same_tree = Domain(hip, HILBERT, kb, rb, 64 * bucket_focus, bucket_focus, theta, cstone_amd.make_cbox(lim, bc))
+
+    def expect(v, xs, ys, zs, ms):
+        L, M = v.num_focus_leaves, v.num_focus_nodes
+        octree = dict(prefixes=dom.fetch(v.prefixes, M, kdt), child_offsets=dom.fetch(v.child_offsets, M + 1, np.int32),
+                      level_range=dom.fetch(v.level_range, max_level(kb) + 2, np.int32))
+        l2i = dom.fetch(v.leaf_to_internal, M, np.int32)[M - L:]
+        layout = dom.fetch(v.layout, L + 1, np.uint32)
+        ctr = oracle.leaf_source_centers(xs, ys, zs, ms, l2i, layout, M, rb)
+        ctr = oracle.upsweep_centers(octree, ctr, max_level(kb))
+        box = Box(list(v.box.lim), bc)
+        # (1 / theta in float arithmetic, like the library and the reference: 1.0f / theta_)
+        return oracle.mac_spheres(HILBERT, 1, octree["prefixes"], box, float(np.float32(1.0) / np.float32(theta)), rb, ctr)
+
+    for s in range(3):
+        t = [torch.from_numpy(a.copy()).cuda() for a in (x, y, z, h)]
+        # (every buffer that takes part in the exchange offers n elements of the coordinates' size: float32 masses next to
+        #  float64 coordinates sit in the first half of a tensor of 2 n)
+        mbuf = torch.zeros(n * (rb // mass_bits), dtype=torch.float64 if mass_bits == 64 else torch.float32, device="cuda")
+        mbuf[:n] = torch.from_numpy(m.copy()).cuda()
+        keys = torch.zeros(n, dtype=torch.int64 if kb == 64 else torch.int32, device="cuda")
+        scratch = [torch.empty_like(t[0]) for _ in range(3)]
+        ident = torch.arange(n, dtype=t[0].dtype, device="cuda")
+        keys, xd, yd, zd, hd, md, scratch, (ident,) = dom.sync_grav(keys, *t, mbuf[:n], scratch, [ident])
+        v = dom.view()
+        order = ident.cpu().numpy().astype(np.int64)
+        assert np.array_equal(md.cpu().numpy(), m[order]) and np.array_equal(xd.cpu().numpy(), x[order])
+        assert v.expansion_centers
+        got = dom.fetch(v.expansion_centers, 4 * v.num_focus_nodes, rdt).reshape(-1, 4)
+        want = expect(v, x[order], y[order], z[order], m[order])
+        assert np.array_equal(got[:, :3], want[:, :3]), (s, "centres", int((got[:, :3] != want[:, :3]).any(1).sum()))
+        assert np.array_equal(got[:, 3], want[:, 3]), (s, "MAC radii", int((got[:, 3] != want[:, 3]).sum()),
+                                                        float(np.abs(got[:, 3] / want[:, 3] - 1).max()))
+        # the root: the centre of mass of the whole cloud (to rounding), a positive MAC radius
+        com = (m[:, None].astype(np.float64) * np.stack([x, y, z], 1)).sum(0) / m.sum(dtype=np.float64)
+        assert np.allclose(got[0, :3], com, rtol=1e-4 if rb == 32 else 1e-10, atol=1e-6) and got[0, 3] > 0
+        # the same tree as a plain sync of the same input
+        t2 = [torch.from_numpy(a.copy()).cuda() for a in (x, y, z, h)]
+        k2 = torch.zeros_like(keys)
+        same_tree.sync(k2, *t2, [torch.empty_like(t2[0]) for _ in range(3)])
+        v2 = same_tree.view()
+        assert v2.num_focus_leaves == v.num_focus_leaves and not v2.expansion_centers
+        assert np.array_equal(same_tree.fetch(v2.focus_leaves, v2.num_focus_leaves + 1, kdt),
+                              dom.fetch(v.focus_leaves, v.num_focus_leaves + 1, kdt))
+        # Domain::updateExpansionCenters with other masses on the synced arrays
+        m2 = (m[order] * rng.uniform(0.5, 1.5, n)).astype(mdt)
+        m2d = torch.from_numpy(m2).cuda()
+        dom.update_expansion_centers(xd, yd, zd, m2d)
+        got2 = dom.fetch(dom.view().expansion_centers, 4 * v.num_focus_nodes, rdt).reshape(-1, 4)
+        assert np.array_equal(got2, expect(v, x[order], y[order], z[order], m2)), s
+        # move
+        x = np.clip(x + rng.normal(0, 0.01, n).astype(rdt), -0.99, 0.99).astype(rdt)
+        z = np.clip(z + rng.normal(0, 0.01, n).astype(rdt), -0.49, 0.49).astype(rdt)
+    with pytest.raises(Exception):
+        Domain(hip, HILBERT, kb, rb, 64, 16, theta, cstone_amd.make_cbox(lim, bc)).update_expansion_centers(xd, yd, zd, md)
